@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself on CPU.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+It imports /root/reference/ha (read-only) and records, for seeded inputs, what the reference
+computes.  Only data (inputs, seeds, expected outputs) is written; no reference source.
+Inputs/weights come from oracle.cpu_ref.make_params / synthetic_batch so the tests can
+rebuild the large ones from a seed instead of storing 50 MB of weights.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+import types
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim   # the reference
+
+from oracle import cpu_ref
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def build_reference_model(enc_p, rec_p, F_, C, H, L, V):
+    enc = ha.rnn.Encoder(input_dim=F_, subsample_dim=C, hidden_dim=H)
+    if L != 3:
+        enc.lstm = nn.LSTM(C, H, num_layers=L, batch_first=True, dropout=0.2)
+    rec = ha.recognizer.TemporalClassifier(feat_dim=H, vocab_size=V)
+    enc.load_state_dict(enc_p)
+    rec.load_state_dict(rec_p)
+    return enc, rec
+
+
+def run_model_case(F_, C, H, L, V, B, T, S, seed, ragged):
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, seed)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, seed)
+    if ragged:
+        il = torch.tensor([T - 3 * i for i in range(B)], dtype=torch.int64)
+    enc, rec = build_reference_model(enc_p, rec_p, F_, C, H, L, V)
+    enc.eval(); rec.eval()
+    kept = {}
+
+    def keep_logits(module, args, out):
+        if out.requires_grad:
+            out.retain_grad()
+            kept['logits'] = out
+
+    rec.classifier.register_forward_hook(keep_logits)
+    feats, flen, _ = enc(x, il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg, flen, tl)
+    loss.backward()
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+        hyps, hlen, ali, scores, _ = rec.decode(feats, flen, tl)
+    grads = {('encoder.' + k): p.grad for k, p in enc.named_parameters()}
+    grads.update({('recognizer.' + k): p.grad for k, p in rec.named_parameters()})
+    return dict(enc_p=enc_p, rec_p=rec_p, x=x, il=il, tg=tg, tl=tl, feats=feats.detach(), flen=flen,
+                loss=loss.detach(), lp=lp, grads=grads, dlogits=kept['logits'].grad, dfeats=feats.grad,
+                ali=ali, scores=scores, hyps=[[int(v) for v in h] for h in hyps], hlen=hlen)
+
+
+def save_tiny():
+    for name, L in (('g1_tiny_l2', 2), ('g1_tiny_l3', 3)):
+        cfg = dict(F_=12, C=16, H=32, L=L, V=9, B=3, T=41, S=4, seed=7, ragged=True)
+        r = run_model_case(**cfg)
+        d = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+        for k, v in r['enc_p'].items():
+            d['encoder.' + k] = v.numpy()
+        for k, v in r['rec_p'].items():
+            d['recognizer.' + k] = v.numpy()
+        for k in ('x', 'il', 'tg', 'tl', 'feats', 'flen', 'loss', 'lp', 'dlogits', 'dfeats', 'ali', 'scores', 'hlen'):
+            d[k] = r[k].numpy()
+        for k, v in r['grads'].items():
+            d['grad.' + k] = v.numpy()
+        maxlen = max(1, max(len(h) for h in r['hyps']))
+        d['hyps'] = np.array([h + [-1] * (maxlen - len(h)) for h in r['hyps']], dtype=np.int64)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+        print(name, 'loss', float(r['loss']), 'hyps', r['hyps'])
+
+
+def save_lc2x1024():
+    cfg = dict(F_=80, C=128, H=1024, L=2, V=32, B=4, T=80, S=10, seed=42, ragged=True)
+    r = run_model_case(**cfg)
+    d = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+    for k in ('il', 'flen', 'loss', 'lp', 'dlogits', 'ali', 'scores', 'hlen'):
+        d[k] = r[k].numpy()
+    d['feats_slice'] = r['feats'][:, :, ::61].numpy()          # 17 of 1024 columns
+    d['feats_sum'] = r['feats'].double().sum().numpy()
+    d['dfeats_slice'] = r['dfeats'][:, :, ::61].numpy()
+    for k, v in r['grads'].items():
+        d['gradnorm.' + k] = v.double().norm().numpy()
+        d['gradslice.' + k] = v.reshape(-1)[::9973].numpy()
+    maxlen = max(1, max(len(h) for h in r['hyps']))
+    d['hyps'] = np.array([h + [-1] * (maxlen - len(h)) for h in r['hyps']], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'g1_lc2x1024.npz'), **d)
+    print('g1_lc2x1024 loss', float(r['loss']))
+
+
+def save_train_steps():
+    """Three optimizer steps the way ha/loop.py:176-196 runs them (eval-mode dropout)."""
+    cfg = dict(F_=12, C=16, H=32, L=2, V=9, B=3, T=41, S=4, seed=11)
+    enc_p, rec_p = cpu_ref.make_params(cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'], cfg['seed'])
+    enc, rec = build_reference_model(enc_p, rec_p, cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'])
+    enc.eval(); rec.eval()
+    model = nn.ModuleDict({'encoder': enc, 'recognizer': rec})
+    args = types.SimpleNamespace(lr=3e-3, weight_decay=0.01, beta1=0.9, beta2=0.99)
+    opt = ha.optim.configure_optimizers(model, args, device_type='cpu', decay_lm_head=False)
+    losses, gnorms = [], []
+    d = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+    d['cfg_lr'] = np.array(args.lr)
+    for step in range(3):
+        x, il, tg, tl = cpu_ref.synthetic_batch(cfg['B'], cfg['T'], cfg['F_'], cfg['V'], cfg['S'], 100 + step)
+        feats, flen, _ = enc(x, il)
+        loss, _ = rec(feats, tg, flen, tl)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 0.1, error_if_nonfinite=False)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        losses.append(float(loss)); gnorms.append(float(gn))
+    d['losses'] = np.array(losses); d['gnorms'] = np.array(gnorms)
+    for k, v in enc.state_dict().items():
+        d['final.encoder.' + k] = v.numpy()
+    for k, v in rec.state_dict().items():
+        d['final.recognizer.' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g1_train3.npz'), **d)
+    print('g1_train3 losses', losses, 'gnorms', gnorms)
+
+
+def ctc_case(name, T, N, C, S, seed, targets=None, il=None, tl=None):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(T, N, C, generator=g).requires_grad_(True)
+    em = logits.log_softmax(-1)
+    if targets is None:
+        targets = torch.randint(1, C, (N, S), generator=g)
+    if il is None:
+        il = torch.full((N,), T, dtype=torch.int64)
+    if tl is None:
+        tl = torch.full((N,), S, dtype=torch.int64)
+    with torch.no_grad():
+        nll3 = ha.ctc.ctc_forward_score3(em, targets, il, tl)
+        red3 = ha.ctc.ctc_reduce_mean(nll3, tl)
+    nll_t = F.ctc_loss(em, targets, il, tl, blank=0, reduction='none')
+    mean_t = F.ctc_loss(em, targets, il, tl, blank=0, reduction='mean')
+    finite = torch.isfinite(nll_t).all()
+    if finite:
+        mean_t.backward()
+        dlogits = logits.grad.clone()
+    else:
+        dlogits = torch.zeros_like(logits)
+    return {name + '.logits': logits.detach().numpy(), name + '.targets': targets.numpy(),
+            name + '.il': il.numpy(), name + '.tl': tl.numpy(), name + '.score3': nll3.numpy(),
+            name + '.reduce_mean3': red3.numpy(), name + '.torch_none': nll_t.detach().numpy(),
+            name + '.torch_mean': mean_t.detach().numpy(), name + '.dlogits_mean': dlogits.numpy(),
+            name + '.has_grad': np.array(bool(finite))}
+
+
+def save_ctc():
+    d = {}
+    d.update(ctc_case('random', 21, 4, 32, 10, 0, tl=torch.tensor([10, 7, 5, 9])))
+    d.update(ctc_case('repeat', 21, 3, 8, 6, 1, targets=torch.tensor([[3, 3, 3, 3, 3, 3], [1, 1, 2, 2, 1, 1], [5, 4, 4, 4, 5, 5]])))
+    d.update(ctc_case('s1', 9, 2, 6, 1, 2))
+    d.update(ctc_case('ragged', 21, 4, 32, 10, 3, il=torch.tensor([21, 17, 20, 12]), tl=torch.tensor([3, 10, 1, 6])))
+    d.update(ctc_case('infeasible', 6, 2, 5, 4, 4, targets=torch.tensor([[1, 1, 1, 1], [1, 2, 3, 4]])))
+    d.update(ctc_case('wide', 50, 2, 300, 40, 5, tl=torch.tensor([40, 33])))
+    # the reference's own __main__ demo (ha/ctc.py:181-238): seed 2
+    torch.manual_seed(2)
+    l0 = torch.randn(5, 7).log_softmax(-1)
+    t0 = torch.LongTensor([1, 2, 3, 3])
+    d['demo.l0'] = l0.numpy(); d['demo.t0'] = t0.numpy()
+    d['demo.score1'] = ha.ctc.ctc_forward_score1(l0, t0).numpy()
+    d['demo.score2'] = ha.ctc.ctc_forward_score2(l0, t0).numpy()
+    l1 = torch.randn(5, 7).log_softmax(-1)
+    t1 = torch.LongTensor([1, 2, 3, 4])
+    em = torch.stack([l0, l1], dim=1); tg = torch.stack([t0, t1], dim=0)
+    d['demo.em'] = em.numpy(); d['demo.tg'] = tg.numpy()
+    d['demo.score3'] = ha.ctc.ctc_forward_score3(em, tg, torch.LongTensor([5, 5]), torch.LongTensor([3, 4])).numpy()
+    # long-T single-sequence cases where score1's wrap-around skip (ctc.py:29) shows
+    g = torch.Generator().manual_seed(9)
+    l2 = torch.randn(12, 5, generator=g).log_softmax(-1)
+    t2 = torch.LongTensor([2, 4])
+    d['wrap.l'] = l2.numpy(); d['wrap.t'] = t2.numpy()
+    d['wrap.score1'] = ha.ctc.ctc_forward_score1(l2, t2).numpy()
+    d['wrap.score2'] = ha.ctc.ctc_forward_score2(l2, t2).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g2_ctc.npz'), **d)
+    print('g2_ctc demo', d['demo.score1'], d['demo.score2'], d['demo.score3'], 'wrap', d['wrap.score1'], d['wrap.score2'],
+          'infeasible', d['infeasible.score3'], d['infeasible.torch_none'])
+
+
+def pad_seqs(seqs):
+    m = max(1, max(len(s) for s in seqs))
+    return (np.array([list(s) + [-1] * (m - len(s)) for s in seqs], dtype=np.int64),
+            np.array([len(s) for s in seqs], dtype=np.int64))
+
+
+def save_beam():
+    d = {}
+    probs = F.one_hot(torch.tensor([0, 3, 1, 2, 2, 0, 0, 2, 0, 0, 0, 1, 2, 3])).float()   # ha/beam.py:144
+    seqs, sc = ha.beam.ctc_beam_search_decode_logits(torch.log(probs))
+    d['onehot.logits'] = torch.log(probs).numpy()
+    d['onehot.seqs'], d['onehot.lens'] = pad_seqs(seqs); d['onehot.scores'] = sc.numpy(); d['onehot.beam'] = np.array(3)
+    for name, T, V, beam, seed in (('r21x32b16', 21, 32, 16, 0), ('r21x32b3', 21, 32, 3, 0), ('r6x4b4', 6, 4, 4, 0),
+                                   ('r30x9b5', 30, 9, 5, 3), ('r21x32b33', 21, 32, 33, 5)):
+        g = torch.Generator().manual_seed(seed)
+        lg = torch.randn(T, V, generator=g).log_softmax(-1)
+        seqs, sc = ha.beam.ctc_beam_search_decode_logits(lg, beam_size=beam)
+        d[name + '.logits'] = lg.numpy(); d[name + '.beam'] = np.array(beam)
+        d[name + '.seqs'], d[name + '.lens'] = pad_seqs(seqs); d[name + '.scores'] = sc.numpy()
+    # probability-domain twin: NameError as shipped (beam.py:46) ...
+    try:
+        ha.beam.ctc_beam_search_decode_probs(probs)
+        d['probs.raises_nameerror'] = np.array(False)
+    except NameError:
+        d['probs.raises_nameerror'] = np.array(True)
+    # ... and what it computes once the missing module global exists
+    ha.beam.device = 'cpu'
+    g = torch.Generator().manual_seed(1)
+    pr = torch.randn(12, 6, generator=g).softmax(-1)
+    seqs, sc = ha.beam.ctc_beam_search_decode_probs(pr, beam_size=4)
+    d['probs.probs'] = pr.numpy(); d['probs.beam'] = np.array(4)
+    d['probs.seqs'], d['probs.lens'] = pad_seqs(seqs); d['probs.scores'] = sc.numpy()
+    seqs, sc = ha.beam.ctc_beam_search_decode_probs(probs)
+    d['probs_onehot.seqs'], d['probs_onehot.lens'] = pad_seqs(seqs); d['probs_onehot.scores'] = sc.numpy()
+    del ha.beam.device
+    # beam wider than 1+V at t=0 -> topk raises RuntimeError
+    try:
+        ha.beam.ctc_beam_search_decode_logits(torch.zeros(3, 4).log_softmax(-1), beam_size=6)
+        d['toowide.raises'] = np.array(False)
+    except RuntimeError:
+        d['toowide.raises'] = np.array(True)
+    np.savez_compressed(os.path.join(OUT, 'g3_beam.npz'), **d)
+    print('g3_beam onehot', d['onehot.seqs'].tolist(), d['onehot.scores'], 'r6x4b4', d['r6x4b4.seqs'][0], d['r6x4b4.scores'][0])
+
+
+if __name__ == '__main__':
+    save_tiny()
+    save_train_steps()
+    save_ctc()
+    save_beam()
+    save_lc2x1024()

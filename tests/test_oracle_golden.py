@@ -1,0 +1,138 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref, lattice, philox
+from conftest import load_golden
+
+
+def _params(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+
+
+def _unpad(seqs, lens):
+    return [list(map(int, s[:n])) for s, n in zip(seqs, lens)]
+
+
+@pytest.mark.parametrize('name', ['g1_tiny_l2', 'g1_tiny_l3'])
+def test_model_forward_backward_matches_reference(name):
+    g = load_golden(name)
+    enc = {k: v.requires_grad_(True) for k, v in _params(g, 'encoder.').items()}
+    rec = {k: v.requires_grad_(True) for k, v in _params(g, 'recognizer.').items()}
+    x, il, tg, tl = (torch.from_numpy(g[k]) for k in ('x', 'il', 'tg', 'tl'))
+    loss, feats, flen = cpu_ref.lstm_ctc_loss(enc, rec, x, il, tg, tl)
+    assert flen.dtype == torch.int32
+    assert np.array_equal(flen.numpy(), g['flen'])
+    np.testing.assert_allclose(feats.detach().numpy(), g['feats'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-6)
+    loss.backward()
+    for k, v in list(enc.items()) + list(rec.items()):
+        key = 'grad.' + ('encoder.' if k in enc else 'recognizer.') + k
+        np.testing.assert_allclose(v.grad.numpy(), g[key], rtol=1e-4, atol=1e-7, err_msg=key)
+    lp = cpu_ref.classifier_log_probs(rec, feats.detach())
+    np.testing.assert_allclose(lp.detach().numpy(), g['lp'], atol=1e-6)
+    hyps, hlen, ali, scores = lattice.greedy_decode(lp.detach())
+    assert np.array_equal(ali.numpy(), g['ali'])
+    assert np.array_equal(hlen.numpy(), g['hlen'])
+    assert hyps == _unpad(g['hyps'], g['hlen'])
+
+
+def test_lc2x1024_matches_reference():
+    g = load_golden('g1_lc2x1024')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    il = torch.from_numpy(g['il'])
+    with torch.no_grad():
+        loss, feats, flen = cpu_ref.lstm_ctc_loss(enc, rec, x, il, tg, tl)
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-6)
+    np.testing.assert_allclose(feats[:, :, ::61].numpy(), g['feats_slice'], atol=1e-6)
+    assert np.array_equal(flen.numpy(), g['flen'])
+
+
+def test_train_steps_match_reference():
+    g = load_golden('g1_train3')
+    c = {k[4:]: v for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = cpu_ref.make_params(int(c['F_']), int(c['C']), int(c['H']), int(c['L']), int(c['V']), int(c['seed']))
+    tr = cpu_ref.Trainer(enc, rec, lr=float(c['lr']))
+    for step in range(3):
+        x, il, tg, tl = cpu_ref.synthetic_batch(int(c['B']), int(c['T']), int(c['F_']), int(c['V']), int(c['S']), 100 + step)
+        loss, gn = tr.step(x, il, tg, tl)
+        np.testing.assert_allclose(float(loss), g['losses'][step], rtol=1e-5)
+        np.testing.assert_allclose(float(gn), g['gnorms'][step], rtol=1e-4)
+    for k, v in tr.enc.items():
+        np.testing.assert_allclose(v.detach().numpy(), g['final.encoder.' + k], atol=2e-6, err_msg=k)
+    for k, v in tr.rec.items():
+        np.testing.assert_allclose(v.detach().numpy(), g['final.recognizer.' + k], atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('case', ['random', 'repeat', 's1', 'ragged', 'infeasible', 'wide'])
+def test_ctc_score3_matches_reference(case):
+    g = load_golden('g2_ctc')
+    em = torch.from_numpy(g[case + '.logits']).log_softmax(-1)
+    tg, il, tl = (torch.from_numpy(g[case + '.' + k]) for k in ('targets', 'il', 'tl'))
+    nll = lattice.ctc_forward_score3(em, tg, il, tl)
+    np.testing.assert_array_equal(nll.numpy(), g[case + '.score3'])          # same ATen ops -> bit equal
+    np.testing.assert_array_equal(lattice.ctc_reduce_mean(nll, tl).numpy(), g[case + '.reduce_mean3'])
+    ok = np.isfinite(g[case + '.torch_none'])
+    np.testing.assert_allclose(nll.numpy()[ok], g[case + '.torch_none'][ok], rtol=2e-5)
+    if case == 'infeasible':
+        assert g['infeasible.torch_none'][0] == np.inf and nll[0] == torch.finfo(torch.float32).max
+
+
+def test_ctc_single_sequence_variants():
+    g = load_golden('g2_ctc')
+    l0, t0 = torch.from_numpy(g['demo.l0']), torch.from_numpy(g['demo.t0'])
+    np.testing.assert_allclose(float(lattice.ctc_forward_score1(l0, t0)), float(g['demo.score1']), rtol=1e-6)
+    np.testing.assert_allclose(float(lattice.ctc_forward_score2(l0, t0)), float(g['demo.score2']), rtol=1e-6)
+    assert abs(float(g['demo.score1']) - 7.6325) < 1e-4          # ha/ctc.py __main__ print, seed 2
+    em, tg = torch.from_numpy(g['demo.em']), torch.from_numpy(g['demo.tg'])
+    s3 = lattice.ctc_forward_score3(em, tg, torch.tensor([5, 5]), torch.tensor([3, 4]))
+    np.testing.assert_array_equal(s3.numpy(), g['demo.score3'])
+    lw, tw = torch.from_numpy(g['wrap.l']), torch.from_numpy(g['wrap.t'])
+    np.testing.assert_allclose(float(lattice.ctc_forward_score1(lw, tw)), float(g['wrap.score1']), rtol=1e-6)
+    np.testing.assert_allclose(float(lattice.ctc_forward_score2(lw, tw)), float(g['wrap.score2']), rtol=1e-6)
+    assert abs(float(g['wrap.score1']) - float(g['wrap.score2'])) > 1.0   # the wrap quirk is real
+
+
+def test_ctc_lattice_equals_brute_force():
+    gen = torch.Generator().manual_seed(3)
+    lp = torch.randn(5, 3, generator=gen).log_softmax(-1)
+    for target in ([1], [1, 2], [2, 2], [1, 2, 1]):
+        tg = torch.tensor([target])
+        nll = lattice.ctc_forward_score3(lp[:, None, :], tg, torch.tensor([5]), torch.tensor([len(target)]))
+        assert abs(float(nll[0]) - lattice.ctc_brute_force_nll(lp, target)) < 1e-5
+
+
+@pytest.mark.parametrize('case', ['onehot', 'r21x32b16', 'r21x32b3', 'r6x4b4', 'r30x9b5', 'r21x32b33'])
+def test_beam_logits_matches_reference(case):
+    g = load_golden('g3_beam')
+    seqs, scores = lattice.ctc_beam_search_decode_logits(torch.from_numpy(g[case + '.logits']), int(g[case + '.beam']))
+    assert seqs == _unpad(g[case + '.seqs'], g[case + '.lens'])
+    np.testing.assert_array_equal(scores.numpy(), g[case + '.scores'])
+
+
+def test_beam_probs_matches_patched_reference():
+    g = load_golden('g3_beam')
+    assert bool(g['probs.raises_nameerror'])        # as shipped, ha/beam.py:46 raises
+    seqs, scores = lattice.ctc_beam_search_decode_probs(torch.from_numpy(g['probs.probs']), int(g['probs.beam']))
+    assert seqs == _unpad(g['probs.seqs'], g['probs.lens'])
+    np.testing.assert_allclose(scores.numpy(), g['probs.scores'], rtol=1e-6)
+    with pytest.raises(RuntimeError):
+        lattice.ctc_beam_search_decode_logits(torch.zeros(3, 4).log_softmax(-1), beam_size=6)
+    assert bool(g['toowide.raises'])
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32-10, ctr=0 key=0 and ctr=key=ffffffff
+    z = np.zeros(1, dtype=np.uint32)
+    r = philox.philox4x32_10(z, z, z, z, 0, 0)
+    assert [int(v[0]) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = np.full(1, 0xffffffff, dtype=np.uint32)
+    r = philox.philox4x32_10(f, f, f, f, 0xffffffff, 0xffffffff)
+    assert [int(v[0]) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    m = philox.dropout_mask(100000, 0.2, 1234, 1, 0)
+    assert abs((m == 0).mean() - 0.2) < 0.01
+    assert set(np.unique(m)) == {np.float32(0), np.float32(1.25)}
