@@ -1,0 +1,88 @@
+"""ctypes binding of libhalo.so (include/halo.h).  There is NO fallback: if the HIP library is
+missing or a call fails, the product raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
+
+HALO_ABI_VERSION = 1
+HALO_GEMM_RELU = 1
+HALO_CTC_FULL_LATTICE = 1
+HALO_CTC_FINITE_MIN = 2
+HALO_CTC_NO_LEAD_BLANK_LOOP = 4
+HALO_CTC_WRAP_SKIP = 8
+HALO_STREAM_SUBSAMPLE = 1
+HALO_STREAM_CLASSIFIER = 2
+HALO_STREAM_LSTM_LAYER0 = 16
+HALO_SUMSQ_PARTS = 1024
+
+_vp, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+
+# name -> (restype, argtypes); one entry per function declared in include/halo.h
+SIGNATURES = {
+    'halo_abi_version': (_i, []),
+    'halo_strerror': (C.c_char_p, [_i]),
+    'halo_device_info': (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
+    'halo_dropout_fwd': (_i, [_vp, _vp, _sz, _f, _u64, _u32, _u32, _vp, _vp]),
+    'halo_counter_inc': (_i, [_vp, _vp]),
+    'halo_gemm_f32': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
+    'halo_subsample_col_bytes': (_sz, [_i] * 6),
+    'halo_subsample_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
+    'halo_subsample_bwd': (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp]),
+    'halo_lstm_reserve_bytes': (_sz, [_i] * 4),
+    'halo_lstm_bwd_workspace_bytes': (_sz, [_i] * 5),
+    'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
+    'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
+    'halo_log_softmax_fwd': (_i, [_vp, _vp, _i, _i, _vp]),
+    'halo_log_softmax_bwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'halo_colsum': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'halo_ctc_fwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'halo_ctc_bwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp]),
+    'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'halo_ctc_beam_workspace_bytes': (_sz, [_i] * 4),
+    'halo_ctc_beam': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
+    'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
+    'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class HaloError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing or mismatched."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HaloError(f'{LIB_PATH} not found: build it with `make -C haloop_amd/csrc` '
+                            '(or __graft_entry__.build()); haloop_amd has no CPU fallback')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)            # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.halo_abi_version() != HALO_ABI_VERSION:
+            raise HaloError('libhalo.so ABI version mismatch: rebuild it')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HaloError(f'{what} failed: {lib().halo_strerror(rc).decode()} ({rc})')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (kept alive by the caller for the duration of the call)."""
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

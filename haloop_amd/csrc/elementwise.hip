@@ -1,0 +1,213 @@
+// Small memory-bound kernels around the GEMMs: dropout, im2col for the stride-4 subsample conv,
+// relu/dropout backward, row-wise log-softmax, column sums, transpose.
+#include "halo_common.h"
+#include "halo_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          size_t n4, size_t n, DropoutCfg d) {
+    // 4 elements per thread: one Philox call covers exactly one float4
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = q * 4;
+        const f32x4 m = dropout_mult4(d, e);
+        if (e + 3 < n) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(x + e);
+            v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
+            *reinterpret_cast<f32x4 *>(y + e) = v;
+        } else {
+            for (int i = 0; i < 4 && e + i < n; ++i) y[e + i] = x[e + i] * m[i];
+        }
+    }
+}
+
+// col[(t*B + b)][c*ks + kk] = x[b][t*stride - pad + kk][c]
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, float *__restrict__ col, int B,
+                                                     int T, int F, int Tp, int ks, int stride, int pad) {
+    const int row = blockIdx.x;               // t*B + b
+    const int t = row / B, b = row % B;
+    const int K = F * ks;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int c = k / ks, kk = k % ks;
+        const int tt = t * stride - pad + kk;
+        float v = 0.f;
+        if (tt >= 0 && tt < T) v = x[((long)b * T + tt) * F + c];
+        col[(long)row * K + k] = v;
+    }
+}
+
+// dpre = dy * (y > 0 ? scale : 0): backward of relu followed by inverted dropout, read off y
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                               float *__restrict__ dpre, size_t n, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dpre[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (long)row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += expf(xr[c] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    float *yr = y + (long)row * cols;
+    for (int c = lane; c < cols; c += 64) yr[c] = xr[c] - lse;
+}
+
+// dx = dy - exp(y) * sum(dy)
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                              float *__restrict__ dx, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *dr = dy + (long)row * cols, *yr = y + (long)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += dr[c];
+    s = wave_sum(s);
+    float *xr = dx + (long)row * cols;
+    for (int c = lane; c < cols; c += 64) xr[c] = dr[c] - expf(yr[c]) * s;
+}
+
+// out[n] = sum_m x[m*ld + n]; block = 32 columns x 8 row slices, fixed summation order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int rows, int cols, int ld,
+                                                     float *__restrict__ out) {
+    __shared__ float part[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int slice = threadIdx.x >> 5;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = slice; r < rows; r += 8) s += x[(long)r * ld + c];
+    part[slice][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (slice == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];
+        out[c] = t;
+    }
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows,
+                                                        int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(long)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+__global__ void counter_inc_kernel(uint32_t *c) { *c += 1u; }
+
+__global__ __launch_bounds__(256) void fill_kernel(float *p, size_t n, float v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline unsigned grid_for(size_t n, unsigned per_block = 256, unsigned cap = 4096) {
+    size_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ---- internal helpers used by lstm.hip --------------------------------------------------------
+int halo_transpose(const float *in, float *out, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    return halo_launch_status();
+}
+int halo_fill(float *p, size_t n, float v, hipStream_t st) {
+    if (n == 0) return HALO_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n, v);
+    return halo_launch_status();
+}
+
+static inline int subsampled_len(int T, int ks, int stride, int pad) { return (T + 2 * pad - ks) / stride + 1; }
+
+extern "C" {
+
+int halo_dropout_fwd(const float *x, float *y, size_t n, float p, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                     const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && y);
+    HALO_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0));
+    if (n == 0) return HALO_OK;
+    const size_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, n,
+                       make_dropout(p, seed, stream_id, offset, offset_dev));
+    return halo_launch_status();
+}
+
+int halo_counter_inc(uint32_t *counter, halo_stream_t stream) {
+    HALO_CHECK_ARG(counter);
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+    return halo_launch_status();
+}
+
+size_t halo_subsample_col_bytes(int B, int T, int F, int ks, int stride, int pad) {
+    if (B <= 0 || T <= 0 || F <= 0 || ks <= 0 || stride <= 0 || T + 2 * pad < ks) return 0;
+    return (size_t)subsampled_len(T, ks, stride, pad) * B * F * ks * sizeof(float);
+}
+
+int halo_subsample_fwd(const float *x, const float *w, const float *bias, float *y, float *col, int B, int T, int F,
+                       int C, int ks, int stride, int pad, float p_drop, uint64_t seed, uint32_t offset,
+                       const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && w && y && col);
+    HALO_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0 && ks > 0 && stride > 0 && pad >= 0 && T + 2 * pad >= ks);
+    const int Tp = subsampled_len(T, ks, stride, pad);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(im2col_kernel, dim3(Tp * B), dim3(256), 0, st, x, col, B, T, F, Tp, ks, stride, pad);
+    int rc = halo_launch_status();
+    if (rc) return rc;
+    // y[T'B, C] = col[T'B, F*ks] * w[C, F*ks]^T + bias, relu, dropout on the time-major index
+    return halo_gemm_f32(1, 1, Tp * B, C, F * ks, col, F * ks, w, F * ks, y, C, bias, nullptr, HALO_GEMM_RELU, p_drop,
+                         seed, HALO_STREAM_SUBSAMPLE, offset, offset_dev, stream);
+}
+
+int halo_subsample_bwd(const float *dy, const float *y, const float *col, float *dpre, float *dw, float *dbias, int B,
+                       int T, int F, int C, int ks, int stride, int pad, float p_drop, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && y && col && dpre && dw && dbias);
+    HALO_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0 && ks > 0 && stride > 0 && pad >= 0 && T + 2 * pad >= ks);
+    const int Tp = subsampled_len(T, ks, stride, pad);
+    const size_t n = (size_t)Tp * B * C;
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, y, dpre, n, scale);
+    int rc = halo_launch_status();
+    if (rc) return rc;
+    // dw[C, F*ks] = dpre[T'B, C]^T * col[T'B, F*ks]
+    rc = halo_gemm_f32(0, 0, C, F * ks, Tp * B, dpre, C, col, F * ks, dw, F * ks, nullptr, nullptr, 0, 0.f, 0, 0, 0,
+                       nullptr, stream);
+    if (rc) return rc;
+    return halo_colsum(dpre, Tp * B, C, C, dbias, stream);
+}
+
+int halo_log_softmax_fwd(const float *x, float *y, int rows, int cols, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && y && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
+    return halo_launch_status();
+}
+
+int halo_log_softmax_bwd(const float *dy, const float *y, float *dx, int rows, int cols, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && y && dx && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, dx, rows,
+                       cols);
+    return halo_launch_status();
+}
+
+int halo_colsum(const float *x, int rows, int cols, int ld, float *out, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, out);
+    return halo_launch_status();
+}
+
+}  // extern "C"

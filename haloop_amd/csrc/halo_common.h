@@ -1,0 +1,111 @@
+// Shared device/host helpers for libhalo (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "halo.h"
+
+#define HALO_WAVE 64
+
+#define HALO_CHECK_ARG(cond) \
+    do {                     \
+        if (!(cond)) return HALO_EINVAL; \
+    } while (0)
+
+static inline int halo_launch_status() {
+    return hipGetLastError() == hipSuccess ? HALO_OK : HALO_ELAUNCH;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- Philox4x32-10 (Random123 constants).  Must match oracle/philox.py bit for bit. -------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+struct DropoutCfg {
+    uint32_t k0, k1;      // seed
+    uint32_t stream_id;
+    uint32_t offset;
+    const uint32_t *offset_dev;   // optional device counter added to offset (graph replays advance it)
+    uint32_t threshold;   // keep iff r >= threshold
+    float scale;          // 1/(1-p); p<=0 -> disabled (threshold 0, scale 1)
+};
+
+static inline DropoutCfg make_dropout(float p, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                                      const uint32_t *offset_dev) {
+    DropoutCfg d;
+    d.offset_dev = p > 0.f ? offset_dev : nullptr;
+    d.k0 = (uint32_t)(seed & 0xffffffffu);
+    d.k1 = (uint32_t)(seed >> 32);
+    d.stream_id = stream_id;
+    d.offset = offset;
+    if (p > 0.f) {
+        double t = (double)p * 4294967296.0;
+        d.threshold = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+        d.scale = 1.0f / (1.0f - p);
+    } else {
+        d.threshold = 0u;
+        d.scale = 1.0f;
+    }
+    return d;
+}
+
+// mask multiplier for flat element index e
+__device__ __forceinline__ float dropout_mult(const DropoutCfg &d, uint64_t e) {
+    const uint64_t q = e >> 2;
+    const uint32_t off = d.offset + (d.offset_dev ? *d.offset_dev : 0u);
+    const Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), d.stream_id, off, d.k0, d.k1);
+    const uint32_t lane = (uint32_t)(e & 3);
+    const uint32_t v = lane == 0 ? r.v[0] : lane == 1 ? r.v[1] : lane == 2 ? r.v[2] : r.v[3];
+    return v >= d.threshold ? d.scale : 0.f;
+}
+
+// four multipliers for elements 4q..4q+3 (e must be a multiple of 4)
+__device__ __forceinline__ f32x4 dropout_mult4(const DropoutCfg &d, uint64_t e) {
+    const uint64_t q = e >> 2;
+    const uint32_t off = d.offset + (d.offset_dev ? *d.offset_dev : 0u);
+    const Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), d.stream_id, off, d.k0, d.k1);
+    f32x4 m;
+    m[0] = r.v[0] >= d.threshold ? d.scale : 0.f;
+    m[1] = r.v[1] >= d.threshold ? d.scale : 0.f;
+    m[2] = r.v[2] >= d.threshold ? d.scale : 0.f;
+    m[3] = r.v[3] >= d.threshold ? d.scale : 0.f;
+    return m;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float log_add_exp(float a, float b) {
+    // torch.logaddexp semantics: equal infinities return themselves
+    if (isinf(a) && a == b) return a;
+    const float m = fmaxf(a, b);
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

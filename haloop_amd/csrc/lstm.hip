@@ -1,0 +1,385 @@
+// Multi-layer LSTM forward/backward for gfx950.
+//
+// Structure (per layer): one exact-f32 MFMA GEMM for the input projection of all T frames, then T
+// dependent "step" kernels, each fusing the recurrent GEMM h_{t-1} W_hh^T (v_mfma_f32_16x16x4_f32),
+// the gate non-linearities and the state update.  The chain of step launches is what the caller
+// captures in a hipGraph: on this chip a dependent kernel boundary (~1.5 us) is cheaper than a
+// grid-wide barrier inside a persistent kernel (~4-5 us; MI355X_MICROARCH.md price list, rows
+// "boundary" vs "barrier-xcd"), so the time recursion is cut at every step.
+//
+// Step kernel tiling: one workgroup owns a 16(batch) x 16(hidden unit) tile and all four gates
+// of it.  Waves are (gate, k-slice) pairs for the forward, k-slices of the 4H-deep contraction
+// for the backward; partial 16x16 accumulators meet in LDS, then 256 threads do the pointwise
+// cell update for their (b, j) element.  Buffers are time-major: h/c [T+1,B,H], gates [T,B,4H].
+#include "halo_common.h"
+#include "halo_internal.h"
+
+namespace {
+
+enum YMode { Y_NONE = 0, Y_PLAIN = 1, Y_RELU = 2, Y_DROPOUT = 3 };
+
+struct StepFwdArgs {
+    const float *hprev;   // [B,H]
+    const float *cprev;   // [B,H]
+    const float *whh;     // [4H,H]
+    float *gates;         // [B,4H] in: x W_ih^T + b ; out: activated i,f,g,o
+    float *hout;          // [B,H]
+    float *cout;          // [B,H]
+    float *y;             // optional second output of h (strided)
+    long y_stride_b;
+    int y_mode;
+    uint64_t drop_base;   // flat index of (t, b=0, j=0) in the time-major dropout tensor
+    DropoutCfg drop;
+    int B, H;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdArgs p) {
+    constexpr int NW = 4 * KS;
+    __shared__ float red[NW][256];
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gate = wave & 3, ks = wave >> 2;
+    const int r = lane & 15, q = lane >> 4;
+    const int H = p.H;
+
+    // A operand rows = batch (clamped; masked at the stores), B operand rows = W_hh rows of this gate
+    const int brow = min(b0 + r, p.B - 1);
+    const int klen = H / KS;
+    const float *ap = p.hprev + (long)brow * H + ks * klen + 4 * q;
+    const float *bp = p.whh + ((long)gate * H + j0 + r) * H + ks * klen + 4 * q;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int nblk = klen / 16;
+#pragma unroll 4
+    for (int blk = 0; blk < nblk; blk += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + blk * 16);
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(bp + blk * 16);
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+        if (blk + 1 < nblk) {
+            a1 = *reinterpret_cast<const f32x4 *>(ap + blk * 16 + 16);
+            w1 = *reinterpret_cast<const f32x4 *>(bp + blk * 16 + 16);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], w0[m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m], w1[m], acc1, 0, 0, 0);
+        }
+    }
+    // D layout: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc0[e] + acc1[e];
+    __syncthreads();
+
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        const int b = b0 + i;
+        if (b < p.B) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) s += red[k * 4 + g][threadIdx.x];
+                pre[g] = s + p.gates[(long)b * 4 * H + (long)g * H + j0 + j];
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const long e = (long)b * H + j0 + j;
+            const float c = fg * p.cprev[e] + ig * gg;
+            const float h = og * tanhf(c);
+            float *gp = p.gates + (long)b * 4 * H + j0 + j;
+            gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
+            p.cout[e] = c;
+            p.hout[e] = h;
+            if (p.y_mode != Y_NONE) {
+                float v = h;
+                if (p.y_mode == Y_RELU) v = fmaxf(h, 0.f);
+                else if (p.y_mode == Y_DROPOUT) v = h * dropout_mult(p.drop, p.drop_base + (uint64_t)e);
+                p.y[(long)b * p.y_stride_b + j0 + j] = v;
+            }
+        }
+    }
+}
+
+struct StepBwdArgs {
+    const float *dgnext;  // [B,4H] gate gradients of step t+1, or NULL at t = T-1
+    const float *whhT;    // [H,4H]
+    float *gates;         // [B,4H] in: activated gates of step t ; out: gradients w.r.t. pre-activations
+    const float *c;       // [B,H] c_t
+    const float *cprev;   // [B,H] c_{t-1}
+    float *dc;            // [B,H] carry, in/out
+    const float *dy;      // gradient arriving from above for step t (strided), may be NULL
+    long dy_stride_b;
+    int dy_relu;          // dy is w.r.t. relu(h): mask with h > 0
+    const float *dhinit;  // [B,H] extra dh added at this step (dhn at t = T-1), or NULL
+    int first;            // t == T-1: dc carry starts from dcinit (or 0)
+    const float *dcinit;  // [B,H] or NULL
+    int B, H;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArgs p) {
+    __shared__ float red[NW][256];
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int H = p.H, K = 4 * H;
+
+    if (p.dgnext) {
+        const int brow = min(b0 + r, p.B - 1);
+        const int klen = K / NW;
+        const float *ap = p.dgnext + (long)brow * K + wave * klen + 4 * q;
+        const float *bp = p.whhT + (long)(j0 + r) * K + wave * klen + 4 * q;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int nblk = klen / 16;
+#pragma unroll 4
+        for (int blk = 0; blk < nblk; blk += 2) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + blk * 16);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(bp + blk * 16);
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+            if (blk + 1 < nblk) {
+                a1 = *reinterpret_cast<const f32x4 *>(ap + blk * 16 + 16);
+                w1 = *reinterpret_cast<const f32x4 *>(bp + blk * 16 + 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], w0[m], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m], w1[m], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc0[e] + acc1[e];
+    }
+    __syncthreads();
+
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        const int b = b0 + i;
+        if (b < p.B) {
+            const long e = (long)b * H + j0 + j;
+            float dh = 0.f;
+            if (p.dgnext) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) dh += red[k][threadIdx.x];
+            }
+            if (p.dhinit) dh += p.dhinit[e];
+            float *gp = p.gates + (long)b * K + j0 + j;
+            const float ig = gp[0], fg = gp[H], gg = gp[2 * (long)H], og = gp[3 * (long)H];
+            const float c = p.c[e];
+            const float tc = tanhf(c);
+            if (p.dy) {
+                float d = p.dy[(long)b * p.dy_stride_b + j0 + j];
+                if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
+                dh += d;
+            }
+            float dcc = p.first ? (p.dcinit ? p.dcinit[e] : 0.f) : p.dc[e];
+            dcc += dh * og * (1.f - tc * tc);
+            const float d_o = dh * tc;
+            const float d_i = dcc * gg, d_f = dcc * p.cprev[e], d_g = dcc * ig;
+            p.dc[e] = dcc * fg;
+            gp[0] = d_i * ig * (1.f - ig);
+            gp[H] = d_f * fg * (1.f - fg);
+            gp[2 * (long)H] = d_g * (1.f - gg * gg);
+            gp[3 * (long)H] = d_o * og * (1.f - og);
+        }
+    }
+}
+
+struct LayerBufs {
+    float *h, *c, *gates, *ydrop;
+};
+
+inline size_t layer_floats(int T, int B, int H) { return (size_t)(2 * (T + 1) + 5 * T) * B * H; }
+
+inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
+    float *base = reserve + (size_t)l * layer_floats(T, B, H);
+    LayerBufs lb;
+    lb.h = base;
+    lb.c = lb.h + (size_t)(T + 1) * B * H;
+    lb.gates = lb.c + (size_t)(T + 1) * B * H;
+    lb.ydrop = lb.gates + (size_t)T * B * 4 * H;
+    return lb;
+}
+
+inline int pick_fwd_ks(int H) { return (H % 64 == 0) ? 4 : (H % 32 == 0) ? 2 : 1; }
+inline int pick_bwd_nw(int H) { return (H % 64 == 0) ? 16 : (H % 32 == 0) ? 8 : 4; }
+
+int launch_step_fwd(const StepFwdArgs &a, hipStream_t st) {
+    dim3 grid(a.H / 16, (a.B + 15) / 16);
+    switch (pick_fwd_ks(a.H)) {
+        case 4: hipLaunchKernelGGL(lstm_step_fwd_kernel<4>, grid, dim3(1024), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(256), 0, st, a); break;
+    }
+    return halo_launch_status();
+}
+
+int launch_step_bwd(const StepBwdArgs &a, hipStream_t st) {
+    dim3 grid(a.H / 16, (a.B + 15) / 16);
+    switch (pick_bwd_nw(a.H)) {
+        case 16: hipLaunchKernelGGL(lstm_step_bwd_kernel<16>, grid, dim3(1024), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(lstm_step_bwd_kernel<8>, grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL(lstm_step_bwd_kernel<4>, grid, dim3(256), 0, st, a); break;
+    }
+    return halo_launch_status();
+}
+
+#define HALO_TRY(expr)            \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != HALO_OK) return rc_; \
+    } while (0)
+
+inline int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? HALO_OK : HALO_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t halo_lstm_reserve_bytes(int T, int B, int H, int L) {
+    if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
+    return (size_t)L * layer_floats(T, B, H) * sizeof(float);
+}
+
+size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
+    if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
+    (void)in0;
+    // W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
+    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H) * sizeof(float);
+}
+
+int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+                  const float *const *b_hh, const float *h0, const float *c0, float *y, long y_stride_t,
+                  long y_stride_b, int y_relu, float *hn, float *cn, float *reserve, int T, int B, int in0, int H,
+                  int L, float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev,
+                  halo_stream_t stream) {
+    HALO_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && reserve);
+    HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
+    if (H % 16 != 0) return HALO_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BH = (size_t)B * H;
+    for (int l = 0; l < L; ++l) {
+        HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
+        const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+        const bool last = (l == L - 1);
+        const bool drop_out = !last && p_drop > 0.f;
+        const float *in;
+        int in_dim;
+        if (l == 0) { in = x; in_dim = in0; }
+        else {
+            const LayerBufs pb = layer_bufs(reserve, l - 1, T, B, H);
+            in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
+            in_dim = H;
+        }
+        // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
+        HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
+                               b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
+        if (h0) HALO_TRY(copy_d2d(lb.h, h0 + (size_t)l * BH, BH, st));
+        else HALO_TRY(halo_fill(lb.h, BH, 0.f, st));
+        if (c0) HALO_TRY(copy_d2d(lb.c, c0 + (size_t)l * BH, BH, st));
+        else HALO_TRY(halo_fill(lb.c, BH, 0.f, st));
+        const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
+        for (int t = 0; t < T; ++t) {
+            StepFwdArgs a;
+            a.hprev = lb.h + (size_t)t * BH;
+            a.cprev = lb.c + (size_t)t * BH;
+            a.whh = w_hh[l];
+            a.gates = lb.gates + (size_t)t * B * 4 * H;
+            a.hout = lb.h + (size_t)(t + 1) * BH;
+            a.cout = lb.c + (size_t)(t + 1) * BH;
+            a.B = B; a.H = H;
+            a.drop = dc;
+            a.drop_base = (uint64_t)t * BH;
+            if (last && y) {
+                a.y = y + (long)t * y_stride_t;
+                a.y_stride_b = y_stride_b;
+                a.y_mode = y_relu ? Y_RELU : Y_PLAIN;
+            } else if (drop_out) {
+                a.y = lb.ydrop + (size_t)t * BH;
+                a.y_stride_b = H;
+                a.y_mode = Y_DROPOUT;
+            } else {
+                a.y = nullptr; a.y_stride_b = 0; a.y_mode = Y_NONE;
+            }
+            HALO_TRY(launch_step_fwd(a, st));
+        }
+        if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
+        if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
+    }
+    return HALO_OK;
+}
+
+int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *dy,
+                  long y_stride_t, long y_stride_b, int y_relu, const float *dhn, const float *dcn, float *reserve,
+                  float *workspace, float *dx, float *const *dw_ih, float *const *dw_hh, float *const *db_ih,
+                  float *const *db_hh, int T, int B, int in0, int H, int L, float p_drop, uint64_t seed,
+                  uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && w_ih && w_hh && reserve && workspace && dw_ih && dw_hh && db_ih && db_hh);
+    HALO_CHECK_ARG(dy || dhn || dcn);
+    HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
+    if (H % 16 != 0) return HALO_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BH = (size_t)B * H;
+    float *whhT = workspace;
+    float *dcarry = whhT + (size_t)H * 4 * H;
+    float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
+    for (int l = L - 1; l >= 0; --l) {
+        HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
+        const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+        const bool last = (l == L - 1);
+        HALO_TRY(halo_transpose(w_hh[l], whhT, 4 * H, H, st));
+        for (int t = T - 1; t >= 0; --t) {
+            StepBwdArgs a;
+            a.dgnext = (t == T - 1) ? nullptr : lb.gates + (size_t)(t + 1) * B * 4 * H;
+            a.whhT = whhT;
+            a.gates = lb.gates + (size_t)t * B * 4 * H;
+            a.c = lb.c + (size_t)(t + 1) * BH;
+            a.cprev = lb.c + (size_t)t * BH;
+            a.dc = dcarry;
+            if (last) {
+                a.dy = dy ? dy + (long)t * y_stride_t : nullptr;
+                a.dy_stride_b = y_stride_b;
+                a.dy_relu = y_relu;
+            } else {
+                a.dy = din + (size_t)t * BH;
+                a.dy_stride_b = H;
+                a.dy_relu = 0;
+            }
+            a.first = (t == T - 1);
+            a.dhinit = (t == T - 1 && dhn) ? dhn + (size_t)l * BH : nullptr;
+            a.dcinit = (t == T - 1 && dcn) ? dcn + (size_t)l * BH : nullptr;
+            a.B = B; a.H = H;
+            HALO_TRY(launch_step_bwd(a, st));
+        }
+        // parameter gradients over all frames at once
+        const float *in;
+        int in_dim;
+        if (l == 0) { in = x; in_dim = in0; }
+        else {
+            const LayerBufs pb = layer_bufs(reserve, l - 1, T, B, H);
+            in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
+            in_dim = H;
+        }
+        // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
+        HALO_TRY(halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f, 0,
+                               0, 0, nullptr, stream));
+        // dW_ih[4H,in] = dG^T * in
+        HALO_TRY(halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
+                               nullptr, 0, 0.f, 0, 0, 0, nullptr, stream));
+        HALO_TRY(halo_colsum(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], stream));
+        HALO_TRY(copy_d2d(db_hh[l], db_ih[l], (size_t)4 * H, st));
+        if (l > 0) {
+            // gradient w.r.t. the (dropped) output of layer l-1, with that layer's dropout mask folded in
+            HALO_TRY(halo_gemm_f32(1, 0, T * B, H, 4 * H, lb.gates, 4 * H, w_ih[l], H, din, H, nullptr, nullptr, 0,
+                                   p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l - 1), offset, offset_dev, stream));
+        } else if (dx) {
+            HALO_TRY(halo_gemm_f32(1, 0, T * B, in0, 4 * H, lb.gates, 4 * H, w_ih[0], in0, dx, in0, nullptr, nullptr, 0,
+                                   0.f, 0, 0, 0, nullptr, stream));
+        }
+    }
+    return HALO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// Gradient-norm clipping and AdamW on flat fp32 buffers (one pass each over the parameters).
+#include <math.h>
+#include "halo_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ partials, int count, float max_norm,
+                                                        float *coef, float *norm_out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        const float c = max_norm / (norm + 1e-6f);
+        *coef = c > 1.0f ? 1.0f : c;
+        if (norm_out) *norm_out = norm;
+    }
+}
+
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    size_t n;
+    float decay_mul;     // 1 - lr*wd
+    float beta1_w;       // 1 - beta1
+    float beta2;
+    float beta2_w;       // 1 - beta2
+    float step_size;     // lr / (1 - beta1^t)
+    float bc2_sqrt;      // sqrt(1 - beta2^t)
+    float eps;
+    const float *grad_scale;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
+    const float gs = a.grad_scale ? *a.grad_scale : 1.0f;
+    const size_t n4 = a.n / 4;
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 p = p4[i], m = m4[i], v = v4[i];
+        const f32x4 g = g4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = a.grad_scale ? g[e] * gs : g[e];
+            float pe = p[e] * a.decay_mul;
+            const float me = m[e] + (ge - m[e]) * a.beta1_w;
+            const float ve = v[e] * a.beta2 + a.beta2_w * ge * ge;
+            const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
+            pe -= a.step_size * (me / denom);
+            p[e] = pe; m[e] = me; v[e] = ve;
+        }
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = n4 * 4 + threadIdx.x; i < a.n; i += 256) {
+            const float ge = a.grad_scale ? a.g[i] * gs : a.g[i];
+            float pe = a.p[i] * a.decay_mul;
+            const float me = a.m[i] + (ge - a.m[i]) * a.beta1_w;
+            const float ve = a.v[i] * a.beta2 + a.beta2_w * ge * ge;
+            const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
+            pe -= a.step_size * (me / denom);
+            a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && partials && ((uintptr_t)x % 16 == 0));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(HALO_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    return halo_launch_status();
+}
+
+int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
+                   halo_stream_t stream) {
+    HALO_CHECK_ARG(partials && coef && count > 0);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, count, max_norm, coef,
+                       norm_out);
+    return halo_launch_status();
+}
+
+int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, const float *grad_scale, halo_stream_t stream) {
+    HALO_CHECK_ARG(p && g && m && v && step >= 1);
+    HALO_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0));
+    if (n == 0) return HALO_OK;
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+    // scalar prep in double like torch's python-side bias corrections (optim/adamw.py, _single_tensor)
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    a.beta1_w = (float)(1.0 - (double)beta1);
+    a.beta2 = beta2;
+    a.beta2_w = (float)(1.0 - (double)beta2);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = eps;
+    a.grad_scale = grad_scale;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return halo_launch_status();
+}
+
+}  // extern "C"

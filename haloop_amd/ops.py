@@ -1,0 +1,258 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).  Every function enqueues on torch's
+current HIP stream and allocates its outputs/workspaces with torch (device memory plumbing only).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, ptr_array
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f'{name}: expected a contiguous float32 HIP tensor, got {t.dtype} {t.device} '
+                         f'contiguous={t.is_contiguous()}')
+    return t
+
+
+class Dropout:
+    """Value bundle (p, seed, offset, device step counter) for one forward/backward pair."""
+    __slots__ = ('p', 'seed', 'offset', 'counter')
+
+    def __init__(self, p=0.0, seed=0, offset=0, counter=None):
+        self.p, self.seed, self.offset, self.counter = float(p), int(seed), int(offset), counter
+
+    @property
+    def counter_ptr(self):
+        return ptr(self.counter)
+
+
+NO_DROPOUT = Dropout()
+
+
+def subsampled_length(T, ks=5, stride=4, pad=3):
+    return (T + 2 * pad - ks) // stride + 1
+
+
+def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, relu=False,
+         drop=NO_DROPOUT, stream_id=0):
+    lda = a.shape[-1]
+    ldb = b.shape[-1]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    check(lib().halo_gemm_f32(int(a_kcontig), int(b_kcontig), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), N,
+                              ptr(bias1), ptr(bias2), _lib.HALO_GEMM_RELU if relu else 0, drop.p, drop.seed,
+                              stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_gemm_f32')
+    return out
+
+
+def dropout_fwd(x, drop, stream_id):
+    _f32c(x, 'x')
+    y = torch.empty_like(x)
+    check(lib().halo_dropout_fwd(ptr(x), ptr(y), x.numel(), drop.p, drop.seed, stream_id, drop.offset,
+                                 drop.counter_ptr, _stream()), 'halo_dropout_fwd')
+    return y
+
+
+def subsample_fwd(x, w, bias, drop, ks=5, stride=4, pad=3):
+    """x [B,T,F] -> y [T',B,C] time-major, col (saved im2col image)."""
+    _f32c(x, 'inputs'); _f32c(w, 'subsample.weight'); _f32c(bias, 'subsample.bias')
+    B, T, F = x.shape
+    Cc = w.shape[0]
+    Tp = subsampled_length(T, ks, stride, pad)
+    y = torch.empty(Tp, B, Cc, device=x.device, dtype=torch.float32)
+    col = torch.empty(Tp * B, F * ks, device=x.device, dtype=torch.float32)
+    check(lib().halo_subsample_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(col), B, T, F, Cc, ks, stride, pad,
+                                   drop.p, drop.seed, drop.offset, drop.counter_ptr, _stream()), 'halo_subsample_fwd')
+    return y, col
+
+
+def subsample_bwd(dy, y, col, B, T, F, Cc, p_drop, dw=None, dbias=None, ks=5, stride=4, pad=3):
+    _f32c(dy, 'dy')
+    dpre = torch.empty_like(y)
+    if dw is None:
+        dw = torch.empty(Cc, F, ks, device=y.device, dtype=torch.float32)
+    if dbias is None:
+        dbias = torch.empty(Cc, device=y.device, dtype=torch.float32)
+    check(lib().halo_subsample_bwd(ptr(dy), ptr(y), ptr(col), ptr(dpre), ptr(dw), ptr(dbias), B, T, F, Cc, ks, stride,
+                                   pad, p_drop, _stream()), 'halo_subsample_bwd')
+    return dw, dbias
+
+
+def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=None, y_relu=False,
+             want_state=False, drop=NO_DROPOUT):
+    """x_tm [T,B,in] time-major.  Returns (y, hn, cn, reserve).
+
+    y defaults to a time-major [T,B,H] tensor; pass a preallocated ``y`` with ``y_strides`` =
+    (stride_t, stride_b) in elements to have the last layer write e.g. batch-first."""
+    _f32c(x_tm, 'x')
+    T, B, in0 = x_tm.shape
+    L = len(w_hh)
+    H = w_hh[0].shape[1]
+    for t in list(w_ih) + list(w_hh) + list(b_ih) + list(b_hh):
+        _f32c(t, 'lstm parameter')
+    dev = x_tm.device
+    if y is None:
+        y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        y_strides = (B * H, H)
+    reserve = torch.empty(lib().halo_lstm_reserve_bytes(T, B, H, L) // 4, device=dev, dtype=torch.float32)
+    hn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
+    cn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
+    if h0 is not None:
+        _f32c(h0, 'h0'); _f32c(c0, 'c0')
+    a_ih, a_hh, a_bi, a_bh = ptr_array(w_ih), ptr_array(w_hh), ptr_array(b_ih), ptr_array(b_hh)
+    check(lib().halo_lstm_fwd(ptr(x_tm), a_ih, a_hh, a_bi, a_bh, ptr(h0), ptr(c0), ptr(y), y_strides[0], y_strides[1],
+                              int(y_relu), ptr(hn), ptr(cn), ptr(reserve), T, B, in0, H, L, drop.p, drop.seed,
+                              drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_fwd')
+    return y, hn, cn, reserve
+
+
+def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=None, want_dx=False,
+             grads=None, drop=NO_DROPOUT):
+    """Returns (dx or None, dw_ih, dw_hh, db_ih, db_hh) lists.  ``grads`` may carry preallocated
+    output tensors as a dict of lists with those four names."""
+    T, B, in0 = x_tm.shape
+    L = len(w_hh)
+    H = w_hh[0].shape[1]
+    dev = x_tm.device
+    if grads is None:
+        grads = {
+            'dw_ih': [torch.empty_like(w) for w in w_ih],
+            'dw_hh': [torch.empty_like(w) for w in w_hh],
+            'db_ih': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
+            'db_hh': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
+        }
+    ws = torch.empty(lib().halo_lstm_bwd_workspace_bytes(T, B, in0, H, L) // 4, device=dev, dtype=torch.float32)
+    dx = torch.empty(T, B, in0, device=dev, dtype=torch.float32) if want_dx else None
+    a_ih, a_hh = ptr_array(w_ih), ptr_array(w_hh)
+    g_ih, g_hh = ptr_array(grads['dw_ih']), ptr_array(grads['dw_hh'])
+    g_bi, g_bh = ptr_array(grads['db_ih']), ptr_array(grads['db_hh'])
+    check(lib().halo_lstm_bwd(ptr(x_tm), a_ih, a_hh, ptr(dy), y_strides[0], y_strides[1], int(y_relu), ptr(dhn),
+                              ptr(dcn), ptr(reserve), ptr(ws), ptr(dx), g_ih, g_hh, g_bi, g_bh, T, B, in0, H, L,
+                              drop.p, drop.seed, drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_bwd')
+    return dx, grads
+
+
+def log_softmax_fwd(x2d):
+    _f32c(x2d, 'logits')
+    y = torch.empty_like(x2d)
+    check(lib().halo_log_softmax_fwd(ptr(x2d), ptr(y), x2d.shape[0], x2d.shape[1], _stream()), 'halo_log_softmax_fwd')
+    return y
+
+
+def log_softmax_bwd(dy2d, y2d):
+    _f32c(dy2d, 'dy'); _f32c(y2d, 'y')
+    dx = torch.empty_like(y2d)
+    check(lib().halo_log_softmax_bwd(ptr(dy2d), ptr(y2d), ptr(dx), y2d.shape[0], y2d.shape[1], _stream()),
+          'halo_log_softmax_bwd')
+    return dx
+
+
+def colsum(x2d, out=None):
+    _f32c(x2d, 'x')
+    if out is None:
+        out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
+    check(lib().halo_colsum(ptr(x2d), x2d.shape[0], x2d.shape[1], x2d.shape[1], ptr(out), _stream()), 'halo_colsum')
+    return out
+
+
+def _i64c(t, name):
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    if not t.is_cuda:
+        raise ValueError(f'{name}: expected a HIP tensor')
+    return t.contiguous()
+
+
+def ctc_fwd(lp, time_major, targets, input_lengths, target_lengths, flags=0):
+    """lp: [T,N,C] (time_major) or [N,T,C]; any strides with a unit class stride.  -> (nll [N], alpha)."""
+    if lp.dtype != torch.float32 or lp.stride(-1) != 1:
+        raise ValueError('log-probs must be float32 with unit class stride')
+    if time_major:
+        T, N, Cn = lp.shape
+        st, sn = lp.stride(0), lp.stride(1)
+    else:
+        N, T, Cn = lp.shape
+        sn, st = lp.stride(0), lp.stride(1)
+    targets = _i64c(targets, 'targets')
+    if targets.dim() != 2:
+        raise ValueError('targets must be [N,S] (padded); concatenated targets are not supported')
+    S = targets.shape[1]
+    tl = _i64c(target_lengths, 'target_lengths')
+    il = None if input_lengths is None else _i64c(input_lengths, 'input_lengths')
+    alpha = torch.empty(N, T, 2 * S + 1, device=lp.device, dtype=torch.float32)
+    nll = torch.empty(N, device=lp.device, dtype=torch.float32)
+    check(lib().halo_ctc_fwd(ptr(lp), st, sn, T, N, Cn, ptr(targets), targets.stride(0), S, ptr(il), ptr(tl), flags,
+                             ptr(alpha), ptr(nll), _stream()), 'halo_ctc_fwd')
+    return nll, alpha, (targets, il, tl)
+
+
+def ctc_bwd(lp, time_major, saved, alpha, nll, grad_out):
+    targets, il, tl = saved
+    if time_major:
+        T, N, Cn = lp.shape
+        st, sn = lp.stride(0), lp.stride(1)
+    else:
+        N, T, Cn = lp.shape
+        sn, st = lp.stride(0), lp.stride(1)
+    S = targets.shape[1]
+    grad = torch.empty(lp.shape, device=lp.device, dtype=torch.float32)
+    gst, gsn = (grad.stride(0), grad.stride(1)) if time_major else (grad.stride(1), grad.stride(0))
+    beta = torch.empty_like(alpha)
+    grad_out = grad_out.to(torch.float32).contiguous()
+    check(lib().halo_ctc_bwd(ptr(lp), st, sn, T, N, Cn, ptr(targets), targets.stride(0), S, ptr(il), ptr(tl),
+                             ptr(alpha), ptr(nll), ptr(grad_out), ptr(beta), ptr(grad), gst, gsn, _stream()),
+          'halo_ctc_bwd')
+    return grad
+
+
+def ctc_greedy(lp):
+    _f32c(lp, 'log-probs')
+    N, T, Cn = lp.shape
+    dev = lp.device
+    ali = torch.empty(N, T, device=dev, dtype=torch.int64)
+    scores = torch.empty(N, T, device=dev, dtype=torch.float32)
+    hyp = torch.zeros(N, T, device=dev, dtype=torch.int64)
+    hyp_len = torch.empty(N, device=dev, dtype=torch.int64)
+    check(lib().halo_ctc_greedy(ptr(lp), N, T, Cn, ptr(ali), ptr(scores), ptr(hyp), ptr(hyp_len), _stream()),
+          'halo_ctc_greedy')
+    return ali, scores, hyp, hyp_len
+
+
+def ctc_beam(em, beam, log_domain=True):
+    """em [N,T,V] -> (seqs [N,beam,T] int64, lens [N,beam] int32, scores [N,beam])."""
+    _f32c(em, 'emissions')
+    N, T, V = em.shape
+    dev = em.device
+    seqs = torch.empty(N, beam, T, device=dev, dtype=torch.int64)
+    lens = torch.empty(N, beam, device=dev, dtype=torch.int32)
+    scores = torch.empty(N, beam, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().halo_ctc_beam_workspace_bytes(N, T, V, beam), device=dev, dtype=torch.uint8)
+    check(lib().halo_ctc_beam(ptr(em), N, T, V, beam, int(log_domain), ptr(seqs), ptr(lens), ptr(scores), ptr(ws),
+                              _stream()), 'halo_ctc_beam')
+    return seqs, lens, scores
+
+
+def sumsq_partials(flat, partials=None):
+    if partials is None:
+        partials = torch.empty(_lib.HALO_SUMSQ_PARTS, device=flat.device, dtype=torch.float32)
+    check(lib().halo_sumsq(ptr(flat), flat.numel(), ptr(partials), _stream()), 'halo_sumsq')
+    return partials
+
+
+def clip_coef(partials, count, max_norm, coef, norm):
+    check(lib().halo_clip_coef(ptr(partials), count, float(max_norm), ptr(coef), ptr(norm), _stream()), 'halo_clip_coef')
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    check(lib().halo_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                           ptr(grad_scale), _stream()), 'halo_adamw')
+
+
+def counter_inc(counter):
+    check(lib().halo_counter_inc(ptr(counter), _stream()), 'halo_counter_inc')

@@ -1,0 +1,197 @@
+/*
+ * halo.h -- C ABI of libhalo.so, the MI355X (gfx950) engine for haloop's acoustic hot path.
+ *
+ * The reference (proger/haloop, /root/reference) has no FFI: its "boundary" is the Python
+ * surface of ha.rnn / ha.recognizer / ha.ctc / ha.beam, under which it calls stock torch
+ * operators (cuDNN LSTM, ATen ctc_loss, ...).  Each entry point below replaces one of those
+ * operator call sites; the citation after "replaces:" is the reference line that makes the call.
+ * The modules under haloop_amd/ are the binding (ctypes) that keeps the reference's Python signatures.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers unless a parameter is documented "host";
+ *   - every buffer (outputs, reserve, workspace) is caller-allocated; *_bytes() queries sizes;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing here allocates,
+ *     frees, synchronises or throws, so calls are capturable in a hipGraph;
+ *   - return value: HALO_OK (0) or a negative HALO_E* code; halo_strerror() names it;
+ *   - thread-safe for distinct streams; dense fp32 math runs on the exact-f32 MFMA
+ *     (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), i.e. k-ordered fmaf chains, no reduced precision.
+ */
+#ifndef HALO_H
+#define HALO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALO_ABI_VERSION 1
+
+#define HALO_OK 0
+#define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define HALO_ENOTSUP (-95)   /* shape outside what the kernels were built for */
+#define HALO_ELAUNCH (-5)    /* hipLaunchKernel reported an error */
+
+typedef void *halo_stream_t; /* hipStream_t */
+
+int halo_abi_version(void);
+const char *halo_strerror(int code);
+/* Device sanity for the loader: returns HALO_OK and fills arch (e.g. "gfx950") and CU count. */
+int halo_device_info(int device, char *arch, int arch_len, int *cu_count);
+
+/* ------------------------------------------------------------------------------------------
+ * Dropout stream.  Philox4x32-10, counter = (lo32(e>>2), hi32(e>>2), stream_id, offset),
+ * key = seed, value = out[e&3], keep iff value >= uint32(p*2^32), scale 1/(1-p).
+ * e is the flat element index of the tensor the mask is applied to.  Every entry point that
+ * takes `offset` also takes `offset_dev`, an optional DEVICE uint32 that is added to it when the
+ * kernel runs, so a captured hipGraph draws fresh masks on every replay.
+ * replaces: torch's nn.Dropout RNG at ha/rnn.py:8,24, nn.LSTM(dropout=) rnn.py:11 and
+ * ha/recognizer.py:41,44 (the reference stream itself is not reproducible).
+ * ------------------------------------------------------------------------------------------ */
+#define HALO_STREAM_SUBSAMPLE 1u
+#define HALO_STREAM_CLASSIFIER 2u
+#define HALO_STREAM_LSTM_LAYER0 16u /* + layer index */
+
+/* y[i] = x[i] * mask(i);  replaces: self.dropout(features) ha/recognizer.py:44 */
+int halo_dropout_fwd(const float *x, float *y, size_t n, float p, uint64_t seed, uint32_t stream_id,
+                     uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+/* *counter += 1 (the device-side step counter that offset_dev points at) */
+int halo_counter_inc(uint32_t *counter, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense GEMM on the exact-f32 MFMA.  C[M,N] = opA(A)[M,K] * opB(B)[K,N]  (+ epilogue)
+ *   a_kcontig = 1: A stored [M,K] (row stride lda), 0: A stored [K,M]
+ *   b_kcontig = 1: B stored [N,K] (row stride ldb), 0: B stored [K,N]
+ * epilogue, in this order: + bias1[n] + bias2[n] (either may be NULL); relu if HALO_GEMM_RELU;
+ *   * dropout mask(e = m*ldc + n) if p_drop > 0.
+ * replaces: the ATen/oneDNN/cuBLAS matmuls under nn.Conv1d rnn.py:22, nn.LSTM input
+ * projections rnn.py:25 and nn.Linear recognizer.py:45, and their autograd backward GEMMs.
+ * ------------------------------------------------------------------------------------------ */
+#define HALO_GEMM_RELU 1
+int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float *A, int lda,
+                  const float *B, int ldb, float *C, int ldc, const float *bias1, const float *bias2,
+                  int flags, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                  const uint32_t *offset_dev, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv1d stride-s subsample + relu + dropout.   replaces: ha/rnn.py:22-24
+ *   x [B,T,F] (N,T,C contiguous, as the caller holds it before .mT), w [C,F,ks], bias [C]
+ *   y [T',B,C] TIME-MAJOR, T' = floor((T + 2*pad - ks)/stride) + 1
+ *   col: workspace [T'*B, F*ks] floats (im2col image, also the saved input for backward)
+ * ------------------------------------------------------------------------------------------ */
+size_t halo_subsample_col_bytes(int B, int T, int F, int ks, int stride, int pad);
+int halo_subsample_fwd(const float *x, const float *w, const float *bias, float *y, float *col, int B,
+                       int T, int F, int C, int ks, int stride, int pad, float p_drop, uint64_t seed,
+                       uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+/* dy [T',B,C] is the gradient w.r.t. y; y is the forward output (relu/dropout mask is read off it);
+ * dpre: workspace [T'*B, C]; dw [C,F,ks], dbias [C] are overwritten.  Input gradient is not
+ * produced (mel features are leaves without grad in ha/loop.py:116). */
+int halo_subsample_bwd(const float *dy, const float *y, const float *col, float *dpre, float *dw,
+                       float *dbias, int B, int T, int F, int C, int ks, int stride, int pad, float p_drop,
+                       halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-layer LSTM, gate order i,f,g,o, two bias vectors per layer.
+ * replaces: nn.LSTM forward/backward (cuDNN RNN / oneDNN) at ha/rnn.py:25 (batch_first encoder)
+ * and ha/rnn.py:50,63 (time-major Decoder with carried state).
+ *   x [T,B,in0] time-major.  w_ih[l] [4H,in_l], w_hh[l] [4H,H], b_ih[l], b_hh[l] [4H]: HOST arrays
+ *   of L device pointers.  h0/c0 [L,B,H] or NULL (zeros).  hn/cn [L,B,H] or NULL.
+ *   y: last layer's output h_t written at y + t*y_stride_t + b*y_stride_b + j (so the caller picks
+ *   batch-first or time-major); relu applied when y_relu (the encoder's x.relu(), rnn.py:26).
+ *   Inter-layer dropout p_drop (train only) uses stream HALO_STREAM_LSTM_LAYER0 + l on the
+ *   time-major [T,B,H] index.
+ *   reserve: halo_lstm_reserve_bytes(); holds per layer h[T+1,B,H], c[T+1,B,H], gates[T,B,4H],
+ *   dropped output [T,B,H]; consumed (overwritten with gate gradients) by halo_lstm_bwd.
+ * ------------------------------------------------------------------------------------------ */
+size_t halo_lstm_reserve_bytes(int T, int B, int H, int L);
+size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L);
+int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh,
+                  const float *const *b_ih, const float *const *b_hh, const float *h0, const float *c0,
+                  float *y, long y_stride_t, long y_stride_b, int y_relu, float *hn, float *cn,
+                  float *reserve, int T, int B, int in0, int H, int L, float p_drop, uint64_t seed,
+                  uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+/* dy has the strides of y; dhn/dcn [L,B,H] or NULL.  dx [T,B,in0] or NULL.
+ * dw_ih/dw_hh/db_ih/db_hh: HOST arrays of L device pointers, overwritten. */
+int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *dy,
+                  long y_stride_t, long y_stride_b, int y_relu, const float *dhn, const float *dcn,
+                  float *reserve, float *workspace, float *dx, float *const *dw_ih, float *const *dw_hh,
+                  float *const *db_ih, float *const *db_hh, int T, int B, int in0, int H, int L,
+                  float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev,
+                  halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise log-softmax.   replaces: features.log_softmax(dim=-1) ha/recognizer.py:46
+ * ------------------------------------------------------------------------------------------ */
+int halo_log_softmax_fwd(const float *x, float *y, int rows, int cols, halo_stream_t stream);
+int halo_log_softmax_bwd(const float *dy, const float *y, float *dx, int rows, int cols,
+                         halo_stream_t stream);
+/* column sums: out[n] = sum_m x[m*ld + n]  (bias gradients) */
+int halo_colsum(const float *x, int rows, int cols, int ld, float *out, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CTC lattice, blank = 0, one workgroup per utterance.
+ * replaces: F.ctc_loss (ATen ctc_loss_gpu alpha/beta kernels) at ha/recognizer.py:71 and the
+ * pure-torch recursion ha/ctc.py:110-174 (ctc_forward_score3), ctc.py:4-107 (score1/score2).
+ *   lp: log-probabilities, element (t,n,c) at lp + t*stride_t + n*stride_n + c
+ *   targets [N,S] int64 (row stride tg_stride), input_lengths/target_lengths [N] int64
+ *   alpha [N,T,2S+1] out;  nll [N] out (positive negative-log-likelihood)
+ *   flags:
+ *     HALO_CTC_FULL_LATTICE  run all T frames over all 2S+1 states and read out at
+ *                            (il-1, 2*tl), (il-1, 2*tl-1) like ctc.py:131-174; otherwise restrict
+ *                            to the utterance's own lengths like F.ctc_loss.
+ *     HALO_CTC_FINITE_MIN    "log 0" is -FLT_MAX (ctc.py:135) instead of -inf
+ *     HALO_CTC_NO_LEAD_BLANK_LOOP  state 0 is never updated after t=0 (ctc.py:26, :103)
+ *     HALO_CTC_WRAP_SKIP     state 1 also receives alpha[t-1, last] (python index -1, ctc.py:29)
+ * ------------------------------------------------------------------------------------------ */
+#define HALO_CTC_FULL_LATTICE 1
+#define HALO_CTC_FINITE_MIN 2
+#define HALO_CTC_NO_LEAD_BLANK_LOOP 4
+#define HALO_CTC_WRAP_SKIP 8
+int halo_ctc_fwd(const float *lp, long stride_t, long stride_n, int T, int N, int C,
+                 const int64_t *targets, long tg_stride, int S, const int64_t *input_lengths,
+                 const int64_t *target_lengths, int flags, float *alpha, float *nll,
+                 halo_stream_t stream);
+/* Gradient in F.ctc_loss's convention (ATen ctc_loss_backward): for t < il
+ *   grad(t,n,c) = grad_out[n] * (exp(lp) - exp(logsum_{s: l'_s=c}(alpha+beta) + nll - lp)), else 0.
+ * beta: workspace [N,T,2S+1].  grad has lp's strides (gstride_t, gstride_n). */
+int halo_ctc_bwd(const float *lp, long stride_t, long stride_n, int T, int N, int C,
+                 const int64_t *targets, long tg_stride, int S, const int64_t *input_lengths,
+                 const int64_t *target_lengths, const float *alpha, const float *nll,
+                 const float *grad_out, float *beta, float *grad, long gstride_t, long gstride_n,
+                 halo_stream_t stream);
+
+/* Greedy decode.   replaces: logits.max(-1) + unique_consecutive + drop-0 loop, recognizer.py:51-55
+ *   lp [N,T,C] contiguous; alignments [N,T] int64, scores [N,T] f32, hyp [N,T] int64 (first
+ *   hyp_len[n] entries valid), hyp_len [N] int64.  Input lengths are ignored, as in the reference. */
+int halo_ctc_greedy(const float *lp, int N, int T, int C, int64_t *alignments, float *scores,
+                    int64_t *hyp, int64_t *hyp_len, halo_stream_t stream);
+
+/* Beam search with the reference's exact (quirky) semantics, one workgroup per utterance.
+ * replaces: ha/beam.py:71-137 (logits) and ha/beam.py:5-68 (probs, log_domain = 0).
+ *   em [N,T,V]; seqs [N,beam,T] int64, lens [N,beam] int32, scores [N,beam] f32, ranked best first.
+ *   workspace: halo_ctc_beam_workspace_bytes().  Requires beam <= 1+V (reference: topk raises). */
+size_t halo_ctc_beam_workspace_bytes(int N, int T, int V, int beam);
+int halo_ctc_beam(const float *em, int N, int T, int V, int beam, int log_domain, int64_t *seqs,
+                  int32_t *lens, float *scores, void *workspace, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step on flat buffers.
+ * replaces: clip_grad_norm_ ha/loop.py:184 and torch.optim.AdamW(fused) ha/optim.py:137-139
+ *   halo_sumsq: partials[0..HALO_SUMSQ_PARTS) = per-workgroup sums of x^2 (fixed order, so the
+ *   norm is bitwise reproducible); halo_clip_coef: norm = sqrt(sum partials[0..count)),
+ *   coef = min(1, max_norm / (norm + 1e-6)) as clip_grad_norm_ computes it; both device scalars.
+ *   halo_adamw: torch.optim.AdamW single-tensor arithmetic; grad is multiplied by *grad_scale
+ *   (device scalar, may be NULL) before use.  step >= 1 is the 1-based update count.
+ * ------------------------------------------------------------------------------------------ */
+#define HALO_SUMSQ_PARTS 1024
+int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
+int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
+                   halo_stream_t stream);
+int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, const float *grad_scale, halo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO_H */

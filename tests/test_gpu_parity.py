@@ -1,0 +1,301 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures.  Integer outputs must be exact; floating point within the stated tolerances:
+
+    fp32-exact mode (the only mode built so far): loss rel <= 1e-5, features max-abs <= 1e-4,
+    logits-gradient max-abs <= 1e-5 (the reference's own two CTC
+    implementations agree to 5-8e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def hal():
+    import haloop_amd
+    from haloop_amd import _lib, ops, functional, rnn, recognizer, ctc, beam
+    _lib.lib()           # raises if libhalo.so is missing: there is no fallback to test
+    return dict(ops=ops, F=functional, rnn=rnn, recognizer=recognizer, ctc=ctc, beam=beam, lib=_lib)
+
+
+def _unpad(seqs, lens):
+    return [list(map(int, s[:n])) for s, n in zip(seqs, lens)]
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('akc,bkc', [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize('M,N,K', [(1344, 4096, 128), (256, 200, 400), (70, 32, 1024), (4096, 1024, 84), (33, 17, 5)])
+def test_gemm_layouts(hal, akc, bkc, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.double() @ b.double() + bias.double()).clamp_min(0)
+    A = (a if akc else a.t().contiguous()).to(DEV)
+    B = (b.t().contiguous() if bkc else b).to(DEV)
+    out = hal['ops'].gemm(A, B, akc, bkc, M, N, K, bias1=bias.to(DEV), relu=True)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * 8, err
+
+
+# -------------------------------------------------------------------------------------------- CTC
+@pytest.mark.parametrize('case', ['random', 'repeat', 's1', 'ragged', 'infeasible', 'wide'])
+def test_ctc_against_reference_goldens(hal, case):
+    g = load_golden('g2_ctc')
+    logits = torch.from_numpy(g[case + '.logits']).to(DEV).requires_grad_(True)
+    tg, il, tl = (torch.from_numpy(g[case + '.' + k]).to(DEV) for k in ('targets', 'il', 'tl'))
+    em = hal['F'].log_softmax(logits)
+    # ha.ctc.ctc_forward_score3 surface
+    s3 = hal['ctc'].ctc_forward_score3(em.detach(), tg, il, tl).cpu().numpy()
+    np.testing.assert_allclose(s3, g[case + '.score3'], rtol=1e-5)
+    np.testing.assert_allclose(hal['ctc'].ctc_reduce_mean(torch.from_numpy(s3), tl.cpu()).numpy(),
+                               g[case + '.reduce_mean3'], rtol=1e-5)
+    # F.ctc_loss surface
+    nll = hal['F'].ctc_loss(em, tg, il, tl, reduction='none')
+    ref = g[case + '.torch_none']
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(nll.detach().cpu().numpy()[ok], ref[ok], rtol=1e-5)
+    assert np.array_equal(np.isinf(nll.detach().cpu().numpy()), ~ok)
+    if bool(g[case + '.has_grad']):
+        loss = hal['F'].ctc_loss(em, tg, il, tl, reduction='mean')
+        np.testing.assert_allclose(loss.item(), float(g[case + '.torch_mean']), rtol=1e-5)
+        loss.backward()
+        np.testing.assert_allclose(logits.grad.cpu().numpy(), g[case + '.dlogits_mean'], atol=1e-5)
+
+
+def test_ctc_single_sequence_variants(hal):
+    g = load_golden('g2_ctc')
+    for pre in ('demo', 'wrap'):
+        l = torch.from_numpy(g[pre + ('.l0' if pre == 'demo' else '.l')]).to(DEV)
+        t = torch.from_numpy(g[pre + ('.t0' if pre == 'demo' else '.t')]).to(DEV)
+        np.testing.assert_allclose(hal['ctc'].ctc_forward_score1(l, t).item(), float(g[pre + '.score1']), rtol=1e-5)
+        np.testing.assert_allclose(hal['ctc'].ctc_forward_score2(l, t).item(), float(g[pre + '.score2']), rtol=1e-5)
+
+
+def test_ctc_lattice_vs_oracle_random_sizes(hal):
+    from oracle import lattice
+    gen = torch.Generator().manual_seed(11)
+    for T, N, C, S in [(1, 1, 3, 1), (7, 5, 4, 3), (64, 3, 11, 31), (130, 2, 40, 70), (21, 64, 32, 10)]:
+        em = torch.randn(T, N, C, generator=gen).log_softmax(-1)
+        tg = torch.randint(1, C, (N, S), generator=gen)
+        il = torch.randint(max(1, T // 2), T + 1, (N,), generator=gen)
+        tl = torch.randint(1, S + 1, (N,), generator=gen)
+        want = lattice.ctc_forward_score3(em, tg, il, tl).numpy()
+        got = hal['ctc'].ctc_forward_score3(em.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-5)
+        want_t = torch.nn.functional.ctc_loss(em, tg, il, tl, reduction='none').numpy()
+        got_t = hal['F'].ctc_loss(em.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV), reduction='none').cpu().numpy()
+        fin = np.isfinite(want_t)
+        np.testing.assert_allclose(got_t[fin], want_t[fin], rtol=2e-5)
+        assert np.array_equal(np.isinf(got_t), ~fin)
+
+
+def test_ctc_gradient_vs_torch_cpu(hal):
+    gen = torch.Generator().manual_seed(5)
+    T, N, C, S = 33, 6, 9, 8
+    logits = torch.randn(T, N, C, generator=gen)
+    tg = torch.randint(1, C, (N, S), generator=gen)
+    il = torch.tensor([33, 30, 20, 33, 17, 25])
+    tl = torch.tensor([8, 3, 5, 1, 7, 2])
+    lc = logits.clone().requires_grad_(True)
+    torch.nn.functional.ctc_loss(lc.log_softmax(-1), tg, il, tl).backward()
+    lg = logits.to(DEV).requires_grad_(True)
+    hal['F'].ctc_loss(hal['F'].log_softmax(lg), tg.to(DEV), il.to(DEV), tl.to(DEV)).backward()
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), lc.grad.numpy(), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------- greedy / beam
+def test_greedy_matches_reference(hal):
+    g = load_golden('g1_tiny_l2')
+    lp = torch.from_numpy(g['lp']).to(DEV)
+    ali, scores, hyp, hlen = hal['ops'].ctc_greedy(lp)
+    assert np.array_equal(ali.cpu().numpy(), g['ali'])
+    np.testing.assert_array_equal(scores.cpu().numpy(), g['scores'])
+    assert np.array_equal(hlen.cpu().numpy(), g['hlen'])
+    got = [hyp[i, :n].tolist() for i, n in enumerate(hlen.tolist())]
+    assert got == _unpad(g['hyps'], g['hlen'])
+
+
+def test_greedy_vs_oracle_long(hal):
+    from oracle import lattice
+    gen = torch.Generator().manual_seed(2)
+    lp = (torch.randn(5, 150, 4, generator=gen) * 3).log_softmax(-1)      # T > 64: multi-pass carry
+    hyps, lens, ali, _ = lattice.greedy_decode(lp)
+    a, s, h, hl = hal['ops'].ctc_greedy(lp.to(DEV))
+    assert np.array_equal(a.cpu().numpy(), ali.numpy())
+    assert hl.tolist() == lens.tolist()
+    assert [h[i, :n].tolist() for i, n in enumerate(hl.tolist())] == hyps
+
+
+@pytest.mark.parametrize('case', ['r21x32b16', 'r21x32b3', 'r6x4b4', 'r30x9b5', 'r21x32b33'])
+def test_beam_logits_matches_reference(hal, case):
+    g = load_golden('g3_beam')
+    seqs, scores = hal['beam'].ctc_beam_search_decode_logits(torch.from_numpy(g[case + '.logits']).to(DEV),
+                                                             int(g[case + '.beam']))
+    assert seqs == _unpad(g[case + '.seqs'], g[case + '.lens'])            # token ids: exact
+    np.testing.assert_allclose(scores.cpu().numpy(), g[case + '.scores'], rtol=1e-5, atol=1e-5)
+
+
+def test_beam_probs_and_errors(hal):
+    g = load_golden('g3_beam')
+    seqs, scores = hal['beam'].ctc_beam_search_decode_probs(torch.from_numpy(g['probs.probs']).to(DEV), int(g['probs.beam']))
+    assert seqs == _unpad(g['probs.seqs'], g['probs.lens'])
+    np.testing.assert_allclose(scores.cpu().numpy(), g['probs.scores'], rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        hal['beam'].ctc_beam_search_decode_logits(torch.zeros(3, 4, device=DEV).log_softmax(-1), beam_size=6)
+
+
+def test_beam_batch_vs_oracle(hal):
+    from oracle import lattice
+    gen = torch.Generator().manual_seed(8)
+    em = torch.randn(6, 21, 32, generator=gen).log_softmax(-1)
+    out, scores = hal['beam'].decode_batch(em.to(DEV), 16, True)
+    for n in range(6):
+        want_seqs, want_scores = lattice.ctc_beam_search_decode_logits(em[n], 16)
+        assert out[n] == want_seqs
+        np.testing.assert_allclose(scores[n].cpu().numpy(), want_scores.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- dropout stream parity
+def test_philox_mask_equals_oracle(hal):
+    from oracle import philox
+    n = 100003
+    x = torch.ones(n, device=DEV)
+    d = hal['ops'].Dropout(0.2, seed=0x123456789abcdef, offset=7)
+    y = hal['ops'].dropout_fwd(x, d, 5)
+    want = philox.dropout_mask(n, 0.2, 0x123456789abcdef, 5, 7)
+    np.testing.assert_array_equal(y.cpu().numpy(), want)
+    ctr = torch.tensor([3], dtype=torch.int32, device=DEV)
+    d2 = hal['ops'].Dropout(0.2, seed=0x123456789abcdef, offset=4, counter=ctr)
+    np.testing.assert_array_equal(hal['ops'].dropout_fwd(x, d2, 5).cpu().numpy(), want)   # 4 + 3 == 7
+
+
+# -------------------------------------------------------------------------------- the model path
+def _load_modules(hal, g, F_, C, H, L, V):
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L)
+    rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict({k[len('encoder.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('encoder.')})
+    rec.load_state_dict({k[len('recognizer.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('recognizer.')})
+    return enc.to(DEV), rec.to(DEV)
+
+
+@pytest.mark.parametrize('name', ['g1_tiny_l2', 'g1_tiny_l3'])
+def test_tiny_model_matches_reference(hal, name):
+    g = load_golden(name)
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = _load_modules(hal, g, c['F_'], c['C'], c['H'], c['L'], c['V'])
+    enc.eval(); rec.eval()
+    x, il, tg, tl = (torch.from_numpy(g[k]).to(DEV) for k in ('x', 'il', 'tg', 'tl'))
+    feats, flen, _ = enc(x, il)
+    assert flen.dtype == torch.int32 and np.array_equal(flen.cpu().numpy(), g['flen'])
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), g['feats'], atol=1e-5)
+    loss, _ = rec(feats, tg, flen, tl)
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-5)
+    loss.backward()
+    for k, p in list(enc.named_parameters()) + list(rec.named_parameters()):
+        key = 'grad.' + ('recognizer.' if k.startswith('classifier') else 'encoder.') + k
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[key], rtol=1e-3, atol=2e-6, err_msg=key)
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+        np.testing.assert_allclose(lp.cpu().numpy(), g['lp'], atol=1e-5)
+        hyps, hlen, ali, scores, none = rec.decode(feats, flen, tl)
+    assert none is None and np.array_equal(ali.cpu().numpy(), g['ali']) and np.array_equal(hlen.numpy(), g['hlen'])
+    assert [h.tolist() for h in hyps.unbind()] == _unpad(g['hyps'], g['hlen'])
+
+
+def test_lc2x1024_matches_reference(hal):
+    """BASELINE config 1 shapes: 2-layer H=1024, 80x80 mel, B=4, V=32 against the reference's numbers."""
+    from oracle import cpu_ref
+    g = load_golden('g1_lc2x1024')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc_p, rec_p = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    enc = hal['rnn'].Encoder(c['F_'], c['C'], c['H'], num_layers=c['L'])
+    rec = hal['recognizer'].TemporalClassifier(c['H'], c['V'])
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    il = torch.from_numpy(g['il']).to(DEV)
+    feats, flen, _ = enc(x.to(DEV), il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg.to(DEV), flen, tl.to(DEV))
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-5)
+    np.testing.assert_allclose(feats[:, :, ::61].detach().cpu().numpy(), g['feats_slice'], atol=1e-4)
+    assert np.array_equal(flen.cpu().numpy(), g['flen'])
+    loss.backward()
+    np.testing.assert_allclose(feats.grad[:, :, ::61].cpu().numpy(), g['dfeats_slice'], atol=1e-6)
+    for k, p in list(enc.named_parameters()) + list(rec.named_parameters()):
+        key = ('recognizer.' if k.startswith('classifier') else 'encoder.') + k
+        np.testing.assert_allclose(p.grad.double().norm().item(), float(g['gradnorm.' + key]), rtol=1e-4, err_msg=key)
+        np.testing.assert_allclose(p.grad.reshape(-1)[::9973].cpu().numpy(), g['gradslice.' + key], rtol=1e-3, atol=1e-6,
+                                   err_msg=key)
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+    np.testing.assert_allclose(lp.cpu().numpy(), g['lp'], atol=1e-4)
+    ali, scores, hyp, hlen = hal['ops'].ctc_greedy(lp.contiguous())
+    assert np.array_equal(ali.cpu().numpy(), g['ali']) and np.array_equal(hlen.cpu().numpy(), g['hlen'])
+
+
+def test_training_mode_matches_oracle_with_same_masks(hal):
+    """Dropout on: the HIP path and the CPU restatement consume the same Philox masks."""
+    from oracle import cpu_ref
+    F_, C, H, L, V, B, T, S = 12, 16, 32, 3, 9, 5, 41, 4
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 21)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, 22)
+    Tp = int(cpu_ref.subsampled_lengths(il)[0])
+    seed, offset = 99, 3
+    masks = cpu_ref.philox_masks(B, Tp, C, H, L, 0.2, 0.2, seed, offset)
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc_p.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec_p.items()}
+    loss_ref, feats_ref, _ = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl, masks=masks)
+    loss_ref.backward()
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).train(); rec.to(DEV).train()
+    for m in (enc, rec):
+        m.dropout_stream.seed, m.dropout_stream.offset = seed, offset
+    feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+    loss, _ = rec(feats, tg.to(DEV), flen, tl.to(DEV))
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), feats_ref.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    loss.backward()
+    for k, p in enc.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), pe[k].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
+    for k, p in rec.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_decoder_lm_matches_torch_lstm(hal):
+    """ha.rnn.Decoder surface: time-major LSTM with carried state + tied output layer."""
+    V, E, L, T, N = 50, 32, 2, 9, 3
+    torch.manual_seed(4)
+    dec = hal['rnn'].Decoder(V, E, E, L)
+    ref = torch.nn.LSTM(E, E, L)
+    ref.load_state_dict({k: v for k, v in dec.rnn.state_dict().items()})
+    emb_w, out_b = dec.embedding.weight.detach().clone(), dec.out_layer.bias.detach().clone()
+    tokens = torch.randint(0, V, (T, N))
+    h0, c0 = torch.randn(L, N, E) * 0.1, torch.randn(L, N, E) * 0.1
+    out_ref, (hn_ref, cn_ref) = ref(torch.nn.functional.embedding(tokens, emb_w), (h0, c0))
+    logits_ref = torch.nn.functional.linear(out_ref, emb_w, out_b).view(-1, V)
+    dec.to(DEV)
+    logits, (hn, cn) = dec(tokens.to(DEV), (h0.to(DEV), c0.to(DEV)))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), logits_ref.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), hn_ref.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(cn.detach().cpu().numpy(), cn_ref.detach().numpy(), atol=1e-5)
+    logits.square().mean().backward()
+    logits_ref.square().mean().backward()
+    for k, p in dec.rnn.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), getattr(ref, k).grad.numpy(), rtol=1e-3, atol=1e-6, err_msg=k)
+    lbf, _ = dec.forward_batch_first(tokens.t().to(DEV), (h0.to(DEV), c0.to(DEV)))
+    np.testing.assert_allclose(lbf.detach().cpu().numpy(), logits_ref.detach().view(T, N, V).transpose(0, 1).numpy(), atol=1e-5)
+
+
+def test_product_fails_loudly_on_cpu_tensors(hal):
+    enc = hal['rnn'].Encoder(12, 16, 32, num_layers=1)
+    with pytest.raises(hal['lib'].HaloError):
+        enc(torch.randn(2, 20, 12), torch.tensor([20, 20]))
