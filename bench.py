@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/sec of the LSTM-CTC training step (BASELINE.json configs[1]).
+
+Workload: 2-layer H=1024 LSTM-CTC ("LC-2x1024"), 64 utterances of 80 frames x
+80 mels per GPU, char vocab 32, dropout 0.2 on, full step = forward + CTC loss + backward +
+encoder-only clip + AdamW (ha/loop.py:176-196).  Synthetic inputs resident in HBM; fp32 arithmetic
+on the exact-f32 MFMA.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- the dominant kernel (the fused LSTM step) against the HBM roof, duration measured
+                  here with HIP events on the launch stream;
+  cpu_baseline -- the CPU restatement of the reference path (oracle/, kind "port") timed on this
+                  box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+B_PER_GPU, T, F, C_SUB, H, L, V, S = 64, 80, 80, 128, 1024, 2, 32, 10
+T_SUB = (T + 6 - 5) // 4 + 1   # 21
+
+
+def algorithmic_step_bytes(B):
+    """10 * 4 * P parameter-side bytes + 2.12 MB of activations per utterance."""
+    P = 13_207_712
+    return 10 * 4 * P + 2_120_000 * B
+
+
+def lstm_step_algorithmic_bytes(B):
+    """Bytes one fused LSTM step launch must move (fp32): W_hh [4H,H] read; h_{t-1}, c_{t-1} read;
+    gate pre-activations [B,4H] read and activated gates written; h_t, c_t written."""
+    return 4 * (4 * H * H + 2 * B * H + 2 * B * 4 * H + 2 * B * H)
+
+
+def build_model(device, seed=42):
+    from haloop_amd import rnn, recognizer
+    from oracle import cpu_ref            # only for the shared deterministic init + synthetic batch
+    enc_p, rec_p = cpu_ref.make_params(F, C_SUB, H, L, V, seed)
+    enc = rnn.Encoder(F, C_SUB, H, num_layers=L)
+    rec = recognizer.TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p)
+    rec.load_state_dict(rec_p)
+    return enc.to(device).train(), rec.to(device).train(), (enc_p, rec_p)
+
+
+def time_dominant_kernel(device, iters=200):
+    """Average duration of one fused LSTM forward step launch (H=1024, B=64), HIP events on the launch stream."""
+    from haloop_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(iters, B_PER_GPU, H, generator=g).to(device) * 0.1
+    w = [(torch.rand(4 * H, H, generator=g) - 0.5).mul(0.06).to(device)]
+    b = [torch.zeros(4 * H, device=device)]
+    for _ in range(2):
+        ops.lstm_fwd(x, w, w, b, b)
+    torch.cuda.synchronize()
+    # whole call = 1 input-projection GEMM + 2 fills + `iters` step launches; subtract the non-step part
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    ops.lstm_fwd(x, w, w, b, b)
+    e1.record()
+    ops.lstm_fwd(x[:1], w, w, b, b)
+    e2.record()
+    torch.cuda.synchronize()
+    full_ms, one_ms = e0.elapsed_time(e1), e1.elapsed_time(e2)
+    gemm = ops.gemm
+    xs = x.view(-1, H)
+    e3, e4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e3.record()
+    gemm(xs, w[0], True, True, xs.shape[0], 4 * H, H)
+    e4.record()
+    torch.cuda.synchronize()
+    gemm_ms = e3.elapsed_time(e4)
+    step_ms = max(full_ms - gemm_ms, 1e-6) / iters
+    return step_ms, one_ms
+
+
+def host_cores():
+    """Cores this process may actually use (affinity mask and cgroup quota), not the machine's count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('HALO_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(params, budget_s=20.0):
+    from oracle import cpu_ref
+    enc_p, rec_p = params
+    torch.set_num_threads(host_cores())
+    tr = cpu_ref.Trainer(enc_p, rec_p)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B_PER_GPU, T, F, V, S, 42)
+    for _ in range(2):
+        tr.step(x, il, tg, tl, p_torch=0.2)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(x, il, tg, tl, p_torch=0.2)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 200:
+            break
+    return {'value': round(n * B_PER_GPU / dt, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'{n} training steps of the same B={B_PER_GPU} workload '
+                                      f'(stock torch CPU ops: conv1d, nn.LSTM kernel, ctc_loss, clip, AdamW), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    from haloop_amd import _lib
+    from haloop_amd.train import LstmCtcTrainer
+    from oracle import cpu_ref
+    _lib.lib()                                              # loud failure if the HIP library is absent
+
+    enc, rec, params = build_model(device)
+    trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph)
+    x, il, tg, tl = (t.to(device) for t in cpu_ref.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
+
+    for _ in range(args.warmup):
+        trainer.step(x, il, tg, tl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(x, il, tg, tl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    loss = trainer.loss.item()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B_PER_GPU * args.steps / elapsed
+        step_ms, _ = time_dominant_kernel(device)
+        kbytes = lstm_step_algorithmic_bytes(B_PER_GPU)
+        achieved = kbytes / (step_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'lstm_step_traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'utterances/sec, LSTM-CTC training step (fwd + CTC loss + bwd + clip + AdamW)',
+            'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
+                                   '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
+                       'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
+                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph},
+            'final_loss': round(loss, 5),
+            'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel<4> (H=1024, B=64)',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': kbytes, 'avg_launch_us': round(step_ms * 1e3, 3)},
+            'step_roofline': {'algorithmic_bytes_per_step': algorithmic_step_bytes(B_PER_GPU),
+                              'achieved_GBs': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9, 1),
+                              'frac_of_hbm_peak': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

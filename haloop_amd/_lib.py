@@ -42,6 +42,7 @@ SIGNATURES = {
     'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_ctc_beam_workspace_bytes': (_sz, [_i] * 4),
     'halo_ctc_beam': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'halo_topk_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -175,6 +175,129 @@ __global__ void ctc_beta_grad_kernel(const CtcBwdArgs p) {
     }
 }
 
+// ---- single-wavefront fast paths (2S+1 <= 64 and the utterance's log-probs fit in LDS) ----------------
+// The utterance's [T,C] log-prob rows are staged into LDS once; the lattice row lives in registers,
+// one state per lane, and the s-1 / s-2 (s+1 / s+2) neighbours come from wave shuffles, so the
+// T-step recursion has no memory round trips in its dependency chain.
+
+__global__ __launch_bounds__(64) void ctc_alpha_wave_kernel(const CtcArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lp_s[];   // [T*C]
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int S_ = 2 * p.S + 1, T = p.T, C = p.C;
+    const int64_t *tg = p.targets + (long)n * p.tg_stride;
+    const bool full = p.flags & HALO_CTC_FULL_LATTICE;
+    const float neg = (p.flags & HALO_CTC_FINITE_MIN) ? -FLT_MAX : -INFINITY;
+    const int il_raw = p.il ? (int)p.il[n] : T;
+    const int il = max(0, min(il_raw, T));
+    const int tl = max(0, min((int)p.tl[n], p.S));
+    const int states = full ? S_ : 2 * tl + 1;
+    const int frames = full ? T : il;
+    const float *lp = p.lp + (long)n * p.stride_n;
+    float *alpha = p.alpha + (long)n * T * S_;
+    for (int idx = lane; idx < T * C; idx += 64) lp_s[idx] = lp[(long)(idx / C) * p.stride_t + (idx % C)];
+    __syncthreads();
+
+    const int lab = lane < S_ ? ext_label(tg, lane) : 0;
+    const int lab2 = __shfl_up(lab, 2, 64);
+    const bool can_skip = lane >= 2 && lab != 0 && lab != lab2;
+    int tlast, slast, sprev;
+    if (full) { tlast = max(0, min(il_raw - 1, T - 1)); slast = min(2 * (int)p.tl[n], S_ - 1); sprev = (slast - 1 + S_) % S_; }
+    else      { tlast = il - 1; slast = 2 * tl; sprev = tl > 0 ? 2 * tl - 1 : -1; }
+
+    float prev = (frames > 0 && lane < states && lane < 2) ? lp_s[lab] : neg;
+    if (lane < S_) alpha[lane] = prev;
+    float ra = 0.f, rb = 0.f;
+    if (tlast == 0) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
+    for (int t = 1; t < T; ++t) {
+        const float p1 = __shfl_up(prev, 1, 64), p2 = __shfl_up(prev, 2, 64);
+        const float plast = __shfl(prev, states - 1, 64);
+        float v = neg;
+        if (t < frames && lane < states) {
+            if (lane == 0) {
+                v = (p.flags & HALO_CTC_NO_LEAD_BLANK_LOOP) ? neg : prev + lp_s[t * C];
+            } else {
+                float acc = log_add_exp(prev, p1);
+                if (lane >= 2) { if (can_skip) acc = log_add_exp(acc, p2); }
+                else if (p.flags & HALO_CTC_WRAP_SKIP) acc = log_add_exp(acc, plast);
+                v = acc + lp_s[t * C + lab];
+            }
+        }
+        prev = v;
+        if (lane < S_) alpha[(long)t * S_ + lane] = v;
+        if (t == tlast) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
+    }
+    if (lane == 0) {
+        float out;
+        if (!full && il == 0) out = tl == 0 ? 0.f : INFINITY;
+        else out = -log_add_exp(ra, rb);
+        p.nll[n] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void ctc_beta_grad_wave_kernel(const CtcBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int S_ = 2 * p.S + 1, T = p.T, C = p.C;
+    float *lp_s = smem;               // [T*C]
+    float *ab = smem + T * C;         // [T*S_] alpha, then alpha + beta
+    const int64_t *tg = p.targets + (long)n * p.tg_stride;
+    const int il = max(0, min(p.il ? (int)p.il[n] : T, T));
+    const int tl = max(0, min((int)p.tl[n], p.S));
+    const int states = 2 * tl + 1;
+    const float *lp = p.lp + (long)n * p.stride_n;
+    const float *alpha = p.alpha + (long)n * T * S_;
+    float *beta = p.beta + (long)n * T * S_;
+    float *grad = p.grad + (long)n * p.gstride_n;
+    const float nll = p.nll[n], go = p.grad_out[n];
+    const float ninf = -INFINITY;
+    for (int idx = tid; idx < T * C; idx += 256) lp_s[idx] = lp[(long)(idx / C) * p.stride_t + (idx % C)];
+    for (int idx = tid; idx < T * S_; idx += 256) ab[idx] = alpha[idx];
+    __syncthreads();
+    if (tid < 64 && il > 0) {         // wave 0 runs the recursion, one state per lane
+        const int lab = lane < S_ ? ext_label(tg, lane) : 0;
+        const int labn2 = __shfl_down(lab, 2, 64);
+        const bool can_skip = lane + 2 < states && labn2 != 0 && labn2 != lab;
+        float nxt = ninf;
+        for (int t = il - 1; t >= 0; --t) {
+            const float n1 = __shfl_down(nxt, 1, 64), n2 = __shfl_down(nxt, 2, 64);
+            float v = ninf;
+            if (lane < states) {
+                if (t == il - 1) {
+                    if (lane == states - 1 || lane == states - 2) v = lp_s[t * C + lab];
+                } else {
+                    float acc = log_add_exp(nxt, lane + 1 < states ? n1 : ninf);
+                    if (can_skip) acc = log_add_exp(acc, n2);
+                    v = acc + lp_s[t * C + lab];
+                }
+                beta[(long)t * S_ + lane] = v;
+                ab[t * S_ + lane] += v;
+            }
+            nxt = v;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * C; idx += 256) {
+        const int t = idx / C, c = idx % C;
+        float g = 0.f;
+        if (t < il) {
+            const float *row = ab + t * S_;
+            float m = ninf;
+            if (c == 0) { for (int s = 0; s < states; s += 2) m = fmaxf(m, row[s]); }
+            else        { for (int s = 1; s < states; s += 2) if ((int)tg[s >> 1] == c) m = fmaxf(m, row[s]); }
+            float lcab = ninf;
+            if (m > ninf) {
+                float sum = 0.f;
+                if (c == 0) { for (int s = 0; s < states; s += 2) sum += expf(row[s] - m); }
+                else        { for (int s = 1; s < states; s += 2) if ((int)tg[s >> 1] == c) sum += expf(row[s] - m); }
+                lcab = m + logf(sum);
+            }
+            const float l = lp_s[idx];
+            g = (expf(l) - expf(lcab + nll - l)) * go;
+        }
+        grad[(long)t * p.gstride_t + c] = g;
+    }
+}
+
 // Greedy decode: one wave per utterance, a lane per frame, 64 frames per pass.
 __global__ __launch_bounds__(64) void ctc_greedy_kernel(const float *__restrict__ lp, int N, int T, int C,
                                                         int64_t *__restrict__ ali, float *__restrict__ scores,
@@ -229,7 +352,11 @@ int halo_ctc_fwd(const float *lp, long stride_t, long stride_n, int T, int N, in
     a.lp = lp; a.stride_t = stride_t; a.stride_n = stride_n; a.T = T; a.N = N; a.C = C;
     a.targets = targets; a.tg_stride = tg_stride; a.S = S; a.il = input_lengths; a.tl = target_lengths;
     a.flags = flags; a.alpha = alpha; a.nll = nll;
-    hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(block_for_states(S_)), shmem, (hipStream_t)stream, a);
+    const size_t wave_shmem = (size_t)T * C * sizeof(float);
+    if (S_ <= 64 && wave_shmem <= 60 * 1024)
+        hipLaunchKernelGGL(ctc_alpha_wave_kernel, dim3(N), dim3(64), wave_shmem, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(block_for_states(S_)), shmem, (hipStream_t)stream, a);
     return halo_launch_status();
 }
 
@@ -247,8 +374,13 @@ int halo_ctc_bwd(const float *lp, long stride_t, long stride_n, int T, int N, in
     a.targets = targets; a.tg_stride = tg_stride; a.S = S; a.il = input_lengths; a.tl = target_lengths;
     a.alpha = alpha; a.nll = nll; a.grad_out = grad_out; a.beta = beta; a.grad = grad;
     a.gstride_t = gstride_t; a.gstride_n = gstride_n;
-    int block = block_for_states(S_ > C ? S_ : C);
-    hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(N), dim3(block), shmem, (hipStream_t)stream, a);
+    const size_t wave_shmem = ((size_t)T * C + (size_t)T * S_) * sizeof(float);
+    if (S_ <= 64 && wave_shmem <= 60 * 1024) {
+        hipLaunchKernelGGL(ctc_beta_grad_wave_kernel, dim3(N), dim3(256), wave_shmem, (hipStream_t)stream, a);
+    } else {
+        int block = block_for_states(S_ > C ? S_ : C);
+        hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(N), dim3(block), shmem, (hipStream_t)stream, a);
+    }
     return halo_launch_status();
 }
 

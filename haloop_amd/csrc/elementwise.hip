@@ -75,21 +75,30 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
     for (int c = lane; c < cols; c += 64) xr[c] = dr[c] - expf(yr[c]) * s;
 }
 
-// out[n] = sum_m x[m*ld + n]; block = 32 columns x 8 row slices, fixed summation order
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int rows, int cols, int ld,
-                                                     float *__restrict__ out) {
-    __shared__ float part[8][33];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+// out[n] = sum_m x[m*ld + n]; block = 32 columns x 32 row slices, fixed summation order
+__global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ x, int rows, int cols, int ld,
+                                                      float *__restrict__ out) {
+    __shared__ float part[32][33];
+    const int lane_c = threadIdx.x & 31;
+    const int c = blockIdx.x * 32 + lane_c;
     const int slice = threadIdx.x >> 5;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = slice; r < rows; r += 8) s += x[(long)r * ld + c];
-    part[slice][threadIdx.x & 31] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int r = slice;
+        for (; r + 96 < rows; r += 128) {
+            s0 += x[(long)r * ld + c];
+            s1 += x[(long)(r + 32) * ld + c];
+            s2 += x[(long)(r + 64) * ld + c];
+            s3 += x[(long)(r + 96) * ld + c];
+        }
+        for (; r < rows; r += 32) s0 += x[(long)r * ld + c];
+    }
+    part[slice][lane_c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && c < cols) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];
+        for (int i = 0; i < 32; ++i) t += part[i][lane_c];
         out[c] = t;
     }
 }
@@ -206,7 +215,7 @@ int halo_log_softmax_bwd(const float *dy, const float *y, float *dx, int rows, i
 
 int halo_colsum(const float *x, int rows, int cols, int ld, float *out, halo_stream_t stream) {
     HALO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols);
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(1024), 0, (hipStream_t)stream, x, rows, cols, ld, out);
     return halo_launch_status();
 }
 

@@ -1,12 +1,12 @@
 // Exact-f32 GEMM on v_mfma_f32_32x32x2_f32 (gfx950).  C[M,N] = opA(A) * opB(B) + epilogue.
 //
-// Tile BM x BN x 16, 256 threads = 4 waves in a 2x2 grid, each wave (BM/2) x (BN/2) of 32x32 MFMA
+// Tile BM x BN x 32, 256 threads = 4 waves in a 2x2 grid, each wave (BM/2) x (BN/2) of 32x32 MFMA
 // tiles.  Operands are staged global -> registers -> LDS (double buffered, one barrier per
 // K-step).  The LDS image depends on which dimension of the operand is contiguous in memory:
-//   K-contiguous operand  -> [rows][16+1]  (float4 global loads along K, padded rows so that the
+//   K-contiguous operand  -> [rows][32+1]  (float4 global loads along K, padded rows so that the
 //                                           MFMA operand read -- 32 consecutive rows, one k -- is
 //                                           bank-conflict free)
-//   row-contiguous operand -> [16][rows]   (float4 global loads along the row dimension, b128 LDS
+//   row-contiguous operand -> [32][rows]   (float4 global loads along the row dimension, b128 LDS
 //                                           stores, operand read = 32 consecutive floats)
 // The f32 MFMA is an exact k-ordered fmaf chain (MI355X_MICROARCH.md, Matrix cores), so results
 // differ from a CPU sgemm only by summation order.
@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
 struct GemmArgs {
     const float *A;
@@ -40,7 +40,7 @@ struct TileIO {
     static_assert(PER_THREAD >= 1, "tile too small for 256 threads");
 
     __device__ static __forceinline__ void unit_coords(int u, int &r, int &k) {
-        if (KC) { r = u >> 2; k = (u & 3) * 4; }
+        if (KC) { r = u / (BK / 4); k = (u % (BK / 4)) * 4; }
         else    { k = u / (ROWS / 4); r = (u % (ROWS / 4)) * 4; }
     }
 

@@ -10,7 +10,16 @@
 // Step kernel tiling: one workgroup owns a 16(batch) x 16(hidden unit) tile and all four gates
 // of it.  Waves are (gate, k-slice) pairs for the forward, k-slices of the 4H-deep contraction
 // for the backward; partial 16x16 accumulators meet in LDS, then 256 threads do the pointwise
-// cell update for their (b, j) element.  Buffers are time-major: h/c [T+1,B,H], gates [T,B,4H].
+// cell update for their (b, j) element.
+//
+// Operand layout: both MFMA operands are read from MFMA-PACKED images, [tile][k-block][lane][4]:
+// the float4 a lane feeds to four consecutive 16x16x4 MFMAs sits at lane*16 bytes of a contiguous
+// 1 KiB block, so every wave-level load is one fully coalesced 1 KiB request.  (Reading the
+// row-major [B,H]/[4H,H] arrays directly makes each load touch 16 rows 4 KiB apart: same L1 set,
+// same L2 channel -- measured 18 us per step instead of ~5.)  W_hh is packed once per call; the
+// packed copy of h_t (and of the gate gradients in the backward) is written by the previous step's
+// epilogue next to the row-major copy that the batched GEMMs consume.
+// Row-major buffers are time-major: h/c [T+1,B,H], gates [T,B,4H].
 #include "halo_common.h"
 #include "halo_internal.h"
 
@@ -18,12 +27,60 @@ namespace {
 
 enum YMode { Y_NONE = 0, Y_PLAIN = 1, Y_RELU = 2, Y_DROPOUT = 3 };
 
+constexpr int CHUNK = 4;   // k-blocks (of 16) per register stage
+
+__device__ __forceinline__ void load_chunk(f32x4 (&a)[CHUNK], f32x4 (&w)[CHUNK], const float *ap, const float *bp,
+                                           int blk0) {
+#pragma unroll
+    for (int i = 0; i < CHUNK; ++i) {
+        a[i] = *reinterpret_cast<const f32x4 *>(ap + (long)(blk0 + i) * 256);
+        w[i] = *reinterpret_cast<const f32x4 *>(bp + (long)(blk0 + i) * 256);
+    }
+}
+
+__device__ __forceinline__ void mma_chunk(const f32x4 (&a)[CHUNK], const f32x4 (&w)[CHUNK], f32x4 &acc0, f32x4 &acc1) {
+#pragma unroll
+    for (int i = 0; i < CHUNK; i += 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], w[i][m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i + 1][m], w[i + 1][m], acc1, 0, 0, 0);
+        }
+    }
+}
+
+// sum over k-blocks [0, nblk) of A-block x B-block; ap/bp point at this lane's float4 of block 0
+__device__ __forceinline__ f32x4 packed_dot(const float *ap, const float *bp, int nblk) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (nblk % (2 * CHUNK) == 0) {
+        // two register stages, branch-free so that hipcc can keep the next stage's loads in flight
+        // behind a counted vmcnt while the MFMAs of the current stage run
+        f32x4 a0[CHUNK], w0[CHUNK], a1[CHUNK], w1[CHUNK];
+        load_chunk(a0, w0, ap, bp, 0);
+        for (int c = 0; c < nblk; c += 2 * CHUNK) {
+            load_chunk(a1, w1, ap, bp, c + CHUNK);
+            mma_chunk(a0, w0, acc0, acc1);
+            load_chunk(a0, w0, ap, bp, min(c + 2 * CHUNK, nblk - CHUNK));   // last pass: harmless re-read
+            mma_chunk(a1, w1, acc0, acc1);
+        }
+    } else {
+        for (int blk = 0; blk < nblk; ++blk) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (long)blk * 256);
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + (long)blk * 256);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[m], acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
 struct StepFwdArgs {
-    const float *hprev;   // [B,H]
+    const float *hp_prev; // packed h_{t-1}  [BT/16][H/16][64][4]
     const float *cprev;   // [B,H]
-    const float *whh;     // [4H,H]
+    const float *wp;      // packed W_hh     [H/16][4][H/16][64][4]
     float *gates;         // [B,4H] in: x W_ih^T + b ; out: activated i,f,g,o
-    float *hout;          // [B,H]
+    float *hout;          // [B,H] row-major h_t
+    float *hp_out;        // packed h_t
     float *cout;          // [B,H]
     float *y;             // optional second output of h (strided)
     long y_stride_b;
@@ -37,43 +94,28 @@ template <int KS>
 __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdArgs p) {
     constexpr int NW = 4 * KS;
     __shared__ float red[NW][256];
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int jt = blockIdx.x, bt = blockIdx.y;
+    const int j0 = jt * 16, b0 = bt * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gate = wave & 3, ks = wave >> 2;
-    const int r = lane & 15, q = lane >> 4;
-    const int H = p.H;
+    const int H = p.H, nkb = H >> 4;
+    const int nblk = nkb / KS;
 
-    // A operand rows = batch (clamped; masked at the stores), B operand rows = W_hh rows of this gate
-    const int brow = min(b0 + r, p.B - 1);
-    const int klen = H / KS;
-    const float *ap = p.hprev + (long)brow * H + ks * klen + 4 * q;
-    const float *bp = p.whh + ((long)gate * H + j0 + r) * H + ks * klen + 4 * q;
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int nblk = klen / 16;
-#pragma unroll 4
-    for (int blk = 0; blk < nblk; blk += 2) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + blk * 16);
-        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(bp + blk * 16);
-        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-        if (blk + 1 < nblk) {
-            a1 = *reinterpret_cast<const f32x4 *>(ap + blk * 16 + 16);
-            w1 = *reinterpret_cast<const f32x4 *>(bp + blk * 16 + 16);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], w0[m], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m], w1[m], acc1, 0, 0, 0);
-        }
-    }
+    const float *ap = p.hp_prev + ((long)bt * nkb + ks * nblk) * 256 + lane * 4;
+    const float *bp = p.wp + (((long)jt * 4 + gate) * nkb + ks * nblk) * 256 + lane * 4;
+    const f32x4 acc = packed_dot(ap, bp, nblk);
     // D layout: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch)
+    {
+        const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc0[e] + acc1[e];
+        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
+    }
     __syncthreads();
 
     if (threadIdx.x < 256) {
         const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
         const int b = b0 + i;
+        float h = 0.f;
         if (b < p.B) {
             float pre[4];
 #pragma unroll
@@ -86,7 +128,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
             const long e = (long)b * H + j0 + j;
             const float c = fg * p.cprev[e] + ig * gg;
-            const float h = og * tanhf(c);
+            h = og * tanhf(c);
             float *gp = p.gates + (long)b * 4 * H + j0 + j;
             gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
             p.cout[e] = c;
@@ -98,67 +140,55 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
                 p.y[(long)b * p.y_stride_b + j0 + j] = v;
             }
         }
+        // packed copy for the next step: k-block = this hidden tile, lane = (j>>2)*16 + i, elem j&3
+        p.hp_out[((long)bt * nkb + jt) * 256 + ((j >> 2) * 16 + i) * 4 + (j & 3)] = h;
     }
 }
 
 struct StepBwdArgs {
-    const float *dgnext;  // [B,4H] gate gradients of step t+1, or NULL at t = T-1
-    const float *whhT;    // [H,4H]
-    float *gates;         // [B,4H] in: activated gates of step t ; out: gradients w.r.t. pre-activations
-    const float *c;       // [B,H] c_t
-    const float *cprev;   // [B,H] c_{t-1}
-    float *dc;            // [B,H] carry, in/out
-    const float *dy;      // gradient arriving from above for step t (strided), may be NULL
+    const float *dgp_next; // packed gate gradients of step t+1 [BT/16][4H/16][64][4], or NULL at t = T-1
+    const float *wpT;      // packed W_hh^T  [H/16][4H/16][64][4]
+    float *gates;          // [B,4H] in: activated gates of step t ; out: gradients w.r.t. pre-activations
+    float *dgp_out;        // packed copy of the gate gradients written here
+    const float *c;        // [B,H] c_t
+    const float *cprev;    // [B,H] c_{t-1}
+    float *dc;             // [B,H] carry, in/out
+    const float *dy;       // gradient arriving from above for step t (strided), may be NULL
     long dy_stride_b;
-    int dy_relu;          // dy is w.r.t. relu(h): mask with h > 0
-    const float *dhinit;  // [B,H] extra dh added at this step (dhn at t = T-1), or NULL
-    int first;            // t == T-1: dc carry starts from dcinit (or 0)
-    const float *dcinit;  // [B,H] or NULL
+    int dy_relu;           // dy is w.r.t. relu(h): mask with h > 0
+    const float *dhinit;   // [B,H] extra dh added at this step (dhn at t = T-1), or NULL
+    int first;             // t == T-1: dc carry starts from dcinit (or 0)
+    const float *dcinit;   // [B,H] or NULL
     int B, H;
 };
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArgs p) {
     __shared__ float red[NW][256];
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int jt = blockIdx.x, bt = blockIdx.y;
+    const int j0 = jt * 16, b0 = bt * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & 15, q = lane >> 4;
-    const int H = p.H, K = 4 * H;
+    const int H = p.H, K = 4 * H, nkb4 = K >> 4;
 
-    if (p.dgnext) {
-        const int brow = min(b0 + r, p.B - 1);
-        const int klen = K / NW;
-        const float *ap = p.dgnext + (long)brow * K + wave * klen + 4 * q;
-        const float *bp = p.whhT + (long)(j0 + r) * K + wave * klen + 4 * q;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const int nblk = klen / 16;
-#pragma unroll 4
-        for (int blk = 0; blk < nblk; blk += 2) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + blk * 16);
-            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(bp + blk * 16);
-            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-            if (blk + 1 < nblk) {
-                a1 = *reinterpret_cast<const f32x4 *>(ap + blk * 16 + 16);
-                w1 = *reinterpret_cast<const f32x4 *>(bp + blk * 16 + 16);
-            }
+    if (p.dgp_next) {
+        const int nblk = nkb4 / NW;
+        const float *ap = p.dgp_next + ((long)bt * nkb4 + wave * nblk) * 256 + lane * 4;
+        const float *bp = p.wpT + ((long)jt * nkb4 + wave * nblk) * 256 + lane * 4;
+        const f32x4 acc = packed_dot(ap, bp, nblk);
+        const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], w0[m], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m], w1[m], acc1, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc0[e] + acc1[e];
+        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
     }
     __syncthreads();
 
     if (threadIdx.x < 256) {
         const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
         const int b = b0 + i;
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (b < p.B) {
             const long e = (long)b * H + j0 + j;
             float dh = 0.f;
-            if (p.dgnext) {
+            if (p.dgp_next) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) dh += red[k][threadIdx.x];
             }
@@ -177,27 +207,89 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArg
             const float d_o = dh * tc;
             const float d_i = dcc * gg, d_f = dcc * p.cprev[e], d_g = dcc * ig;
             p.dc[e] = dcc * fg;
-            gp[0] = d_i * ig * (1.f - ig);
-            gp[H] = d_f * fg * (1.f - fg);
-            gp[2 * (long)H] = d_g * (1.f - gg * gg);
-            gp[3 * (long)H] = d_o * og * (1.f - og);
+            dg[0] = d_i * ig * (1.f - ig);
+            dg[1] = d_f * fg * (1.f - fg);
+            dg[2] = d_g * (1.f - gg * gg);
+            dg[3] = d_o * og * (1.f - og);
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
         }
+        const int nkb = H >> 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            p.dgp_out[((long)bt * nkb4 + g * nkb + jt) * 256 + ((j >> 2) * 16 + i) * 4 + (j & 3)] = dg[g];
+    }
+}
+
+// wp[jt][g][kb][lane][e] = W[g*H + jt*16 + (lane&15)][kb*16 + 4*(lane>>4) + e]
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__ w, float *__restrict__ wp, int H) {
+    const int nkb = H >> 4;
+    const long total = (long)4 * H * H / 4;     // float4 units
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const int lane = (int)(u & 63);
+        long blk = u >> 6;
+        const int kb = (int)(blk % nkb); blk /= nkb;
+        const int g = (int)(blk & 3);
+        const int jt = (int)(blk >> 2);
+        const long row = (long)g * H + jt * 16 + (lane & 15);
+        const int k = kb * 16 + 4 * (lane >> 4);
+        *reinterpret_cast<f32x4 *>(wp + u * 4) = *reinterpret_cast<const f32x4 *>(w + row * H + k);
+    }
+}
+
+// wpT[jt][kb][lane][e] = W[kb*16 + 4*(lane>>4) + e][jt*16 + (lane&15)],  kb over the 4H rows of W
+__global__ __launch_bounds__(256) void pack_whhT_kernel(const float *__restrict__ w, float *__restrict__ wpT, int H) {
+    const int nkb4 = (4 * H) >> 4;
+    const long total = (long)4 * H * H / 4;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const int lane = (int)(u & 63);
+        long blk = u >> 6;
+        const int kb = (int)(blk % nkb4);
+        const int jt = (int)(blk / nkb4);
+        const long row = (long)kb * 16 + 4 * (lane >> 4);
+        const int col = jt * 16 + (lane & 15);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = w[(row + e) * H + col];
+        *reinterpret_cast<f32x4 *>(wpT + u * 4) = v;
+    }
+}
+
+// packed[bt][kb][lane][e] = x[bt*16 + (lane&15)][kb*16 + 4*(lane>>4) + e]  (rows >= B -> 0); x NULL -> zeros
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ x, float *__restrict__ xp, int B, int W) {
+    const int nkb = W >> 4;
+    const int BT = (B + 15) / 16;
+    const long total = (long)BT * 16 * W / 4;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const int lane = (int)(u & 63);
+        const long blk = u >> 6;
+        const int kb = (int)(blk % nkb);
+        const int bt = (int)(blk / nkb);
+        const int b = bt * 16 + (lane & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (x && b < B) v = *reinterpret_cast<const f32x4 *>(x + (long)b * W + kb * 16 + 4 * (lane >> 4));
+        *reinterpret_cast<f32x4 *>(xp + u * 4) = v;
     }
 }
 
 struct LayerBufs {
-    float *h, *c, *gates, *ydrop;
+    float *h, *c, *gates, *ydrop, *hp;
 };
 
-inline size_t layer_floats(int T, int B, int H) { return (size_t)(2 * (T + 1) + 5 * T) * B * H; }
+inline size_t bt16(int B) { return (size_t)((B + 15) / 16) * 16; }
 
+inline size_t layer_floats(int T, int B, int H) {
+    return (size_t)(2 * (T + 1) + 5 * T) * B * H + (size_t)(T + 1) * bt16(B) * H;
+}
+
+// reserve = [ packed W_hh scratch (4H*H) | layer 0 | layer 1 | ... ]
 inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
-    float *base = reserve + (size_t)l * layer_floats(T, B, H);
+    float *base = reserve + (size_t)4 * H * H + (size_t)l * layer_floats(T, B, H);
     LayerBufs lb;
     lb.h = base;
     lb.c = lb.h + (size_t)(T + 1) * B * H;
     lb.gates = lb.c + (size_t)(T + 1) * B * H;
     lb.ydrop = lb.gates + (size_t)T * B * 4 * H;
+    lb.hp = lb.ydrop + (size_t)T * B * H;
     return lb;
 }
 
@@ -224,6 +316,11 @@ int launch_step_bwd(const StepBwdArgs &a, hipStream_t st) {
     return halo_launch_status();
 }
 
+inline unsigned pack_grid(size_t units) {
+    size_t g = (units + 255) / 256;
+    return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
 #define HALO_TRY(expr)            \
     do {                          \
         int rc_ = (expr);         \
@@ -240,14 +337,15 @@ extern "C" {
 
 size_t halo_lstm_reserve_bytes(int T, int B, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
-    return (size_t)L * layer_floats(T, B, H) * sizeof(float);
+    return ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float);
 }
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
     (void)in0;
-    // W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
-    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H) * sizeof(float);
+    // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
+    // + two packed gate-gradient images [BT16, 4H]
+    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + 2 * bt16(B) * 4 * H) * sizeof(float);
 }
 
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
@@ -259,7 +357,8 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
     if (H % 16 != 0) return HALO_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
-    const size_t BH = (size_t)B * H;
+    const size_t BH = (size_t)B * H, PH = bt16(B) * H;
+    float *wp = reserve;
     for (int l = 0; l < L; ++l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
@@ -276,18 +375,24 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
         // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
         HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
                                b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
-        if (h0) HALO_TRY(copy_d2d(lb.h, h0 + (size_t)l * BH, BH, st));
+        hipLaunchKernelGGL(pack_whh_kernel, dim3(pack_grid((size_t)H * H)), dim3(256), 0, st, w_hh[l], wp, H);
+        HALO_TRY(halo_launch_status());
+        const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
+        if (h0l) HALO_TRY(copy_d2d(lb.h, h0l, BH, st));
         else HALO_TRY(halo_fill(lb.h, BH, 0.f, st));
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_grid(PH / 4)), dim3(256), 0, st, h0l, lb.hp, B, H);
+        HALO_TRY(halo_launch_status());
         if (c0) HALO_TRY(copy_d2d(lb.c, c0 + (size_t)l * BH, BH, st));
         else HALO_TRY(halo_fill(lb.c, BH, 0.f, st));
         const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
         for (int t = 0; t < T; ++t) {
             StepFwdArgs a;
-            a.hprev = lb.h + (size_t)t * BH;
+            a.hp_prev = lb.hp + (size_t)t * PH;
             a.cprev = lb.c + (size_t)t * BH;
-            a.whh = w_hh[l];
+            a.wp = wp;
             a.gates = lb.gates + (size_t)t * B * 4 * H;
             a.hout = lb.h + (size_t)(t + 1) * BH;
+            a.hp_out = lb.hp + (size_t)(t + 1) * PH;
             a.cout = lb.c + (size_t)(t + 1) * BH;
             a.B = B; a.H = H;
             a.drop = dc;
@@ -321,19 +426,22 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
     if (H % 16 != 0) return HALO_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
-    const size_t BH = (size_t)B * H;
-    float *whhT = workspace;
-    float *dcarry = whhT + (size_t)H * 4 * H;
+    const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H;
+    float *wpT = workspace;
+    float *dcarry = wpT + (size_t)H * 4 * H;
     float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
+    float *dgp = din + (size_t)T * BH; // two packed gate-gradient images, ping-pong
     for (int l = L - 1; l >= 0; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
-        HALO_TRY(halo_transpose(w_hh[l], whhT, 4 * H, H, st));
+        hipLaunchKernelGGL(pack_whhT_kernel, dim3(pack_grid((size_t)H * H)), dim3(256), 0, st, w_hh[l], wpT, H);
+        HALO_TRY(halo_launch_status());
         for (int t = T - 1; t >= 0; --t) {
             StepBwdArgs a;
-            a.dgnext = (t == T - 1) ? nullptr : lb.gates + (size_t)(t + 1) * B * 4 * H;
-            a.whhT = whhT;
+            a.dgp_next = (t == T - 1) ? nullptr : dgp + (size_t)((t + 1) & 1) * PG;
+            a.dgp_out = dgp + (size_t)(t & 1) * PG;
+            a.wpT = wpT;
             a.gates = lb.gates + (size_t)t * B * 4 * H;
             a.c = lb.c + (size_t)(t + 1) * BH;
             a.cprev = lb.c + (size_t)t * BH;

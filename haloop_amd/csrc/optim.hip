@@ -32,7 +32,11 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict_
     if (threadIdx.x == 0) {
         const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
         const float c = max_norm / (norm + 1e-6f);
-        *coef = c > 1.0f ? 1.0f : c;
+        const bool finite = isfinite(norm);
+        // a non-finite norm poisons both scales: halo_adamw skips the update when its scale is NaN
+        // (the reference skips the batch on a NaN/Inf loss or gradient norm, ha/loop.py:167-189)
+        coef[0] = finite ? (c > 1.0f ? 1.0f : c) : NAN;
+        coef[1] = finite ? 1.0f : NAN;
         if (norm_out) *norm_out = norm;
     }
 }
@@ -55,6 +59,7 @@ struct AdamArgs {
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     const float gs = a.grad_scale ? *a.grad_scale : 1.0f;
+    if (gs != gs) return;   // NaN scale: skip this update entirely
     const size_t n4 = a.n / 4;
     f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);

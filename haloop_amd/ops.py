@@ -238,6 +238,18 @@ def ctc_beam(em, beam, log_domain=True):
     return seqs, lens, scores
 
 
+def topk(values2d, k):
+    """Row-wise top-k in torch.topk's CPU order (ties included). -> (values [rows,k], indices [rows,k] int64)"""
+    _f32c(values2d, 'values')
+    rows, n = values2d.shape
+    dev = values2d.device
+    vals = torch.empty(rows, k, device=dev, dtype=torch.float32)
+    idx = torch.empty(rows, k, device=dev, dtype=torch.int64)
+    ws = torch.empty(rows * n * 8, device=dev, dtype=torch.uint8)
+    check(lib().halo_topk_f32(ptr(values2d), rows, n, k, ptr(vals), ptr(idx), ptr(ws), _stream()), 'halo_topk_f32')
+    return vals, idx
+
+
 def sumsq_partials(flat, partials=None):
     if partials is None:
         partials = torch.empty(_lib.HALO_SUMSQ_PARTS, device=flat.device, dtype=torch.float32)

@@ -1,0 +1,196 @@
+"""The LSTM-CTC training step as haloop runs it (ha/loop.py:113-196), straight on the C ABI.
+
+One step = encoder forward -> CTC head -> CTC/classifier/LSTM/conv backward -> (data-parallel
+gradient average) -> clip the ENCODER's gradient norm to 0.1 (loop.py:184) -> AdamW
+(ha/optim.py:132-139: conv/linear weights and all nn.LSTM parameters decay, other biases do not).
+Parameters, gradients and Adam moments live in flat fp32 buffers so clip and AdamW are one pass
+each; the modules' ``nn.Parameter``s are views into them, so ``state_dict()`` stays the
+reference's.  The whole step is captured in a HIP graph (~150 dependent launches otherwise).
+
+Data parallel: one process per GPU, parameters broadcast from rank 0,
+gradients averaged with one RCCL all-reduce per step over the flat gradient buffer -- the
+semantics of DistributedDataParallel in ha/attention_loop.py:154.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from .ops import Dropout, NO_DROPOUT
+from .rnn import lstm_param_list
+
+
+def decay_groups(encoder, recognizer):
+    """(decay, no_decay) lists of (qualified name, parameter), ha/optim.py:84-106 applied to this model."""
+    decay, no_decay = [], []
+    for prefix, mod in (('encoder.', encoder), ('recognizer.', recognizer)):
+        for name, p in mod.named_parameters():
+            is_lstm = name.startswith('lstm.') or name.startswith('rnn.')
+            if is_lstm or not name.endswith('bias'):
+                decay.append((prefix + name, p))
+            else:
+                no_decay.append((prefix + name, p))
+    return decay, no_decay
+
+
+class FlatParams:
+    """Re-homes parameters into one flat buffer laid out [enc decay | enc no-decay | rec decay | rec no-decay]."""
+
+    def __init__(self, encoder, recognizer):
+        decay, no_decay = decay_groups(encoder, recognizer)
+        groups = [[(n, p) for n, p in decay if n.startswith('encoder.')],
+                  [(n, p) for n, p in no_decay if n.startswith('encoder.')],
+                  [(n, p) for n, p in decay if n.startswith('recognizer.')],
+                  [(n, p) for n, p in no_decay if n.startswith('recognizer.')]]
+        self.decays = [True, False, True, False]
+        dev = next(encoder.parameters()).device
+        off, self.ranges, self.slots = 0, [], []
+        for g in groups:
+            start = off
+            for n, p in g:
+                self.slots.append((n, p, off))
+                off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            self.ranges.append((start, off))
+        self.total = off
+        self.encoder_range = (self.ranges[0][0], self.ranges[1][1])
+        self.params = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad_views = {}
+        with torch.no_grad():
+            for n, p, o in self.slots:
+                view = self.params[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self.grad_views[n] = self.grads[o:o + p.numel()].view(p.shape)
+
+    def attach_grads(self):
+        for n, p, _ in self.slots:
+            p.grad = self.grad_views[n]
+
+
+class LstmCtcTrainer:
+    def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
+                 clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None):
+        self.encoder, self.recognizer = encoder, recognizer
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip_grad_norm
+        self.flat = FlatParams(encoder, recognizer)
+        dev = self.flat.params.device
+        self.device = dev
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.counter = torch.zeros(1, device=dev, dtype=torch.int32)     # device-side step counter (dropout offset)
+        self.partials = torch.zeros(_lib.HALO_SUMSQ_PARTS, device=dev, dtype=torch.float32)
+        self.coef = torch.ones(2, device=dev, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.loss = torch.zeros((), device=dev, dtype=torch.float32)
+        self.step_count = 0
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        if self.world > 1:
+            dist.broadcast(self.flat.params, src=0, group=process_group)   # DDP ctor semantics (C2)
+        self._graphs = None
+        self._static = None
+
+    # ---- pieces -------------------------------------------------------------------------------
+    def _dropout(self):
+        p = self.encoder.dropout.p if self.encoder.training else 0.0
+        return Dropout(p, self.seed, 0, self.counter) if p > 0 else NO_DROPOUT
+
+    def _forward_backward(self, x, il, tg, tl):
+        enc, rec, gv = self.encoder, self.recognizer, self.flat.grad_views
+        drop = self._dropout()
+        B, T, F = x.shape
+        L = enc.lstm.num_layers
+        lp_list = lstm_param_list(enc.lstm)
+        w_ih, w_hh, b_ih, b_hh = lp_list[0::4], lp_list[1::4], lp_list[2::4], lp_list[3::4]
+        H, Cc = w_hh[0].shape[1], enc.subsample.weight.shape[0]
+        V = rec.classifier.weight.shape[0]
+        # forward (ha/rnn.py:20-26, ha/recognizer.py:43-46,61-73)
+        y_sub, col = ops.subsample_fwd(x, enc.subsample.weight, enc.subsample.bias, drop)
+        Tp = y_sub.shape[0]
+        feats = torch.empty(B, Tp, H, device=x.device, dtype=torch.float32)
+        _, _, _, reserve = ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True, drop=drop)
+        p_cls = rec.dropout.p if rec.training else 0.0
+        cdrop = Dropout(p_cls, self.seed, 0, self.counter) if p_cls > 0 else NO_DROPOUT
+        fdrop = ops.dropout_fwd(feats, cdrop, _lib.HALO_STREAM_CLASSIFIER) if p_cls > 0 else feats
+        f2d = fdrop.view(B * Tp, H)
+        logits = ops.gemm(f2d, rec.classifier.weight, True, True, B * Tp, V, H, bias1=rec.classifier.bias)
+        lp = ops.log_softmax_fwd(logits)
+        flen = torch.floor((il + 2 * 3 - 5) / 4 + 1).to(torch.int64)          # ha/rnn.py:13-18
+        nll, alpha, saved = ops.ctc_fwd(lp.view(B, Tp, V), False, tg, flen, tl)
+        tlf = tl.to(torch.float32).clamp_min(1)
+        self.loss.copy_((nll / tlf).mean())                                    # reduction='mean', recognizer.py:71
+        # backward
+        grad_out = 1.0 / (tlf * B)
+        dlp = ops.ctc_bwd(lp.view(B, Tp, V), False, saved, alpha, nll, grad_out)
+        dlogits = ops.log_softmax_bwd(dlp.view(B * Tp, V), lp)
+        ops.gemm(dlogits, f2d, False, False, V, H, B * Tp, out=gv['recognizer.classifier.weight'])
+        ops.colsum(dlogits, out=gv['recognizer.classifier.bias'])
+        dfeats = ops.gemm(dlogits, rec.classifier.weight, True, False, B * Tp, H, V, drop=cdrop,
+                          stream_id=_lib.HALO_STREAM_CLASSIFIER)
+        grads = {'dw_ih': [gv[f'encoder.lstm.weight_ih_l{k}'] for k in range(L)],
+                 'dw_hh': [gv[f'encoder.lstm.weight_hh_l{k}'] for k in range(L)],
+                 'db_ih': [gv[f'encoder.lstm.bias_ih_l{k}'] for k in range(L)],
+                 'db_hh': [gv[f'encoder.lstm.bias_hh_l{k}'] for k in range(L)]}
+        dy_sub, _ = ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, want_dx=True, grads=grads, drop=drop)
+        ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
+                          dbias=gv['encoder.subsample.bias'])
+
+    def _all_reduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            self.flat.grads.mul_(1.0 / self.world)
+
+    def _optimizer(self, step):
+        f = self.flat
+        e0, e1 = f.encoder_range
+        ops.sumsq_partials(f.grads[e0:e1], self.partials)
+        ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm)
+        for (a, b), decays in zip(f.ranges, f.decays):
+            if b == a:
+                continue
+            scale = self.coef[0:1] if b <= e1 else self.coef[1:2]
+            ops.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay if decays else 0.0, step, scale)
+        ops.counter_inc(self.counter)
+
+    # ---- public -------------------------------------------------------------------------------
+    def step(self, x, input_lengths, targets, target_lengths):
+        """One optimizer step.  Returns the (device) loss tensor; nothing here synchronises."""
+        self.step_count += 1
+        if not self.use_graph:
+            self._forward_backward(x, input_lengths, targets, target_lengths)
+            self._all_reduce()
+            self._optimizer(self.step_count)
+            return self.loss
+        return self._graph_step(x, input_lengths, targets, target_lengths)
+
+    def _graph_step(self, x, il, tg, tl):
+        # AdamW's bias corrections depend on the step number, a host scalar baked into the kernel
+        # arguments: the optimizer part is therefore re-captured per step count only while the
+        # correction still moves (it is 1.0 to fp32 precision after a few thousand steps); simpler
+        # and exact: capture forward/backward once, run the (6-launch) optimizer eagerly.
+        if self._graphs is None or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
+            self._static = (x.clone(), il.clone(), tg.clone(), tl.clone())
+            sx, sil, stg, stl = self._static
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up outside capture (lazy module loads)
+                self._forward_backward(sx, sil, stg, stl)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward_backward(sx, sil, stg, stl)
+            self._graphs = g
+        sx, sil, stg, stl = self._static
+        if x.data_ptr() != sx.data_ptr():
+            sx.copy_(x); sil.copy_(il); stg.copy_(tg); stl.copy_(tl)
+        self._graphs.replay()
+        self._all_reduce()
+        self._optimizer(self.step_count)
+        return self.loss
+
+    def static_inputs(self):
+        """The graph's input buffers (fill these in place to avoid the per-step copy)."""
+        return self._static

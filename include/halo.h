@@ -175,12 +175,22 @@ size_t halo_ctc_beam_workspace_bytes(int N, int T, int V, int beam);
 int halo_ctc_beam(const float *em, int N, int T, int V, int beam, int log_domain, int64_t *seqs,
                   int32_t *lens, float *scores, void *workspace, halo_stream_t stream);
 
+/* Row-wise top-k with the order torch.topk(largest=True, sorted=True) produces on CPU, equal keys
+ * included (ATen TopKImpl.h: partial_sort when k*64 <= n, else nth_element + sort; libstdc++).
+ * replaces: seq_logits.topk(beam_size) ha/beam.py:129 (and beam.py:60).
+ *   values [rows,n]; out_values [rows,k] f32; out_indices [rows,k] int64; workspace rows*n*8 bytes. */
+int halo_topk_f32(const float *values, int rows, int n, int k, float *out_values, int64_t *out_indices,
+                  void *workspace, halo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers.
  * replaces: clip_grad_norm_ ha/loop.py:184 and torch.optim.AdamW(fused) ha/optim.py:137-139
  *   halo_sumsq: partials[0..HALO_SUMSQ_PARTS) = per-workgroup sums of x^2 (fixed order, so the
  *   norm is bitwise reproducible); halo_clip_coef: norm = sqrt(sum partials[0..count)),
- *   coef = min(1, max_norm / (norm + 1e-6)) as clip_grad_norm_ computes it; both device scalars.
+ *   coef[0] = min(1, max_norm / (norm + 1e-6)) as clip_grad_norm_ computes it, coef[1] = 1; when
+ *   the norm is not finite both are NaN, and halo_adamw skips the whole update when *grad_scale
+ *   is NaN -- the on-device form of the reference's "skip batch" on NaN/Inf loss or gradient norm
+ *   (ha/loop.py:167-174,185-189).  coef is a device float[2], norm_out a device float (or NULL).
  *   halo_adamw: torch.optim.AdamW single-tensor arithmetic; grad is multiplied by *grad_scale
  *   (device scalar, may be NULL) before use.  step >= 1 is the 1-based update count.
  * ------------------------------------------------------------------------------------------ */

@@ -216,6 +216,14 @@ def save_beam():
         seqs, sc = ha.beam.ctc_beam_search_decode_logits(lg, beam_size=beam)
         d[name + '.logits'] = lg.numpy(); d[name + '.beam'] = np.array(beam)
         d[name + '.seqs'], d[name + '.lens'] = pad_seqs(seqs); d[name + '.scores'] = sc.numpy()
+    # peaked emissions (what a trained model produces): rankings never hinge on sub-ulp ties
+    for name, T, V, beam, seed, scale in (('p21x32b16', 21, 32, 16, 10, 6.0), ('p40x32b8', 40, 32, 8, 11, 8.0),
+                                          ('p21x256b4', 21, 256, 4, 12, 6.0), ('p64x9b9', 64, 9, 9, 13, 5.0)):
+        g = torch.Generator().manual_seed(seed)
+        lg = (torch.randn(T, V, generator=g) * scale).log_softmax(-1)
+        seqs, sc = ha.beam.ctc_beam_search_decode_logits(lg, beam_size=beam)
+        d[name + '.logits'] = lg.numpy(); d[name + '.beam'] = np.array(beam)
+        d[name + '.seqs'], d[name + '.lens'] = pad_seqs(seqs); d[name + '.scores'] = sc.numpy()
     # probability-domain twin: NameError as shipped (beam.py:46) ...
     try:
         ha.beam.ctc_beam_search_decode_probs(probs)

@@ -106,7 +106,8 @@ def test_ctc_lattice_equals_brute_force():
         assert abs(float(nll[0]) - lattice.ctc_brute_force_nll(lp, target)) < 1e-5
 
 
-@pytest.mark.parametrize('case', ['onehot', 'r21x32b16', 'r21x32b3', 'r6x4b4', 'r30x9b5', 'r21x32b33'])
+@pytest.mark.parametrize('case', ['onehot', 'r21x32b16', 'r21x32b3', 'r6x4b4', 'r30x9b5', 'r21x32b33',
+                                  'p21x32b16', 'p40x32b8', 'p21x256b4', 'p64x9b9'])
 def test_beam_logits_matches_reference(case):
     g = load_golden('g3_beam')
     seqs, scores = lattice.ctc_beam_search_decode_logits(torch.from_numpy(g[case + '.logits']), int(g[case + '.beam']))
