@@ -14,7 +14,7 @@ semantics of DistributedDataParallel in ha/attention_loop.py:154.
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops
+from . import _lib, dp, ops
 from .ops import Dropout, NO_DROPOUT
 from .rnn import lstm_param_list
 
@@ -86,9 +86,10 @@ class LstmCtcTrainer:
         self.step_count = 0
         self.use_graph = use_graph
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        if self.world > 1:
-            dist.broadcast(self.flat.params, src=0, group=process_group)   # DDP ctor semantics (C2)
+        self.world = dp.world_size(process_group)
+        dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
+        self.averager = dp.GradientAverager(self.flat.grads, process_group,
+                                            boundaries=[r[0] for r in self.flat.ranges])
         self._graphs = None
         self._static = None
 
@@ -138,9 +139,7 @@ class LstmCtcTrainer:
                           dbias=gv['encoder.subsample.bias'])
 
     def _all_reduce(self):
-        if self.world > 1:
-            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat.grads.mul_(1.0 / self.world)
+        self.averager.average()
 
     def _optimizer(self, step):
         f = self.flat

@@ -1,0 +1,88 @@
+"""Data-parallel semantics on CPU: world_size 2, gloo.  The compute here is the CPU oracle (the HIP
+path needs a GPU); what is under test is haloop_amd.dp -- broadcast, sharding and gradient
+averaging -- and that an N-rank step equals the single-process step on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from haloop_amd import dp
+        from oracle import cpu_ref
+        torch.set_num_threads(1)
+        F_, C, H, L, V, B, T, S = 12, 16, 32, 2, 9, 4, 41, 4
+        # every rank draws its own init (like seed 1337+rank, attention_loop.py:75); rank 0's must win
+        enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 100 + rank)
+        names = [('e', k) for k in enc_p] + [('r', k) for k in rec_p]
+        tensors = [enc_p[k] if w == 'e' else rec_p[k] for w, k in names]
+        flat = torch.cat([t.reshape(-1) for t in tensors]).clone()
+        dp.broadcast_parameters(flat)
+        off, pe, pr = 0, {}, {}
+        for (w, k), t in zip(names, tensors):
+            v = flat[off:off + t.numel()].view(t.shape).clone().requires_grad_(True)
+            (pe if w == 'e' else pr)[k] = v
+            off += t.numel()
+        x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, 7)
+        sl = dp.shard_slice(B, rank, world)
+        loss, _, _ = cpu_ref.lstm_ctc_loss(pe, pr, x[sl], il[sl], tg[sl], tl[sl])
+        loss.backward()
+        grads = torch.cat([(pe[k] if w == 'e' else pr[k]).grad.reshape(-1) for w, k in names])
+        avg = dp.GradientAverager(grads, bucket_bytes=4096, boundaries=[1000, 5000])
+        assert len(avg.buckets) > 3
+        avg.average()
+        if rank == 0:
+            out.put((flat.numpy(), grads.numpy(), float(loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_single_process_on_concatenated_batch():
+    from oracle import cpu_ref
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat, grads, _ = out.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    F_, C, H, L, V, B, T, S = 12, 16, 32, 2, 9, 4, 41, 4
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 100)              # rank 0's init
+    want_flat = torch.cat([t.reshape(-1) for t in list(enc_p.values()) + list(rec_p.values())]).numpy()
+    np.testing.assert_array_equal(flat, want_flat)                        # broadcast from rank 0
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc_p.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec_p.items()}
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, 7)
+    loss, _, _ = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl)
+    loss.backward()
+    want = torch.cat([v.grad.reshape(-1) for v in list(pe.values()) + list(pr.values())]).numpy()
+    np.testing.assert_allclose(grads, want, rtol=1e-4, atol=1e-7)         # mean of shard means == global mean
+
+
+def test_shard_slice_and_buckets():
+    from haloop_amd import dp
+    assert dp.shard_slice(64, 3, 8) == slice(24, 32)
+    with pytest.raises(ValueError):
+        dp.shard_slice(10, 0, 4)
+    g = torch.zeros(1000)
+    a = dp.GradientAverager(g, bucket_bytes=400, boundaries=[250])
+    assert a.buckets[0] == (0, 100) and (200, 250) in a.buckets and a.buckets[-1][1] == 1000
+    assert sum(b - a_ for a_, b in a.buckets) == 1000
+    a.average()                                                           # world 1: no-op, no process group needed
