@@ -125,6 +125,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--math', choices=['f32', 'bf16x3'], default='bf16x3',
+                    help='arithmetic of the large LSTM GEMMs (both meet the fp32 parity tolerances)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -142,6 +144,7 @@ def main():
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
     _lib.lib()                                              # loud failure if the HIP library is absent
+    _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
     trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph)
@@ -183,7 +186,7 @@ def main():
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph},
+                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math},
             'final_loss': round(loss, 5),
             'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel<4> (H=1024, B=64)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -16,6 +16,8 @@ HALO_STREAM_SUBSAMPLE = 1
 HALO_STREAM_CLASSIFIER = 2
 HALO_STREAM_LSTM_LAYER0 = 16
 HALO_SUMSQ_PARTS = 1024
+HALO_MATH_F32 = 0
+HALO_MATH_BF16X3 = 1
 
 _vp, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 
@@ -24,13 +26,16 @@ SIGNATURES = {
     'halo_abi_version': (_i, []),
     'halo_strerror': (C.c_char_p, [_i]),
     'halo_device_info': (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
+    'halo_set_math_mode': (_i, [_i]),
+    'halo_get_math_mode': (_i, []),
+    'halo_set_scratch': (_i, [_vp, _sz]),
     'halo_dropout_fwd': (_i, [_vp, _vp, _sz, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_counter_inc': (_i, [_vp, _vp]),
     'halo_gemm_f32': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_subsample_col_bytes': (_sz, [_i] * 6),
     'halo_subsample_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
     'halo_subsample_bwd': (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp]),
-    'halo_lstm_reserve_bytes': (_sz, [_i] * 4),
+    'halo_lstm_reserve_bytes': (_sz, [_i] * 5),
     'halo_lstm_bwd_workspace_bytes': (_sz, [_i] * 5),
     'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
     'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
@@ -70,7 +75,33 @@ def lib():
         if handle.halo_abi_version() != HALO_ABI_VERSION:
             raise HaloError('libhalo.so ABI version mismatch: rebuild it')
         _lib = handle
+        mode = os.environ.get('HALO_MATH')
+        if mode:
+            set_math_mode(mode)
     return _lib
+
+
+def set_math_mode(mode):
+    """'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16, three MFMAs per product) for the large LSTM GEMMs."""
+    code = {'f32': HALO_MATH_F32, 'bf16x3': HALO_MATH_BF16X3}[mode]
+    check(lib().halo_set_math_mode(code), 'halo_set_math_mode')
+
+
+def get_math_mode():
+    return {HALO_MATH_F32: 'f32', HALO_MATH_BF16X3: 'bf16x3'}[lib().halo_get_math_mode()]
+
+
+_scratch = None
+
+
+def lend_scratch(nbytes=64 << 20, device=None):
+    """Allocate (once, with torch) and lend the library its split-K scratch buffer."""
+    global _scratch
+    import torch
+    if _scratch is None or _scratch.numel() < nbytes:
+        _scratch = torch.empty(nbytes, dtype=torch.uint8, device=device or 'cuda')
+        check(lib().halo_set_scratch(_scratch.data_ptr(), _scratch.numel()), 'halo_set_scratch')
+    return _scratch
 
 
 def check(rc, what):

@@ -11,6 +11,7 @@
 // The f32 MFMA is an exact k-ordered fmaf chain (MI355X_MICROARCH.md, Matrix cores), so results
 // differ from a CPU sgemm only by summation order.
 #include "halo_common.h"
+#include "halo_internal.h"
 
 namespace {
 
@@ -29,6 +30,9 @@ struct GemmArgs {
     int tiles_n;
     DropoutCfg drop;
     int use_drop;
+    int ntiles;         // output tiles; grid = ntiles * ksplit
+    int ksplit, kper;   // split-K: slice s covers k in [s*kper, min(K, (s+1)*kper)), raw sums go to slab[s]
+    float *slab;
 };
 
 // One operand tile loader.  KC: memory is [rows][K]; else memory is [K][rows].
@@ -105,8 +109,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     float *const As0 = lds;
     float *const Bs0 = lds + 2 * IOA::LDS_FLOATS;
 
-    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+    const int tile = blockIdx.x % p.ntiles, kslice = blockIdx.x / p.ntiles;
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = kslice * p.kper, kend = min(p.K, kbeg + p.kper);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
@@ -120,10 +126,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[IOA::PER_THREAD], rb[IOB::PER_THREAD];
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
 
-    IOA::load(p.A, p.lda, m0, 0, p.M, p.K, p.a_vec, ra);
-    IOB::load(p.B, p.ldb, n0, 0, p.N, p.K, p.b_vec, rb);
+    IOA::load(p.A, p.lda, m0, kbeg, p.M, kend, p.a_vec, ra);
+    IOB::load(p.B, p.ldb, n0, kbeg, p.N, kend, p.b_vec, rb);
     IOA::store(As0, ra);
     IOB::store(Bs0, rb);
     __syncthreads();
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) {
-            IOA::load(p.A, p.lda, m0, (t + 1) * BK, p.M, p.K, p.a_vec, ra);
-            IOB::load(p.B, p.ldb, n0, (t + 1) * BK, p.N, p.K, p.b_vec, rb);
+            IOA::load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, p.a_vec, ra);
+            IOB::load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, p.b_vec, rb);
         }
         const float *as = As0 + cur * IOA::LDS_FLOATS, *bs = Bs0 + cur * IOB::LDS_FLOATS;
 #pragma unroll
@@ -162,6 +168,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + lr;
             if (col >= p.N) continue;
+            if (p.ksplit > 1) {
+                float *slab = p.slab + (long)kslice * p.M * p.N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < p.M) slab[(long)row * p.N + col] = acc[i][j][r];
+                }
+                continue;
+            }
             float bias = 0.f;
             if (p.bias1) bias += p.bias1[col];
             if (p.bias2) bias += p.bias2[col];
@@ -179,19 +194,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     }
 }
 
+}  // namespace
+
+// C = epilogue(sum_s slab[s]); shared with the split-bf16 GEMM
+__global__ __launch_bounds__(256) void halo_splitk_reduce_kernel(const float *__restrict__ slab, int ksplit, int M, int N,
+                                                                 float *__restrict__ C, int ldc, const float *bias1,
+                                                                 const float *bias2, int relu, DropoutCfg drop, int use_drop) {
+    const long total = (long)M * N;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int row = (int)(e / N), col = (int)(e % N);
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += slab[(long)s * total + e];
+        if (bias1) v += bias1[col];
+        if (bias2) v += bias2[col];
+        if (relu) v = fmaxf(v, 0.f);
+        const long o = (long)row * ldc + col;
+        if (use_drop) v *= dropout_mult(drop, (uint64_t)o);
+        C[o] = v;
+    }
+}
+
+int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, int ldc, const float *bias1,
+                       const float *bias2, int relu, const DropoutCfg &drop, int use_drop, hipStream_t st) {
+    long blocks = ((long)M * N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(halo_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, ksplit, M, N, C, ldc, bias1,
+                       bias2, relu, drop, use_drop);
+    return halo_launch_status();
+}
+
+// how many K slices make an under-filled grid cover the chip, given the caller-provided scratch
+int halo_pick_ksplit(long tiles, int k_steps, long out_elems) {
+    if (tiles >= 128 || k_steps < 8) return 1;
+    void *scratch; size_t bytes;
+    halo_get_scratch(&scratch, &bytes);
+    if (!scratch) return 1;
+    long s = (256 + tiles - 1) / tiles;
+    if (s > k_steps / 4) s = k_steps / 4;
+    const long cap = (long)(bytes / (sizeof(float) * (size_t)out_elems));
+    if (s > cap) s = cap;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
+
+namespace {
+
+template <bool A_KC, bool B_KC, int BM, int BN>
+int launch_tile(GemmArgs &p, hipStream_t st) {
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.ntiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    const int k_steps = (p.K + BK - 1) / BK;
+    p.ksplit = halo_pick_ksplit(p.ntiles, k_steps, (long)p.M * p.N);
+    p.kper = ((k_steps + p.ksplit - 1) / p.ksplit) * BK;
+    p.ksplit = (p.K + p.kper - 1) / p.kper;
+    void *scratch; size_t bytes;
+    halo_get_scratch(&scratch, &bytes);
+    p.slab = (float *)scratch;
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, BM, BN>), dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 0, st, p);
+    int rc = halo_launch_status();
+    if (rc != HALO_OK || p.ksplit == 1) return rc;
+    return halo_splitk_reduce(p.slab, p.ksplit, p.M, p.N, p.C, p.ldc, p.bias1, p.bias2, p.relu, p.drop, p.use_drop, st);
+}
+
 template <bool A_KC, bool B_KC>
 int launch_gemm(GemmArgs &p, hipStream_t st) {
     // pick the tile so that the grid covers the chip (256 CUs) when the problem allows it
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (tiles128 >= 200 && p.M >= 128 && p.N >= 128) {
-        p.tiles_n = (p.N + 127) / 128;
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 128, 128>), dim3((unsigned)tiles128), dim3(256), 0, st, p);
-    } else {
-        p.tiles_n = (p.N + 63) / 64;
-        const long tiles = (long)((p.M + 63) / 64) * p.tiles_n;
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 64, 64>), dim3((unsigned)tiles), dim3(256), 0, st, p);
-    }
-    return halo_launch_status();
+    if (tiles128 >= 200 && p.M >= 128 && p.N >= 128) return launch_tile<A_KC, B_KC, 128, 128>(p, st);
+    return launch_tile<A_KC, B_KC, 64, 64>(p, st);
 }
 
 }  // namespace

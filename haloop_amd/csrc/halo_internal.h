@@ -2,6 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "halo_common.h"
 
 int halo_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);
 int halo_fill(float *p, size_t n, float v, hipStream_t st);
+
+// ---- split-bf16 GEMM on pre-tiled operand images (gemm_bf16x3.hip) ----
+size_t halo_tiled_image_bytes(int R, int K);
+// image <- split/tiled copy of logical X[R][K]; src_transposed: memory is [K][R] (leading dim ld)
+int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, void *image, hipStream_t st);
+// C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
+int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
+                           const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);
+int halo_math_mode();   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
+
+// ---- caller-provided scratch (halo_set_scratch) and split-K helpers ----
+void halo_get_scratch(void **ptr, size_t *bytes);
+int halo_pick_ksplit(long tiles, int k_steps, long out_elems);
+int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, int ldc, const float *bias1,
+                       const float *bias2, int relu, const DropoutCfg &drop, int use_drop, hipStream_t st);

@@ -281,7 +281,7 @@ inline size_t layer_floats(int T, int B, int H) {
     return (size_t)(2 * (T + 1) + 5 * T) * B * H + (size_t)(T + 1) * bt16(B) * H;
 }
 
-// reserve = [ packed W_hh scratch (4H*H) | layer 0 | layer 1 | ... ]
+// reserve = [ packed W_hh scratch (4H*H) | layer 0 | layer 1 | ... | tiled images for the input projection ]
 inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
     float *base = reserve + (size_t)4 * H * H + (size_t)l * layer_floats(T, B, H);
     LayerBufs lb;
@@ -335,17 +335,21 @@ inline int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st) {
 
 extern "C" {
 
-size_t halo_lstm_reserve_bytes(int T, int B, int H, int L) {
-    if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
-    return ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float);
+size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
+    if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
+    const int kin = in0 > H ? in0 : H;
+    return ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float) +
+           halo_tiled_image_bytes(T * B, kin) + halo_tiled_image_bytes(4 * H, kin);
 }
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
-    (void)in0;
-    // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
-    // + two packed gate-gradient images [BT16, 4H]
-    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + 2 * bt16(B) * 4 * H) * sizeof(float);
+        // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
+    // + two packed gate-gradient images [BT16, 4H] + tiled images for the batched gradient GEMMs
+    const int kin = in0 > H ? in0 : H;
+    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + 2 * bt16(B) * 4 * H) * sizeof(float) +
+           halo_tiled_image_bytes(4 * H, T * B) + halo_tiled_image_bytes(T * B, 4 * H) +
+           2 * halo_tiled_image_bytes(kin, T * B) + halo_tiled_image_bytes(kin, 4 * H);
 }
 
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
@@ -359,6 +363,9 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PH = bt16(B) * H;
     float *wp = reserve;
+    const int kin = in0 > H ? in0 : H;
+    char *img_in = (char *)(reserve + (size_t)4 * H * H + (size_t)L * layer_floats(T, B, H));
+    char *img_w = img_in + halo_tiled_image_bytes(T * B, kin);
     for (int l = 0; l < L; ++l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
@@ -373,8 +380,15 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             in_dim = H;
         }
         // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
-        HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
-                               b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
+        if (halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64) {
+            HALO_TRY(halo_prep_tiles(in, T * B, in_dim, in_dim, 0, img_in, st));
+            HALO_TRY(halo_prep_tiles(w_ih[l], 4 * H, in_dim, in_dim, 0, img_w, st));
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, lb.gates, 4 * H, b_ih[l], b_hh[l], 0,
+                                            nullptr, st));
+        } else {
+            HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
+                                   b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
+        }
         hipLaunchKernelGGL(pack_whh_kernel, dim3(pack_grid((size_t)H * H)), dim3(256), 0, st, w_hh[l], wp, H);
         HALO_TRY(halo_launch_status());
         const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
@@ -431,6 +445,12 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     float *dcarry = wpT + (size_t)H * 4 * H;
     float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
     float *dgp = din + (size_t)T * BH; // two packed gate-gradient images, ping-pong
+    const int kin = in0 > H ? in0 : H;
+    char *img_gT = (char *)(dgp + 2 * PG);
+    char *img_g = img_gT + halo_tiled_image_bytes(4 * H, T * B);
+    char *img_hT = img_g + halo_tiled_image_bytes(T * B, 4 * H);
+    char *img_inT = img_hT + halo_tiled_image_bytes(kin, T * B);
+    char *img_wT = img_inT + halo_tiled_image_bytes(kin, T * B);
     for (int l = L - 1; l >= 0; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
@@ -470,22 +490,39 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
             in_dim = H;
         }
-        // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
-        HALO_TRY(halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f, 0,
-                               0, 0, nullptr, stream));
-        // dW_ih[4H,in] = dG^T * in
-        HALO_TRY(halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
-                               nullptr, 0, 0.f, 0, 0, 0, nullptr, stream));
+        const bool need_din = (l > 0) || dx;
+        float *din_out = l > 0 ? din : dx;
+        const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
+                                              offset, offset_dev);
+        if (halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64) {
+            // every operand is split/tiled once; transposes are absorbed by the prep pass
+            HALO_TRY(halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, st));     // dG^T  [4H][TB]
+            HALO_TRY(halo_prep_tiles(lb.h, H, T * B, H, 1, img_hT, st));                 // h_prev^T [H][TB]
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, st));
+            HALO_TRY(halo_prep_tiles(in, in_dim, T * B, in_dim, 1, img_inT, st));        // in^T [in][TB]
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
+                                            nullptr, st));
+            if (need_din) {
+                HALO_TRY(halo_prep_tiles(lb.gates, T * B, 4 * H, 4 * H, 0, img_g, st));           // dG [TB][4H]
+                HALO_TRY(halo_prep_tiles(w_ih[l], in_dim, 4 * H, in_dim, 1, img_wT, st));         // W_ih^T [in][4H]
+                HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
+                                                &ddrop, st));
+            }
+        } else {
+            // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
+            HALO_TRY(halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f,
+                                   0, 0, 0, nullptr, stream));
+            // dW_ih[4H,in] = dG^T * in
+            HALO_TRY(halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
+                                   nullptr, 0, 0.f, 0, 0, 0, nullptr, stream));
+            // gradient w.r.t. the layer's input; for l > 0 with layer l-1's dropout mask folded in
+            if (need_din)
+                HALO_TRY(halo_gemm_f32(1, 0, T * B, in_dim, 4 * H, lb.gates, 4 * H, w_ih[l], in_dim, din_out, in_dim,
+                                       nullptr, nullptr, 0, l > 0 ? p_drop : 0.f, seed,
+                                       HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0), offset, offset_dev, stream));
+        }
         HALO_TRY(halo_colsum(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], stream));
         HALO_TRY(copy_d2d(db_hh[l], db_ih[l], (size_t)4 * H, st));
-        if (l > 0) {
-            // gradient w.r.t. the (dropped) output of layer l-1, with that layer's dropout mask folded in
-            HALO_TRY(halo_gemm_f32(1, 0, T * B, H, 4 * H, lb.gates, 4 * H, w_ih[l], H, din, H, nullptr, nullptr, 0,
-                                   p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l - 1), offset, offset_dev, stream));
-        } else if (dx) {
-            HALO_TRY(halo_gemm_f32(1, 0, T * B, in0, 4 * H, lb.gates, 4 * H, w_ih[0], in0, dx, in0, nullptr, nullptr, 0,
-                                   0.f, 0, 0, 0, nullptr, stream));
-        }
     }
     return HALO_OK;
 }

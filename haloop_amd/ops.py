@@ -100,7 +100,7 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     if y is None:
         y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
         y_strides = (B * H, H)
-    reserve = torch.empty(lib().halo_lstm_reserve_bytes(T, B, H, L) // 4, device=dev, dtype=torch.float32)
+    reserve = torch.empty((lib().halo_lstm_reserve_bytes(T, B, in0, H, L) + 3) // 4, device=dev, dtype=torch.float32)
     hn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
     cn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
     if h0 is not None:
@@ -127,7 +127,7 @@ def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=Non
             'db_ih': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
             'db_hh': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
         }
-    ws = torch.empty(lib().halo_lstm_bwd_workspace_bytes(T, B, in0, H, L) // 4, device=dev, dtype=torch.float32)
+    ws = torch.empty((lib().halo_lstm_bwd_workspace_bytes(T, B, in0, H, L) + 3) // 4, device=dev, dtype=torch.float32)
     dx = torch.empty(T, B, in0, device=dev, dtype=torch.float32) if want_dx else None
     a_ih, a_hh = ptr_array(w_ih), ptr_array(w_hh)
     g_ih, g_hh = ptr_array(grads['dw_ih']), ptr_array(grads['dw_hh'])

@@ -76,6 +76,7 @@ class LstmCtcTrainer:
         self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip_grad_norm
         self.flat = FlatParams(encoder, recognizer)
         dev = self.flat.params.device
+        _lib.lend_scratch(device=dev)                      # split-K slabs for the under-filled GEMMs
         self.device = dev
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.counter = torch.zeros(1, device=dev, dtype=torch.int32)     # device-side step counter (dropout offset)

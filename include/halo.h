@@ -40,6 +40,23 @@ const char *halo_strerror(int code);
 /* Device sanity for the loader: returns HALO_OK and fills arch (e.g. "gfx950") and CU count. */
 int halo_device_info(int device, char *arch, int arch_len, int *cu_count);
 
+/* Arithmetic of the large LSTM GEMMs (input projections, weight/input gradients):
+ *   HALO_MATH_F32     exact-f32 MFMA (default)
+ *   HALO_MATH_BF16X3  operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
+ *                     (~2^-16 relative error per product; 5.3x the f32 matrix rate)
+ * Process-wide; set it before the first call / graph capture. */
+#define HALO_MATH_F32 0
+#define HALO_MATH_BF16X3 1
+int halo_set_math_mode(int mode);
+int halo_get_math_mode(void);
+
+/* Optional scratch for split-K partial sums.  The library never allocates: the caller may lend it
+ * one persistent device buffer (16-byte aligned; 64 MiB is plenty for this model).  With it, GEMMs
+ * whose output has too few tiles to fill 256 CUs are split along K into slabs that a second launch
+ * sums in a fixed order (bitwise reproducible); without it they run unsplit.  Calls that use the
+ * scratch must be ordered on one stream.  Pass NULL to withdraw it. */
+int halo_set_scratch(void *device_ptr, size_t bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Dropout stream.  Philox4x32-10, counter = (lo32(e>>2), hi32(e>>2), stream_id, offset),
  * key = seed, value = out[e&3], keep iff value >= uint32(p*2^32), scale 1/(1-p).
@@ -104,7 +121,7 @@ int halo_subsample_bwd(const float *dy, const float *y, const float *col, float 
  *   reserve: halo_lstm_reserve_bytes(); holds per layer h[T+1,B,H], c[T+1,B,H], gates[T,B,4H],
  *   dropped output [T,B,H]; consumed (overwritten with gate gradients) by halo_lstm_bwd.
  * ------------------------------------------------------------------------------------------ */
-size_t halo_lstm_reserve_bytes(int T, int B, int H, int L);
+size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L);
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L);
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh,
                   const float *const *b_ih, const float *const *b_hh, const float *h0, const float *c0,

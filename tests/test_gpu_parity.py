@@ -21,6 +21,7 @@ def hal():
     import haloop_amd
     from haloop_amd import _lib, ops, functional, rnn, recognizer, ctc, beam
     _lib.lib()           # raises if libhalo.so is missing: there is no fallback to test
+    _lib.lend_scratch()  # exercise the split-K path of the under-filled GEMMs
     return dict(ops=ops, F=functional, rnn=rnn, recognizer=recognizer, ctc=ctc, beam=beam, lib=_lib)
 
 
@@ -252,8 +253,18 @@ def test_tiny_model_matches_reference(hal, name):
     assert [h.tolist() for h in hyps.unbind()] == _unpad(g['hyps'], g['hlen'])
 
 
-def test_lc2x1024_matches_reference(hal):
-    """BASELINE config 1 shapes: 2-layer H=1024, 80x80 mel, B=4, V=32 against the reference's numbers."""
+@pytest.fixture
+def math_mode(request, hal):
+    prev = hal['lib'].get_math_mode()
+    hal['lib'].set_math_mode(request.param)
+    yield request.param
+    hal['lib'].set_math_mode(prev)
+
+
+@pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+def test_lc2x1024_matches_reference(hal, math_mode):
+    """BASELINE config 1 shapes: 2-layer H=1024, 80x80 mel, B=4, V=32 against the reference's numbers.
+    Both arithmetic modes must meet the fp32-exact tolerances (bf16x3 keeps ~16 bits per operand)."""
     from oracle import cpu_ref
     g = load_golden('g1_lc2x1024')
     c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
