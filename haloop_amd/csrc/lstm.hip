@@ -27,14 +27,42 @@ namespace {
 
 enum YMode { Y_NONE = 0, Y_PLAIN = 1, Y_RELU = 2, Y_DROPOUT = 3 };
 
-constexpr int CHUNK = 4;   // k-blocks (of 16) per register stage
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void load_chunk(f32x4 (&a)[CHUNK], f32x4 (&w)[CHUNK], const float *ap, const float *bp,
-                                           int blk0) {
+// ---- packed operand images --------------------------------------------------------------------
+// F32 format : k-block = 16,  block = [64 lanes][4 f32]            = 1 KiB, feeds 4 x mfma_f32_16x16x4_f32
+// X3  format : k-block = 32,  block = [hi|lo][64 lanes][8 bf16]    = 2 KiB, feeds 3 x mfma_f32_16x16x32_bf16
+//              (x ~ hi + lo, product = lo*hi' + hi*lo' + hi*hi', fp32 accumulate: see gemm_bf16x3.hip)
+// Lane l of a block holds row (l & 15) of the 16-row tile and the k-group (l >> 4).
+template <bool X3>
+struct Packed {
+    static constexpr int KB = X3 ? 32 : 16;            // k per block
+    static constexpr int BLOCK_BYTES = X3 ? 2048 : 1024;
+    // store one element (tile row i, absolute k) of tile `tile` whose K extent is nk
+    __device__ static __forceinline__ void store(void *img, int tile, int nk, int i, int k, float v) {
+        const int blk = k / KB, kk = k % KB;
+        char *base = (char *)img + ((long)tile * (nk / KB) + blk) * BLOCK_BYTES;
+        if (X3) {
+            const int lane = (kk >> 3) * 16 + i, e = kk & 7;
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            reinterpret_cast<__bf16 *>(base)[lane * 8 + e] = hi;
+            reinterpret_cast<__bf16 *>(base + 1024)[lane * 8 + e] = lo;
+        } else {
+            const int lane = (kk >> 2) * 16 + i, e = kk & 3;
+            reinterpret_cast<float *>(base)[lane * 4 + e] = v;
+        }
+    }
+};
+
+constexpr int CHUNK = 4;    // F32: k-blocks per register stage
+constexpr int CHUNK3 = 2;   // X3:  k-blocks per register stage (4 x 16 B per lane and block)
+
+__device__ __forceinline__ void load_chunk(f32x4 (&a)[CHUNK], f32x4 (&w)[CHUNK], const char *ap, const char *bp, int blk0) {
 #pragma unroll
     for (int i = 0; i < CHUNK; ++i) {
-        a[i] = *reinterpret_cast<const f32x4 *>(ap + (long)(blk0 + i) * 256);
-        w[i] = *reinterpret_cast<const f32x4 *>(bp + (long)(blk0 + i) * 256);
+        a[i] = *reinterpret_cast<const f32x4 *>(ap + (long)(blk0 + i) * 1024);
+        w[i] = *reinterpret_cast<const f32x4 *>(bp + (long)(blk0 + i) * 1024);
     }
 }
 
@@ -49,38 +77,85 @@ __device__ __forceinline__ void mma_chunk(const f32x4 (&a)[CHUNK], const f32x4 (
     }
 }
 
-// sum over k-blocks [0, nblk) of A-block x B-block; ap/bp point at this lane's float4 of block 0
-__device__ __forceinline__ f32x4 packed_dot(const float *ap, const float *bp, int nblk) {
+struct Frag3 {
+    bf16x8 ah, al, wh, wl;
+};
+
+__device__ __forceinline__ void load_chunk3(Frag3 (&f)[CHUNK3], const char *ap, const char *bp, int blk0) {
+#pragma unroll
+    for (int i = 0; i < CHUNK3; ++i) {
+        const char *a = ap + (long)(blk0 + i) * 2048, *w = bp + (long)(blk0 + i) * 2048;
+        f[i].ah = *reinterpret_cast<const bf16x8 *>(a);
+        f[i].al = *reinterpret_cast<const bf16x8 *>(a + 1024);
+        f[i].wh = *reinterpret_cast<const bf16x8 *>(w);
+        f[i].wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
+    }
+}
+
+__device__ __forceinline__ void mma_chunk3(const Frag3 (&f)[CHUNK3], f32x4 &acc0, f32x4 &acc1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].al, f[0].wh, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].al, f[1].wh, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].ah, f[0].wl, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].ah, f[1].wl, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].ah, f[0].wh, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].ah, f[1].wh, acc1, 0, 0, 0);
+}
+
+// sum over k-blocks [0, nblk) of A-block x B-block; ap/bp point at this lane's 16 bytes of block 0
+template <bool X3>
+__device__ __forceinline__ f32x4 packed_dot(const char *ap, const char *bp, int nblk) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (nblk % (2 * CHUNK) == 0) {
-        // two register stages, branch-free so that hipcc can keep the next stage's loads in flight
-        // behind a counted vmcnt while the MFMAs of the current stage run
-        f32x4 a0[CHUNK], w0[CHUNK], a1[CHUNK], w1[CHUNK];
-        load_chunk(a0, w0, ap, bp, 0);
-        for (int c = 0; c < nblk; c += 2 * CHUNK) {
-            load_chunk(a1, w1, ap, bp, c + CHUNK);
-            mma_chunk(a0, w0, acc0, acc1);
-            load_chunk(a0, w0, ap, bp, min(c + 2 * CHUNK, nblk - CHUNK));   // last pass: harmless re-read
-            mma_chunk(a1, w1, acc0, acc1);
+    if (X3) {
+        if (nblk % (2 * CHUNK3) == 0) {
+            Frag3 f0[CHUNK3], f1[CHUNK3];
+            load_chunk3(f0, ap, bp, 0);
+            for (int c = 0; c < nblk; c += 2 * CHUNK3) {
+                load_chunk3(f1, ap, bp, c + CHUNK3);
+                mma_chunk3(f0, acc0, acc1);
+                load_chunk3(f0, ap, bp, min(c + 2 * CHUNK3, nblk - CHUNK3));   // last pass: harmless re-read
+                mma_chunk3(f1, acc0, acc1);
+            }
+        } else {
+            for (int blk = 0; blk < nblk; ++blk) {
+                const char *a = ap + (long)blk * 2048, *w = bp + (long)blk * 2048;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(a), al = *reinterpret_cast<const bf16x8 *>(a + 1024);
+                const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(w), wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc0, 0, 0, 0);
+            }
         }
     } else {
-        for (int blk = 0; blk < nblk; ++blk) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (long)blk * 256);
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + (long)blk * 256);
+        if (nblk % (2 * CHUNK) == 0) {
+            // two register stages, branch-free so that hipcc can keep the next stage's loads in flight
+            // behind a counted vmcnt while the MFMAs of the current stage run
+            f32x4 a0[CHUNK], w0[CHUNK], a1[CHUNK], w1[CHUNK];
+            load_chunk(a0, w0, ap, bp, 0);
+            for (int c = 0; c < nblk; c += 2 * CHUNK) {
+                load_chunk(a1, w1, ap, bp, c + CHUNK);
+                mma_chunk(a0, w0, acc0, acc1);
+                load_chunk(a0, w0, ap, bp, min(c + 2 * CHUNK, nblk - CHUNK));
+                mma_chunk(a1, w1, acc0, acc1);
+            }
+        } else {
+            for (int blk = 0; blk < nblk; ++blk) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (long)blk * 1024);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + (long)blk * 1024);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[m], acc0, 0, 0, 0);
+                for (int m = 0; m < 4; ++m) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[m], acc0, 0, 0, 0);
+            }
         }
     }
     return acc0 + acc1;
 }
 
 struct StepFwdArgs {
-    const float *hp_prev; // packed h_{t-1}  [BT/16][H/16][64][4]
+    const void *hp_prev;  // packed h_{t-1}  [BT/16][H/KB] blocks
     const float *cprev;   // [B,H]
-    const float *wp;      // packed W_hh     [H/16][4][H/16][64][4]
+    const void *wp;       // packed W_hh     [H/16][4][H/KB] blocks
     float *gates;         // [B,4H] in: x W_ih^T + b ; out: activated i,f,g,o
     float *hout;          // [B,H] row-major h_t
-    float *hp_out;        // packed h_t
+    void *hp_out;         // packed h_t
     float *cout;          // [B,H]
     float *y;             // optional second output of h (strided)
     long y_stride_b;
@@ -90,20 +165,32 @@ struct StepFwdArgs {
     int B, H;
 };
 
-template <int KS>
+template <int KS, bool X3>
 __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdArgs p) {
     constexpr int NW = 4 * KS;
+    using PK = Packed<X3>;
     __shared__ float red[NW][256];
     const int jt = blockIdx.x, bt = blockIdx.y;
     const int j0 = jt * 16, b0 = bt * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gate = wave & 3, ks = wave >> 2;
-    const int H = p.H, nkb = H >> 4;
+    const int H = p.H, nkb = H / PK::KB;
     const int nblk = nkb / KS;
 
-    const float *ap = p.hp_prev + ((long)bt * nkb + ks * nblk) * 256 + lane * 4;
-    const float *bp = p.wp + (((long)jt * 4 + gate) * nkb + ks * nblk) * 256 + lane * 4;
-    const f32x4 acc = packed_dot(ap, bp, nblk);
+    // the cell update's own operands are requested first so that they arrive under the MFMA loop
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int b = b0 + i;
+    const bool cell = threadIdx.x < 256 && b < p.B;
+    float gin[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gin[g] = p.gates[(long)b * 4 * H + (long)g * H + j0 + j];
+        cprev = p.cprev[(long)b * H + j0 + j];
+    }
+
+    const char *ap = (const char *)p.hp_prev + ((long)bt * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
+    const char *bp = (const char *)p.wp + (((long)jt * 4 + gate) * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
+    const f32x4 acc = packed_dot<X3>(ap, bp, nblk);
     // D layout: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch)
     {
         const int r = lane & 15, q = lane >> 4;
@@ -113,21 +200,19 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
     __syncthreads();
 
     if (threadIdx.x < 256) {
-        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
-        const int b = b0 + i;
         float h = 0.f;
-        if (b < p.B) {
+        if (cell) {
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < KS; ++k) s += red[k * 4 + g][threadIdx.x];
-                pre[g] = s + p.gates[(long)b * 4 * H + (long)g * H + j0 + j];
+                pre[g] = s + gin[g];
             }
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
             const long e = (long)b * H + j0 + j;
-            const float c = fg * p.cprev[e] + ig * gg;
+            const float c = fg * cprev + ig * gg;
             h = og * tanhf(c);
             float *gp = p.gates + (long)b * 4 * H + j0 + j;
             gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
@@ -140,16 +225,15 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
                 p.y[(long)b * p.y_stride_b + j0 + j] = v;
             }
         }
-        // packed copy for the next step: k-block = this hidden tile, lane = (j>>2)*16 + i, elem j&3
-        p.hp_out[((long)bt * nkb + jt) * 256 + ((j >> 2) * 16 + i) * 4 + (j & 3)] = h;
+        PK::store(p.hp_out, bt, H, i, j0 + j, h);      // packed copy for the next step (rows >= B: zeros)
     }
 }
 
 struct StepBwdArgs {
-    const float *dgp_next; // packed gate gradients of step t+1 [BT/16][4H/16][64][4], or NULL at t = T-1
-    const float *wpT;      // packed W_hh^T  [H/16][4H/16][64][4]
+    const void *dgp_next;  // packed gate gradients of step t+1 [BT/16][4H/KB] blocks, or NULL at t = T-1
+    const void *wpT;       // packed W_hh^T  [H/16][4H/KB] blocks
     float *gates;          // [B,4H] in: activated gates of step t ; out: gradients w.r.t. pre-activations
-    float *dgp_out;        // packed copy of the gate gradients written here
+    void *dgp_out;         // packed copy of the gate gradients written here
     const float *c;        // [B,H] c_t
     const float *cprev;    // [B,H] c_{t-1}
     float *dc;             // [B,H] carry, in/out
@@ -162,112 +246,121 @@ struct StepBwdArgs {
     int B, H;
 };
 
-template <int NW>
+template <int NW, bool X3>
 __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArgs p) {
+    using PK = Packed<X3>;
     __shared__ float red[NW][256];
     const int jt = blockIdx.x, bt = blockIdx.y;
     const int j0 = jt * 16, b0 = bt * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int H = p.H, K = 4 * H, nkb4 = K >> 4;
+    const int H = p.H, K = 4 * H, nkb4 = K / PK::KB;
+
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int b = b0 + i;
+    const bool cell = threadIdx.x < 256 && b < p.B;
+    const long e = (long)b * H + j0 + j;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f, cprev = 0.f, dyv = 0.f, dcin = 0.f, dh0 = 0.f;
+    if (cell) {     // requested before the MFMA loop, consumed after it
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = p.gates[(long)b * K + (long)g * H + j0 + j];
+        c = p.c[e];
+        cprev = p.cprev[e];
+        if (p.dy) dyv = p.dy[(long)b * p.dy_stride_b + j0 + j];
+        dcin = p.first ? (p.dcinit ? p.dcinit[e] : 0.f) : p.dc[e];
+        if (p.dhinit) dh0 = p.dhinit[e];
+    }
 
     if (p.dgp_next) {
         const int nblk = nkb4 / NW;
-        const float *ap = p.dgp_next + ((long)bt * nkb4 + wave * nblk) * 256 + lane * 4;
-        const float *bp = p.wpT + ((long)jt * nkb4 + wave * nblk) * 256 + lane * 4;
-        const f32x4 acc = packed_dot(ap, bp, nblk);
+        const char *ap = (const char *)p.dgp_next + ((long)bt * nkb4 + wave * nblk) * PK::BLOCK_BYTES + lane * 16;
+        const char *bp = (const char *)p.wpT + ((long)jt * nkb4 + wave * nblk) * PK::BLOCK_BYTES + lane * 16;
+        const f32x4 acc = packed_dot<X3>(ap, bp, nblk);
         const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
+        for (int e2 = 0; e2 < 4; ++e2) red[wave][(4 * q + e2) * 16 + r] = acc[e2];
     }
     __syncthreads();
 
     if (threadIdx.x < 256) {
-        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
-        const int b = b0 + i;
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
-        if (b < p.B) {
-            const long e = (long)b * H + j0 + j;
-            float dh = 0.f;
+        if (cell) {
+            float dh = dh0;
             if (p.dgp_next) {
 #pragma unroll
                 for (int k = 0; k < NW; ++k) dh += red[k][threadIdx.x];
             }
-            if (p.dhinit) dh += p.dhinit[e];
-            float *gp = p.gates + (long)b * K + j0 + j;
-            const float ig = gp[0], fg = gp[H], gg = gp[2 * (long)H], og = gp[3 * (long)H];
-            const float c = p.c[e];
+            const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
             const float tc = tanhf(c);
             if (p.dy) {
-                float d = p.dy[(long)b * p.dy_stride_b + j0 + j];
+                float d = dyv;
                 if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
                 dh += d;
             }
-            float dcc = p.first ? (p.dcinit ? p.dcinit[e] : 0.f) : p.dc[e];
-            dcc += dh * og * (1.f - tc * tc);
+            float dcc = dcin + dh * og * (1.f - tc * tc);
             const float d_o = dh * tc;
-            const float d_i = dcc * gg, d_f = dcc * p.cprev[e], d_g = dcc * ig;
+            const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
             p.dc[e] = dcc * fg;
             dg[0] = d_i * ig * (1.f - ig);
             dg[1] = d_f * fg * (1.f - fg);
             dg[2] = d_g * (1.f - gg * gg);
             dg[3] = d_o * og * (1.f - og);
+            float *gp = p.gates + (long)b * K + j0 + j;
             gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
         }
-        const int nkb = H >> 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            p.dgp_out[((long)bt * nkb4 + g * nkb + jt) * 256 + ((j >> 2) * 16 + i) * 4 + (j & 3)] = dg[g];
+        for (int g = 0; g < 4; ++g) PK::store(p.dgp_out, bt, K, i, g * H + j0 + j, dg[g]);
     }
 }
 
-// wp[jt][g][kb][lane][e] = W[g*H + jt*16 + (lane&15)][kb*16 + 4*(lane>>4) + e]
-__global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__ w, float *__restrict__ wp, int H) {
-    const int nkb = H >> 4;
-    const long total = (long)4 * H * H / 4;     // float4 units
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+// ---- pack kernels: one thread per (block, lane) ------------------------------------------------
+// logical operand X[row][k]; element (row, k) of tile `tile` (16 rows) goes through Packed<X3>::store's map.
+// wp  : tile = (jt*4 + g), row r -> W[g*H + jt*16 + r][k]            (k over H)
+// wpT : tile = jt,         row r -> W[k][jt*16 + r]                  (k over 4H)
+// rows: tile = bt,         row r -> x[bt*16 + r][k] (0 beyond B)     (k over W)
+template <bool X3, int MODE>   // MODE 0: wp, 1: wpT, 2: rows
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src, void *__restrict__ dst, int H, int B,
+                                                   int Kdim, long units) {
+    using PK = Packed<X3>;
+    constexpr int EPL = X3 ? 8 : 4;            // elements per lane and block
+    const int nkb = Kdim / PK::KB;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
         const int lane = (int)(u & 63);
         long blk = u >> 6;
-        const int kb = (int)(blk % nkb); blk /= nkb;
-        const int g = (int)(blk & 3);
-        const int jt = (int)(blk >> 2);
-        const long row = (long)g * H + jt * 16 + (lane & 15);
-        const int k = kb * 16 + 4 * (lane >> 4);
-        *reinterpret_cast<f32x4 *>(wp + u * 4) = *reinterpret_cast<const f32x4 *>(w + row * H + k);
-    }
-}
-
-// wpT[jt][kb][lane][e] = W[kb*16 + 4*(lane>>4) + e][jt*16 + (lane&15)],  kb over the 4H rows of W
-__global__ __launch_bounds__(256) void pack_whhT_kernel(const float *__restrict__ w, float *__restrict__ wpT, int H) {
-    const int nkb4 = (4 * H) >> 4;
-    const long total = (long)4 * H * H / 4;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
-        const int lane = (int)(u & 63);
-        long blk = u >> 6;
-        const int kb = (int)(blk % nkb4);
-        const int jt = (int)(blk / nkb4);
-        const long row = (long)kb * 16 + 4 * (lane >> 4);
-        const int col = jt * 16 + (lane & 15);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = w[(row + e) * H + col];
-        *reinterpret_cast<f32x4 *>(wpT + u * 4) = v;
-    }
-}
-
-// packed[bt][kb][lane][e] = x[bt*16 + (lane&15)][kb*16 + 4*(lane>>4) + e]  (rows >= B -> 0); x NULL -> zeros
-__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ x, float *__restrict__ xp, int B, int W) {
-    const int nkb = W >> 4;
-    const int BT = (B + 15) / 16;
-    const long total = (long)BT * 16 * W / 4;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
-        const int lane = (int)(u & 63);
-        const long blk = u >> 6;
         const int kb = (int)(blk % nkb);
-        const int bt = (int)(blk / nkb);
-        const int b = bt * 16 + (lane & 15);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (x && b < B) v = *reinterpret_cast<const f32x4 *>(x + (long)b * W + kb * 16 + 4 * (lane >> 4));
-        *reinterpret_cast<f32x4 *>(xp + u * 4) = v;
+        const int tile = (int)(blk / nkb);
+        const int r = lane & 15, k0 = kb * PK::KB + (lane >> 4) * EPL;
+        float x[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            float v = 0.f;
+            if (MODE == 0) {
+                const int g = tile & 3, jt = tile >> 2;
+                v = src[((long)g * H + jt * 16 + r) * H + k0 + e];
+            } else if (MODE == 1) {
+                v = src[(long)(k0 + e) * H + tile * 16 + r];
+            } else {
+                const int bb = tile * 16 + r;
+                if (src && bb < B) v = src[(long)bb * Kdim + k0 + e];
+            }
+            x[e] = v;
+        }
+        char *base = (char *)dst + blk * PK::BLOCK_BYTES;
+        if (X3) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hh = (__bf16)x[e];
+                hi[e] = hh;
+                lo[e] = (__bf16)(x[e] - (float)hh);
+            }
+            *reinterpret_cast<bf16x8 *>(base + lane * 16) = hi;
+            *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
+        } else {
+            f32x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = x[e];
+            *reinterpret_cast<f32x4 *>(base + lane * 16) = v4;
+        }
     }
 }
 
@@ -293,26 +386,54 @@ inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
     return lb;
 }
 
-inline int pick_fwd_ks(int H) { return (H % 64 == 0) ? 4 : (H % 32 == 0) ? 2 : 1; }
-inline int pick_bwd_nw(int H) { return (H % 64 == 0) ? 16 : (H % 32 == 0) ? 8 : 4; }
+inline bool use_x3(int H) { return halo_math_mode() == HALO_MATH_BF16X3 && H % 32 == 0; }
 
-int launch_step_fwd(const StepFwdArgs &a, hipStream_t st) {
+// waves = (gate, k-slice): the slice count must divide the number of k-blocks
+inline int pick_fwd_ks(int H, bool x3) {
+    const int nkb = H / (x3 ? 32 : 16);
+    return (nkb % 4 == 0) ? 4 : (nkb % 2 == 0) ? 2 : 1;
+}
+inline int pick_bwd_nw(int H, bool x3) {
+    const int nkb4 = 4 * H / (x3 ? 32 : 16);
+    return (nkb4 % 16 == 0) ? 16 : (nkb4 % 8 == 0) ? 8 : 4;
+}
+
+template <bool X3>
+int launch_step_fwd_t(const StepFwdArgs &a, hipStream_t st) {
     dim3 grid(a.H / 16, (a.B + 15) / 16);
-    switch (pick_fwd_ks(a.H)) {
-        case 4: hipLaunchKernelGGL(lstm_step_fwd_kernel<4>, grid, dim3(1024), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(256), 0, st, a); break;
+    switch (pick_fwd_ks(a.H, X3)) {
+        case 4: hipLaunchKernelGGL((lstm_step_fwd_kernel<4, X3>), grid, dim3(1024), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((lstm_step_fwd_kernel<2, X3>), grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((lstm_step_fwd_kernel<1, X3>), grid, dim3(256), 0, st, a); break;
     }
     return halo_launch_status();
 }
+int launch_step_fwd(const StepFwdArgs &a, bool x3, hipStream_t st) {
+    return x3 ? launch_step_fwd_t<true>(a, st) : launch_step_fwd_t<false>(a, st);
+}
 
-int launch_step_bwd(const StepBwdArgs &a, hipStream_t st) {
+template <bool X3>
+int launch_step_bwd_t(const StepBwdArgs &a, hipStream_t st) {
     dim3 grid(a.H / 16, (a.B + 15) / 16);
-    switch (pick_bwd_nw(a.H)) {
-        case 16: hipLaunchKernelGGL(lstm_step_bwd_kernel<16>, grid, dim3(1024), 0, st, a); break;
-        case 8: hipLaunchKernelGGL(lstm_step_bwd_kernel<8>, grid, dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL(lstm_step_bwd_kernel<4>, grid, dim3(256), 0, st, a); break;
+    switch (pick_bwd_nw(a.H, X3)) {
+        case 16: hipLaunchKernelGGL((lstm_step_bwd_kernel<16, X3>), grid, dim3(1024), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((lstm_step_bwd_kernel<8, X3>), grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((lstm_step_bwd_kernel<4, X3>), grid, dim3(256), 0, st, a); break;
     }
+    return halo_launch_status();
+}
+int launch_step_bwd(const StepBwdArgs &a, bool x3, hipStream_t st) {
+    return x3 ? launch_step_bwd_t<true>(a, st) : launch_step_bwd_t<false>(a, st);
+}
+
+// MODE 0: W_hh for the forward, 1: W_hh^T for the backward, 2: row-major [B,W] rows (initial state)
+template <int MODE>
+int launch_pack(const float *src, void *dst, int H, int B, int Kdim, int tiles, bool x3, hipStream_t st) {
+    const long units = (long)tiles * (Kdim / (x3 ? 32 : 16)) * 64;
+    long g = (units + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (x3) hipLaunchKernelGGL((pack_kernel<true, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units);
+    else hipLaunchKernelGGL((pack_kernel<false, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units);
     return halo_launch_status();
 }
 
@@ -363,6 +484,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PH = bt16(B) * H;
     float *wp = reserve;
+    const bool x3 = use_x3(H);
     const int kin = in0 > H ? in0 : H;
     char *img_in = (char *)(reserve + (size_t)4 * H * H + (size_t)L * layer_floats(T, B, H));
     char *img_w = img_in + halo_tiled_image_bytes(T * B, kin);
@@ -389,13 +511,11 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
                                    b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
         }
-        hipLaunchKernelGGL(pack_whh_kernel, dim3(pack_grid((size_t)H * H)), dim3(256), 0, st, w_hh[l], wp, H);
-        HALO_TRY(halo_launch_status());
+        HALO_TRY(launch_pack<0>(w_hh[l], wp, H, B, H, (H / 16) * 4, x3, st));
         const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
         if (h0l) HALO_TRY(copy_d2d(lb.h, h0l, BH, st));
         else HALO_TRY(halo_fill(lb.h, BH, 0.f, st));
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_grid(PH / 4)), dim3(256), 0, st, h0l, lb.hp, B, H);
-        HALO_TRY(halo_launch_status());
+        HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st));
         if (c0) HALO_TRY(copy_d2d(lb.c, c0 + (size_t)l * BH, BH, st));
         else HALO_TRY(halo_fill(lb.c, BH, 0.f, st));
         const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
@@ -422,7 +542,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             } else {
                 a.y = nullptr; a.y_stride_b = 0; a.y_mode = Y_NONE;
             }
-            HALO_TRY(launch_step_fwd(a, st));
+            HALO_TRY(launch_step_fwd(a, x3, st));
         }
         if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
         if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
@@ -441,6 +561,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     if (H % 16 != 0) return HALO_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H;
+    const bool x3 = use_x3(H);
     float *wpT = workspace;
     float *dcarry = wpT + (size_t)H * 4 * H;
     float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
@@ -455,8 +576,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
-        hipLaunchKernelGGL(pack_whhT_kernel, dim3(pack_grid((size_t)H * H)), dim3(256), 0, st, w_hh[l], wpT, H);
-        HALO_TRY(halo_launch_status());
+        HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
         for (int t = T - 1; t >= 0; --t) {
             StepBwdArgs a;
             a.dgp_next = (t == T - 1) ? nullptr : dgp + (size_t)((t + 1) & 1) * PG;
@@ -479,7 +599,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.dhinit = (t == T - 1 && dhn) ? dhn + (size_t)l * BH : nullptr;
             a.dcinit = (t == T - 1 && dcn) ? dcn + (size_t)l * BH : nullptr;
             a.B = B; a.H = H;
-            HALO_TRY(launch_step_bwd(a, st));
+            HALO_TRY(launch_step_bwd(a, x3, st));
         }
         // parameter gradients over all frames at once
         const float *in;

@@ -229,8 +229,20 @@ def _load_modules(hal, g, F_, C, H, L, V):
     return enc.to(DEV), rec.to(DEV)
 
 
+@pytest.fixture
+def math_mode(request, hal):
+    prev = hal['lib'].get_math_mode()
+    hal['lib'].set_math_mode(request.param)
+    yield request.param
+    hal['lib'].set_math_mode(prev)
+
+
+BOTH_MODES = pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+
+
+@BOTH_MODES
 @pytest.mark.parametrize('name', ['g1_tiny_l2', 'g1_tiny_l3'])
-def test_tiny_model_matches_reference(hal, name):
+def test_tiny_model_matches_reference(hal, name, math_mode):
     g = load_golden(name)
     c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
     enc, rec = _load_modules(hal, g, c['F_'], c['C'], c['H'], c['L'], c['V'])
@@ -253,15 +265,7 @@ def test_tiny_model_matches_reference(hal, name):
     assert [h.tolist() for h in hyps.unbind()] == _unpad(g['hyps'], g['hlen'])
 
 
-@pytest.fixture
-def math_mode(request, hal):
-    prev = hal['lib'].get_math_mode()
-    hal['lib'].set_math_mode(request.param)
-    yield request.param
-    hal['lib'].set_math_mode(prev)
-
-
-@pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+@BOTH_MODES
 def test_lc2x1024_matches_reference(hal, math_mode):
     """BASELINE config 1 shapes: 2-layer H=1024, 80x80 mel, B=4, V=32 against the reference's numbers.
     Both arithmetic modes must meet the fp32-exact tolerances (bf16x3 keeps ~16 bits per operand)."""
@@ -295,7 +299,8 @@ def test_lc2x1024_matches_reference(hal, math_mode):
     assert np.array_equal(ali.cpu().numpy(), g['ali']) and np.array_equal(hlen.cpu().numpy(), g['hlen'])
 
 
-def test_training_mode_matches_oracle_with_same_masks(hal):
+@BOTH_MODES
+def test_training_mode_matches_oracle_with_same_masks(hal, math_mode):
     """Dropout on: the HIP path and the CPU restatement consume the same Philox masks."""
     from oracle import cpu_ref
     F_, C, H, L, V, B, T, S = 12, 16, 32, 3, 9, 5, 41, 4
@@ -324,7 +329,8 @@ def test_training_mode_matches_oracle_with_same_masks(hal):
         np.testing.assert_allclose(p.grad.cpu().numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
 
 
-def test_decoder_lm_matches_torch_lstm(hal):
+@BOTH_MODES
+def test_decoder_lm_matches_torch_lstm(hal, math_mode):
     """ha.rnn.Decoder surface: time-major LSTM with carried state + tied output layer."""
     V, E, L, T, N = 50, 32, 2, 9, 3
     torch.manual_seed(4)
@@ -356,8 +362,9 @@ def test_product_fails_loudly_on_cpu_tensors(hal):
 
 
 # ------------------------------------------------------------------------- the optimizer step
+@BOTH_MODES
 @pytest.mark.parametrize('use_graph', [False, True])
-def test_train_steps_match_reference(hal, use_graph):
+def test_train_steps_match_reference(hal, use_graph, math_mode):
     """Three full steps (fwd, CTC, bwd, encoder-only clip 0.1, AdamW with ha/optim.py's decay groups)
     against the reference's own run recorded in g1_train3.npz."""
     from oracle import cpu_ref
@@ -376,8 +383,11 @@ def test_train_steps_match_reference(hal, use_graph):
         np.testing.assert_allclose(loss.item(), g['losses'][step], rtol=2e-5)
         np.testing.assert_allclose(tr.grad_norm.item(), g['gnorms'][step], rtol=1e-4)
     sd = {**{'encoder.' + k: v for k, v in enc.state_dict().items()}, **{'recognizer.' + k: v for k, v in rec.state_dict().items()}}
+    # Adam normalises by sqrt(v): an element whose gradient is at noise level turns a 1e-7 gradient
+    # difference into a visible update difference (lr = 3e-3 here); split-bf16 operands add ~2^-16.
+    atol = 5e-6 if math_mode == 'f32' else 2e-5
     for k, v in sd.items():
-        np.testing.assert_allclose(v.cpu().numpy(), g['final.' + k], atol=5e-6, err_msg=k)
+        np.testing.assert_allclose(v.cpu().numpy(), g['final.' + k], atol=atol, err_msg=k)
 
 
 def test_trainer_skips_update_on_nonfinite_gradients(hal):
