@@ -6,7 +6,30 @@
 static int g_math_mode = 0;
 static void *g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
-void halo_get_scratch(void **ptr, size_t *bytes) { *ptr = g_scratch; *bytes = g_scratch_bytes; }
+static int g_scratch_slot = 0;
+// the scratch is cut in two halves so that work forked onto a side stream (slot 1) never shares
+// split-K slabs with the main stream (slot 0)
+void halo_set_scratch_slot(int slot) { g_scratch_slot = slot ? 1 : 0; }
+void halo_get_scratch(void **ptr, size_t *bytes) {
+    const size_t half = (g_scratch_bytes / 2) & ~(size_t)255;
+    *ptr = g_scratch ? (char *)g_scratch + (size_t)g_scratch_slot * half : nullptr;
+    *bytes = g_scratch ? half : 0;
+}
+
+// side stream + events for fork/join inside one C-ABI call (created once, on first use, outside capture)
+static hipStream_t g_side_stream = nullptr;
+static hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
+int halo_side_stream(hipStream_t *side, hipEvent_t *fork_ev, hipEvent_t *join_ev) {
+    if (!g_side_stream) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent
+        if (hipStreamCreateWithPriority(&g_side_stream, hipStreamNonBlocking, lo) != hipSuccess) return HALO_ELAUNCH;
+        if (hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming) != hipSuccess) return HALO_ELAUNCH;
+        if (hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) != hipSuccess) return HALO_ELAUNCH;
+    }
+    *side = g_side_stream; *fork_ev = g_fork_event; *join_ev = g_join_event;
+    return HALO_OK;
+}
 int halo_math_mode() { return g_math_mode; }
 
 extern "C" {

@@ -18,6 +18,8 @@ int halo_math_mode();   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the l
 
 // ---- caller-provided scratch (halo_set_scratch) and split-K helpers ----
 void halo_get_scratch(void **ptr, size_t *bytes);
+void halo_set_scratch_slot(int slot);
+int halo_side_stream(hipStream_t *side, hipEvent_t *fork_ev, hipEvent_t *join_ev);
 int halo_pick_ksplit(long tiles, int k_steps, long out_elems);
 int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, int ldc, const float *bias1,
                        const float *bias2, int relu, const DropoutCfg &drop, int use_drop, hipStream_t st);

@@ -20,6 +20,7 @@
 // packed copy of h_t (and of the gate gradients in the backward) is written by the previous step's
 // epilogue next to the row-major copy that the batched GEMMs consume.
 // Row-major buffers are time-major: h/c [T+1,B,H], gates [T,B,4H].
+#include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
 
@@ -562,6 +563,11 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H;
     const bool x3 = use_x3(H);
+    hipStream_t side;
+    hipEvent_t fork_ev, join_ev;
+    HALO_TRY(halo_side_stream(&side, &fork_ev, &join_ev));
+    static const bool use_side = getenv("HALO_SIDE_STREAM") && atoi(getenv("HALO_SIDE_STREAM")) != 0;
+    if (!use_side) side = st;
     float *wpT = workspace;
     float *dcarry = wpT + (size_t)H * 4 * H;
     float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
@@ -614,35 +620,51 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         float *din_out = l > 0 ? din : dx;
         const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
                                               offset, offset_dev);
-        if (halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64) {
-            // every operand is split/tiled once; transposes are absorbed by the prep pass
-            HALO_TRY(halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, st));     // dG^T  [4H][TB]
-            HALO_TRY(halo_prep_tiles(lb.h, H, T * B, H, 1, img_hT, st));                 // h_prev^T [H][TB]
-            HALO_TRY(halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, st));
-            HALO_TRY(halo_prep_tiles(in, in_dim, T * B, in_dim, 1, img_inT, st));        // in^T [in][TB]
-            HALO_TRY(halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
-                                            nullptr, st));
-            if (need_din) {
+        const bool tiled = halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64;
+        // (1) critical path, main stream: the gradient w.r.t. this layer's input feeds layer l-1's steps
+        if (need_din) {
+            if (tiled) {
                 HALO_TRY(halo_prep_tiles(lb.gates, T * B, 4 * H, 4 * H, 0, img_g, st));           // dG [TB][4H]
                 HALO_TRY(halo_prep_tiles(w_ih[l], in_dim, 4 * H, in_dim, 1, img_wT, st));         // W_ih^T [in][4H]
                 HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
                                                 &ddrop, st));
-            }
-        } else {
-            // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
-            HALO_TRY(halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f,
-                                   0, 0, 0, nullptr, stream));
-            // dW_ih[4H,in] = dG^T * in
-            HALO_TRY(halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
-                                   nullptr, 0, 0.f, 0, 0, 0, nullptr, stream));
-            // gradient w.r.t. the layer's input; for l > 0 with layer l-1's dropout mask folded in
-            if (need_din)
+            } else {
                 HALO_TRY(halo_gemm_f32(1, 0, T * B, in_dim, 4 * H, lb.gates, 4 * H, w_ih[l], in_dim, din_out, in_dim,
                                        nullptr, nullptr, 0, l > 0 ? p_drop : 0.f, seed,
                                        HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0), offset, offset_dev, stream));
+            }
         }
-        HALO_TRY(halo_colsum(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], stream));
-        HALO_TRY(copy_d2d(db_hh[l], db_ih[l], (size_t)4 * H, st));
+        // (2) off the critical path, side stream: this layer's parameter gradients run beside the next
+        //     layer's (latency-bound) step chain.  Fork after the steps, join at the end of the call.
+        if (side != st) {
+            HALO_CHECK_ARG(hipEventRecord(fork_ev, st) == hipSuccess);
+            HALO_CHECK_ARG(hipStreamWaitEvent(side, fork_ev, 0) == hipSuccess);
+        }
+        halo_set_scratch_slot(1);
+        int rc = HALO_OK;
+        if (tiled) {
+            rc = halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, side);                       // dG^T [4H][TB]
+            if (!rc) rc = halo_prep_tiles(lb.h, H, T * B, H, 1, img_hT, side);                          // h_prev^T [H][TB]
+            if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
+            if (!rc) rc = halo_prep_tiles(in, in_dim, T * B, in_dim, 1, img_inT, side);                 // in^T [in][TB]
+            if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
+                                                 nullptr, side);
+        } else {
+            // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
+            rc = halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f, 0, 0,
+                               0, nullptr, (halo_stream_t)side);
+            // dW_ih[4H,in] = dG^T * in
+            if (!rc) rc = halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
+                                        nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
+        }
+        if (!rc) rc = halo_colsum(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], (halo_stream_t)side);
+        if (!rc) rc = copy_d2d(db_hh[l], db_ih[l], (size_t)4 * H, side);
+        halo_set_scratch_slot(0);
+        if (rc) return rc;
+    }
+    if (side != st) {
+        HALO_CHECK_ARG(hipEventRecord(join_ev, side) == hipSuccess);
+        HALO_CHECK_ARG(hipStreamWaitEvent(st, join_ev, 0) == hipSuccess);
     }
     return HALO_OK;
 }
