@@ -10,6 +10,7 @@
 // The GEMM kernel therefore stages tiles with global_load_lds (16 B/lane, linear 1 KiB per wave
 // instruction, no address math, no VALU conversion in the hot loop), zero-padded at the edges so
 // the main loop has no bounds checks.  Prep also absorbs every transpose: all GEMMs become "NT".
+#include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
 
@@ -125,17 +126,46 @@ __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int
     }
 }
 
+constexpr int STAGE_BYTES = 2 * BLOCK_BYTES;    // one ring slot: A block | B block = 32 KiB
+constexpr int LOADS_PER_STAGE = 8;              // global_load_lds per thread and stage
+
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    // counted wait (the newest N LDS-DMA loads of this wave may stay in flight), then a raw barrier:
+    // __syncthreads() would drain vmcnt(0) because LDS-DMA counts as a pending LDS write
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
+// blocks that share an L2), so give each XCD a CONTIGUOUS run of output tiles (a few tile rows x all
+// tile columns): its L2 then holds the A panels it needs instead of all of A.  Bijective for any
+// count (cdna_hip_programming.md T1); placement only changes speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];       // 2 stages x (A block | B block) = 64 KiB
-    const int tile = blockIdx.x % p.ntiles, kslice = blockIdx.x / p.ntiles;
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int kslice = blockIdx.x / p.ntiles;
+    // within an XCD's contiguous run, walk the tiles in groups of 8 tile rows, column by column: the
+    // ~64 workgroups resident on one XCD then cover an 8x8 block (8 A panels + 8 B panels, in k
+    // lockstep) instead of 2 x 32, so each staged k-tile is fetched from beyond L2 once, not 4 times
+    const int tile = xcd_remap(blockIdx.x % p.ntiles, p.ntiles);
+    const int tiles_m = p.ntiles / p.tiles_n;
+    const int GM = 8;
+    const int group = tile / (GM * p.tiles_n), first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m), in_group = tile % (GM * p.tiles_n);
+    const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
     const int kt0 = kslice * p.ktper, kt1 = min(p.KT, kt0 + p.ktper);
+    const int nkt = kt1 - kt0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const char *Ablk = p.A + (long)tile_m * p.KT * BLOCK_BYTES;
-    const char *Bblk = p.B + (long)tile_n * p.KT * BLOCK_BYTES;
+    const char *Ablk = p.A + ((long)tile_m * p.KT + kt0) * BLOCK_BYTES;
+    const char *Bblk = p.B + ((long)tile_n * p.KT + kt0) * BLOCK_BYTES;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -155,38 +185,49 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             boff[i][ks] = swz_byte(wn * 64 + i * 32 + lr, ks * 2 + lh);
         }
 
-    stage_block(Ablk + (long)kt0 * BLOCK_BYTES, lds, wave, lane);
-    stage_block(Bblk + (long)kt0 * BLOCK_BYTES, lds + BLOCK_BYTES, wave, lane);
-    for (int t = kt0; t < kt1; ++t) {
-        char *cur = lds + ((t - kt0) & 1) * 2 * BLOCK_BYTES;
-        char *nxt = lds + ((t - kt0 + 1) & 1) * 2 * BLOCK_BYTES;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();            // tile t has landed for every wave; everyone is done with the other stage
-        if (t + 1 < kt1) {
-            stage_block(Ablk + (long)(t + 1) * BLOCK_BYTES, nxt, wave, lane);
-            stage_block(Bblk + (long)(t + 1) * BLOCK_BYTES, nxt + BLOCK_BYTES, wave, lane);
-        }
-        const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + BLOCK_BYTES, *bl = cur + BLOCK_BYTES + PART_BYTES;
+    // prologue: NSTAGE-1 k-tiles in flight.  Tiles past the end are clamped to the last one (a
+    // harmless re-read into a ring slot nobody reads again) so every iteration issues exactly
+    // LOADS_PER_STAGE loads and the vmcnt arithmetic stays exact.
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        const int t = min(s, nkt - 1);
+        stage_block(Ablk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES, wave, lane);
+        stage_block(Bblk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES + BLOCK_BYTES, wave, lane);
+    }
+    for (int t = 0; t < nkt; ++t) {
+        // tile t is complete once all but the newest (NSTAGE-2) stages have landed
+        wait_vm_and_barrier<(NSTAGE - 2) * LOADS_PER_STAGE>();
+        {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
+            const int tn = min(t + NSTAGE - 1, nkt - 1);
+            char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * STAGE_BYTES;
+            stage_block(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
+            stage_block(Bblk + (long)tn * BLOCK_BYTES, slot + BLOCK_BYTES, wave, lane);
+        }
+        const char *cur = lds + (t % NSTAGE) * STAGE_BYTES;
+        const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + BLOCK_BYTES, *bl = cur + BLOCK_BYTES + PART_BYTES;
+        // both k-steps' fragments are requested up front: the second set lands under the first set's MFMAs
+        bf16x8 fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fah[i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
-                fal[i] = *reinterpret_cast<const bf16x8 *>(al + aoff[i][ks]);
-                fbh[i] = *reinterpret_cast<const bf16x8 *>(bh + boff[i][ks]);
-                fbl[i] = *reinterpret_cast<const bf16x8 *>(bl + boff[i][ks]);
+                fah[ks][i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
+                fal[ks][i] = *reinterpret_cast<const bf16x8 *>(al + aoff[i][ks]);
+                fbh[ks][i] = *reinterpret_cast<const bf16x8 *>(bh + boff[i][ks]);
+                fbl[ks][i] = *reinterpret_cast<const bf16x8 *>(bl + boff[i][ks]);
             }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbl[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
                 }
-        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail loads before the workgroup retires
 
     // epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     const int m0 = tile_m * TR, n0 = tile_n * TR;
@@ -239,13 +280,17 @@ int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, 
 
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        // 64 KiB of dynamic LDS: opt in once (idempotent)
-        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                4 * BLOCK_BYTES) != hipSuccess)
+    static int nstage = 0;
+    if (!nstage) {
+        // ring depth: 2 slots = 64 KiB (two workgroups per CU), 4 slots = 128 KiB (one); opt in to the LDS size once
+        const char *e = getenv("HALO_GEMM_STAGES");
+        const int want = e ? atoi(e) : 2;
+        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
-        attr_set = true;
+        nstage = want == 4 ? 4 : 2;
     }
     TiledGemmArgs p;
     p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.bias1 = bias1; p.bias2 = bias2;
@@ -260,8 +305,38 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
     void *scratch; size_t bytes;
     halo_get_scratch(&scratch, &bytes);
     p.slab = (float *)scratch;
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 4 * BLOCK_BYTES, st, p);
+    if (nstage == 4)
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 4 * STAGE_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
     if (rc != HALO_OK || p.ksplit == 1) return rc;
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);
 }
+
+
+// ---- public entry points (include/halo.h) -----------------------------------------------------
+extern "C" {
+
+size_t halo_split_image_bytes(int rows, int k) {
+    if (rows <= 0 || k <= 0) return 0;
+    return halo_tiled_image_bytes(rows, k);
+}
+
+int halo_split_image(const float *src, int rows, int k, int ld, int src_transposed, void *image, halo_stream_t stream) {
+    HALO_CHECK_ARG(src && image && rows > 0 && k > 0);
+    HALO_CHECK_ARG(ld >= (src_transposed ? rows : k));
+    HALO_CHECK_ARG((uintptr_t)image % 16 == 0);
+    return halo_prep_tiles(src, rows, k, ld, src_transposed, image, (hipStream_t)stream);
+}
+
+int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *bias1,
+                    const float *bias2, int flags, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                    const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(a_image && b_image && C && M > 0 && N > 0 && K > 0 && ldc >= N);
+    const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, (flags & HALO_GEMM_RELU) ? 1 : 0, &d,
+                                  (hipStream_t)stream);
+}
+
+}  // extern "C"

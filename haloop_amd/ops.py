@@ -51,6 +51,25 @@ def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, 
     return out
 
 
+def split_image(x2d, transposed=False):
+    """bf16 hi/lo tiled image of logical X[rows][k]; x2d is [rows,k], or [k,rows] when ``transposed``."""
+    _f32c(x2d, 'x')
+    rows, k = (x2d.shape[1], x2d.shape[0]) if transposed else x2d.shape
+    img = torch.empty(lib().halo_split_image_bytes(rows, k), device=x2d.device, dtype=torch.uint8)
+    check(lib().halo_split_image(ptr(x2d), rows, k, x2d.shape[1], int(transposed), ptr(img), _stream()), 'halo_split_image')
+    return img
+
+
+def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0):
+    """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate)."""
+    if out is None:
+        out = torch.empty(M, N, device=a_img.device, dtype=torch.float32)
+    check(lib().halo_gemm_split(ptr(a_img), ptr(b_img), M, N, K, ptr(out), N, ptr(bias1), ptr(bias2),
+                                _lib.HALO_GEMM_RELU if relu else 0, drop.p, drop.seed, stream_id, drop.offset,
+                                drop.counter_ptr, _stream()), 'halo_gemm_split')
+    return out
+
+
 def dropout_fwd(x, drop, stream_id):
     _f32c(x, 'x')
     y = torch.empty_like(x)

@@ -91,6 +91,20 @@ int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float
                   int flags, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
                   const uint32_t *offset_dev, halo_stream_t stream);
 
+/* Split-bf16 GEMM on pre-tiled operand images (the HALO_MATH_BF16X3 path, usable on its own).
+ *   halo_split_image: logical X[rows][k] (fp32; memory [rows][k], or [k][rows] when src_transposed,
+ *     leading dimension ld) -> image of halo_split_image_bytes(rows, k) bytes holding bf16 hi/lo
+ *     parts in 128x32 tiles laid out as the MFMA fragment reads want them (zero padded).
+ *   halo_gemm_split: C[M,N] = A[M,K] * B[N,K]^T from two images (fp32 accumulate, three bf16 MFMAs
+ *     per product), epilogue as halo_gemm_f32.  An operand used by several GEMMs is split once.
+ * replaces: the same matmuls as halo_gemm_f32. */
+size_t halo_split_image_bytes(int rows, int k);
+int halo_split_image(const float *src, int rows, int k, int ld, int src_transposed, void *image,
+                     halo_stream_t stream);
+int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc,
+                    const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
+                    uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Conv1d stride-s subsample + relu + dropout.   replaces: ha/rnn.py:22-24
  *   x [B,T,F] (N,T,C contiguous, as the caller holds it before .mT), w [C,F,ks], bias [C]
