@@ -55,35 +55,40 @@ def build_model(device, seed=42):
     return enc.to(device).train(), rec.to(device).train(), (enc_p, rec_p)
 
 
-def time_dominant_kernel(device, iters=200):
-    """Average duration of one fused LSTM forward step launch (H=1024, B=64), HIP events on the launch stream."""
+def _event_ms(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1)
+        best = t if best is None else min(best, t)
+    return best
+
+
+def time_dominant_kernel(device, math, iters=200):
+    """Average duration of one fused LSTM forward step launch (H=1024, B=64): HIP events on the launch
+    stream around a 1-layer, T=`iters` halo_lstm_fwd call, minus the same call's non-step work (its
+    input-projection GEMM and operand preparation, timed on their own with the same entry points)."""
     from haloop_amd import ops
     g = torch.Generator().manual_seed(0)
     x = torch.randn(iters, B_PER_GPU, H, generator=g).to(device) * 0.1
     w = [(torch.rand(4 * H, H, generator=g) - 0.5).mul(0.06).to(device)]
     b = [torch.zeros(4 * H, device=device)]
-    for _ in range(2):
-        ops.lstm_fwd(x, w, w, b, b)
-    torch.cuda.synchronize()
-    # whole call = 1 input-projection GEMM + 2 fills + `iters` step launches; subtract the non-step part
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    e0.record()
     ops.lstm_fwd(x, w, w, b, b)
-    e1.record()
-    ops.lstm_fwd(x[:1], w, w, b, b)
-    e2.record()
     torch.cuda.synchronize()
-    full_ms, one_ms = e0.elapsed_time(e1), e1.elapsed_time(e2)
-    gemm = ops.gemm
+    full_ms = _event_ms(lambda: ops.lstm_fwd(x, w, w, b, b))
     xs = x.view(-1, H)
-    e3, e4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e3.record()
-    gemm(xs, w[0], True, True, xs.shape[0], 4 * H, H)
-    e4.record()
-    torch.cuda.synchronize()
-    gemm_ms = e3.elapsed_time(e4)
-    step_ms = max(full_ms - gemm_ms, 1e-6) / iters
-    return step_ms, one_ms
+    out = torch.empty(xs.shape[0], 4 * H, device=device)
+    if math == 'bf16x3':
+        ai, bi = ops.split_image(xs), ops.split_image(w[0])
+        other_ms = (_event_ms(lambda: ops.split_image(xs)) + _event_ms(lambda: ops.split_image(w[0])) +
+                    _event_ms(lambda: ops.gemm_split(ai, bi, xs.shape[0], 4 * H, H, out=out, bias1=b[0], bias2=b[0])))
+    else:
+        other_ms = _event_ms(lambda: ops.gemm(xs, w[0], True, True, xs.shape[0], 4 * H, H, out=out, bias1=b[0], bias2=b[0]))
+    return max(full_ms - other_ms, 1e-6) / iters
 
 
 def host_cores():
@@ -171,7 +176,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B_PER_GPU * args.steps / elapsed
-        step_ms, _ = time_dominant_kernel(device)
+        step_ms = time_dominant_kernel(device, args.math)
         kbytes = lstm_step_algorithmic_bytes(B_PER_GPU)
         achieved = kbytes / (step_ms * 1e-3) / 1e9
         traffic = None
@@ -188,7 +193,7 @@ def main():
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
                        'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math},
             'final_loss': round(loss, 5),
-            'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel<4> (H=1024, B=64)',
+            'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel (H=1024, B=64), 42 launches per step; the backward twin runs within 10%',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': kbytes, 'avg_launch_us': round(step_ms * 1e3, 3)},
