@@ -47,6 +47,8 @@ SIGNATURES = {
     'halo_colsum': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'halo_ctc_fwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'halo_ctc_bwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp]),
+    'halo_ctc_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'halo_ctc_mean_loss': (_i, [_vp, _vp, _i, _vp, _vp]),
     'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_ctc_beam_workspace_bytes': (_sz, [_i] * 4),
     'halo_ctc_beam': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
 
 // out[n] = sum_m x[m*ld + n]; block = 32 columns x 32 row slices, fixed summation order
 __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ x, int rows, int cols, int ld,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, float *__restrict__ out2) {
     __shared__ float part[32][33];
     const int lane_c = threadIdx.x & 31;
     const int c = blockIdx.x * 32 + lane_c;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 32; ++i) t += part[i][lane_c];
         out[c] = t;
+        if (out2) out2[c] = t;
     }
 }
 
@@ -118,6 +119,30 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 
 __global__ void counter_inc_kernel(uint32_t *c) { *c += 1u; }
 
+// subsampled lengths (float floor like ha/rnn.py:13-18) and the per-utterance weights of the CTC mean
+__global__ __launch_bounds__(256) void ctc_prepare_kernel(const int64_t *__restrict__ il, const int64_t *__restrict__ tl,
+                                                          int n, int ks, int stride, int pad, int64_t *__restrict__ flen,
+                                                          float *__restrict__ grad_out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float o = (float)(il[i] + 2 * pad - ks);
+        flen[i] = (int64_t)floorf(o / (float)stride + 1.0f);
+        const float t = fmaxf((float)tl[i], 1.0f);
+        grad_out[i] = 1.0f / (t * (float)n);
+    }
+}
+
+// loss = mean_n(nll[n] / max(tl[n], 1)), summed in a fixed order
+__global__ __launch_bounds__(256) void ctc_mean_loss_kernel(const float *__restrict__ nll, const int64_t *__restrict__ tl,
+                                                            int n, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += nll[i] / fmaxf((float)tl[i], 1.0f);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float *p, size_t n, float v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -133,6 +158,10 @@ inline unsigned grid_for(size_t n, unsigned per_block = 256, unsigned cap = 4096
 // ---- internal helpers used by lstm.hip --------------------------------------------------------
 int halo_transpose(const float *in, float *out, int rows, int cols, hipStream_t st) {
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    return halo_launch_status();
+}
+int halo_colsum2(const float *x, int rows, int cols, int ld, float *out, float *out2, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(1024), 0, st, x, rows, cols, ld, out, out2);
     return halo_launch_status();
 }
 int halo_fill(float *p, size_t n, float v, hipStream_t st) {
@@ -153,6 +182,20 @@ int halo_dropout_fwd(const float *x, float *y, size_t n, float p, uint64_t seed,
     const size_t n4 = (n + 3) / 4;
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, n,
                        make_dropout(p, seed, stream_id, offset, offset_dev));
+    return halo_launch_status();
+}
+
+int halo_ctc_prepare(const int64_t *input_lengths, const int64_t *target_lengths, int n, int ks, int stride, int pad,
+                     int64_t *feature_lengths, float *grad_out, halo_stream_t stream) {
+    HALO_CHECK_ARG(input_lengths && target_lengths && feature_lengths && grad_out && n > 0 && ks > 0 && stride > 0 && pad >= 0);
+    hipLaunchKernelGGL(ctc_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, input_lengths,
+                       target_lengths, n, ks, stride, pad, feature_lengths, grad_out);
+    return halo_launch_status();
+}
+
+int halo_ctc_mean_loss(const float *nll, const int64_t *target_lengths, int n, float *loss, halo_stream_t stream) {
+    HALO_CHECK_ARG(nll && target_lengths && loss && n > 0);
+    hipLaunchKernelGGL(ctc_mean_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, target_lengths, n, loss);
     return halo_launch_status();
 }
 
@@ -215,8 +258,7 @@ int halo_log_softmax_bwd(const float *dy, const float *y, float *dx, int rows, i
 
 int halo_colsum(const float *x, int rows, int cols, int ld, float *out, halo_stream_t stream) {
     HALO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols);
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(1024), 0, (hipStream_t)stream, x, rows, cols, ld, out);
-    return halo_launch_status();
+    return halo_colsum2(x, rows, cols, ld, out, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

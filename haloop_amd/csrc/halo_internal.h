@@ -6,6 +6,7 @@
 
 int halo_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);
 int halo_fill(float *p, size_t n, float v, hipStream_t st);
+int halo_colsum2(const float *x, int rows, int cols, int ld, float *out, float *out2, hipStream_t st);
 
 // ---- split-bf16 GEMM on pre-tiled operand images (gemm_bf16x3.hip) ----
 size_t halo_tiled_image_bytes(int R, int K);

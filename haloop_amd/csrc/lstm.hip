@@ -150,6 +150,88 @@ __device__ __forceinline__ f32x4 packed_dot(const char *ap, const char *bp, int 
     return acc0 + acc1;
 }
 
+// ---- forward variant with the h_{t-1} tile staged once in LDS ---------------------------------
+// The four gate waves of a k-slice read the same A blocks; staging the 16 x H tile (64 KiB at H=1024)
+// with global_load_lds and reading fragments with ds_read_b128 takes three quarters of the A traffic
+// off the vector-memory path, which is what bounds this kernel (512 KiB per CU per step otherwise).
+typedef __attribute__((address_space(3))) const char lds_cchar;
+
+constexpr int WCH = 4;   // W k-blocks per register stage in the LDS-A variant
+
+struct ATileStage {      // what to copy into LDS before the first fragment read
+    const char *src;     // this batch tile's packed blocks (global, contiguous)
+    char *dst;           // LDS
+    int pieces;          // 1 KiB pieces
+    int wave, nwaves, lane;
+    __device__ __forceinline__ void run() const {
+        for (int pc = wave; pc < pieces; pc += nwaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+};
+
+template <bool X3>
+__device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a_lds, const char *bp, int nblk) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (X3) {
+        bf16x8 wh0[WCH], wl0[WCH], wh1[WCH], wl1[WCH];
+        auto loadw = [&](bf16x8 (&wh)[WCH], bf16x8 (&wl)[WCH], int blk0) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                wh[i] = *reinterpret_cast<const bf16x8 *>(bp + (long)(blk0 + i) * 2048);
+                wl[i] = *reinterpret_cast<const bf16x8 *>(bp + (long)(blk0 + i) * 2048 + 1024);
+            }
+        };
+        auto mma = [&](const bf16x8 (&wh)[WCH], const bf16x8 (&wl)[WCH], int blk0) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                typedef __attribute__((address_space(3))) const bf16x8 lds_frag;
+                const bf16x8 ah = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 2048);
+                const bf16x8 al = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 2048 + 1024);
+                f32x4 &acc = (i & 1) ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[i], acc, 0, 0, 0);
+            }
+        };
+        stage.run();
+        loadw(wh0, wl0, 0);
+        for (int c = 0; c < nblk; c += 2 * WCH) {
+            loadw(wh1, wl1, c + WCH);
+            mma(wh0, wl0, c);
+            loadw(wh0, wl0, min(c + 2 * WCH, nblk - WCH));
+            mma(wh1, wl1, c + WCH);
+        }
+    } else {
+        f32x4 w0[WCH], w1[WCH];
+        auto loadw = [&](f32x4 (&w)[WCH], int blk0) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) w[i] = *reinterpret_cast<const f32x4 *>(bp + (long)(blk0 + i) * 1024);
+        };
+        auto mma = [&](const f32x4 (&w)[WCH], int blk0) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                typedef __attribute__((address_space(3))) const f32x4 lds_frag;
+                const f32x4 a = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 1024);
+                f32x4 &acc = (i & 1) ? acc1 : acc0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[i][m], acc, 0, 0, 0);
+            }
+        };
+        stage.run();
+        loadw(w0, 0);
+        for (int c = 0; c < nblk; c += 2 * WCH) {
+            loadw(w1, c + WCH);
+            mma(w0, c);
+            loadw(w0, min(c + 2 * WCH, nblk - WCH));
+            mma(w1, c + WCH);
+        }
+    }
+    return acc0 + acc1;
+}
+
 struct StepFwdArgs {
     const void *hp_prev;  // packed h_{t-1}  [BT/16][H/KB] blocks
     const float *cprev;   // [B,H]
@@ -166,11 +248,12 @@ struct StepFwdArgs {
     int B, H;
 };
 
-template <int KS, bool X3>
+template <int KS, bool X3, bool ALDS>
 __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdArgs p) {
     constexpr int NW = 4 * KS;
     using PK = Packed<X3>;
-    __shared__ float red[NW][256];
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];    // [red: NW*256 f32][A tile: (H/KB) blocks]
+    float (*red)[256] = reinterpret_cast<float (*)[256]>(dyn_lds);
     const int jt = blockIdx.x, bt = blockIdx.y;
     const int j0 = jt * 16, b0 = bt * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -189,9 +272,19 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
         cprev = p.cprev[(long)b * H + j0 + j];
     }
 
-    const char *ap = (const char *)p.hp_prev + ((long)bt * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
     const char *bp = (const char *)p.wp + (((long)jt * 4 + gate) * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
-    const f32x4 acc = packed_dot<X3>(ap, bp, nblk);
+    f32x4 acc;
+    if (ALDS) {
+        // stage this batch tile's packed h_{t-1} (nkb blocks, contiguous) into LDS, 1 KiB per wave instruction
+        char *a_tile = dyn_lds + NW * 256 * sizeof(float);
+        const char *a_src = (const char *)p.hp_prev + (long)bt * nkb * PK::BLOCK_BYTES;
+        const ATileStage stage = {a_src, a_tile, nkb * PK::BLOCK_BYTES / 1024, __builtin_amdgcn_readfirstlane(wave), NW, lane};
+        lds_cchar *a_lds = (lds_cchar *)(a_tile + (long)ks * nblk * PK::BLOCK_BYTES + lane * 16);
+        acc = dot_lds_a<X3>(stage, a_lds, bp, nblk);
+    } else {
+        const char *ap = (const char *)p.hp_prev + ((long)bt * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
+        acc = packed_dot<X3>(ap, bp, nblk);
+    }
     // D layout: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch)
     {
         const int r = lane & 15, q = lane >> 4;
@@ -318,9 +411,11 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArg
 // wp  : tile = (jt*4 + g), row r -> W[g*H + jt*16 + r][k]            (k over H)
 // wpT : tile = jt,         row r -> W[k][jt*16 + r]                  (k over 4H)
 // rows: tile = bt,         row r -> x[bt*16 + r][k] (0 beyond B)     (k over W)
+// MODE 2 also initialises the layer's row-major state rows: h_rm <- src (or 0), c_rm <- csrc (or 0)
 template <bool X3, int MODE>   // MODE 0: wp, 1: wpT, 2: rows
 __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src, void *__restrict__ dst, int H, int B,
-                                                   int Kdim, long units) {
+                                                   int Kdim, long units, float *__restrict__ h_rm,
+                                                   const float *__restrict__ csrc, float *__restrict__ c_rm) {
     using PK = Packed<X3>;
     constexpr int EPL = X3 ? 8 : 4;            // elements per lane and block
     const int nkb = Kdim / PK::KB;
@@ -342,6 +437,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src
             } else {
                 const int bb = tile * 16 + r;
                 if (src && bb < B) v = src[(long)bb * Kdim + k0 + e];
+                if (bb < B) {
+                    if (h_rm) h_rm[(long)bb * Kdim + k0 + e] = v;
+                    if (c_rm) c_rm[(long)bb * Kdim + k0 + e] = csrc ? csrc[(long)bb * Kdim + k0 + e] : 0.f;
+                }
             }
             x[e] = v;
         }
@@ -399,15 +498,37 @@ inline int pick_bwd_nw(int H, bool x3) {
     return (nkb4 % 16 == 0) ? 16 : (nkb4 % 8 == 0) ? 8 : 4;
 }
 
-template <bool X3>
-int launch_step_fwd_t(const StepFwdArgs &a, hipStream_t st) {
+template <int KS, bool X3>
+int launch_step_fwd_ks(const StepFwdArgs &a, hipStream_t st) {
     dim3 grid(a.H / 16, (a.B + 15) / 16);
-    switch (pick_fwd_ks(a.H, X3)) {
-        case 4: hipLaunchKernelGGL((lstm_step_fwd_kernel<4, X3>), grid, dim3(1024), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((lstm_step_fwd_kernel<2, X3>), grid, dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL((lstm_step_fwd_kernel<1, X3>), grid, dim3(256), 0, st, a); break;
+    const int nkb = a.H / (X3 ? 32 : 16);
+    const size_t red_bytes = (size_t)4 * KS * 256 * sizeof(float);
+    const size_t tile_bytes = (size_t)nkb * (X3 ? 2048 : 1024);
+    // LDS-staged A tile when the per-wave block count suits its 2-stage W pipeline and the tile fits
+    static const bool want_alds = !(getenv("HALO_LSTM_ALDS") && atoi(getenv("HALO_LSTM_ALDS")) == 0);
+    const bool alds = want_alds && ((nkb / KS) % (2 * WCH) == 0) && red_bytes + tile_bytes <= 128 * 1024;
+    if (alds) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void *)lstm_step_fwd_kernel<KS, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    128 * 1024) != hipSuccess)
+                return HALO_ELAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, true>), grid, dim3(256 * KS), red_bytes + tile_bytes, st, a);
+    } else {
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, false>), grid, dim3(256 * KS), red_bytes, st, a);
     }
     return halo_launch_status();
+}
+
+template <bool X3>
+int launch_step_fwd_t(const StepFwdArgs &a, hipStream_t st) {
+    switch (pick_fwd_ks(a.H, X3)) {
+        case 4: return launch_step_fwd_ks<4, X3>(a, st);
+        case 2: return launch_step_fwd_ks<2, X3>(a, st);
+        default: return launch_step_fwd_ks<1, X3>(a, st);
+    }
 }
 int launch_step_fwd(const StepFwdArgs &a, bool x3, hipStream_t st) {
     return x3 ? launch_step_fwd_t<true>(a, st) : launch_step_fwd_t<false>(a, st);
@@ -429,12 +550,13 @@ int launch_step_bwd(const StepBwdArgs &a, bool x3, hipStream_t st) {
 
 // MODE 0: W_hh for the forward, 1: W_hh^T for the backward, 2: row-major [B,W] rows (initial state)
 template <int MODE>
-int launch_pack(const float *src, void *dst, int H, int B, int Kdim, int tiles, bool x3, hipStream_t st) {
+int launch_pack(const float *src, void *dst, int H, int B, int Kdim, int tiles, bool x3, hipStream_t st,
+                float *h_rm = nullptr, const float *csrc = nullptr, float *c_rm = nullptr) {
     const long units = (long)tiles * (Kdim / (x3 ? 32 : 16)) * 64;
     long g = (units + 255) / 256;
     if (g > 2048) g = 2048;
-    if (x3) hipLaunchKernelGGL((pack_kernel<true, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units);
-    else hipLaunchKernelGGL((pack_kernel<false, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units);
+    if (x3) hipLaunchKernelGGL((pack_kernel<true, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units, h_rm, csrc, c_rm);
+    else hipLaunchKernelGGL((pack_kernel<false, MODE>), dim3((unsigned)g), dim3(256), 0, st, src, dst, H, B, Kdim, units, h_rm, csrc, c_rm);
     return halo_launch_status();
 }
 
@@ -514,11 +636,8 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
         }
         HALO_TRY(launch_pack<0>(w_hh[l], wp, H, B, H, (H / 16) * 4, x3, st));
         const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
-        if (h0l) HALO_TRY(copy_d2d(lb.h, h0l, BH, st));
-        else HALO_TRY(halo_fill(lb.h, BH, 0.f, st));
-        HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st));
-        if (c0) HALO_TRY(copy_d2d(lb.c, c0 + (size_t)l * BH, BH, st));
-        else HALO_TRY(halo_fill(lb.c, BH, 0.f, st));
+        // one launch: packed h_{-1}, row-major h_{-1} and c_{-1} (zeros when no initial state is given)
+        HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st, lb.h, c0 ? c0 + (size_t)l * BH : nullptr, lb.c));
         const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
         for (int t = 0; t < T; ++t) {
             StepFwdArgs a;
@@ -657,8 +776,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             if (!rc) rc = halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
                                         nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
         }
-        if (!rc) rc = halo_colsum(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], (halo_stream_t)side);
-        if (!rc) rc = copy_d2d(db_hh[l], db_ih[l], (size_t)4 * H, side);
+        if (!rc) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
         halo_set_scratch_slot(0);
         if (rc) return rc;
     }

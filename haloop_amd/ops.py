@@ -230,6 +230,22 @@ def ctc_bwd(lp, time_major, saved, alpha, nll, grad_out):
     return grad
 
 
+def ctc_prepare(input_lengths, target_lengths, ks=5, stride=4, pad=3):
+    """-> (feature_lengths int64 [N], grad_out f32 [N]) in one launch."""
+    il, tl = _i64c(input_lengths, 'input_lengths'), _i64c(target_lengths, 'target_lengths')
+    n = il.numel()
+    flen = torch.empty(n, device=il.device, dtype=torch.int64)
+    gout = torch.empty(n, device=il.device, dtype=torch.float32)
+    check(lib().halo_ctc_prepare(ptr(il), ptr(tl), n, ks, stride, pad, ptr(flen), ptr(gout), _stream()), 'halo_ctc_prepare')
+    return flen, gout
+
+
+def ctc_mean_loss(nll, target_lengths, out):
+    tl = _i64c(target_lengths, 'target_lengths')
+    check(lib().halo_ctc_mean_loss(ptr(nll), ptr(tl), nll.numel(), ptr(out), _stream()), 'halo_ctc_mean_loss')
+    return out
+
+
 def ctc_greedy(lp):
     _f32c(lp, 'log-probs')
     N, T, Cn = lp.shape

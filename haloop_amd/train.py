@@ -119,12 +119,10 @@ class LstmCtcTrainer:
         f2d = fdrop.view(B * Tp, H)
         logits = ops.gemm(f2d, rec.classifier.weight, True, True, B * Tp, V, H, bias1=rec.classifier.bias)
         lp = ops.log_softmax_fwd(logits)
-        flen = torch.floor((il + 2 * 3 - 5) / 4 + 1).to(torch.int64)          # ha/rnn.py:13-18
+        flen, grad_out = ops.ctc_prepare(il, tl)                               # ha/rnn.py:13-18 lengths; d(mean)/d(nll)
         nll, alpha, saved = ops.ctc_fwd(lp.view(B, Tp, V), False, tg, flen, tl)
-        tlf = tl.to(torch.float32).clamp_min(1)
-        self.loss.copy_((nll / tlf).mean())                                    # reduction='mean', recognizer.py:71
+        ops.ctc_mean_loss(nll, tl, self.loss)                                  # reduction='mean', recognizer.py:71
         # backward
-        grad_out = 1.0 / (tlf * B)
         dlp = ops.ctc_bwd(lp.view(B, Tp, V), False, saved, alpha, nll, grad_out)
         dlogits = ops.log_softmax_bwd(dlp.view(B * Tp, V), lp)
         ops.gemm(dlogits, f2d, False, False, V, H, B * Tp, out=gv['recognizer.classifier.weight'])
@@ -172,7 +170,7 @@ class LstmCtcTrainer:
         # correction still moves (it is 1.0 to fp32 precision after a few thousand steps); simpler
         # and exact: capture forward/backward once, run the (6-launch) optimizer eagerly.
         if self._graphs is None or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
-            self._static = (x.clone(), il.clone(), tg.clone(), tl.clone())
+            self._static = tuple(t.contiguous() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
             sx, sil, stg, stl = self._static
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -184,8 +182,9 @@ class LstmCtcTrainer:
                 self._forward_backward(sx, sil, stg, stl)
             self._graphs = g
         sx, sil, stg, stl = self._static
-        if x.data_ptr() != sx.data_ptr():
-            sx.copy_(x); sil.copy_(il); stg.copy_(tg); stl.copy_(tl)
+        for dst, src in ((sx, x), (sil, il), (stg, tg), (stl, tl)):
+            if src.data_ptr() != dst.data_ptr():       # a new batch: refill the captured input buffers
+                dst.copy_(src)
         self._graphs.replay()
         self._all_reduce()
         self._optimizer(self.step_count)

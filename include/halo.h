@@ -192,6 +192,15 @@ int halo_ctc_bwd(const float *lp, long stride_t, long stride_n, int T, int N, in
                  const float *grad_out, float *beta, float *grad, long gstride_t, long gstride_n,
                  halo_stream_t stream);
 
+/* Two scalar-glue launches of the training step (ha/rnn.py:13-18, ha/recognizer.py:71 reduction='mean'):
+ *   halo_ctc_prepare: feature_lengths[n] = floor((il[n] + 2*pad - ks)/stride + 1) computed in float like
+ *     the reference, grad_out[n] = 1 / (max(tl[n],1) * N) = d(mean loss)/d(nll[n]);
+ *   halo_ctc_mean_loss: *loss = mean_n(nll[n] / max(tl[n],1)), fixed summation order. */
+int halo_ctc_prepare(const int64_t *input_lengths, const int64_t *target_lengths, int n, int ks, int stride,
+                     int pad, int64_t *feature_lengths, float *grad_out, halo_stream_t stream);
+int halo_ctc_mean_loss(const float *nll, const int64_t *target_lengths, int n, float *loss,
+                       halo_stream_t stream);
+
 /* Greedy decode.   replaces: logits.max(-1) + unique_consecutive + drop-0 loop, recognizer.py:51-55
  *   lp [N,T,C] contiguous; alignments [N,T] int64, scores [N,T] f32, hyp [N,T] int64 (first
  *   hyp_len[n] entries valid), hyp_len [N] int64.  Input lengths are ignored, as in the reference. */
