@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 1
+HALO_ABI_VERSION = 2
 HALO_GEMM_RELU = 1
 HALO_CTC_FULL_LATTICE = 1
 HALO_CTC_FINITE_MIN = 2
@@ -41,7 +41,7 @@ SIGNATURES = {
     'halo_lstm_reserve_bytes': (_sz, [_i] * 5),
     'halo_lstm_bwd_workspace_bytes': (_sz, [_i] * 5),
     'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
-    'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
+    'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
     'halo_log_softmax_fwd': (_i, [_vp, _vp, _i, _i, _vp]),
     'halo_log_softmax_bwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'halo_colsum': (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -491,7 +491,8 @@ inline bool use_x3(int H) { return halo_math_mode() == HALO_MATH_BF16X3 && H % 3
 // waves = (gate, k-slice): the slice count must divide the number of k-blocks
 inline int pick_fwd_ks(int H, bool x3) {
     const int nkb = H / (x3 ? 32 : 16);
-    return (nkb % 4 == 0) ? 4 : (nkb % 2 == 0) ? 2 : 1;
+    static const int cap = getenv("HALO_LSTM_KS") ? atoi(getenv("HALO_LSTM_KS")) : 2;   // 8 waves measured best at H=1024
+    return (nkb % 4 == 0 && cap >= 4) ? 4 : (nkb % 2 == 0 && cap >= 2) ? 2 : 1;
 }
 inline int pick_bwd_nw(int H, bool x3) {
     const int nkb4 = 4 * H / (x3 ? 32 : 16);
@@ -673,10 +674,11 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
 int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *dy,
                   long y_stride_t, long y_stride_b, int y_relu, const float *dhn, const float *dcn, float *reserve,
                   float *workspace, float *dx, float *const *dw_ih, float *const *dw_hh, float *const *db_ih,
-                  float *const *db_hh, int T, int B, int in0, int H, int L, float p_drop, uint64_t seed,
-                  uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
+                  float *const *db_hh, int T, int B, int in0, int H, int L, int layer_begin, int layer_end,
+                  float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
     HALO_CHECK_ARG(x && w_ih && w_hh && reserve && workspace && dw_ih && dw_hh && db_ih && db_hh);
-    HALO_CHECK_ARG(dy || dhn || dcn);
+    HALO_CHECK_ARG(0 <= layer_begin && layer_begin < layer_end && layer_end <= L);
+    HALO_CHECK_ARG(layer_end < L || dy || dhn || dcn);
     HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
     if (H % 16 != 0) return HALO_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
@@ -697,7 +699,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     char *img_hT = img_g + halo_tiled_image_bytes(T * B, 4 * H);
     char *img_inT = img_hT + halo_tiled_image_bytes(kin, T * B);
     char *img_wT = img_inT + halo_tiled_image_bytes(kin, T * B);
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = layer_end - 1; l >= layer_begin; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);

@@ -30,30 +30,45 @@ def shard_slice(global_batch, rank, world):
 
 
 class GradientAverager:
-    """All-reduce(SUM)/world of a flat gradient buffer in ``bucket_bytes`` pieces.
+    """All-reduce(SUM)/world of ``flat_grads[span]`` in ``bucket_bytes`` pieces.
 
-    ``boundaries`` (element offsets) lets the caller align buckets with parameter groups so that
-    a bucket can be launched as soon as its gradients are final (overlap with the rest of backward)."""
+    ``start()`` launches the collectives asynchronously (they run on the backend's own stream, ordered
+    after the work already enqueued on the current stream) and ``finish()`` waits for them and applies
+    the 1/world scale, so a caller can keep enqueueing backward work in between (overlap).
+    ``boundaries`` (element offsets) aligns bucket cuts with parameter groups."""
 
-    def __init__(self, flat_grads, group=None, bucket_bytes=64 << 20, boundaries=None):
+    def __init__(self, flat_grads, group=None, bucket_bytes=64 << 20, boundaries=None, span=None):
         self.flat, self.group = flat_grads, group
         self.world = world_size(group)
-        n = flat_grads.numel()
+        lo, hi = span if span is not None else (0, flat_grads.numel())
+        self.span = (lo, hi)
         per = max(1, bucket_bytes // flat_grads.element_size())
-        cuts = sorted(set([0, n] + [b for b in (boundaries or []) if 0 < b < n]))
+        cuts = sorted(set([lo, hi] + [b for b in (boundaries or []) if lo < b < hi]))
         self.buckets = []
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            for a in range(lo, hi, per):
-                self.buckets.append((a, min(a + per, hi)))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            for c in range(a, b, per):
+                self.buckets.append((c, min(c + per, b)))
+        # RCCL averages in the collective itself; gloo has no AVG, so scale afterwards
+        self._avg_op = dist.is_initialized() and dist.get_backend(group) == 'nccl'
 
     def reduce_bucket(self, i, async_op=False):
         a, b = self.buckets[i]
-        return dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+        return dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=async_op)
 
-    def average(self):
+    def start(self):
+        if self.world == 1:
+            return []
+        return [self.reduce_bucket(i, async_op=True) for i in range(len(self.buckets))]
+
+    def finish(self, works):
         if self.world == 1:
             return
-        works = [self.reduce_bucket(i, async_op=True) for i in range(len(self.buckets))]
         for w in works:
             w.wait()
-        self.flat.mul_(1.0 / self.world)
+        if not self._avg_op:
+            lo, hi = self.span
+            self.flat[lo:hi].mul_(1.0 / self.world)
+
+    def average(self):
+        self.finish(self.start())

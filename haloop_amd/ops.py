@@ -131,10 +131,17 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     return y, hn, cn, reserve
 
 
+def lstm_bwd_workspace(x_tm, w_hh):
+    T, B, in0 = x_tm.shape
+    return torch.empty((lib().halo_lstm_bwd_workspace_bytes(T, B, in0, w_hh[0].shape[1], len(w_hh)) + 3) // 4,
+                       device=x_tm.device, dtype=torch.float32)
+
+
 def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=None, want_dx=False,
-             grads=None, drop=NO_DROPOUT):
-    """Returns (dx or None, dw_ih, dw_hh, db_ih, db_hh) lists.  ``grads`` may carry preallocated
-    output tensors as a dict of lists with those four names."""
+             grads=None, drop=NO_DROPOUT, layers=None, workspace=None, dx=None):
+    """Returns (dx or None, grads dict of lists dw_ih/dw_hh/db_ih/db_hh).  ``grads`` may carry
+    preallocated outputs.  ``layers=(lo, hi)`` runs only that range (top down); a split backward
+    passes the same ``workspace`` (ops.lstm_bwd_workspace) to both calls."""
     T, B, in0 = x_tm.shape
     L = len(w_hh)
     H = w_hh[0].shape[1]
@@ -146,13 +153,15 @@ def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=Non
             'db_ih': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
             'db_hh': [torch.empty(4 * H, device=dev, dtype=torch.float32) for _ in range(L)],
         }
-    ws = torch.empty((lib().halo_lstm_bwd_workspace_bytes(T, B, in0, H, L) + 3) // 4, device=dev, dtype=torch.float32)
-    dx = torch.empty(T, B, in0, device=dev, dtype=torch.float32) if want_dx else None
+    ws = workspace if workspace is not None else lstm_bwd_workspace(x_tm, w_hh)
+    lo, hi = layers if layers is not None else (0, L)
+    if dx is None and want_dx and lo == 0:
+        dx = torch.empty(T, B, in0, device=dev, dtype=torch.float32)
     a_ih, a_hh = ptr_array(w_ih), ptr_array(w_hh)
     g_ih, g_hh = ptr_array(grads['dw_ih']), ptr_array(grads['dw_hh'])
     g_bi, g_bh = ptr_array(grads['db_ih']), ptr_array(grads['db_hh'])
     check(lib().halo_lstm_bwd(ptr(x_tm), a_ih, a_hh, ptr(dy), y_strides[0], y_strides[1], int(y_relu), ptr(dhn),
-                              ptr(dcn), ptr(reserve), ptr(ws), ptr(dx), g_ih, g_hh, g_bi, g_bh, T, B, in0, H, L,
+                              ptr(dcn), ptr(reserve), ptr(ws), ptr(dx), g_ih, g_hh, g_bi, g_bh, T, B, in0, H, L, lo, hi,
                               drop.p, drop.seed, drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_bwd')
     return dx, grads
 

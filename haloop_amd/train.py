@@ -33,25 +33,41 @@ def decay_groups(encoder, recognizer):
 
 
 class FlatParams:
-    """Re-homes parameters into one flat buffer laid out [enc decay | enc no-decay | rec decay | rec no-decay]."""
+    """Re-homes parameters into one flat buffer laid out
+
+        [enc no-decay | enc decay, lower layers | enc decay, top LSTM layer | rec decay | rec no-decay]
+
+    so that (a) the encoder (the clipped part, ha/loop.py:184) is one contiguous range, (b) each
+    AdamW launch covers one contiguous (weight-decay, clip-scale) range, and (c) the gradients that
+    are final first in backward -- recognizer and top LSTM layer -- form one contiguous suffix,
+    the first all-reduce bucket of the data-parallel step."""
 
     def __init__(self, encoder, recognizer):
         decay, no_decay = decay_groups(encoder, recognizer)
-        groups = [[(n, p) for n, p in decay if n.startswith('encoder.')],
-                  [(n, p) for n, p in no_decay if n.startswith('encoder.')],
+        top = getattr(encoder, 'lstm', None)
+        top_tag = f'_l{top.num_layers - 1}' if top is not None and top.num_layers > 1 else None
+        is_top = lambda n: top_tag is not None and n.startswith('encoder.lstm.') and n.endswith(top_tag)
+        groups = [[(n, p) for n, p in no_decay if n.startswith('encoder.')],
+                  [(n, p) for n, p in decay if n.startswith('encoder.') and not is_top(n)],
+                  [(n, p) for n, p in decay if n.startswith('encoder.') and is_top(n)],
                   [(n, p) for n, p in decay if n.startswith('recognizer.')],
                   [(n, p) for n, p in no_decay if n.startswith('recognizer.')]]
-        self.decays = [True, False, True, False]
+        decays = [False, True, True, True, False]
         dev = next(encoder.parameters()).device
-        off, self.ranges, self.slots = 0, [], []
+        off, bounds, self.slots = 0, [], []
         for g in groups:
             start = off
             for n, p in g:
                 self.slots.append((n, p, off))
                 off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
-            self.ranges.append((start, off))
+            bounds.append((start, off))
         self.total = off
-        self.encoder_range = (self.ranges[0][0], self.ranges[1][1])
+        self.encoder_range = (bounds[0][0], bounds[2][1])
+        self.early_range = (bounds[2][0], off)            # final after the top LSTM layer's backward
+        self.late_range = (0, bounds[2][0])
+        # AdamW ranges: (begin, end, weight-decayed, clipped)
+        self.ranges = [(bounds[0][0], bounds[0][1], False, True), (bounds[1][0], bounds[2][1], True, True),
+                       (bounds[3][0], bounds[3][1], True, False), (bounds[4][0], bounds[4][1], False, False)]
         self.params = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -89,8 +105,9 @@ class LstmCtcTrainer:
         self.pg = process_group
         self.world = dp.world_size(process_group)
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
-        self.averager = dp.GradientAverager(self.flat.grads, process_group,
-                                            boundaries=[r[0] for r in self.flat.ranges])
+        # two buckets in readiness order: [top layer + recognizer] then [the rest]
+        self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range)
+        self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range)
         self._graphs = None
         self._static = None
 
@@ -100,6 +117,11 @@ class LstmCtcTrainer:
         return Dropout(p, self.seed, 0, self.counter) if p > 0 else NO_DROPOUT
 
     def _forward_backward(self, x, il, tg, tl):
+        self._backward_rest(self._forward_backward_top(x, il, tg, tl))
+
+    def _forward_backward_top(self, x, il, tg, tl):
+        """Forward, loss, and backward down to (and including) the top LSTM layer: every gradient of
+        FlatParams.early_range is final when this returns."""
         enc, rec, gv = self.encoder, self.recognizer, self.flat.grad_views
         drop = self._dropout()
         B, T, F = x.shape
@@ -133,22 +155,36 @@ class LstmCtcTrainer:
                  'dw_hh': [gv[f'encoder.lstm.weight_hh_l{k}'] for k in range(L)],
                  'db_ih': [gv[f'encoder.lstm.bias_ih_l{k}'] for k in range(L)],
                  'db_hh': [gv[f'encoder.lstm.bias_hh_l{k}'] for k in range(L)]}
-        dy_sub, _ = ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, want_dx=True, grads=grads, drop=drop)
+        ws = ops.lstm_bwd_workspace(y_sub, w_hh)
+        dy_sub = torch.empty_like(y_sub)
+        top = L - 1 if L > 1 else 0
+        ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(top, L),
+                     workspace=ws, dx=dy_sub)
+        return (y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L))
+
+    def _backward_rest(self, st):
+        """The lower LSTM layers and the subsample conv: completes FlatParams.late_range."""
+        y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L) = st
+        gv = self.flat.grad_views
+        if top > 0:
+            ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
+                         workspace=ws, dx=dy_sub)
         ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
                           dbias=gv['encoder.subsample.bias'])
 
     def _all_reduce(self):
-        self.averager.average()
+        self.avg_early.average()
+        self.avg_late.average()
 
     def _optimizer(self, step):
         f = self.flat
         e0, e1 = f.encoder_range
         ops.sumsq_partials(f.grads[e0:e1], self.partials)
         ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm)
-        for (a, b), decays in zip(f.ranges, f.decays):
+        for a, b, decays, clipped in f.ranges:
             if b == a:
                 continue
-            scale = self.coef[0:1] if b <= e1 else self.coef[1:2]
+            scale = self.coef[0:1] if clipped else self.coef[1:2]
             ops.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay if decays else 0.0, step, scale)
         ops.counter_inc(self.counter)
@@ -158,17 +194,21 @@ class LstmCtcTrainer:
         """One optimizer step.  Returns the (device) loss tensor; nothing here synchronises."""
         self.step_count += 1
         if not self.use_graph:
-            self._forward_backward(x, input_lengths, targets, target_lengths)
-            self._all_reduce()
+            st = self._forward_backward_top(x, input_lengths, targets, target_lengths)
+            w1 = self.avg_early.start()          # overlaps the rest of backward (world > 1)
+            self._backward_rest(st)
+            w2 = self.avg_late.start()
+            self.avg_early.finish(w1)
+            self.avg_late.finish(w2)
             self._optimizer(self.step_count)
             return self.loss
         return self._graph_step(x, input_lengths, targets, target_lengths)
 
     def _graph_step(self, x, il, tg, tl):
-        # AdamW's bias corrections depend on the step number, a host scalar baked into the kernel
-        # arguments: the optimizer part is therefore re-captured per step count only while the
-        # correction still moves (it is 1.0 to fp32 precision after a few thousand steps); simpler
-        # and exact: capture forward/backward once, run the (6-launch) optimizer eagerly.
+        # AdamW's bias corrections depend on the step number (a host scalar in the kernel arguments), so
+        # forward/backward are captured and the 7-launch optimizer runs eagerly.  With data parallelism
+        # backward is captured as TWO graphs so that the first gradient bucket's all-reduce (eager, on
+        # RCCL's stream) runs beside the second graph.
         if self._graphs is None or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
             self._static = tuple(t.contiguous() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
             sx, sil, stg, stl = self._static
@@ -177,16 +217,32 @@ class LstmCtcTrainer:
             with torch.cuda.stream(side):                 # warm-up outside capture (lazy module loads)
                 self._forward_backward(sx, sil, stg, stl)
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._forward_backward(sx, sil, stg, stl)
-            self._graphs = g
+            if self.world == 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward_backward(sx, sil, stg, stl)
+                self._graphs = (g,)
+            else:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    state = self._forward_backward_top(sx, sil, stg, stl)
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._backward_rest(state)
+                self._graphs = (g1, g2)
+                self._keep = state                       # buffers shared by the two graphs stay alive
         sx, sil, stg, stl = self._static
         for dst, src in ((sx, x), (sil, il), (stg, tg), (stl, tl)):
             if src.data_ptr() != dst.data_ptr():       # a new batch: refill the captured input buffers
                 dst.copy_(src)
-        self._graphs.replay()
-        self._all_reduce()
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
+        else:
+            self._graphs[0].replay()
+            w1 = self.avg_early.start()
+            self._graphs[1].replay()
+            w2 = self.avg_late.start()
+            self.avg_early.finish(w1)
+            self.avg_late.finish(w2)
         self._optimizer(self.step_count)
         return self.loss
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 1
+#define HALO_ABI_VERSION 2
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -143,13 +143,16 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
                   float *reserve, int T, int B, int in0, int H, int L, float p_drop, uint64_t seed,
                   uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
 /* dy has the strides of y; dhn/dcn [L,B,H] or NULL.  dx [T,B,in0] or NULL.
- * dw_ih/dw_hh/db_ih/db_hh: HOST arrays of L device pointers, overwritten. */
+ * dw_ih/dw_hh/db_ih/db_hh: HOST arrays of L device pointers, overwritten.
+ * Layers [layer_begin, layer_end) are processed, top down.  A whole backward is (0, L); a caller
+ * that wants the upper layers' gradients early (to start their all-reduce) calls (k, L) and later
+ * (0, k) with the SAME workspace, which carries the gradient between the two calls. */
 int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *dy,
                   long y_stride_t, long y_stride_b, int y_relu, const float *dhn, const float *dcn,
                   float *reserve, float *workspace, float *dx, float *const *dw_ih, float *const *dw_hh,
                   float *const *db_ih, float *const *db_hh, int T, int B, int in0, int H, int L,
-                  float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev,
-                  halo_stream_t stream);
+                  int layer_begin, int layer_end, float p_drop, uint64_t seed, uint32_t offset,
+                  const uint32_t *offset_dev, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise log-softmax.   replaces: features.log_softmax(dim=-1) ha/recognizer.py:46

@@ -31,41 +31,64 @@ def _build(seed):
     return enc.to('cuda:0').eval(), rec.to('cuda:0').eval()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, use_graph):
+    import datetime
+    import traceback
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
+        _worker_body(rank, world, out, use_graph)
+    except Exception:                                   # a dead rank must not leave its peer (or pytest) waiting
+        out.put(('error', rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_body(rank, world, out, use_graph):
+    if True:
         from haloop_amd import dp
         from haloop_amd.train import LstmCtcTrainer
         from oracle import cpu_ref
         c = CFG
         enc, rec = _build(100 + rank)                      # different init per rank: rank 0's must win
-        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=False)
+        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph)
         x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
             tr.step(x[sl].cuda(), il[sl].cuda(), tg[sl].cuda(), tl[sl].cuda())
         torch.cuda.synchronize()
         if rank == 0:
-            out.put((tr.flat.params.cpu().numpy(), float(tr.grad_norm.item())))
-    finally:
-        dist.destroy_process_group()
+            out.put(('ok', tr.flat.params.cpu().numpy(), float(tr.grad_norm.item())))
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_equal_single_process_on_concatenated_batch():
+@pytest.mark.parametrize('use_graph', [False, True])     # True: two captured graphs with the all-reduce between them
+def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph):
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph)) for r in range(2)]
     for p in procs:
         p.start()
-    params2, gnorm2 = out.get()
+    import time
+    deadline, msg = time.time() + 150, None
+    while msg is None and time.time() < deadline:
+        if not out.empty():
+            msg = out.get()
+        elif not any(p.is_alive() for p in procs):
+            break
+        else:
+            time.sleep(0.2)
     for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+        p.join(20)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, 'workers produced no result'
+    assert msg[0] == 'ok', msg
+    _, params2, gnorm2 = msg
     c = CFG
     enc, rec = _build(100)
     tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=False)
