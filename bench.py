@@ -91,6 +91,24 @@ def time_dominant_kernel(device, math, iters=200):
     return max(full_ms - other_ms, 1e-6) / iters
 
 
+def time_inference(enc, rec, x, steps):
+    """Second half of the metric: forward-only + greedy decode, eval mode."""
+    from haloop_amd.infer import LstmCtcRecognizer
+    was_training = enc.training
+    reco = LstmCtcRecognizer(enc, rec)
+    for _ in range(5):
+        reco.recognize(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        reco.recognize(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    enc.train(was_training); rec.train(was_training)
+    return {'metric': 'utterances/sec, forward + greedy CTC decode (eval)', 'value': round(steps * x.shape[0] / dt, 1),
+            'unit': 'utterances/s', 'ms_per_batch': round(1e3 * dt / steps, 4), 'batch': x.shape[0]}
+
+
 def host_cores():
     """Cores this process may actually use (affinity mask and cgroup quota), not the machine's count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -201,6 +219,8 @@ def main():
                               'achieved_GBs': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9, 1),
                               'frac_of_hbm_peak': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if world == 1:
+            out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(params)
         print(json.dumps(out), flush=True)

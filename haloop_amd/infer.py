@@ -1,0 +1,50 @@
+"""Forward-only recognition (ha/loop.py:263-303 evaluate path for the CTC head): encoder forward ->
+log-probs -> greedy collapse, straight on the C ABI and replayed from one HIP graph per input shape."""
+import torch
+
+from . import _lib, ops
+from .ops import NO_DROPOUT
+from .rnn import lstm_param_list
+
+
+class LstmCtcRecognizer:
+    def __init__(self, encoder, recognizer, use_graph=True):
+        self.encoder, self.recognizer, self.use_graph = encoder.eval(), recognizer.eval(), use_graph
+        self._graph = None
+        self._static = None
+        self._out = None
+        _lib.lend_scratch(device=next(encoder.parameters()).device)
+
+    def _run(self, x):
+        enc, rec = self.encoder, self.recognizer
+        B, T, F = x.shape
+        p = lstm_param_list(enc.lstm)
+        w_ih, w_hh, b_ih, b_hh = p[0::4], p[1::4], p[2::4], p[3::4]
+        H, V = w_hh[0].shape[1], rec.classifier.weight.shape[0]
+        y_sub, _ = ops.subsample_fwd(x, enc.subsample.weight, enc.subsample.bias, NO_DROPOUT)
+        Tp = y_sub.shape[0]
+        feats = torch.empty(B, Tp, H, device=x.device, dtype=torch.float32)
+        ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True)
+        logits = ops.gemm(feats.view(B * Tp, H), rec.classifier.weight, True, True, B * Tp, V, H, bias1=rec.classifier.bias)
+        lp = ops.log_softmax_fwd(logits).view(B, Tp, V)
+        return ops.ctc_greedy(lp)          # alignments, scores, hyp (padded), hyp_len
+
+    @torch.no_grad()
+    def recognize(self, x):
+        """x [B,T,F] on the HIP device -> (alignments [B,T'], scores [B,T'], hyp [B,T'] padded, hyp_len [B])."""
+        if not self.use_graph:
+            return self._run(x.contiguous())
+        if self._graph is None or self._static.shape != x.shape:
+            self._static = x.contiguous()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._run(self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out = self._run(self._static)
+        if x.data_ptr() != self._static.data_ptr():
+            self._static.copy_(x)
+        self._graph.replay()
+        return self._out

@@ -404,3 +404,17 @@ def test_trainer_skips_update_on_nonfinite_gradients(hal):
     loss = tr.step(x.to(DEV), torch.tensor([9, 41, 41], device=DEV), tg.to(DEV), torch.tensor([4, 4, 4], device=DEV))
     assert not np.isfinite(loss.item())             # F.ctc_loss gives inf; ha/loop.py:172 skips the batch
     assert torch.equal(tr.flat.params, before)
+
+
+def test_recognizer_graph_matches_module_path(hal):
+    """haloop_amd.infer.LstmCtcRecognizer (one HIP graph) == Encoder + TemporalClassifier.decode."""
+    from haloop_amd.infer import LstmCtcRecognizer
+    g = load_golden('g1_tiny_l2')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = _load_modules(hal, g, c['F_'], c['C'], c['H'], c['L'], c['V'])
+    reco = LstmCtcRecognizer(enc, rec)
+    x = torch.from_numpy(g['x']).to(DEV)
+    for _ in range(2):                                   # second call replays the captured graph
+        ali, scores, hyp, hlen = reco.recognize(x)
+    assert np.array_equal(ali.cpu().numpy(), g['ali']) and np.array_equal(hlen.cpu().numpy(), g['hlen'])
+    assert [hyp[i, :n].tolist() for i, n in enumerate(hlen.tolist())] == _unpad(g['hyps'], g['hlen'])
