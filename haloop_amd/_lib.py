@@ -8,6 +8,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
 HALO_ABI_VERSION = 2
 HALO_GEMM_RELU = 1
+HALO_GEMM_GELU = 2
+HALO_GEMM_ACCUM = 4
 HALO_CTC_FULL_LATTICE = 1
 HALO_CTC_FINITE_MIN = 2
 HALO_CTC_NO_LEAD_BLANK_LOOP = 4
@@ -53,6 +55,10 @@ SIGNATURES = {
     'halo_ctc_beam_workspace_bytes': (_sz, [_i] * 4),
     'halo_ctc_beam': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_topk_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'halo_embed_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'halo_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_attention_causal_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'halo_cross_entropy_fwd': (_i, [_vp, _vp, _vp, _i, _i, _l, _l, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),

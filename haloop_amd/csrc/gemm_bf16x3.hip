@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bias;
-                if (p.relu) v = fmaxf(v, 0.f);
+                v = gemm_activation(v, p.relu);
                 const long e = (long)row * p.ldc + col;
                 if (p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
+                if (p.relu & 4) v += p.C[e];
                 p.C[e] = v;
             }
         }
@@ -335,7 +336,7 @@ int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int 
                     const uint32_t *offset_dev, halo_stream_t stream) {
     HALO_CHECK_ARG(a_image && b_image && C && M > 0 && N > 0 && K > 0 && ldc >= N);
     const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
-    return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, (flags & HALO_GEMM_RELU) ? 1 : 0, &d,
+    return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, flags & 7, &d,
                                   (hipStream_t)stream);
 }
 

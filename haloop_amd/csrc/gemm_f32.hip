@@ -185,9 +185,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bias;
-                if (p.relu) v = fmaxf(v, 0.f);
+                v = gemm_activation(v, p.relu);
                 const long e = (long)row * p.ldc + col;
                 if (p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
+                if (p.relu & 4) v += p.C[e];
                 p.C[e] = v;
             }
         }
@@ -207,9 +208,10 @@ __global__ __launch_bounds__(256) void halo_splitk_reduce_kernel(const float *__
         for (int s = 0; s < ksplit; ++s) v += slab[(long)s * total + e];
         if (bias1) v += bias1[col];
         if (bias2) v += bias2[col];
-        if (relu) v = fmaxf(v, 0.f);
+        v = gemm_activation(v, relu);
         const long o = (long)row * ldc + col;
         if (use_drop) v *= dropout_mult(drop, (uint64_t)o);
+        if (relu & 4) v += C[o];
         C[o] = v;
     }
 }
@@ -278,7 +280,7 @@ extern "C" int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
     p.b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    p.relu = (flags & HALO_GEMM_RELU) ? 1 : 0;
+    p.relu = flags & 7;
     p.use_drop = p_drop > 0.f;
     p.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
     p.tiles_n = 0;

@@ -109,3 +109,10 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result
+__device__ __forceinline__ float gemm_activation(float v, int flags) {
+    if (flags & 1) v = fmaxf(v, 0.f);
+    if (flags & 2) v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    return v;
+}

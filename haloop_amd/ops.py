@@ -39,14 +39,18 @@ def subsampled_length(T, ks=5, stride=4, pad=3):
     return (T + 2 * pad - ks) // stride + 1
 
 
+def _gemm_flags(relu, gelu, accumulate):
+    return (_lib.HALO_GEMM_RELU if relu else 0) | (_lib.HALO_GEMM_GELU if gelu else 0) | (_lib.HALO_GEMM_ACCUM if accumulate else 0)
+
+
 def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, relu=False,
-         drop=NO_DROPOUT, stream_id=0):
+         drop=NO_DROPOUT, stream_id=0, gelu=False, accumulate=False):
     lda = a.shape[-1]
     ldb = b.shape[-1]
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     check(lib().halo_gemm_f32(int(a_kcontig), int(b_kcontig), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), N,
-                              ptr(bias1), ptr(bias2), _lib.HALO_GEMM_RELU if relu else 0, drop.p, drop.seed,
+                              ptr(bias1), ptr(bias2), _gemm_flags(relu, gelu, accumulate), drop.p, drop.seed,
                               stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_gemm_f32')
     return out
 
@@ -60,12 +64,13 @@ def split_image(x2d, transposed=False):
     return img
 
 
-def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0):
+def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0,
+               gelu=False, accumulate=False):
     """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate)."""
     if out is None:
         out = torch.empty(M, N, device=a_img.device, dtype=torch.float32)
     check(lib().halo_gemm_split(ptr(a_img), ptr(b_img), M, N, K, ptr(out), N, ptr(bias1), ptr(bias2),
-                                _lib.HALO_GEMM_RELU if relu else 0, drop.p, drop.seed, stream_id, drop.offset,
+                                _gemm_flags(relu, gelu, accumulate), drop.p, drop.seed, stream_id, drop.offset,
                                 drop.counter_ptr, _stream()), 'halo_gemm_split')
     return out
 
@@ -312,3 +317,38 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None
 
 def counter_inc(counter):
     check(lib().halo_counter_inc(ptr(counter), _stream()), 'halo_counter_inc')
+
+
+# ---- GPT forward operators ------------------------------------------------------------------------
+def embed_fwd(ids, wte, wpe, pos0=0):
+    ids = _i64c(ids, 'input_ids')
+    Bn, T = ids.shape
+    C = wte.shape[1]
+    x = torch.empty(Bn * T, C, device=wte.device, dtype=torch.float32)
+    check(lib().halo_embed_fwd(ptr(ids), ptr(wte), ptr(wpe), ptr(x), Bn * T, T, C, pos0, wte.shape[0], _stream()), 'halo_embed_fwd')
+    return x
+
+
+def layernorm_fwd(x2d, weight, bias=None, eps=1e-5):
+    _f32c(x2d, 'x')
+    y = torch.empty_like(x2d)
+    check(lib().halo_layernorm_fwd(ptr(x2d), ptr(weight), ptr(bias), ptr(y), x2d.shape[0], x2d.shape[1], eps, _stream()),
+          'halo_layernorm_fwd')
+    return y
+
+
+def attention_causal_fwd(qkv2d, B, T, n_head):
+    _f32c(qkv2d, 'qkv')
+    C = qkv2d.shape[1] // 3
+    y = torch.empty(B * T, C, device=qkv2d.device, dtype=torch.float32)
+    check(lib().halo_attention_causal_fwd(ptr(qkv2d), ptr(y), B, T, n_head, C, _stream()), 'halo_attention_causal_fwd')
+    return y
+
+
+def cross_entropy_fwd(logits2d, targets, ignore_index=0):
+    _f32c(logits2d, 'logits')
+    tg = _i64c(targets.reshape(-1), 'targets')
+    loss = torch.empty(logits2d.shape[0], device=logits2d.device, dtype=torch.float32)
+    check(lib().halo_cross_entropy_fwd(ptr(logits2d), ptr(tg), ptr(loss), logits2d.shape[0], logits2d.shape[1],
+                                       logits2d.shape[1], ignore_index, _stream()), 'halo_cross_entropy_fwd')
+    return loss

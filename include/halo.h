@@ -80,12 +80,14 @@ int halo_counter_inc(uint32_t *counter, halo_stream_t stream);
  * Dense GEMM on the exact-f32 MFMA.  C[M,N] = opA(A)[M,K] * opB(B)[K,N]  (+ epilogue)
  *   a_kcontig = 1: A stored [M,K] (row stride lda), 0: A stored [K,M]
  *   b_kcontig = 1: B stored [N,K] (row stride ldb), 0: B stored [K,N]
- * epilogue, in this order: + bias1[n] + bias2[n] (either may be NULL); relu if HALO_GEMM_RELU;
- *   * dropout mask(e = m*ldc + n) if p_drop > 0.
+ * epilogue, in this order: + bias1[n] + bias2[n] (either may be NULL); relu / tanh-GELU per flags;
+ *   * dropout mask(e = m*ldc + n) if p_drop > 0; + previous C if HALO_GEMM_ACCUM.
  * replaces: the ATen/oneDNN/cuBLAS matmuls under nn.Conv1d rnn.py:22, nn.LSTM input
  * projections rnn.py:25 and nn.Linear recognizer.py:45, and their autograd backward GEMMs.
  * ------------------------------------------------------------------------------------------ */
 #define HALO_GEMM_RELU 1
+#define HALO_GEMM_GELU 2   /* tanh-GELU ("new_gelu", ha/attention.py:12-17), applied after the bias */
+#define HALO_GEMM_ACCUM 4  /* C += result (residual connections, ha/attention.py:178-179) */
 int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float *A, int lda,
                   const float *B, int ldb, float *C, int ldc, const float *bias1, const float *bias2,
                   int flags, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
@@ -224,6 +226,23 @@ int halo_ctc_beam(const float *em, int N, int T, int V, int beam, int log_domain
  *   values [rows,n]; out_values [rows,k] f32; out_indices [rows,k] int64; workspace rows*n*8 bytes. */
 int halo_topk_f32(const float *values, int rows, int n, int k, float *out_values, int64_t *out_indices,
                   void *workspace, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GPT forward (scoring) operators.  replaces, in ha/attention.py:
+ *   halo_embed_fwd            wte(input_ids) + wpe(pos)                      :222-224
+ *   halo_layernorm_fwd        F.layer_norm(x, (C,), weight, bias|NULL, eps)  :29  (also StableEmbedding's norm :61)
+ *   halo_attention_causal_fwd F.scaled_dot_product_attention(q,k,v,is_causal=True) on the packed c_attn
+ *                             output qkv [B,T,3C] (q|k|v, heads side by side) -> y [B,T,C]  :113-123,90
+ *   halo_cross_entropy_fwd    F.cross_entropy(logits, targets, ignore_index, reduction='none')  :231
+ * Linear layers, tanh-GELU and the residual adds are halo_gemm_f32 / halo_gemm_split epilogues.
+ * head_dim must be 32 or 64 (GPT-2 small: 64). */
+int halo_embed_fwd(const int64_t *ids, const float *wte, const float *wpe, float *x, int n_tokens, int T, int C,
+                   int pos0, int vocab, halo_stream_t stream);
+int halo_layernorm_fwd(const float *x, const float *weight, const float *bias, float *y, int rows, int C,
+                       float eps, halo_stream_t stream);
+int halo_attention_causal_fwd(const float *qkv, float *y, int B, int T, int n_head, int C, halo_stream_t stream);
+int halo_cross_entropy_fwd(const float *logits, const int64_t *targets, float *loss, int rows, int V, long ld,
+                           long ignore_index, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers.

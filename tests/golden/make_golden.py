@@ -24,9 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim   # the reference
+import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init   # the reference
 
-from oracle import cpu_ref
+from oracle import cpu_ref, gpt_ref
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -250,7 +250,32 @@ def save_beam():
     print('g3_beam onehot', d['onehot.seqs'].tolist(), d['onehot.scores'], 'r6x4b4', d['r6x4b4.seqs'][0], d['r6x4b4.scores'][0])
 
 
+def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, store_params):
+    cfg = ha.init.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head, n_embd=n_embd, bias=bias)
+    model = ha.attention.GPT(cfg).eval()
+    params = gpt_ref.make_gpt_params(vocab, block, n_layer, n_head, n_embd, bias, seed)
+    missing = model.load_state_dict(params, strict=True)
+    inputs, targets = gpt_ref.synthetic_tokens(B, T, vocab, seed + 1)
+    with torch.no_grad():
+        per_tok = model.forward_all(inputs, targets, reduction='none')
+        mean = model.forward_all(inputs, targets, reduction='mean')
+    d = {'cfg': np.array([vocab, block, n_layer, n_head, n_embd, int(bias), B, T, seed]),
+         'inputs': inputs.numpy(), 'targets': targets.numpy(), 'per_token': per_tok.numpy(), 'mean': mean.numpy()}
+    if store_params:
+        for k, v in params.items():
+            d['param.' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'mean nats/token', float(mean))
+
+
+def save_gpt():
+    gpt_case('g5_gpt_tiny_nobias', 97, 32, 2, 2, 64, False, 3, 20, 5, True)
+    gpt_case('g5_gpt_tiny_bias', 97, 48, 3, 1, 64, True, 2, 40, 6, True)
+    gpt_case('g5_gpt2_small', 50304, 1024, 12, 12, 768, False, 1, 1024, 7, False)   # params rebuilt from the seed
+
+
 if __name__ == '__main__':
+    save_gpt()
     save_tiny()
     save_train_steps()
     save_ctc()

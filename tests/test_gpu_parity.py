@@ -418,3 +418,57 @@ def test_recognizer_graph_matches_module_path(hal):
         ali, scores, hyp, hlen = reco.recognize(x)
     assert np.array_equal(ali.cpu().numpy(), g['ali']) and np.array_equal(hlen.cpu().numpy(), g['hlen'])
     assert [hyp[i, :n].tolist() for i, n in enumerate(hlen.tolist())] == _unpad(g['hyps'], g['hlen'])
+
+
+# ------------------------------------------------------------------------------ GPT scoring path
+def _gpt_from_golden(hal, name):
+    from haloop_amd import attention
+    from oracle import gpt_ref
+    g = load_golden(name)
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    if name == 'g5_gpt2_small':
+        params = gpt_ref.make_gpt_params(vocab, block, n_layer, n_head, n_embd, bool(bias), seed)
+    else:
+        params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    model = attention.GPT(attention.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head,
+                                              n_embd=n_embd, bias=bool(bias)))
+    model.load_state_dict(params, strict=True)
+    assert model.transformer.wte.weight is model.lm_head.weight
+    return g, model.to(DEV).eval()
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_tiny_forward_all_matches_reference(hal, name, math_mode):
+    g, model = _gpt_from_golden(hal, name)
+    inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
+    with torch.no_grad():
+        per_tok = model.forward_all(inputs, targets, reduction='none')
+        mean = model.forward_all(inputs, targets, reduction='mean')
+    np.testing.assert_allclose(per_tok.cpu().numpy(), g['per_token'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(mean.item(), float(g['mean']), rtol=1e-5)
+    assert np.array_equal(per_tok.cpu().numpy() == 0, g['targets'].reshape(-1) == 0)       # ignore_index=0
+
+
+@BOTH_MODES
+def test_gpt2_small_nats_per_token_matches_reference(hal, math_mode):
+    """BASELINE config 3 shape: GPT-2 small, one 1024-token sequence; nats/token vs the CPU reference.
+    Tolerance: 1e-4 abs per token, 1e-5 rel on the mean (fp32 path; bf16x3 operands add ~1e-5 per GEMM)."""
+    g, model = _gpt_from_golden(hal, 'g5_gpt2_small')
+    inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
+    with torch.inference_mode():
+        per_tok = model.forward_all(inputs, targets, reduction='none')
+    np.testing.assert_allclose(per_tok.cpu().numpy(), g['per_token'], rtol=0, atol=2e-4)
+    valid = g['targets'].reshape(-1) != 0
+    np.testing.assert_allclose(per_tok.cpu().numpy()[valid].mean(), float(g['mean']), rtol=2e-5)
+
+
+def test_gpt_refuses_what_is_not_built(hal):
+    from haloop_amd import attention
+    cfg = attention.GPTConfig(block_size=16, vocab_size=50, n_layer=1, n_head=1, n_embd=64)
+    model = attention.GPT(cfg).to(DEV)
+    ids = torch.randint(1, 50, (1, 8), device=DEV)
+    with pytest.raises(NotImplementedError):
+        model.forward_all(ids, ids)                      # grad enabled: backward is not built
+    with pytest.raises(NotImplementedError):
+        attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))

@@ -137,3 +137,22 @@ def test_philox_known_answers():
     m = philox.dropout_mask(100000, 0.2, 1234, 1, 0)
     assert abs((m == 0).mean() - 0.2) < 0.01
     assert set(np.unique(m)) == {np.float32(0), np.float32(1.25)}
+
+
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt2_small'])
+def test_gpt_forward_all_matches_reference(name):
+    from oracle import gpt_ref
+    g = load_golden(name)
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    if name == 'g5_gpt2_small':
+        params = gpt_ref.make_gpt_params(vocab, block, n_layer, n_head, n_embd, bool(bias), seed)
+    else:
+        params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
+    with torch.no_grad():
+        per_tok = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='none')
+        mean = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean')
+    np.testing.assert_allclose(per_tok.numpy(), g['per_token'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(float(mean), float(g['mean']), rtol=1e-6)
+    i2, t2 = gpt_ref.synthetic_tokens(B, T, vocab, seed + 1)
+    assert torch.equal(i2, inputs) and torch.equal(t2, targets)
