@@ -163,12 +163,17 @@ struct ATileStage {      // what to copy into LDS before the first fragment read
     char *dst;           // LDS
     int pieces;          // 1 KiB pieces
     int wave, nwaves, lane;
-    __device__ __forceinline__ void run() const {
+    __device__ __forceinline__ void issue() const {
         for (int pc = wave; pc < pieces; pc += nwaves)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)pc * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("" ::: "memory");        // nothing below may be issued ahead of the LDS-DMA requests
+    }
+    // wait for the tile while the NEWER loads (the first W stage, N of them per lane) stay in flight:
+    // vmcnt retires in issue order, so "all but the N youngest" covers exactly the LDS-DMA requests
+    template <int N>
+    __device__ __forceinline__ void wait_keeping() const {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
     }
 };
 
@@ -196,8 +201,10 @@ __device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[i], acc, 0, 0, 0);
             }
         };
-        stage.run();
+        stage.issue();
         loadw(wh0, wl0, 0);
+        asm volatile("" ::: "memory");
+        stage.wait_keeping<2 * WCH>();
         for (int c = 0; c < nblk; c += 2 * WCH) {
             loadw(wh1, wl1, c + WCH);
             mma(wh0, wl0, c);
@@ -220,8 +227,10 @@ __device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a
                 for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[i][m], acc, 0, 0, 0);
             }
         };
-        stage.run();
+        stage.issue();
         loadw(w0, 0);
+        asm volatile("" ::: "memory");
+        stage.wait_keeping<WCH>();
         for (int c = 0; c < nblk; c += 2 * WCH) {
             loadw(w1, c + WCH);
             mma(w0, c);

@@ -472,3 +472,57 @@ def test_gpt_refuses_what_is_not_built(hal):
         model.forward_all(ids, ids)                      # grad enabled: backward is not built
     with pytest.raises(NotImplementedError):
         attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))
+
+
+# ------------------------------------------------------------------- other shapes of the same path
+@BOTH_MODES
+@pytest.mark.parametrize('F_,C,H,L,V,B,T,S', [
+    (13, 128, 96, 3, 40, 5, 83, 6),        # stock 3-layer encoder on 13 MFCCs (ha/rnn.py:6,11), odd sizes, H % 32 == 0
+    (80, 128, 1536, 2, 32, 3, 80, 10),     # the H=1536 variant (ha/init.py:171)
+    (20, 24, 48, 1, 11, 17, 37, 5),        # single layer, H % 32 != 0 (f32-packed fallback), B not a multiple of 16
+])
+def test_other_shapes_match_oracle(hal, math_mode, F_, C, H, L, V, B, T, S):
+    """Sizes outside the goldens are checked against the CPU oracle (itself pinned to the reference)."""
+    from oracle import cpu_ref
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 31)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, 32)
+    il = torch.clamp(il - torch.arange(B) % 7, min=T // 2)
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc_p.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec_p.items()}
+    loss_ref, feats_ref, flen_ref = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl)
+    loss_ref.backward()
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+    loss, _ = rec(feats, tg.to(DEV), flen, tl.to(DEV))
+    assert np.array_equal(flen.cpu().numpy(), flen_ref.numpy())
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), feats_ref.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    loss.backward()
+    for k, p in enc.named_parameters():
+        ref = pe[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+    for k, p in rec.named_parameters():
+        ref = pr[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+
+
+def test_hap_scoring_contract(hal):
+    """ha/score.py:57-83 semantics on token id lists, against the oracle's forward on the same padded batch."""
+    from haloop_amd import attention, score
+    from oracle import gpt_ref
+    g, model = _gpt_from_golden(hal, 'g5_gpt_tiny_nobias')
+    vocab, block, n_layer, n_head = (int(v) for v in g['cfg'][:4])
+    gen = torch.Generator().manual_seed(4)
+    sents = [torch.randint(1, vocab, (n,), generator=gen).tolist() for n in (5, 17, 40, 1)]     # 40 > block_size 32
+    got = score.score_token_batches(model, sents, eos=vocab - 1)
+    params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    comp = torch.nn.utils.rnn.pad_sequence([torch.LongTensor(s) for s in sents], batch_first=True)[:, :block]
+    inp = torch.cat([torch.full((len(sents), 1), vocab - 1), comp[:, :-1]], dim=1)[:, :block]
+    with torch.no_grad():
+        ref = gpt_ref.gpt_forward_all(params, n_layer, n_head, inp, comp, reduction='none').view(len(sents), -1).sum(-1)
+    for (lpt, n, ln), r, s in zip(got, ref.tolist(), sents):
+        assert n == min(block, len(s)) and ln == len(s)
+        np.testing.assert_allclose(lpt, r / n, rtol=2e-5)
+    assert score.format_lines(got)[0].count('\t') == 2
