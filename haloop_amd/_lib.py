@@ -31,6 +31,7 @@ SIGNATURES = {
     'halo_set_math_mode': (_i, [_i]),
     'halo_get_math_mode': (_i, []),
     'halo_set_scratch': (_i, [_vp, _sz]),
+    'halo_set_lstm_fusion': (_i, [_i]),
     'halo_dropout_fwd': (_i, [_vp, _vp, _sz, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_counter_inc': (_i, [_vp, _vp]),
     'halo_gemm_f32': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
@@ -96,6 +97,11 @@ def set_math_mode(mode):
     """'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16, three MFMAs per product) for the large LSTM GEMMs."""
     code = {'f32': HALO_MATH_F32, 'bf16x3': HALO_MATH_BF16X3}[mode]
     check(lib().halo_set_math_mode(code), 'halo_set_math_mode')
+
+
+def set_lstm_fusion(on):
+    """Layer-diagonal fused schedule for multi-layer LSTMs (off by default; see include/halo.h)."""
+    check(lib().halo_set_lstm_fusion(int(bool(on))), 'halo_set_lstm_fusion')
 
 
 def get_math_mode():

@@ -4,6 +4,8 @@
 #include "halo_internal.h"
 
 static int g_math_mode = 0;
+static int g_lstm_fusion = 0;
+int halo_lstm_fusion() { return g_lstm_fusion; }
 static void *g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 static int g_scratch_slot = 0;
@@ -40,6 +42,11 @@ int halo_set_math_mode(int mode) {
     return HALO_OK;
 }
 int halo_get_math_mode(void) { return g_math_mode; }
+
+int halo_set_lstm_fusion(int on) {
+    g_lstm_fusion = on ? 1 : 0;
+    return HALO_OK;
+}
 
 int halo_set_scratch(void *device_ptr, size_t bytes) {
     if (device_ptr && ((uintptr_t)device_ptr % 16 != 0)) return HALO_EINVAL;

@@ -15,7 +15,8 @@ int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, 
 // C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);
-int halo_math_mode();   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
+int halo_math_mode();
+int halo_lstm_fusion();   // 1: run multi-layer LSTMs as layer-diagonal fused launches (halo_set_lstm_fusion)   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
 
 // ---- caller-provided scratch (halo_set_scratch) and split-K helpers ----
 void halo_get_scratch(void **ptr, size_t *bytes);

@@ -473,6 +473,247 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src
     }
 }
 
+
+// =================================================================================================
+// Layer-diagonal ("wavefront") fusion.  Step t of layer l only needs step t of layer l-1 and step
+// t-1 of layer l, so ONE launch runs step d-l of every layer l (grid.z = layer): a 2-layer, T=21
+// forward is 22 launches instead of 42, and each launch moves 2-3x the bytes for the same fixed
+// launch/prologue/epilogue cost.  For l > 0 the input projection is folded into the step as extra
+// contraction depth (A = [packed y_{l-1,t} ; packed h_{l,t-1}], B = packed [W_ih ; W_hh]); in the
+// backward the gradient arriving from the layer above is the second half of an 8H-deep contraction
+// (A = [dG_l[t+1] ; dG_{l+1}[t]], B = [W_hh_l^T ; W_ih_{l+1}^T]) with the dropout mask applied to
+// that half only.  bf16x3 packed format only; requires H % 64 == 0 (else the per-layer path runs).
+// =================================================================================================
+constexpr int MAXL = 4;
+
+struct DiagFwdLayer {
+    const void *hp_prev;   // packed h_{l,t-1}
+    const void *xp;        // packed y_{l-1,t} (l > 0), else NULL
+    const void *wp;        // l = 0: packed W_hh ; l > 0: packed [W_ih ; W_hh] (K = 2H)
+    float *gates;          // [B,4H]  l = 0 in: x W_ih^T + b, out: activated ; l > 0: out only
+    const float *b_ih, *b_hh;   // l > 0
+    const float *cprev;
+    float *hout, *cout;
+    void *hp_out;
+    float *y;              // row-major second output (dropped y for the next layer / relu features), may be NULL
+    long y_stride_b;
+    int y_mode;
+    void *yp_out;          // packed copy of y for the next layer's A operand, may be NULL
+    uint64_t drop_base;
+    DropoutCfg drop;
+    int active;
+};
+struct DiagFwdArgs {
+    DiagFwdLayer layer[MAXL];
+    int B, H;
+};
+
+__global__ __launch_bounds__(512) void lstm_diag_fwd_kernel(const DiagFwdArgs args) {
+    using PK = Packed<true>;
+    constexpr int KS = 2, NW = 8;
+    const DiagFwdLayer &p = args.layer[blockIdx.z];
+    if (!p.active) return;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];    // [red: 8*256 f32][A tile (layer 0)]
+    float (*red)[256] = reinterpret_cast<float (*)[256]>(dyn_lds);
+    const int jt = blockIdx.x, bt = blockIdx.y;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gate = wave & 3, ks = wave >> 2;
+    const int H = args.H, nkb = H / 32;
+
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int b = b0 + i;
+    const bool cell = threadIdx.x < 256 && b < args.B;
+    float gin[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gin[g] = p.xp ? p.b_ih[g * H + j0 + j] + p.b_hh[g * H + j0 + j] : p.gates[(long)b * 4 * H + (long)g * H + j0 + j];
+        cprev = p.cprev[(long)b * H + j0 + j];
+    }
+    f32x4 acc;
+    if (p.xp) {
+        // K = 2H: k-slice 0 contracts the lower layer's output, k-slice 1 the recurrent state
+        const char *a_img = (const char *)(ks == 0 ? p.xp : p.hp_prev);
+        const char *ap = a_img + (long)bt * nkb * PK::BLOCK_BYTES + lane * 16;
+        const char *bp = (const char *)p.wp + (((long)jt * 4 + gate) * 2 * nkb + (long)ks * nkb) * PK::BLOCK_BYTES + lane * 16;
+        acc = packed_dot<true>(ap, bp, nkb);
+    } else {
+        const int nblk = nkb / KS;
+        const char *bp = (const char *)p.wp + (((long)jt * 4 + gate) * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
+        if (nblk % (2 * WCH) == 0) {
+            char *a_tile = dyn_lds + NW * 256 * sizeof(float);
+            const char *a_src = (const char *)p.hp_prev + (long)bt * nkb * PK::BLOCK_BYTES;
+            const ATileStage stage = {a_src, a_tile, nkb * PK::BLOCK_BYTES / 1024, __builtin_amdgcn_readfirstlane(wave), NW, lane};
+            lds_cchar *a_lds = (lds_cchar *)(a_tile + (long)ks * nblk * PK::BLOCK_BYTES + lane * 16);
+            acc = dot_lds_a<true>(stage, a_lds, bp, nblk);
+        } else {
+            const char *ap = (const char *)p.hp_prev + ((long)bt * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
+            acc = packed_dot<true>(ap, bp, nblk);
+        }
+    }
+    {
+        const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
+    }
+    __syncthreads();
+
+    if (threadIdx.x < 256) {
+        float h = 0.f, yv = 0.f;
+        if (cell) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = red[g][threadIdx.x] + red[4 + g][threadIdx.x] + gin[g];
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const long e = (long)b * H + j0 + j;
+            const float c = fg * cprev + ig * gg;
+            h = og * tanhf(c);
+            float *gp = p.gates + (long)b * 4 * H + j0 + j;
+            gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
+            p.cout[e] = c;
+            p.hout[e] = h;
+            yv = h;
+            if (p.y_mode == Y_RELU) yv = fmaxf(h, 0.f);
+            else if (p.y_mode == Y_DROPOUT) yv = h * dropout_mult(p.drop, p.drop_base + (uint64_t)e);
+            if (p.y) p.y[(long)b * p.y_stride_b + j0 + j] = yv;
+        }
+        PK::store(p.hp_out, bt, H, i, j0 + j, h);
+        if (p.yp_out) PK::store(p.yp_out, bt, H, i, j0 + j, yv);
+    }
+}
+
+struct DiagBwdLayer {
+    const void *dgp_next;     // packed dG_l[t+1], NULL at t = T-1
+    const void *dgp_above;    // packed dG_{l+1}[t], NULL for the top layer
+    const void *wpT_hh;       // packed W_hh_l^T        [H/16][4H/32] blocks
+    const void *wpT_ih_above; // packed W_ih_{l+1}^T    [H/16][4H/32] blocks
+    float *gates;
+    void *dgp_out;
+    const float *c, *cprev;
+    float *dc;
+    const float *dy;          // top layer: gradient w.r.t. the (relu'd) output, strided; may be NULL
+    long dy_stride_b;
+    int dy_relu;
+    const float *dhinit, *dcinit;
+    int first;
+    uint64_t drop_base;       // flat index of (t, 0, 0) in this layer's [T,B,H] output (its dropout mask)
+    DropoutCfg drop;
+    int active;
+};
+struct DiagBwdArgs {
+    DiagBwdLayer layer[MAXL];
+    int B, H;
+};
+
+__global__ __launch_bounds__(1024) void lstm_diag_bwd_kernel(const DiagBwdArgs args) {
+    using PK = Packed<true>;
+    constexpr int NW = 16;
+    const DiagBwdLayer &p = args.layer[blockIdx.z];
+    if (!p.active) return;
+    __shared__ float red[NW][256];
+    const int jt = blockIdx.x, bt = blockIdx.y;
+    const int j0 = jt * 16, b0 = bt * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int H = args.H, K = 4 * H, nkb4 = K / 32;
+
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int b = b0 + i;
+    const bool cell = threadIdx.x < 256 && b < args.B;
+    const long e = (long)b * H + j0 + j;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f, cprev = 0.f, dyv = 0.f, dcin = 0.f, dh0 = 0.f;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = p.gates[(long)b * K + (long)g * H + j0 + j];
+        c = p.c[e];
+        cprev = p.cprev[e];
+        if (p.dy) dyv = p.dy[(long)b * p.dy_stride_b + j0 + j];
+        dcin = p.first ? (p.dcinit ? p.dcinit[e] : 0.f) : p.dc[e];
+        if (p.dhinit) dh0 = p.dhinit[e];
+    }
+    // waves 0..7 (or all 16 for the top layer): recurrent half; waves 8..15: the half from the layer above
+    const bool two = p.dgp_above != nullptr;
+    const int seg = two ? (wave >> 3) : 0;
+    const int wseg = two ? (wave & 7) : wave;
+    // H % 64 == 0 makes nkb4 = H/8 a multiple of 8: a segment is cut over 8 waves, or over 16 when it divides
+    const int nw_seg = (!two && nkb4 % 16 == 0) ? 16 : 8;
+    const int nblk = nkb4 / nw_seg;
+    const void *a_img = seg ? p.dgp_above : p.dgp_next;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (a_img && wseg < nw_seg) {
+        const char *ap = (const char *)a_img + ((long)bt * nkb4 + wseg * nblk) * PK::BLOCK_BYTES + lane * 16;
+        const char *bp = (const char *)(seg ? p.wpT_ih_above : p.wpT_hh) + ((long)jt * nkb4 + wseg * nblk) * PK::BLOCK_BYTES + lane * 16;
+        acc = packed_dot<true>(ap, bp, nblk);
+    }
+    {
+        const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) red[wave][(4 * q + e2) * 16 + r] = acc[e2];
+    }
+    __syncthreads();
+
+    if (threadIdx.x < 256) {
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell) {
+            float rec = 0.f, above = 0.f;
+            if (two) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { rec += red[k][threadIdx.x]; above += red[8 + k][threadIdx.x]; }
+                above *= dropout_mult(p.drop, p.drop_base + (uint64_t)e);   // this layer's own output mask
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) rec += red[k][threadIdx.x];
+            }
+            float dh = dh0 + rec + above;
+            const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+            const float tc = tanhf(c);
+            if (p.dy) {
+                float d = dyv;
+                if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
+                dh += d;
+            }
+            float dcc = dcin + dh * og * (1.f - tc * tc);
+            const float d_o = dh * tc;
+            const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
+            p.dc[e] = dcc * fg;
+            dg[0] = d_i * ig * (1.f - ig);
+            dg[1] = d_f * fg * (1.f - fg);
+            dg[2] = d_g * (1.f - gg * gg);
+            dg[3] = d_o * og * (1.f - og);
+            float *gp = p.gates + (long)b * K + j0 + j;
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) PK::store(p.dgp_out, bt, K, i, g * H + j0 + j, dg[g]);
+    }
+}
+
+// packed [W_ih ; W_hh] for the fused forward of a layer l > 0: tile (jt*4+g), k over 2H
+__global__ __launch_bounds__(256) void pack_cat_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                                       void *__restrict__ dst, int H, long units) {
+    const int nkb = 2 * H / 32;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+        const int lane = (int)(u & 63);
+        long blk = u >> 6;
+        const int kb = (int)(blk % nkb);
+        const int tile = (int)(blk / nkb);
+        const int g = tile & 3, jt = tile >> 2;
+        const int r = lane & 15, k0 = kb * 32 + (lane >> 4) * 8;
+        const float *src = k0 < H ? w_ih + ((long)g * H + jt * 16 + r) * H + k0 : w_hh + ((long)g * H + jt * 16 + r) * H + (k0 - H);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = src[e];
+            const __bf16 hh = (__bf16)xv;
+            hi[e] = hh;
+            lo[e] = (__bf16)(xv - (float)hh);
+        }
+        char *base = (char *)dst + blk * 2048;
+        *reinterpret_cast<bf16x8 *>(base + lane * 16) = hi;
+        *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
+    }
+}
+
 struct LayerBufs {
     float *h, *c, *gates, *ydrop, *hp;
 };
@@ -585,15 +826,174 @@ inline int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st) {
     return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? HALO_OK : HALO_ELAUNCH;
 }
 
+// ---- layer-diagonal fused path: eligibility, extra buffers, drivers ------------------------------
+inline bool fused_ok(int H, int L) {
+    return halo_lstm_fusion() && L >= 2 && L <= MAXL && halo_math_mode() == HALO_MATH_BF16X3 && H % 64 == 0;
+}
+// appended to the reserve: packed forward weights of every layer (all layers are live at once) and the
+// packed y_{l,t} images of the non-top layers
+inline size_t fused_fwd_extra_floats(int T, int B, int H, int L) {
+    return (size_t)4 * H * H + (size_t)(L - 1) * 8 * H * H + (size_t)(L - 1) * T * bt16(B) * H;
+}
+inline float *fused_wpk(float *extra, int l, int H) {
+    return l == 0 ? extra : extra + (size_t)4 * H * H + (size_t)(l - 1) * 8 * H * H;
+}
+inline float *fused_yp(float *extra, int l, int T, int B, int H, int L) {
+    return extra + (size_t)4 * H * H + (size_t)(L - 1) * 8 * H * H + (size_t)l * T * bt16(B) * H;
+}
+// appended to the backward workspace, per layer: packed W_hh^T, packed W_ih^T, dc carry, two packed dG images
+inline size_t fused_bwd_layer_floats(int B, int H) { return (size_t)8 * H * H + (size_t)B * H + 2 * bt16(B) * 4 * H; }
+
+int lstm_fwd_fused(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+                   const float *const *b_hh, const float *h0, const float *c0, float *y, long y_stride_t, long y_stride_b,
+                   int y_relu, float *hn, float *cn, float *reserve, float *extra, char *img_in, char *img_w, int T, int B,
+                   int in0, int H, int L, float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev,
+                   hipStream_t st) {
+    const size_t BH = (size_t)B * H, PH = bt16(B) * H;
+    const int nkb = H / 32;
+    // operand preparation for every layer, then layer 0's batched input projection
+    for (int l = 0; l < L; ++l) {
+        const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+        if (l == 0) {
+            HALO_TRY(launch_pack<0>(w_hh[0], fused_wpk(extra, 0, H), H, B, H, (H / 16) * 4, true, st));
+        } else {
+            const long units = (long)(H / 16) * 4 * (2 * nkb) * 64;
+            long g = (units + 255) / 256;
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(pack_cat_kernel, dim3((unsigned)g), dim3(256), 0, st, w_ih[l], w_hh[l], (void *)fused_wpk(extra, l, H), H, units);
+            HALO_TRY(halo_launch_status());
+        }
+        const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
+        HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, true, st, lb.h, c0 ? c0 + (size_t)l * BH : nullptr, lb.c));
+    }
+    {
+        const LayerBufs lb = layer_bufs(reserve, 0, T, B, H);
+        if (in0 >= 64) {
+            HALO_TRY(halo_prep_tiles(x, T * B, in0, in0, 0, img_in, st));
+            HALO_TRY(halo_prep_tiles(w_ih[0], 4 * H, in0, in0, 0, img_w, st));
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in0, lb.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
+        } else {
+            HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in0, x, in0, w_ih[0], in0, lb.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0,
+                                   0, nullptr, (halo_stream_t)st));
+        }
+    }
+    const bool alds = (nkb / 2) % (2 * WCH) == 0;
+    const size_t lds_bytes = (size_t)8 * 256 * sizeof(float) + (alds ? (size_t)nkb * 2048 : 0);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)lstm_diag_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    for (int d = 0; d < T + L - 1; ++d) {
+        DiagFwdArgs a;
+        a.B = B; a.H = H;
+        for (int l = 0; l < MAXL; ++l) {
+            DiagFwdLayer &q = a.layer[l];
+            const int t = d - l;
+            q.active = l < L && t >= 0 && t < T;
+            if (!q.active) continue;
+            const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+            const bool last = (l == L - 1);
+            const bool drop_out = !last && p_drop > 0.f;
+            q.hp_prev = lb.hp + (size_t)t * PH;
+            q.xp = l > 0 ? fused_yp(extra, l - 1, T, B, H, L) + (size_t)t * PH : nullptr;
+            q.wp = fused_wpk(extra, l, H);
+            q.gates = lb.gates + (size_t)t * B * 4 * H;
+            q.b_ih = b_ih[l]; q.b_hh = b_hh[l];
+            q.cprev = lb.c + (size_t)t * BH;
+            q.hout = lb.h + (size_t)(t + 1) * BH;
+            q.cout = lb.c + (size_t)(t + 1) * BH;
+            q.hp_out = lb.hp + (size_t)(t + 1) * PH;
+            q.drop = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
+            q.drop_base = (uint64_t)t * BH;
+            if (last) {
+                q.y = y ? y + (long)t * y_stride_t : nullptr;
+                q.y_stride_b = y_stride_b;
+                q.y_mode = y_relu ? Y_RELU : Y_PLAIN;
+                q.yp_out = nullptr;
+            } else {
+                q.y = drop_out ? lb.ydrop + (size_t)t * BH : nullptr;
+                q.y_stride_b = H;
+                q.y_mode = drop_out ? Y_DROPOUT : Y_PLAIN;
+                q.yp_out = fused_yp(extra, l, T, B, H, L) + (size_t)t * PH;
+            }
+        }
+        hipLaunchKernelGGL(lstm_diag_fwd_kernel, dim3(H / 16, (B + 15) / 16, L), dim3(512), lds_bytes, st, a);
+        HALO_TRY(halo_launch_status());
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+        if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
+        if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
+    }
+    return HALO_OK;
+}
+
+// the backward step chain of ALL layers, fused along layer diagonals; leaves dG of every layer in its gates buffer
+int lstm_bwd_fused_chain(const float *const *w_ih, const float *const *w_hh, const float *dy, long y_stride_t,
+                         long y_stride_b, int y_relu, const float *dhn, const float *dcn, float *reserve, float *extra,
+                         int T, int B, int H, int L, float p_drop, uint64_t seed, uint32_t offset,
+                         const uint32_t *offset_dev, hipStream_t st) {
+    const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H, per = fused_bwd_layer_floats(B, H);
+    for (int l = 0; l < L; ++l) {
+        float *base = extra + (size_t)l * per;
+        HALO_TRY(launch_pack<1>(w_hh[l], base, H, B, 4 * H, H / 16, true, st));
+        if (l > 0) HALO_TRY(launch_pack<1>(w_ih[l], base + (size_t)4 * H * H, H, B, 4 * H, H / 16, true, st));
+    }
+    for (int d = 0; d < T + L - 1; ++d) {
+        DiagBwdArgs a;
+        a.B = B; a.H = H;
+        for (int l = 0; l < MAXL; ++l) {
+            DiagBwdLayer &q = a.layer[l];
+            const int t = l < L ? T - 1 - (d - (L - 1 - l)) : -1;
+            q.active = l < L && t >= 0 && t < T;
+            if (!q.active) continue;
+            const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+            float *base = extra + (size_t)l * per;
+            float *dcarry = base + (size_t)8 * H * H;
+            float *dgp = dcarry + BH;
+            const bool top = (l == L - 1);
+            q.dgp_next = (t == T - 1) ? nullptr : dgp + (size_t)((t + 1) & 1) * PG;
+            q.dgp_out = dgp + (size_t)(t & 1) * PG;
+            q.wpT_hh = base;
+            if (!top) {
+                float *above = extra + (size_t)(l + 1) * per;
+                q.dgp_above = above + (size_t)8 * H * H + BH + (size_t)(t & 1) * PG;
+                q.wpT_ih_above = above + (size_t)4 * H * H;
+            } else {
+                q.dgp_above = nullptr; q.wpT_ih_above = nullptr;
+            }
+            q.gates = lb.gates + (size_t)t * B * 4 * H;
+            q.c = lb.c + (size_t)(t + 1) * BH;
+            q.cprev = lb.c + (size_t)t * BH;
+            q.dc = dcarry;
+            q.dy = (top && dy) ? dy + (long)t * y_stride_t : nullptr;
+            q.dy_stride_b = y_stride_b;
+            q.dy_relu = y_relu;
+            q.first = (t == T - 1);
+            q.dhinit = (t == T - 1 && dhn) ? dhn + (size_t)l * BH : nullptr;
+            q.dcinit = (t == T - 1 && dcn) ? dcn + (size_t)l * BH : nullptr;
+            q.drop = make_dropout(top ? 0.f : p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
+            q.drop_base = (uint64_t)t * BH;
+        }
+        hipLaunchKernelGGL(lstm_diag_bwd_kernel, dim3(H / 16, (B + 15) / 16, L), dim3(1024), 0, st, a);
+        HALO_TRY(halo_launch_status());
+    }
+    return HALO_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
 
 size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
     const int kin = in0 > H ? in0 : H;
     return ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float) +
-           halo_tiled_image_bytes(T * B, kin) + halo_tiled_image_bytes(4 * H, kin);
+           halo_tiled_image_bytes(T * B, kin) + halo_tiled_image_bytes(4 * H, kin) +
+           (L >= 2 ? fused_fwd_extra_floats(T, B, H, L) * sizeof(float) : 0);
 }
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
@@ -603,7 +1003,8 @@ size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     const int kin = in0 > H ? in0 : H;
     return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + 2 * bt16(B) * 4 * H) * sizeof(float) +
            halo_tiled_image_bytes(4 * H, T * B) + halo_tiled_image_bytes(T * B, 4 * H) +
-           2 * halo_tiled_image_bytes(kin, T * B) + halo_tiled_image_bytes(kin, 4 * H);
+           2 * halo_tiled_image_bytes(kin, T * B) + halo_tiled_image_bytes(kin, 4 * H) +
+           (L >= 2 ? (size_t)L * fused_bwd_layer_floats(B, H) * sizeof(float) : 0);
 }
 
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
@@ -621,8 +1022,13 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     const int kin = in0 > H ? in0 : H;
     char *img_in = (char *)(reserve + (size_t)4 * H * H + (size_t)L * layer_floats(T, B, H));
     char *img_w = img_in + halo_tiled_image_bytes(T * B, kin);
+    for (int l = 0; l < L; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
+    if (fused_ok(H, L)) {
+        float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
+        return lstm_fwd_fused(x, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra,
+                              img_in, img_w, T, B, in0, H, L, p_drop, seed, offset, offset_dev, st);
+    }
     for (int l = 0; l < L; ++l) {
-        HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
         const bool drop_out = !last && p_drop > 0.f;
@@ -708,12 +1114,19 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     char *img_hT = img_g + halo_tiled_image_bytes(T * B, 4 * H);
     char *img_inT = img_hT + halo_tiled_image_bytes(kin, T * B);
     char *img_wT = img_inT + halo_tiled_image_bytes(kin, T * B);
+    // layer-diagonal fused step chain: all layers at once, on the call that contains the top layer
+    const bool fused = fused_ok(H, L);
+    if (fused && layer_end == L) {
+        float *extra = (float *)(img_wT + halo_tiled_image_bytes(kin, 4 * H));
+        HALO_TRY(lstm_bwd_fused_chain(w_ih, w_hh, dy, y_stride_t, y_stride_b, y_relu, dhn, dcn, reserve, extra, T, B, H, L,
+                                      p_drop, seed, offset, offset_dev, st));
+    }
     for (int l = layer_end - 1; l >= layer_begin; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
-        HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
-        for (int t = T - 1; t >= 0; --t) {
+        if (!fused) HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
+        for (int t = T - 1; t >= 0 && !fused; --t) {
             StepBwdArgs a;
             a.dgp_next = (t == T - 1) ? nullptr : dgp + (size_t)((t + 1) & 1) * PG;
             a.dgp_out = dgp + (size_t)(t & 1) * PG;
@@ -746,7 +1159,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
             in_dim = H;
         }
-        const bool need_din = (l > 0) || dx;
+        const bool need_din = (l > 0 && !fused) || (l == 0 && dx);   // fused: upper layers fold it into their steps
         float *din_out = l > 0 ? din : dx;
         const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
                                               offset, offset_dev);

@@ -50,6 +50,15 @@ int halo_device_info(int device, char *arch, int arch_len, int *cu_count);
 int halo_set_math_mode(int mode);
 int halo_get_math_mode(void);
 
+/* Multi-layer LSTM schedule (HALO_MATH_BF16X3, H % 64 == 0, 2..4 layers):
+ *   0 (default)  per-layer: each layer's T steps in turn, input projections as batched GEMMs;
+ *   1            layer-diagonal fusion: one launch per diagonal runs step d-l of every layer l, the
+ *                upper layers' input projection (forward) and input gradient (backward) folded into
+ *                the step as extra contraction depth.  Same results; measured 2.7 % slower at
+ *                LC-2x1024/B=64 (the batched GEMMs move W_ih more efficiently than 21 folded steps),
+ *                so it is off by default. */
+int halo_set_lstm_fusion(int on);
+
 /* Optional scratch for split-K partial sums.  The library never allocates: the caller may lend it
  * one persistent device buffer (16-byte aligned; 64 MiB is plenty for this model).  With it, GEMMs
  * whose output has too few tiles to fill 256 CUs are split along K into slabs that a second launch

@@ -240,6 +240,17 @@ def math_mode(request, hal):
 BOTH_MODES = pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
 
 
+@pytest.fixture
+def fusion(request, hal):
+    """Layer-diagonal fused LSTM schedule on/off (only takes effect in bf16x3 mode with H % 64 == 0, L >= 2)."""
+    hal['lib'].set_lstm_fusion(request.param)
+    yield request.param
+    hal['lib'].set_lstm_fusion(False)
+
+
+FUSION = pytest.mark.parametrize('fusion', [False, True], indirect=True)
+
+
 @BOTH_MODES
 @pytest.mark.parametrize('name', ['g1_tiny_l2', 'g1_tiny_l3'])
 def test_tiny_model_matches_reference(hal, name, math_mode):
@@ -265,8 +276,9 @@ def test_tiny_model_matches_reference(hal, name, math_mode):
     assert [h.tolist() for h in hyps.unbind()] == _unpad(g['hyps'], g['hlen'])
 
 
+@FUSION
 @BOTH_MODES
-def test_lc2x1024_matches_reference(hal, math_mode):
+def test_lc2x1024_matches_reference(hal, math_mode, fusion):
     """BASELINE config 1 shapes: 2-layer H=1024, 80x80 mel, B=4, V=32 against the reference's numbers.
     Both arithmetic modes must meet the fp32-exact tolerances (bf16x3 keeps ~16 bits per operand)."""
     from oracle import cpu_ref
@@ -329,10 +341,12 @@ def test_training_mode_matches_oracle_with_same_masks(hal, math_mode):
         np.testing.assert_allclose(p.grad.cpu().numpy(), pr[k].grad.numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
 
 
+@FUSION
 @BOTH_MODES
-def test_decoder_lm_matches_torch_lstm(hal, math_mode):
+@pytest.mark.parametrize('E', [32, 64])       # 64 with fusion: the layer-diagonal path with carried state
+def test_decoder_lm_matches_torch_lstm(hal, math_mode, fusion, E):
     """ha.rnn.Decoder surface: time-major LSTM with carried state + tied output layer."""
-    V, E, L, T, N = 50, 32, 2, 9, 3
+    V, L, T, N = 50, 2, 9, 3
     torch.manual_seed(4)
     dec = hal['rnn'].Decoder(V, E, E, L)
     ref = torch.nn.LSTM(E, E, L)
@@ -475,13 +489,16 @@ def test_gpt_refuses_what_is_not_built(hal):
 
 
 # ------------------------------------------------------------------- other shapes of the same path
+@FUSION
 @BOTH_MODES
 @pytest.mark.parametrize('F_,C,H,L,V,B,T,S', [
     (13, 128, 96, 3, 40, 5, 83, 6),        # stock 3-layer encoder on 13 MFCCs (ha/rnn.py:6,11), odd sizes, H % 32 == 0
     (80, 128, 1536, 2, 32, 3, 80, 10),     # the H=1536 variant (ha/init.py:171)
     (20, 24, 48, 1, 11, 17, 37, 5),        # single layer, H % 32 != 0 (f32-packed fallback), B not a multiple of 16
+    (20, 32, 64, 3, 11, 20, 45, 5),        # smallest shape of the layer-diagonal fused path (H % 64 == 0, L = 3)
+    (40, 64, 128, 2, 32, 64, 80, 10),      # fused path, B = 64
 ])
-def test_other_shapes_match_oracle(hal, math_mode, F_, C, H, L, V, B, T, S):
+def test_other_shapes_match_oracle(hal, math_mode, fusion, F_, C, H, L, V, B, T, S):
     """Sizes outside the goldens are checked against the CPU oracle (itself pinned to the reference)."""
     from oracle import cpu_ref
     enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 31)
