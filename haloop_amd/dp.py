@@ -29,6 +29,22 @@ def shard_slice(global_batch, rank, world):
     return slice(rank * b, (rank + 1) * b)
 
 
+_AVG_PROBE = {}
+
+
+def _avg_supported(like, group):
+    """One tiny collective, identical on every rank, to learn whether ReduceOp.AVG works here."""
+    key = id(group)
+    if key not in _AVG_PROBE:
+        try:
+            t = torch.ones(4, device=like.device, dtype=like.dtype)
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+            _AVG_PROBE[key] = bool(torch.allclose(t, torch.ones_like(t)))
+        except Exception:
+            _AVG_PROBE[key] = False
+    return _AVG_PROBE[key]
+
+
 class GradientAverager:
     """All-reduce(SUM)/world of ``flat_grads[span]`` in ``bucket_bytes`` pieces.
 
@@ -48,8 +64,8 @@ class GradientAverager:
         for a, b in zip(cuts[:-1], cuts[1:]):
             for c in range(a, b, per):
                 self.buckets.append((c, min(c + per, b)))
-        # RCCL averages in the collective itself; gloo has no AVG, so scale afterwards
-        self._avg_op = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        # RCCL averages in the collective itself; gloo has no AVG (and an old RCCL might not): probe once
+        self._avg_op = self.world > 1 and dist.get_backend(group) == 'nccl' and _avg_supported(flat_grads, group)
 
     def reduce_bucket(self, i, async_op=False):
         a, b = self.buckets[i]
