@@ -180,6 +180,15 @@ __global__ void ctc_beta_grad_kernel(const CtcBwdArgs p) {
 // one state per lane, and the s-1 / s-2 (s+1 / s+2) neighbours come from wave shuffles, so the
 // T-step recursion has no memory round trips in its dependency chain.
 
+// log(e^a + e^b) on the hardware exp2/log2 units (v_exp_f32 / v_log_f32): ~1e-7 absolute error per call,
+// an order below the lattice's own fp32 rounding over T steps; the serial chain is ~10x shorter than
+// with the libm-accurate expf/log1pf, which is what bounds a one-wave-per-utterance recursion.
+__device__ __forceinline__ float log_add_exp_fast(float a, float b) {
+    if (isinf(a) && a == b) return a;
+    const float m = fmaxf(a, b);
+    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+}
+
 __global__ __launch_bounds__(64) void ctc_alpha_wave_kernel(const CtcArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lp_s[];   // [T*C]
     const int n = blockIdx.x, lane = threadIdx.x;
@@ -216,9 +225,9 @@ __global__ __launch_bounds__(64) void ctc_alpha_wave_kernel(const CtcArgs p) {
             if (lane == 0) {
                 v = (p.flags & HALO_CTC_NO_LEAD_BLANK_LOOP) ? neg : prev + lp_s[t * C];
             } else {
-                float acc = log_add_exp(prev, p1);
-                if (lane >= 2) { if (can_skip) acc = log_add_exp(acc, p2); }
-                else if (p.flags & HALO_CTC_WRAP_SKIP) acc = log_add_exp(acc, plast);
+                float acc = log_add_exp_fast(prev, p1);
+                if (lane >= 2) { if (can_skip) acc = log_add_exp_fast(acc, p2); }
+                else if (p.flags & HALO_CTC_WRAP_SKIP) acc = log_add_exp_fast(acc, plast);
                 v = acc + lp_s[t * C + lab];
             }
         }
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_wave_kernel(const CtcArgs p) {
     if (lane == 0) {
         float out;
         if (!full && il == 0) out = tl == 0 ? 0.f : INFINITY;
-        else out = -log_add_exp(ra, rb);
+        else out = -log_add_exp_fast(ra, rb);
         p.nll[n] = out;
     }
 }
@@ -265,8 +274,8 @@ __global__ __launch_bounds__(256) void ctc_beta_grad_wave_kernel(const CtcBwdArg
                 if (t == il - 1) {
                     if (lane == states - 1 || lane == states - 2) v = lp_s[t * C + lab];
                 } else {
-                    float acc = log_add_exp(nxt, lane + 1 < states ? n1 : ninf);
-                    if (can_skip) acc = log_add_exp(acc, n2);
+                    float acc = log_add_exp_fast(nxt, lane + 1 < states ? n1 : ninf);
+                    if (can_skip) acc = log_add_exp_fast(acc, n2);
                     v = acc + lp_s[t * C + lab];
                 }
                 beta[(long)t * S_ + lane] = v;
@@ -287,12 +296,12 @@ __global__ __launch_bounds__(256) void ctc_beta_grad_wave_kernel(const CtcBwdArg
             float lcab = ninf;
             if (m > ninf) {
                 float sum = 0.f;
-                if (c == 0) { for (int s = 0; s < states; s += 2) sum += expf(row[s] - m); }
-                else        { for (int s = 1; s < states; s += 2) if ((int)tg[s >> 1] == c) sum += expf(row[s] - m); }
-                lcab = m + logf(sum);
+                if (c == 0) { for (int s = 0; s < states; s += 2) sum += __expf(row[s] - m); }
+                else        { for (int s = 1; s < states; s += 2) if ((int)tg[s >> 1] == c) sum += __expf(row[s] - m); }
+                lcab = m + __logf(sum);
             }
             const float l = lp_s[idx];
-            g = (expf(l) - expf(lcab + nll - l)) * go;
+            g = (__expf(l) - __expf(lcab + nll - l)) * go;
         }
         grad[(long)t * p.gstride_t + c] = g;
     }
