@@ -66,15 +66,16 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restr
 // One workgroup = 64 query rows of one (batch, head); 4 waves x 16 rows.  Keys/values stream through
 // LDS in tiles of 64; S = Q K^T and O += P V run on v_mfma_f32_16x16x4_f32 (exact f32), softmax is the
 // online (running max / running sum) form.  LDS images are chosen for conflict-free MFMA operand reads:
-//   Kt [dim][key]  stride 80  (B operand of Q K^T: lane (key = l&15, dim-group = l>>4))
+//   Ks [key][dim]  stride 66  (B operand of Q K^T: lane (key = l&15, dim-group = l>>4); 2*key + group is
+//                              distinct over a 32-lane read group, and staging writes are 8-byte aligned)
 //   Vs [key][dim]  stride 80  (B operand of P V  : lane (dim = l&15, key-group = l>>4))
 //   Ps [row][key]  stride 66, per wave (P re-laid from the MFMA D layout to the A layout)
 template <int HD>
 __global__ __launch_bounds__(256) void attention_causal_kernel(const float *__restrict__ qkv, float *__restrict__ y, int T,
                                                                int n_head, int C, float scale) {
-    constexpr int KT_STRIDE = 80, VS_STRIDE = HD + 16, PS_STRIDE = 66;
-    __shared__ float Kt[HD * KT_STRIDE];
-    __shared__ float Vs[64 * VS_STRIDE];
+    constexpr int KS_STRIDE = HD + 2, VS_STRIDE = HD + 16, PS_STRIDE = 66;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * VS_STRIDE];
     __shared__ float Ps[4][16 * PS_STRIDE];
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -99,20 +100,35 @@ __global__ __launch_bounds__(256) void attention_causal_kernel(const float *__re
     for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
 
     const int n_ktiles = qt + 1;                          // causal: keys up to the diagonal tile
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-        __syncthreads();                                  // previous tile fully consumed
-        // stage K (transposed) and V: 64 keys x HD dims each; thread -> (key, 4 dims)
-        for (int u = threadIdx.x; u < 64 * (HD / 4); u += 256) {
+    // K/V tiles are fetched one tile ahead into registers (issue early, write to LDS late), so the global
+    // latency of tile kt+1 hides under the MFMAs of tile kt
+    constexpr int UNITS = 64 * (HD / 4) / 256;            // float4 units of K (and of V) per thread and tile
+    f32x4 kreg[UNITS], vreg[UNITS];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = threadIdx.x + 256 * i;
             const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
             const int krow = min(kt * 64 + key, T - 1);
             const float *kp = base + (long)krow * row_stride + C + d4;
-            const f32x4 kv = *reinterpret_cast<const f32x4 *>(kp);
-            const f32x4 vv = *reinterpret_cast<const f32x4 *>(kp + C);
+            kreg[i] = *reinterpret_cast<const f32x4 *>(kp);
+            vreg[i] = *reinterpret_cast<const f32x4 *>(kp + C);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+        __syncthreads();                                  // previous tile fully consumed
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Kt[(d4 + e) * KT_STRIDE + key] = kv[e];
-            *reinterpret_cast<f32x4 *>(&Vs[key * VS_STRIDE + d4]) = vv;
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4]) = f32x2{kreg[i][0], kreg[i][1]};
+            *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4 + 2]) = f32x2{kreg[i][2], kreg[i][3]};
+            *reinterpret_cast<f32x4 *>(&Vs[key * VS_STRIDE + d4]) = vreg[i];
         }
         __syncthreads();
+        if (kt + 1 < n_ktiles) fetch(kt + 1);
         // S = Q K^T : 4 key sub-tiles of 16
         f32x4 sacc[4];
 #pragma unroll
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void attention_causal_kernel(const float *__re
             sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < HD / 4; ++s)
-                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Kt[(4 * s + lq) * KT_STRIDE + 16 * n + lr], sacc[n], 0, 0, 0);
+                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * KS_STRIDE + 4 * s + lq], sacc[n], 0, 0, 0);
         }
         // causal mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
         float alpha[4];
@@ -138,11 +154,11 @@ __global__ __launch_bounds__(256) void attention_causal_kernel(const float *__re
             for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
             const float mnew = fmaxf(mrow[r], mx);
             const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            alpha[r] = expf(mrow[r] - msafe);             // exp(-inf) = 0 on the first tile
+            alpha[r] = __expf(mrow[r] - msafe);           // exp(-inf) = 0 on the first tile (hardware exp2: ~1e-7 rel.)
             float ps = 0.f;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const float pv = expf(sacc[n][r] - msafe);
+                const float pv = __expf(sacc[n][r] - msafe);
                 sacc[n][r] = pv;
                 ps += pv;
             }
