@@ -24,9 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init   # the reference
+import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init, ha.transformer, ha.conv   # the reference
 
-from oracle import cpu_ref, gpt_ref
+from oracle import cpu_ref, gpt_ref, transformer_ref
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -273,8 +273,78 @@ def save_gpt():
     gpt_case('g5_gpt_tiny_bias', 97, 48, 3, 1, 64, True, 2, 40, 6, True)
     gpt_case('g5_gpt2_small', 50304, 1024, 12, 12, 768, False, 1, 1024, 7, False)   # params rebuilt from the seed
 
+def asr_case(name, vocab, head_dim, heads, enc_layers, dec_layers, conv_dim, N, T, S, seed, strides=(2, 2, 2), F_=80):
+    """ha.transformer AudioEncoder + CTCAttentionDecoder (the `transformer:V` family of ha/init.py:234-239) on CPU:
+    encoder features/lengths, teacher-forced losses, joint CTC loss, and the greedy decode under fp16 autocast
+    (the only way the reference's decode runs: its KV caches are float16)."""
+    enc = ha.transformer.AudioEncoder(head_dim=head_dim, heads=heads, layers=enc_layers, p_drop=0.2, input_dim=F_,
+                                      conv_dim=conv_dim, conv_strides=strides).eval()
+    dec = ha.transformer.CTCAttentionDecoder(vocab=vocab, head_dim=head_dim, heads=heads, p_drop=0.2, layers=dec_layers).eval()
+    pe = transformer_ref.make_encoder_params(head_dim, heads, enc_layers, F_, conv_dim, len(strides), seed)
+    pd = transformer_ref.make_decoder_params(vocab, head_dim, heads, dec_layers, seed + 1)
+    enc.load_state_dict(pe, strict=True)
+    dec.load_state_dict(pd, strict=True)
+    x, il, tg, tl = transformer_ref.synthetic_asr_batch(N, T, F_, vocab, S, seed + 2)
+    d = {'cfg': np.array([vocab, head_dim, heads, enc_layers, dec_layers, conv_dim, N, T, S, seed, F_]), 'strides': np.array(strides)}
+    with torch.no_grad():
+        feats, flen, _ = enc(x, il)
+        d['features'], d['feature_lengths'] = feats.numpy(), flen.numpy()
+        for red in ('mean', 'none', 'sumeach'):
+            loss, _ = dec.decoder(feats, tg, flen, tl, reduction=red, drop_labels=False)
+            d['decoder_loss.' + red] = loss.numpy()
+        cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1)       # one prompt token in front
+        joint, _ = dec(feats, cond, flen, tl + 1)
+        d['joint_loss'] = joint.numpy()
+        _, stats = dec.decoder(feats, tg, flen, tl, measure_entropy=True, drop_labels=False)
+        d['meme_entropy'] = torch.stack(stats['meme_entropy']).numpy()
+        d['self_entropy'] = torch.stack(stats['self_entropy']).numpy()
+        with torch.autocast('cpu', dtype=torch.float16):
+            outs, olen, _, lps, ents = dec.decode(feats, flen, tl)
+        d['decode.tokens'], d['decode.token_lens'] = pad_seqs([o.tolist() for o in outs.unbind()])
+        d['decode.output_lengths'], d['decode.log_probs'], d['decode.sum_entropies'] = olen.numpy(), lps.numpy(), ents.numpy()
+        user = torch.tensor([[7, 9]] * N)
+        with torch.autocast('cpu', dtype=torch.float16):
+            outs, olen, _, lps, ents = dec.decode(feats, flen, tl, prompt=user)
+        d['decode_prompt.tokens'], d['decode_prompt.token_lens'] = pad_seqs([o.tolist() for o in outs.unbind()])
+        d['decode_prompt.output_lengths'], d['decode_prompt.log_probs'] = olen.numpy(), lps.numpy()
+        # decisiveness of the fixture: smallest top-2 margin of the oracle's own (fp32, fp16-cache) greedy run
+        o = transformer_ref.decoder_decode(pd, feats, flen, tl, heads, pre='decoder.')
+        top2 = o[4].topk(2, dim=-1).values
+        d['decode.min_margin'] = (top2[..., 0] - top2[..., 1]).min().numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'flen', flen.tolist(), 'dec loss', float(d['decoder_loss.mean']), 'joint', float(joint), 'decode lens',
+          d['decode.output_lengths'].tolist(), 'margin', float(d['decode.min_margin']))
+
+
+def save_asr():
+    # seeds picked (scan over the oracle's greedy run) so that greedy choices are decisive (top-2 margin > 0.15 on every
+    # alive step: fp16-vs-fp32 rounding cannot flip a token), rows differ, and some rows stop early on ETX
+    asr_case('g6_asr_tiny', 32, 16, 2, 2, 2, 32, 3, 80, 6, 125)
+    asr_case('g6_asr_tiny_s221', 40, 32, 1, 1, 2, 48, 4, 53, 5, 89, strides=(2, 2, 1), F_=40)
+    asr_case('g6_asr_tiny_stop', 40, 32, 1, 1, 2, 48, 4, 53, 5, 65, strides=(2, 2, 1), F_=40)
+    asr_case('g6_asr_transformer32', 32, 64, 8, 12, 12, 256, 2, 80, 8, 28)          # ha/init.py:234-239 `transformer:32`
+    asr_case('g6_asr_transformer32_stop', 32, 64, 8, 12, 12, 256, 2, 80, 8, 44)
+    d = {}
+    g = torch.Generator().manual_seed(3)
+    for nm, shape, t0 in (('a', (2, 3, 7, 16), 0), ('b', (1, 2, 1, 64), 11), ('c', (5, 8), 3)):
+        x = torch.randn(shape, generator=g)
+        d[f'rope.{nm}.x'], d[f'rope.{nm}.t0'], d[f'rope.{nm}.y'] = x.numpy(), np.array(t0), ha.transformer.rotate_interleaved(x, t0=t0).numpy()
+    q, k, v = (torch.randn(2, 3, 9, 16, generator=g) for _ in range(3))
+    mask = torch.rand(2, 1, 1, 9, generator=g) > 0.7
+    mask[..., 0] = False
+    y, ent = ha.transformer.attend(q, k, v, mask)
+    d['attend.q'], d['attend.k'], d['attend.v'], d['attend.mask'], d['attend.y'], d['attend.entropy'] = (
+        q.numpy(), k.numpy(), v.numpy(), mask.numpy(), y.numpy(), ent.numpy())
+    conv = ha.conv.ConvEncoder(input_dim=8, hidden_dim=8, output_dim=8, strides=(2, 2, 2))
+    lens = torch.arange(1, 200)
+    d['lengths.in'], d['lengths.s222'] = lens.numpy(), conv.subsampled_lengths(lens).numpy()
+    conv = ha.conv.ConvEncoder(input_dim=8, hidden_dim=8, output_dim=8, strides=(2, 2, 1))
+    d['lengths.s221'] = conv.subsampled_lengths(lens).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g6_asr_parts.npz'), **d)
+
 
 if __name__ == '__main__':
+    save_asr()
     save_gpt()
     save_tiny()
     save_train_steps()

@@ -156,3 +156,73 @@ def test_gpt_forward_all_matches_reference(name):
     np.testing.assert_allclose(float(mean), float(g['mean']), rtol=1e-6)
     i2, t2 = gpt_ref.synthetic_tokens(B, T, vocab, seed + 1)
     assert torch.equal(i2, inputs) and torch.equal(t2, targets)
+
+
+# ------------------------------------------------------------------------------ enc-dec attention ASR (ha/transformer.py)
+ASR_CASES = ['g6_asr_tiny', 'g6_asr_tiny_s221', 'g6_asr_tiny_stop', 'g6_asr_transformer32', 'g6_asr_transformer32_stop']
+
+
+def asr_case_from_golden(name):
+    from oracle import transformer_ref as tr
+    g = load_golden(name)
+    vocab, hd, heads, el, dl, conv_dim, N, T, S, seed, F_ = (int(v) for v in g['cfg'])
+    strides = tuple(int(s) for s in g['strides'])
+    pe = tr.make_encoder_params(hd, heads, el, F_, conv_dim, len(strides), seed)
+    pd = tr.make_decoder_params(vocab, hd, heads, dl, seed + 1)
+    x, il, tg, tl = tr.synthetic_asr_batch(N, T, F_, vocab, S, seed + 2)
+    return g, pe, pd, (x, il, tg, tl), heads, strides
+
+
+@pytest.mark.parametrize('name', ASR_CASES)
+def test_asr_encoder_decoder_matches_reference(name):
+    from oracle import transformer_ref as tr
+    g, pe, pd, (x, il, tg, tl), heads, strides = asr_case_from_golden(name)
+    N = x.shape[0]
+    with torch.no_grad():
+        feats, flen = tr.audio_encoder_forward(pe, x, il, heads, strides)
+        assert flen.dtype == torch.int32 and np.array_equal(flen.numpy(), g['feature_lengths'])
+        np.testing.assert_allclose(feats.numpy(), g['features'], rtol=0, atol=2e-5)
+        feats = torch.from_numpy(g['features'])
+        for red in ('mean', 'none', 'sumeach'):
+            loss = tr.decoder_forward(pd, feats, tg, flen, tl, heads, reduction=red, pre='decoder.')
+            np.testing.assert_allclose(loss.numpy(), g['decoder_loss.' + red], rtol=2e-5, atol=2e-5, err_msg=red)
+        cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1)
+        joint, _, _ = tr.ctc_attention_forward(pd, feats, cond, flen, tl + 1, heads)
+        np.testing.assert_allclose(float(joint), float(g['joint_loss']), rtol=1e-5)
+        ents = []
+        tr.decoder_forward(pd, feats, tg, flen, tl, heads, pre='decoder.', entropies=ents)
+        np.testing.assert_allclose(np.array([float(m) for m, _ in ents]), g['meme_entropy'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(np.array([float(t) for _, t in ents]), g['self_entropy'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ASR_CASES)
+def test_asr_greedy_decode_matches_reference_fp16_autocast(name):
+    """The reference's decode only runs under fp16 autocast; the oracle keeps fp16-rounded caches and fp32
+    arithmetic: tokens and lengths exact on these decisive fixtures, accumulated scores to fp16 tolerance."""
+    from oracle import transformer_ref as tr
+    g, pe, pd, (x, il, tg, tl), heads, strides = asr_case_from_golden(name)
+    feats, flen = torch.from_numpy(g['features']), torch.from_numpy(g['feature_lengths'])
+    with torch.no_grad():
+        outs, olen, lps, ents, _ = tr.decoder_decode(pd, feats, flen, tl, heads, pre='decoder.')
+        assert olen.dtype == torch.int32 and np.array_equal(olen.numpy(), g['decode.output_lengths'])
+        assert [o.tolist() for o in outs] == _unpad(g['decode.tokens'], g['decode.token_lens'])
+        np.testing.assert_allclose(lps.numpy(), g['decode.log_probs'], rtol=1e-2, atol=5e-2)
+        np.testing.assert_allclose(ents.numpy(), g['decode.sum_entropies'], rtol=1e-2, atol=5e-2)
+        outs, olen, lps, _, _ = tr.decoder_decode(pd, feats, flen, tl, heads, prompt=torch.tensor([[7, 9]] * len(tl)), pre='decoder.')
+        assert np.array_equal(olen.numpy(), g['decode_prompt.output_lengths'])
+        assert [o.tolist() for o in outs] == _unpad(g['decode_prompt.tokens'], g['decode_prompt.token_lens'])
+        np.testing.assert_allclose(lps.numpy(), g['decode_prompt.log_probs'], rtol=1e-2, atol=5e-2)
+
+
+def test_asr_parts_match_reference():
+    from oracle import transformer_ref as tr
+    g = load_golden('g6_asr_parts')
+    for nm in 'abc':
+        y = tr.rotate_interleaved(torch.from_numpy(g[f'rope.{nm}.x']), t0=int(g[f'rope.{nm}.t0']))
+        np.testing.assert_allclose(y.numpy(), g[f'rope.{nm}.y'], rtol=0, atol=1e-6)
+    y, ent = tr.attend(*(torch.from_numpy(g['attend.' + k]) for k in ('q', 'k', 'v', 'mask')))
+    np.testing.assert_allclose(y.numpy(), g['attend.y'], atol=1e-6)
+    np.testing.assert_allclose(float(ent), float(g['attend.entropy']), rtol=1e-6)
+    lens = torch.from_numpy(g['lengths.in'])
+    assert np.array_equal(tr.subsampled_lengths(lens, (2, 2, 2)).numpy(), g['lengths.s222'])
+    assert np.array_equal(tr.subsampled_lengths(lens, (2, 2, 1)).numpy(), g['lengths.s221'])
