@@ -6,10 +6,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 2
+HALO_ABI_VERSION = 3
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
+HALO_GEMM_GELU_ERF = 8
 HALO_CTC_FULL_LATTICE = 1
 HALO_CTC_FINITE_MIN = 2
 HALO_CTC_NO_LEAD_BLANK_LOOP = 4
@@ -60,6 +61,15 @@ SIGNATURES = {
     'halo_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_attention_causal_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'halo_cross_entropy_fwd': (_i, [_vp, _vp, _vp, _i, _i, _l, _l, _vp]),
+    'halo_attention_fwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'halo_rope_table': (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    'halo_rope_interleaved': (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    'halo_kv_cache_store': (_i, [_vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'halo_attention_decode': (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'halo_logprob_max': (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
+    'halo_greedy_update': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    'halo_im2col_cl': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'halo_dwconv1d_cl': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -1,0 +1,47 @@
+"""Linear layers of the attention paths on the HIP GEMMs: y = x W^T (+ b) with the activation / residual
+add fused into the GEMM epilogue.  Weights are split (bf16 hi/lo) and tiled once per parameter version;
+several nn.Linear weights that read the same input (q|k|v, k|v) are concatenated into one GEMM."""
+import torch
+
+from . import _lib, ops
+
+
+class WeightImages:
+    """Per-module cache of GEMM-ready weight operands, rebuilt only when a weight changes."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def _lookup(self, kind, weights, build):
+        key = (kind,) + tuple(id(w) for w in weights)
+        stamp = tuple((w._version, w.data_ptr()) for w in weights)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, build())
+            self._cache[key] = hit
+        return hit[1]
+
+    def dense(self, weights):
+        """The (concatenated) fp32 weight [sum N_i, K]; conv weights [N, C, ks] are flattened to [N, C*ks]."""
+        if len(weights) == 1 and weights[0].dim() == 2 and weights[0].is_contiguous():
+            return weights[0].detach()
+        return self._lookup('dense', weights,
+                            lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], dim=0).contiguous())
+
+    def split(self, weights):
+        """The split/tiled image of the (concatenated) weight."""
+        return self._lookup('split', weights, lambda: ops.split_image(self.dense(weights).contiguous()))
+
+
+def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False):
+    """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
+    ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
+    and version), not views made per call."""
+    if isinstance(weights, torch.Tensor):
+        weights = (weights,)
+    M, K = x2d.shape
+    N = sum(w.shape[0] for w in weights)
+    if _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64:
+        return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
+                              accumulate=accumulate)
+    return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate)

@@ -1,0 +1,472 @@
+// Attention kernels for gfx950 shared by the GPT path (ha/attention.py) and the encoder-decoder ASR path
+// (ha/transformer.py): general softmax attention forward (causal / key-length masked / plain, optional
+// log-sum-exp and entropy outputs), interleaved rotary embedding, fp16 KV caches and the one-token
+// decode attention over them, and the greedy head of Decoder.decode.
+#include <hip/hip_fp16.h>
+#include "halo_common.h"
+
+namespace {
+
+struct AttnArgs {
+    const float *q, *k, *v;
+    float *y, *lse, *ent;
+    long q_rs, q_bs, kv_rs, kv_bs, y_rs, y_bs;   // row / batch strides in elements; head h sits at column h*HD
+    const int *key_len;                          // [N] keys >= key_len[n] are masked, may be NULL
+    int Tq, Tk, heads, causal;
+    float scale;
+};
+
+// ---- softmax attention forward ---------------------------------------------------------------------
+// One workgroup = 64 query rows of one (batch, head); 4 waves x 16 rows.  Keys/values stream through
+// LDS in tiles of 64; S = Q K^T and O += P V run on v_mfma_f32_16x16x4_f32 (exact f32), softmax is the
+// online (running max / running sum) form.  LDS images are chosen for conflict-free MFMA operand reads:
+//   Ks [key][dim]  stride HD+2  (B operand of Q K^T: lane (key = l&15, dim-group = l>>4); 2*key + group is
+//                                distinct over a 32-lane read group, and staging writes are 8-byte aligned)
+//   Vs [key][dim]  stride HD+16 (B operand of P V  : lane (dim = l&15, key-group = l>>4))
+//   Ps [row][key]  stride 66, per wave (P re-laid from the MFMA D layout to the A layout)
+// Visibility: key j is seen by query i iff j < min(Tk, key_len[n]) and (not causal or j <= i + Tk - Tq).
+// ENT: a second sweep over the keys accumulates the reference's attention-entropy monitor
+// -sum_j att_j * log(att_j + 1e-8) per query row (ha/transformer.py:426).
+template <int HD, bool ENT>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
+    constexpr int KS_STRIDE = HD + 2, VS_STRIDE = HD + 16, PS_STRIDE = 66;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * VS_STRIDE];
+    __shared__ float Ps[4][16 * PS_STRIDE];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int q0 = qt * 64 + wave * 16;                   // this wave's first query row
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;                             // causal: key <= row + coff
+
+    // Q fragments, pre-scaled: A[row = lr][k = 4s + lq]
+    float qa[HD / 4];
+    {
+        const int qrow = min(q0 + lr, Tq - 1);
+        const float *qp = qb + (long)qrow * a.q_rs;
+#pragma unroll
+        for (int s = 0; s < HD / 4; ++s) qa[s] = qp[4 * s + lq] * a.scale;
+    }
+    f32x4 o[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4], erow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; erow[r] = 0.f; }
+
+    int n_ktiles = (klim + 63) / 64;
+    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+    // K/V tiles are fetched one tile ahead into registers (issue early, write to LDS late), so the global
+    // latency of tile kt+1 hides under the MFMAs of tile kt
+    constexpr int UNITS = 64 * (HD / 4) / 256;            // float4 units of K (and of V) per thread and tile
+    f32x4 kreg[UNITS], vreg[UNITS];
+    auto fetch = [&](int kt, bool with_v) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+            const int krow = min(kt * 64 + key, Tk - 1);
+            kreg[i] = *reinterpret_cast<const f32x4 *>(kb + (long)krow * a.kv_rs + d4);
+            if (with_v) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long)krow * a.kv_rs + d4);
+        }
+    };
+    constexpr int N_PASS = ENT ? 2 : 1;
+#pragma unroll
+    for (int pass = 0; pass < N_PASS; ++pass) {
+        if (n_ktiles > 0) fetch(0, pass == 0);
+        for (int kt = 0; kt < n_ktiles; ++kt) {
+            __syncthreads();                              // previous tile fully consumed
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = threadIdx.x + 256 * i;
+                const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4]) = f32x2{kreg[i][0], kreg[i][1]};
+                *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4 + 2]) = f32x2{kreg[i][2], kreg[i][3]};
+                if (pass == 0) *reinterpret_cast<f32x4 *>(&Vs[key * VS_STRIDE + d4]) = vreg[i];
+            }
+            __syncthreads();
+            if (kt + 1 < n_ktiles) fetch(kt + 1, pass == 0);
+            // S = Q K^T : 4 key sub-tiles of 16
+            f32x4 sacc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < HD / 4; ++s)
+                    sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * KS_STRIDE + 4 * s + lq], sacc[n], 0, 0, 0);
+            }
+            if (pass == 1) {
+                // entropy sweep: att = exp(s - m) / l with the final m, l; element (row = 4*lq + r, key = kt*64 + 16n + lr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = q0 + 4 * lq + r;
+                    const float inv = 1.0f / lrow[r];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int key = kt * 64 + 16 * n + lr;
+                        const bool hidden = key >= klim || (a.causal && key > qrow + coff);
+                        const float att = hidden ? 0.f : expf(sacc[n][r] - mrow[r]) * inv;
+                        erow[r] -= att * logf(att + 1e-8f);
+                    }
+                }
+                continue;
+            }
+            // mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
+            float alpha[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = q0 + 4 * lq + r;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int key = kt * 64 + 16 * n + lr;
+                    if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
+                    mx = fmaxf(mx, sacc[n][r]);
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                const float mnew = fmaxf(mrow[r], mx);
+                const float msafe = mnew == -INFINITY ? 0.f : mnew;
+                alpha[r] = __expf(mrow[r] - msafe);       // exp(-inf) = 0 on the first tile (hardware exp2: ~1e-7 rel.)
+                float ps = 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float pv = __expf(sacc[n][r] - msafe);
+                    sacc[n][r] = pv;
+                    ps += pv;
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+                lrow[r] = lrow[r] * alpha[r] + ps;
+                mrow[r] = mnew;
+            }
+            // P from the D layout to the A layout through this wave's LDS patch
+            float *pw = Ps[wave];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[(4 * lq + r) * PS_STRIDE + 16 * n + lr] = sacc[n][r];
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[m][r] *= alpha[r];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // O += P V : 16 key steps of 4
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float pa = pw[lr * PS_STRIDE + 4 * s + lq];
+#pragma unroll
+                for (int m = 0; m < HD / 16; ++m)
+                    o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vs[(4 * s + lq) * VS_STRIDE + 16 * m + lr], o[m], 0, 0, 0);
+            }
+        }
+    }
+    // y[b, row, h*HD + dim] = O / l
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * lq + r;
+        if (qrow >= Tq) continue;
+        const float inv = 1.0f / lrow[r];
+        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) yp[16 * m + lr] = o[m][r] * inv;
+        const long stat = ((long)b * a.heads + h) * Tq + qrow;
+        if (a.lse && lr == 0) a.lse[stat] = mrow[r] + logf(lrow[r]);
+        if (ENT) {
+            float e = erow[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+            if (lr == 0) a.ent[stat] = e;
+        }
+    }
+}
+
+// ---- interleaved rotary embedding (ha/transformer.py:16-31) -----------------------------------------
+// tables [T, hd/2]: angle(t, i) = t * base^(-2i/hd) evaluated as the reference does (fp32 pow, fp32 product)
+__global__ __launch_bounds__(256) void rope_table_kernel(float *__restrict__ cs, float *__restrict__ sn, int T, int half, float base) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * half) return;
+    const int t = idx / half, i = idx % half;
+    const float ex = -2.0f * (float)i / (float)(2 * half);
+    const float theta = (float)pow((double)base, (double)ex);
+    const float ang = theta * (float)t;
+    cs[idx] = (float)cos((double)ang);
+    sn[idx] = (float)sin((double)ang);
+}
+
+// x[row, h*hd + 2i], x[.., 2i+1] rotated by the angle of position t0 + row % T, in place; sign = -1 undoes it
+__global__ __launch_bounds__(256) void rope_apply_kernel(float *__restrict__ x, long row_stride, int n_rows, int T, int heads,
+                                                         int half, int t0, const float *__restrict__ cs,
+                                                         const float *__restrict__ sn, float sign) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_row = (long)heads * half;
+    if (idx >= n_rows * per_row) return;
+    const long row = idx / per_row;
+    const int rem = (int)(idx % per_row), hh = rem / half, i = rem % half;
+    const int t = t0 + (int)(row % T);
+    const float c = cs[(long)t * half + i], s = sign * sn[(long)t * half + i];
+    float *p = x + row * row_stride + (long)hh * 2 * half + 2 * i;
+    const float x0 = p[0], x1 = p[1];
+    p[0] = x0 * c + (-x1) * s;
+    p[1] = x1 * c + x0 * s;
+}
+
+// ---- fp16 KV cache (ha/transformer.py:150-153, 315-339) -----------------------------------------------
+// cache[n, h, t0 + s, :] = half(src[n*S + s, h*hd : (h+1)*hd]) for K and V at once; src rows hold k at col 0, v at col v_off
+__global__ __launch_bounds__(256) void kv_cache_store_kernel(const float *__restrict__ src, long src_rs, long v_off,
+                                                             __half *__restrict__ ck, __half *__restrict__ cv, int N, int S,
+                                                             int heads, int hd, int Tc, int t0) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long C = (long)heads * hd;
+    if (idx >= (long)N * S * C) return;
+    const int c = (int)(idx % C);
+    const long row = idx / C;
+    const int s = (int)(row % S), n = (int)(row / S), h = c / hd, d = c % hd;
+    const float *p = src + row * src_rs + c;
+    const long o = (((long)n * heads + h) * Tc + (t0 + s)) * hd + d;
+    ck[o] = __float2half(p[0]);
+    cv[o] = __float2half(p[v_off]);
+}
+
+// One wave per (n, head): one query token against n_keys cached keys (fp16), optional rotary on the cached keys
+// (positions 0..n_keys-1, rotated from the fp16 bytes exactly like transformer.py:341-343), optional key-length mask.
+template <int MAXK>
+__global__ __launch_bounds__(64) void attention_decode_kernel(const float *__restrict__ q, long q_rs, const __half *__restrict__ ck,
+                                                              const __half *__restrict__ cv, float *__restrict__ y, long y_rs,
+                                                              int heads, int hd, int Tc, int n_keys, const int *__restrict__ key_len,
+                                                              const float *__restrict__ cs, const float *__restrict__ sn, float scale) {
+    __shared__ float qs[128];
+    __shared__ float ps[MAXK];
+    const int h = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const int half = hd / 2;
+    const float *qp = q + (long)n * q_rs + (long)h * hd;
+    for (int d = lane; d < hd; d += 64) qs[d] = qp[d] * scale;
+    __syncthreads();
+    const int klim = key_len ? max(0, min(n_keys, key_len[n])) : n_keys;
+    const __half *kb = ck + ((long)n * heads + h) * Tc * hd;
+    const __half *vb = cv + ((long)n * heads + h) * Tc * hd;
+    float mx = -INFINITY;
+    for (int j = lane; j < klim; j += 64) {
+        const __half2 *kr = reinterpret_cast<const __half2 *>(kb + (long)j * hd);
+        float s = 0.f;
+        for (int i = 0; i < half; ++i) {
+            const float2 kk = __half22float2(kr[i]);
+            float k0 = kk.x, k1 = kk.y;
+            if (cs) {
+                const float c = cs[(long)j * half + i], sv = sn[(long)j * half + i];
+                const float r0 = k0 * c + (-k1) * sv, r1 = k1 * c + k0 * sv;
+                k0 = r0; k1 = r1;
+            }
+            s = fmaf(qs[2 * i], k0, s);
+            s = fmaf(qs[2 * i + 1], k1, s);
+        }
+        ps[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < klim; j += 64) {
+        const float e = expf(ps[j] - mx);
+        ps[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < klim; ++j) acc = fmaf(ps[j], __half2float(vb[(long)j * hd + d]), acc);
+        y[(long)n * y_rs + (long)h * hd + d] = acc * inv;
+    }
+}
+
+// ---- greedy head of Decoder.decode (ha/transformer.py:175-192) -----------------------------------------
+// per row: log_softmax, its max / argmax (first index on ties), and sum_v p*logp/log(2) (the negative entropy in bits)
+__global__ __launch_bounds__(256) void logprob_max_kernel(const float *__restrict__ logits, long ld, int V, float *__restrict__ val,
+                                                          int64_t *__restrict__ idx, float *__restrict__ negent) {
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int n = blockIdx.x;
+    const float *row = logits + (long)n * ld;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += 256) {
+        const float v = row[c];
+        if (v > m || (v == m && c < am)) { m = v; am = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    if ((threadIdx.x & 63) == 0) { redf[threadIdx.x >> 6] = m; redi[threadIdx.x >> 6] = am; }
+    __syncthreads();
+    m = redf[0]; am = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (redf[w] > m || (redf[w] == m && redi[w] < am)) { m = redf[w]; am = redi[w]; }
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float lse = m + logf((redf[0] + redf[1]) + (redf[2] + redf[3]));
+    __syncthreads();
+    float e = 0.f;
+    if (negent) {
+        for (int c = threadIdx.x; c < V; c += 256) {
+            const float lp = row[c] - lse;
+            e += expf(lp) * lp / 0.6931471805599453f;
+        }
+        e = wave_sum(e);
+        if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = e;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        val[n] = m - lse;
+        idx[n] = am;
+        if (negent) negent[n] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+    }
+}
+
+// one workgroup: the bookkeeping of one greedy step over all N rows (alive rows only change)
+__global__ __launch_bounds__(256) void greedy_update_kernel(const float *__restrict__ val, const int64_t *__restrict__ idx,
+                                                            const float *__restrict__ negent, int64_t *__restrict__ tokens, long tok_ld,
+                                                            int t, int plen, int etx, uint8_t *__restrict__ alive,
+                                                            int *__restrict__ out_len, float *__restrict__ log_probs,
+                                                            float *__restrict__ sum_ent, int N) {
+    __shared__ float red[4];
+    float e = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256)
+        if (alive[n]) e += negent[n];
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);     // sic: every alive row receives the sum over ALL alive rows
+    for (int n = threadIdx.x; n < N; n += 256) {
+        if (!alive[n]) continue;
+        sum_ent[n] += total;
+        out_len[n] += 1;
+        log_probs[n] += val[n];
+        int64_t tok = idx[n];
+        if (t < plen) tok = tokens[(long)n * tok_ld + t + 1];
+        tokens[(long)n * tok_ld + t + 1] = tok;
+        if (tok == etx) alive[n] = 0;
+    }
+}
+
+template <int HD>
+int launch_attention(const AttnArgs &a, int N, bool ent, hipStream_t st) {
+    dim3 grid((a.Tq + 63) / 64, a.heads, N);
+    if (ent) hipLaunchKernelGGL((attention_fwd_kernel<HD, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attention_fwd_kernel<HD, false>), grid, dim3(256), 0, st, a);
+    return halo_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
+                       long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
+                       float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k && v && y && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
+    HALO_CHECK_ARG(((uintptr_t)k | (uintptr_t)v) % 16 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0);
+    HALO_CHECK_ARG(N <= 65535 && heads <= 65535);
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.y = y; a.lse = lse; a.ent = entropy;
+    a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
+    a.y_rs = y_row_stride; a.y_bs = y_batch_stride; a.key_len = key_lengths;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    switch (head_dim) {
+        case 64: return launch_attention<64>(a, N, entropy != nullptr, st);
+        case 32: return launch_attention<32>(a, N, entropy != nullptr, st);
+        case 16: return launch_attention<16>(a, N, entropy != nullptr, st);
+        default: return HALO_ENOTSUP;
+    }
+}
+
+int halo_attention_causal_fwd(const float *qkv, float *y, int B, int T, int n_head, int C, halo_stream_t stream) {
+    HALO_CHECK_ARG(qkv && y && B > 0 && T > 0 && n_head > 0 && C > 0 && C % n_head == 0 && C % 4 == 0);
+    return halo_attention_fwd(qkv, 3L * C, 3L * C * T, qkv + C, qkv + 2 * C, 3L * C, 3L * C * T, y, C, (long)C * T, nullptr, nullptr, B,
+                              n_head, C / n_head, T, T, 1, nullptr, stream);
+}
+
+int halo_rope_table(float *cos_table, float *sin_table, int T, int head_dim, float base, halo_stream_t stream) {
+    HALO_CHECK_ARG(cos_table && sin_table && T > 0 && head_dim > 0 && head_dim % 2 == 0 && base > 0.f);
+    const int n = T * (head_dim / 2);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cos_table, sin_table, T,
+                       head_dim / 2, base);
+    return halo_launch_status();
+}
+
+int halo_rope_interleaved(float *x, long row_stride, int n_rows, int T, int heads, int head_dim, int t0, const float *cos_table,
+                          const float *sin_table, int table_rows, int inverse, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && cos_table && sin_table && n_rows > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0 && t0 >= 0);
+    HALO_CHECK_ARG(t0 + T <= table_rows);
+    const long n = (long)n_rows * heads * (head_dim / 2);
+    hipLaunchKernelGGL(rope_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, row_stride, n_rows,
+                       T, heads, head_dim / 2, t0, cos_table, sin_table, inverse ? -1.0f : 1.0f);
+    return halo_launch_status();
+}
+
+int halo_kv_cache_store(const float *src, long src_row_stride, long v_offset, void *cache_k, void *cache_v, int N, int S, int heads,
+                        int head_dim, int cache_len, int t0, halo_stream_t stream) {
+    HALO_CHECK_ARG(src && cache_k && cache_v && N > 0 && S > 0 && heads > 0 && head_dim > 0 && t0 >= 0 && t0 + S <= cache_len);
+    const long n = (long)N * S * heads * head_dim;
+    hipLaunchKernelGGL(kv_cache_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_row_stride,
+                       v_offset, (__half *)cache_k, (__half *)cache_v, N, S, heads, head_dim, cache_len, t0);
+    return halo_launch_status();
+}
+
+int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k, const void *cache_v, float *y, long y_row_stride,
+                          int N, int heads, int head_dim, int cache_len, int n_keys, const int *key_lengths, const float *cos_table,
+                          const float *sin_table, halo_stream_t stream) {
+    HALO_CHECK_ARG(q && cache_k && cache_v && y && N > 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0 && head_dim <= 128);
+    HALO_CHECK_ARG(n_keys > 0 && n_keys <= cache_len && N <= 65535 && (cos_table == nullptr) == (sin_table == nullptr));
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    dim3 grid(heads, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_keys <= 1024)
+        hipLaunchKernelGGL(attention_decode_kernel<1024>, grid, dim3(64), 0, st, q, q_row_stride, (const __half *)cache_k,
+                           (const __half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
+                           scale);
+    else if (n_keys <= 8192)
+        hipLaunchKernelGGL(attention_decode_kernel<8192>, grid, dim3(64), 0, st, q, q_row_stride, (const __half *)cache_k,
+                           (const __half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
+                           scale);
+    else return HALO_ENOTSUP;
+    return halo_launch_status();
+}
+
+int halo_logprob_max(const float *logits, long ld, int rows, int V, float *values, int64_t *indices, float *neg_entropy_bits,
+                     halo_stream_t stream) {
+    HALO_CHECK_ARG(logits && values && indices && rows > 0 && V > 0 && ld >= V);
+    hipLaunchKernelGGL(logprob_max_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, values, indices,
+                       neg_entropy_bits);
+    return halo_launch_status();
+}
+
+int halo_greedy_update(const float *values, const int64_t *indices, const float *neg_entropy_bits, int64_t *tokens, long tokens_ld,
+                       int t, int plen, int etx, uint8_t *alive, int *output_lengths, float *log_probs, float *sum_entropies, int N,
+                       halo_stream_t stream) {
+    HALO_CHECK_ARG(values && indices && neg_entropy_bits && tokens && alive && output_lengths && log_probs && sum_entropies);
+    HALO_CHECK_ARG(N > 0 && t >= 0 && t + 1 < tokens_ld);
+    hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, values, indices, neg_entropy_bits, tokens,
+                       tokens_ld, t, plen, etx, alive, output_lengths, log_probs, sum_entropies, N);
+    return halo_launch_status();
+}
+
+}  // extern "C"

@@ -336,7 +336,7 @@ int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int 
                     const uint32_t *offset_dev, halo_stream_t stream) {
     HALO_CHECK_ARG(a_image && b_image && C && M > 0 && N > 0 && K > 0 && ldc >= N);
     const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
-    return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, flags & 7, &d,
+    return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, flags & 15, &d,
                                   (hipStream_t)stream);
 }
 

@@ -280,7 +280,7 @@ extern "C" int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
     p.b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    p.relu = flags & 7;
+    p.relu = flags & 15;
     p.use_drop = p_drop > 0.f;
     p.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
     p.tiles_n = 0;

@@ -110,9 +110,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result
+// GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result,
+// bit 3 exact (erf) GELU (nn.GELU() / F.gelu: ha/transformer.py:456, ha/conv.py:46)
 __device__ __forceinline__ float gemm_activation(float v, int flags) {
     if (flags & 1) v = fmaxf(v, 0.f);
     if (flags & 2) v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    if (flags & 8) v = 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));
     return v;
 }

@@ -40,7 +40,9 @@ def subsampled_length(T, ks=5, stride=4, pad=3):
 
 
 def _gemm_flags(relu, gelu, accumulate):
-    return (_lib.HALO_GEMM_RELU if relu else 0) | (_lib.HALO_GEMM_GELU if gelu else 0) | (_lib.HALO_GEMM_ACCUM if accumulate else 0)
+    """gelu: False, True / 'tanh' (new_gelu) or 'erf' (nn.GELU())."""
+    g = 0 if not gelu else (_lib.HALO_GEMM_GELU_ERF if gelu == 'erf' else _lib.HALO_GEMM_GELU)
+    return (_lib.HALO_GEMM_RELU if relu else 0) | g | (_lib.HALO_GEMM_ACCUM if accumulate else 0)
 
 
 def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, relu=False,
@@ -352,3 +354,100 @@ def cross_entropy_fwd(logits2d, targets, ignore_index=0):
     check(lib().halo_cross_entropy_fwd(ptr(logits2d), ptr(tg), ptr(loss), logits2d.shape[0], logits2d.shape[1],
                                        logits2d.shape[1], ignore_index, _stream()), 'halo_cross_entropy_fwd')
     return loss
+
+
+# ---- attention / rotary / KV-cache operators (GPT and the enc-dec ASR path) ------------------------------
+def attention_fwd(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, want_lse=False, want_entropy=False):
+    """q: rows [N*Tq, >=C] (a column slice of a packed GEMM output is fine), k/v: rows [N*Tk, ...] sharing one row stride.
+    -> y [N*Tq, C] (+ lse / entropy [N, heads, Tq] when asked)."""
+    C = heads * head_dim
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or not t.is_cuda or t.stride(-1) != 1:
+            raise ValueError('attention operands must be float32 HIP tensors with a unit column stride')
+    if k.stride(0) != v.stride(0):
+        raise ValueError('k and v must share a row stride')
+    dev = q.device
+    y = torch.empty(N * Tq, C, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, heads, Tq, device=dev, dtype=torch.float32) if want_lse else None
+    ent = torch.empty(N, heads, Tq, device=dev, dtype=torch.float32) if want_entropy else None
+    if key_lengths is not None:
+        key_lengths = key_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    check(lib().halo_attention_fwd(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), C,
+                                   C * Tq, ptr(lse), ptr(ent), N, heads, head_dim, Tq, Tk, int(causal), ptr(key_lengths), _stream()),
+          'halo_attention_fwd')
+    return y, lse, ent
+
+
+class RopeTable:
+    """cos/sin tables of rotate_interleaved (ha/transformer.py:16-31) for positions [0, T)."""
+
+    def __init__(self, T, head_dim, device, base=10000.0):
+        self.T, self.head_dim = T, head_dim
+        self.cos = torch.empty(T, head_dim // 2, device=device, dtype=torch.float32)
+        self.sin = torch.empty(T, head_dim // 2, device=device, dtype=torch.float32)
+        check(lib().halo_rope_table(ptr(self.cos), ptr(self.sin), T, head_dim, float(base), _stream()), 'halo_rope_table')
+
+
+def rope_(x2d, T, heads, head_dim, table, t0=0, inverse=False):
+    """Rotate in place the heads*head_dim leading columns of the rows of x2d (row r is at position t0 + r % T)."""
+    if x2d.dtype != torch.float32 or not x2d.is_cuda or x2d.stride(-1) != 1:
+        raise ValueError('rope: expected a float32 HIP tensor with a unit column stride')
+    check(lib().halo_rope_interleaved(ptr(x2d), x2d.stride(0), x2d.shape[0], T, heads, head_dim, t0, ptr(table.cos), ptr(table.sin),
+                                      table.T, int(inverse), _stream()), 'halo_rope_interleaved')
+    return x2d
+
+
+def kv_cache_store(src2d, v_offset, cache_k, cache_v, N, S, heads, head_dim, t0):
+    """cache_{k,v} [N, heads, Tc, head_dim] float16 <- rows [N*S] of src2d (k at column 0, v at column v_offset)."""
+    check(lib().halo_kv_cache_store(ptr(src2d), src2d.stride(0), v_offset, ptr(cache_k), ptr(cache_v), N, S, heads, head_dim,
+                                    cache_k.shape[2], t0, _stream()), 'halo_kv_cache_store')
+
+
+def attention_decode(q2d, cache_k, cache_v, n_keys, key_lengths=None, table=None, out=None):
+    N, heads, Tc, hd = cache_k.shape
+    if out is None:
+        out = torch.empty(N, heads * hd, device=q2d.device, dtype=torch.float32)
+    check(lib().halo_attention_decode(ptr(q2d), q2d.stride(0), ptr(cache_k), ptr(cache_v), ptr(out), out.stride(0), N, heads, hd, Tc,
+                                      n_keys, ptr(key_lengths), ptr(table.cos) if table else None, ptr(table.sin) if table else None,
+                                      _stream()), 'halo_attention_decode')
+    return out
+
+
+def logprob_max(logits2d, want_entropy=False):
+    _f32c(logits2d, 'logits')
+    rows, V = logits2d.shape
+    dev = logits2d.device
+    val = torch.empty(rows, device=dev, dtype=torch.float32)
+    idx = torch.empty(rows, device=dev, dtype=torch.int64)
+    ne = torch.empty(rows, device=dev, dtype=torch.float32) if want_entropy else None
+    check(lib().halo_logprob_max(ptr(logits2d), V, rows, V, ptr(val), ptr(idx), ptr(ne), _stream()), 'halo_logprob_max')
+    return val, idx, ne
+
+
+def greedy_update(val, idx, negent, tokens, t, plen, etx, alive, out_len, log_probs, sum_ent):
+    check(lib().halo_greedy_update(ptr(val), ptr(idx), ptr(negent), ptr(tokens), tokens.stride(0), t, plen, etx, ptr(alive),
+                                   ptr(out_len), ptr(log_probs), ptr(sum_ent), tokens.shape[0], _stream()), 'halo_greedy_update')
+
+
+# ---- channels-last conv front-end (ha/conv.py) -------------------------------------------------------------
+def conv_out_length(T, ks, stride, pad):
+    return (T + 2 * pad - ks) // stride + 1
+
+
+def im2col_cl(x3d, ks, stride, pad):
+    _f32c(x3d, 'x')
+    N, T, Cin = x3d.shape
+    To = conv_out_length(T, ks, stride, pad)
+    col = torch.empty(N * To, Cin * ks, device=x3d.device, dtype=torch.float32)
+    check(lib().halo_im2col_cl(ptr(x3d), ptr(col), N, T, Cin, ks, stride, pad, _stream()), 'halo_im2col_cl')
+    return col, To
+
+
+def dwconv1d_cl(x3d, weight, bias, stride, pad):
+    _f32c(x3d, 'x')
+    N, T, Cn = x3d.shape
+    ks = weight.shape[-1]
+    To = conv_out_length(T, ks, stride, pad)
+    y = torch.empty(N, To, Cn, device=x3d.device, dtype=torch.float32)
+    check(lib().halo_dwconv1d_cl(ptr(x3d), ptr(weight), ptr(bias), ptr(y), N, T, Cn, ks, stride, pad, _stream()), 'halo_dwconv1d_cl')
+    return y

@@ -1,0 +1,367 @@
+"""Drop-in for the inference/scoring side of ha/transformer.py (encoder-decoder attention ASR, `hala`):
+AudioEncoder, Block, MultiHeadAttention, Decoder (teacher-forced loss and batched greedy decode with fp16
+KV caches), CTCAttentionDecoder, rotate_interleaved, attend, attend_chunked -- forward only, on the HIP
+operators of csrc/attn.hip, csrc/conv.hip, csrc/gpt.hip and the GEMMs.
+
+Same constructor arguments, attribute and state-dict names as the reference (``h.{i}.ln_time``,
+``h.{i}.mix_time.{q,k,v,proj}``, ``h.{i}.mix_memory.*``, ``h.{i}.ln_chan``, ``h.{i}.mix_chan.{0,2}``, ``ln_f``,
+``wte``, ``lm_head``, ``recognizer.classifier``), so reference checkpoints load unchanged.
+
+Arithmetic: fp32 state; Linear layers on the split-bf16 (bf16x3) or exact-f32 MFMA GEMMs per
+``halo_set_math_mode``; attention, LayerNorm, softmax, rotary and losses in fp32.  The greedy decoder keeps
+the reference's float16 cache layout ``[L, 2, N, heads, S|T, head_dim]`` (ha/transformer.py:150-153) -- the
+reference itself only decodes under fp16 autocast -- and computes everything around the caches in fp32.
+
+Not built (raises): backward / training mode (dropout, label dropout), ``kv_cache_parts`` on the public
+Block / MultiHeadAttention.forward (Decoder.decode drives the caches itself), arbitrary attention masks
+(only the key-padding masks Block builds, transformer.py:476).
+"""
+import math
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._linear import WeightImages, linear
+from .attention import LayerNorm
+from .conv import ConvEncoder
+from .recognizer import TemporalClassifier
+
+BlockKVCache = namedtuple('BlockKVCache', ['memory', 'time'])
+Stats = namedtuple('Stats', ['meme_entropy', 'self_entropy'])
+
+STX, ETX = 2, 3
+
+
+def _require_inference(module, x):
+    if not x.is_cuda:
+        raise _lib.HaloError(f'haloop_amd.transformer.{type(module).__name__} runs on the HIP device only (no CPU path)')
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError('haloop_amd.transformer is forward-only so far: call it under torch.no_grad() / '
+                                  'inference_mode; the training backward is not built')
+    if module.training:
+        raise NotImplementedError('dropout / label dropout of the training mode are not built; call .eval()')
+
+
+def _rope_table(cache, T, head_dim, device):
+    hit = cache.get((head_dim, str(device)))
+    if hit is None or hit.T < T:
+        hit = ops.RopeTable(max(T, 256), head_dim, device)
+        cache[(head_dim, str(device))] = hit
+    return hit
+
+
+_ROPE_TABLES = {}
+
+
+def rotate_interleaved(x, *, t0=0, base=10000):
+    "rotate query or key embedding as in https://arxiv.org/abs/2104.09864 GPT-J style (ha/transformer.py:16-31)"
+    *lead, T, C = x.shape
+    if not x.is_cuda:
+        raise _lib.HaloError('haloop_amd.transformer.rotate_interleaved runs on the HIP device only')
+    table = ops.RopeTable(t0 + T, C, x.device, base) if base != 10000 else _rope_table(_ROPE_TABLES, t0 + T, C, x.device)
+    y = x.float().contiguous().clone().view(-1, C)
+    ops.rope_(y, T, 1, C, table, t0=t0)
+    return y.view(*lead, T, C)
+
+
+def attend(q, k, v, mask):
+    """(N, heads, T, hd) x (N, heads, S, hd) -> (N, heads, T, hd), entropy (ha/transformer.py:413-430).
+    ``mask`` None or a key-padding mask (N, 1, 1, S) whose True entries form a suffix."""
+    N, H, T, hd = q.shape
+    S = k.shape[-2]
+    lens = None
+    if mask is not None:
+        lens = _suffix_mask_lengths(mask, N, S)
+    q2, k2, v2 = (t.transpose(1, 2).reshape(N * t.shape[2], H * hd).float().contiguous() for t in (q, k, v))
+    y, _, ent = ops.attention_fwd(q2, k2, v2, N, H, hd, T, S, key_lengths=lens, want_entropy=True)
+    return y.view(N, T, H, hd).transpose(1, 2), ent.mean()
+
+
+def attend_chunked(q, k, v, mask, chunk_size=32):
+    "same result as attend without the monitor (ha/transformer.py:374-410); the kernel is already tiled"
+    x, _ = attend(q, k, v, mask)
+    return x, torch.tensor(float('-inf'))
+
+
+def _suffix_mask_lengths(mask, N, S):
+    m = mask.reshape(N, -1, S)
+    if m.shape[1] != 1:
+        raise NotImplementedError('only key-padding masks of shape (N, 1, 1, S) are built')
+    m = m[:, 0]
+    lens = (~m).sum(-1).to(torch.int32)
+    if not bool((m == (torch.arange(S, device=m.device)[None, :] >= lens[:, None])).all()):
+        raise NotImplementedError('only key-padding masks whose masked keys form a suffix are built')
+    return lens
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, head_dim: int = 64, heads: int = 12, p_drop: float = 0.1):
+        super().__init__()
+        self.head_dim = head_dim
+        self.heads = heads
+        self.q = nn.Linear(head_dim * heads, head_dim * heads, bias=False)
+        self.k = nn.Linear(head_dim * heads, head_dim * heads, bias=False)
+        self.v = nn.Linear(head_dim * heads, head_dim * heads, bias=False)
+        self.proj = nn.Linear(head_dim * heads, head_dim * heads, bias=False)
+        self.p_drop = p_drop
+        self.dropout = nn.Dropout(p_drop)
+        self._images = WeightImages()
+        self._tables = {}
+
+    def init_from_flash_mha_(self, mha):
+        step = self.head_dim * self.heads
+        assert mha.Wqkv.weight.shape[0] == step * 3
+        self.q.weight.data = mha.Wqkv.weight.data[0*step:1*step, :]
+        self.k.weight.data = mha.Wqkv.weight.data[1*step:2*step, :]
+        self.v.weight.data = mha.Wqkv.weight.data[2*step:3*step, :]
+        self.proj.weight.data = mha.out_proj.weight.data
+        return self
+
+    def read_memory(self, memory):
+        N, S, C = memory.shape
+        kv = linear(self._images, memory.reshape(N * S, C).float().contiguous(), (self.k.weight, self.v.weight))
+        k, v = kv[:, :C], kv[:, C:]
+        return (k.reshape(N, S, self.heads, self.head_dim).transpose(-3, -2),
+                v.reshape(N, S, self.heads, self.head_dim).transpose(-3, -2))
+
+    # x2d [N*T, C] (already normalised), mem2d [N*S, C] or None for self-attention -> attention output [N*T, C] (before proj)
+    def _attend2d(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, t0=0, measure_entropy=False):
+        C = self.heads * self.head_dim
+        if mem2d is None:
+            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight))       # one GEMM, [N*T, 3C]
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        else:
+            q = linear(self._images, x2d, self.q.weight)
+            kv = linear(self._images, mem2d, (self.k.weight, self.v.weight))
+            k, v = kv[:, :C], kv[:, C:]
+        if rope:
+            table = _rope_table(self._tables, max(t0 + T, S), self.head_dim, x2d.device)
+            ops.rope_(q, T, self.heads, self.head_dim, table, t0=t0)
+            ops.rope_(k, S, self.heads, self.head_dim, table)
+        y, _, ent = ops.attention_fwd(q, k, v, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths,
+                                      want_entropy=measure_entropy)
+        return y, (ent.mean() if measure_entropy else torch.tensor(float('-inf')))
+
+    def forward(self, x, memory, *, mask=None, causal=False, measure_entropy=False, kv_cache_parts=None, t0=0, rope=False,
+                _key_lengths=None):
+        _require_inference(self, x)
+        if kv_cache_parts is not None:
+            raise NotImplementedError('kv_cache_parts: the fp16 caches are driven by haloop_amd.transformer.Decoder.decode')
+        N, T, C = x.shape
+        S = memory.shape[1]
+        if mask is not None and _key_lengths is None:
+            _key_lengths = _suffix_mask_lengths(mask, N, S)
+        x2d = x.reshape(N * T, C).float().contiguous()
+        mem2d = None if memory is x else memory.reshape(N * S, C).float().contiguous()
+        y, ent = self._attend2d(x2d, mem2d, N, T, S, _key_lengths, causal and _key_lengths is None, rope, t0, measure_entropy)
+        return linear(self._images, y, self.proj.weight).view(N, T, C), ent
+
+
+class Block(nn.Module):
+    def __init__(self, head_dim: int, heads: int, p_drop: float, memory=False):
+        super().__init__()
+        self.heads = heads
+        self.head_dim = head_dim
+        self.ln_time = LayerNorm(head_dim * heads, bias=False)
+        self.mix_time = MultiHeadAttention(head_dim=head_dim, heads=heads, p_drop=p_drop)
+        self.mix_memory = MultiHeadAttention(head_dim=head_dim, heads=heads, p_drop=p_drop) if memory else None
+        self.ln_chan = LayerNorm(head_dim * heads, bias=False)
+        self.mix_chan = nn.Sequential(
+            nn.Linear(head_dim * heads, head_dim * heads * 4, bias=False),
+            nn.GELU(),
+            nn.Linear(head_dim * heads * 4, head_dim * heads, bias=False),
+            nn.Dropout(p_drop),
+        )
+        self._images = WeightImages()
+
+    # x2d [N*T, C] is updated IN PLACE (the caller owns it); memory rows [N*S, C]
+    def _forward2d(self, x2d, N, T, causal=False, mem2d=None, S=0, memory_lengths=None, measure_entropy=False, time_lengths=None):
+        x_norm = ops.layernorm_fwd(x2d, self.ln_time.weight)
+        m_ent = torch.tensor(float('-inf'))
+        if self.mix_memory is not None:
+            mm = self.mix_memory
+            m, m_ent = mm._attend2d(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, measure_entropy=measure_entropy)
+            linear(mm._images, m, mm.proj.weight, out=x2d, accumulate=True)                      # x += cross(ln(x), memory)
+        mt = self.mix_time
+        t, t_ent = mt._attend2d(x_norm, None, N, T, T, key_lengths=time_lengths, causal=causal and time_lengths is None, rope=True,
+                                measure_entropy=measure_entropy)                                 # the SAME x_norm (:476-494)
+        linear(mt._images, t, mt.proj.weight, out=x2d, accumulate=True)
+        h = linear(self._images, ops.layernorm_fwd(x2d, self.ln_chan.weight), self.mix_chan[0].weight, gelu='erf')
+        linear(self._images, h, self.mix_chan[2].weight, out=x2d, accumulate=True)
+        return m_ent, t_ent
+
+    def forward(self, x, time_mask=None, causal=False, memory=None, memory_lengths=None, measure_entropy=False,
+                kv_cache_parts=BlockKVCache(memory=None, time=None), t0=0):
+        _require_inference(self, x)
+        if kv_cache_parts.memory is not None or kv_cache_parts.time is not None:
+            raise NotImplementedError('kv_cache_parts: the fp16 caches are driven by haloop_amd.transformer.Decoder.decode')
+        if t0 != 0:
+            raise NotImplementedError('t0 != 0 only occurs with kv caches')
+        N, T, C = x.shape
+        x2d = x.reshape(N * T, C).float().clone()
+        mem2d, S, mlen = None, 0, None
+        if self.mix_memory is not None:
+            S = memory.shape[1]
+            mem2d = memory.reshape(N * S, C).float().contiguous()
+            mlen = memory_lengths.to(device=x.device, dtype=torch.int32)
+        tlen = _suffix_mask_lengths(time_mask, N, T) if time_mask is not None else None
+        ents = self._forward2d(x2d, N, T, causal, mem2d, S, mlen, measure_entropy, tlen)
+        return x2d.view(N, T, C), ents
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, vocab: int, head_dim: int, heads: int, p_drop: float, layers: int):
+        super().__init__()
+        self.wte = nn.Embedding(vocab, head_dim * heads)
+        self.h = nn.ModuleList([Block(head_dim=head_dim, heads=heads, p_drop=p_drop, memory=True) for _ in range(layers)])
+        self.ln_f = LayerNorm(head_dim * heads, bias=False)
+        self.lm_head = nn.Linear(head_dim * heads, vocab, bias=False)
+        self._images = WeightImages()
+
+    def forward(self, features, targets, input_lengths=None, target_lengths=None, star_penalty=None, measure_entropy=False,
+                drop_labels=None, reduction='mean'):
+        _require_inference(self, features)
+        if drop_labels:
+            raise NotImplementedError('label dropout (training) is not built')
+        dev = features.device
+        targets = targets.to(dev)
+        N, T = targets.shape
+        # prompt: STX a b c / target: a b c ETX PAD (ha/transformer.py:84-98)
+        prompt = nn.functional.pad(targets, (1, 0), value=STX)
+        tg = nn.functional.pad(targets, (0, 1), value=0)
+        tg[torch.arange(N, device=dev), target_lengths.to(dev)] = ETX
+        T = T + 1
+        S, C = features.shape[1], features.shape[2]
+        mem2d = features.reshape(N * S, C).float().contiguous()
+        mlen = input_lengths.to(device=dev, dtype=torch.int32)
+        stats = Stats(meme_entropy=[], self_entropy=[])
+        y = ops.embed_fwd(prompt, self.wte.weight, None)
+        for block in self.h:
+            m_ent, t_ent = block._forward2d(y, N, T, True, mem2d, S, mlen, measure_entropy)
+            stats.meme_entropy.append(m_ent)
+            stats.self_entropy.append(t_ent)
+        logits = linear(self._images, ops.layernorm_fwd(y, self.ln_f.weight), self.lm_head.weight)   # [N*T, V]
+        if reduction == 'sumeach':
+            loss = ops.logprob_max(logits)[0].view(N, T).sum(dim=-1)
+        else:
+            per_tok = ops.cross_entropy_fwd(logits, tg.reshape(-1), ignore_index=0)
+            if reduction == 'none':
+                loss = per_tok
+            elif reduction == 'sum':
+                loss = per_tok.sum()
+            elif reduction == 'mean':
+                loss = per_tok.sum() / (tg != 0).sum()
+            else:
+                raise ValueError(f'{reduction} is not a valid value for reduction')
+        return loss, stats._asdict()
+
+    @torch.no_grad()
+    def decode(self, features, input_lengths, target_lengths, prompt=None):
+        "Perform batched greedy decoding (ha/transformer.py:124-199)."
+        _require_inference(self, features)
+        dev = features.device
+        N, S, C = features.shape
+        T = int(target_lengths.max().item()) + 1
+        L = len(self.h)
+        heads, head_dim = self.h[0].heads, self.h[0].head_dim
+        if prompt is None:
+            tokens = torch.full((N, T + 1), ETX, dtype=torch.long, device=dev)
+            tokens[:, 0] = STX
+            plen = 0
+        else:
+            P = prompt.shape[-1]
+            tokens = torch.full((N, T + 1 + P), ETX, dtype=torch.long, device=dev)
+            tokens[:, 0] = STX
+            tokens[:, 1:1 + P] = prompt.to(dev)
+            plen = 1
+        mem_cache = torch.zeros((L, 2, N, heads, S, head_dim), dtype=torch.float16, device=dev)
+        time_cache = torch.zeros((L, 2, N, heads, T, head_dim), dtype=torch.float16, device=dev)
+        mlen = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        mem2d = features.reshape(N * S, C).float().contiguous()
+        for l, block in enumerate(self.h):                                   # cross-attention caches, warmed once (:324-334)
+            mm = block.mix_memory
+            kv = linear(mm._images, mem2d, (mm.k.weight, mm.v.weight))
+            ops.kv_cache_store(kv, C, mem_cache[l, 0], mem_cache[l, 1], N, S, heads, head_dim, 0)
+        table = ops.RopeTable(T, head_dim, dev)
+        alive = torch.ones(N, dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        log_probs = torch.zeros(N, dtype=torch.float32, device=dev)
+        sum_entropies = torch.zeros(N, dtype=torch.float32, device=dev)
+        # every step computes all N rows; rows that are no longer alive are ignored by the update (the reference
+        # compacts to the alive rows instead, which changes no alive row's result) and nothing syncs with the host
+        for t in range(T):
+            y = ops.embed_fwd(tokens[:, t:t + 1], self.wte.weight, None)         # [N, C]
+            for l, block in enumerate(self.h):
+                mm, mt = block.mix_memory, block.mix_time
+                xn = ops.layernorm_fwd(y, block.ln_time.weight)
+                q = linear(mm._images, xn, mm.q.weight)
+                m = ops.attention_decode(q, mem_cache[l, 0], mem_cache[l, 1], S, key_lengths=mlen)
+                linear(mm._images, m, mm.proj.weight, out=y, accumulate=True)
+                qkv = linear(mt._images, xn, (mt.q.weight, mt.k.weight, mt.v.weight))
+                ops.kv_cache_store(qkv[:, C:], C, time_cache[l, 0], time_cache[l, 1], N, 1, heads, head_dim, t)
+                ops.rope_(qkv, 1, heads, head_dim, table, t0=t)                  # q columns only
+                s = ops.attention_decode(qkv, time_cache[l, 0], time_cache[l, 1], t + 1, table=table)
+                linear(mt._images, s, mt.proj.weight, out=y, accumulate=True)
+                h = linear(block._images, ops.layernorm_fwd(y, block.ln_chan.weight), block.mix_chan[0].weight, gelu='erf')
+                linear(block._images, h, block.mix_chan[2].weight, out=y, accumulate=True)
+            logits = linear(self._images, ops.layernorm_fwd(y, self.ln_f.weight), self.lm_head.weight)
+            val, idx, negent = ops.logprob_max(logits, want_entropy=True)
+            ops.greedy_update(val, idx, negent, tokens, t, plen, ETX, alive, out_len, log_probs, sum_entropies)
+        output_lengths = out_len.to(input_lengths.dtype)
+        lens = output_lengths.tolist()
+        outputs = torch.nested.nested_tensor([p[1:l] for p, l in zip(tokens, lens)])
+        alignments = [None] * N
+        return outputs, output_lengths, alignments, log_probs, sum_entropies
+
+
+class CTCAttentionDecoder(nn.Module):
+    "CTC loss on the encoder, CE loss on the decoder (ha/transformer.py:34-57)"
+    def __init__(self, *, vocab: int, head_dim: int, heads: int, p_drop: float, layers: int):
+        super().__init__()
+        self.decoder = Decoder(vocab=vocab, head_dim=head_dim, heads=heads, p_drop=p_drop, layers=layers)
+        self.recognizer = TemporalClassifier(feat_dim=head_dim * heads, vocab_size=vocab)
+
+    def forward(self, features, condtargets, input_lengths=None, condtarget_lengths=None, star_penalty=None,
+                measure_entropy=False, drop_labels=False):
+        # remove prompts for CTC. we assume there is only one prompt token
+        targets = condtargets[:, 1:]
+        target_lengths = condtarget_lengths - 1 if condtarget_lengths is not None else None
+        decoder_loss, decoder_stats = self.decoder(features, condtargets, input_lengths, condtarget_lengths, star_penalty,
+                                                   measure_entropy, drop_labels)
+        recognizer_loss, recognizer_stats = self.recognizer(features, targets, input_lengths, target_lengths, star_penalty)
+        return decoder_loss + 0.3 * recognizer_loss, {**decoder_stats, **recognizer_stats}
+
+    def decode(self, features, input_lengths, target_lengths, prompt=None):
+        return self.decoder.decode(features, input_lengths, target_lengths, prompt=prompt)
+
+
+class AudioEncoder(nn.Module):
+    def __init__(self, *, head_dim: int = 64, heads: int = 12, p_drop: float = 0.2, layers: int = 12, input_dim: int = 80,
+                 conv_dim: int = 256, conv_strides: tuple = (2, 2, 2)):
+        super().__init__()
+        self.head_dim = head_dim
+        self.heads = heads
+        self.conv = ConvEncoder(input_dim=input_dim, hidden_dim=conv_dim, output_dim=head_dim * heads, strides=conv_strides)
+        self.drop = nn.Dropout(p_drop)
+        self.h = nn.ModuleList([Block(head_dim=head_dim, heads=heads, p_drop=p_drop) for _ in range(layers)])
+        self.ln_f = LayerNorm(head_dim * heads, bias=False)
+
+    def subsampled_lengths(self, input_lengths):
+        return self.conv.subsampled_lengths(input_lengths)
+
+    def forward(self, x, input_lengths, measure_entropy=False):
+        """x [N, T, F] -> (features [N, T', C], lengths int32, stats); no time mask, like the reference (:245-247)."""
+        _require_inference(self, x)
+        y = self.conv.forward_cl(x)                                              # channels-last: no .mT round trip
+        input_lengths = self.conv.subsampled_lengths(input_lengths)
+        N, T, C = y.shape
+        y2d = y.view(N * T, C)
+        stats = Stats(meme_entropy=[], self_entropy=[])
+        for block in self.h:
+            m_ent, t_ent = block._forward2d(y2d, N, T, measure_entropy=measure_entropy)
+            stats.meme_entropy.append(m_ent)
+            stats.self_entropy.append(t_ent)
+        out = ops.layernorm_fwd(y2d, self.ln_f.weight).view(N, T, C)
+        return out, input_lengths, stats._asdict()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 2
+#define HALO_ABI_VERSION 3
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -97,6 +97,7 @@ int halo_counter_inc(uint32_t *counter, halo_stream_t stream);
 #define HALO_GEMM_RELU 1
 #define HALO_GEMM_GELU 2   /* tanh-GELU ("new_gelu", ha/attention.py:12-17), applied after the bias */
 #define HALO_GEMM_ACCUM 4  /* C += result (residual connections, ha/attention.py:178-179) */
+#define HALO_GEMM_GELU_ERF 8 /* exact GELU (nn.GELU() ha/transformer.py:456, F.gelu ha/conv.py:46), after the bias */
 int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float *A, int lda,
                   const float *B, int ldb, float *C, int ldc, const float *bias1, const float *bias2,
                   int flags, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
@@ -244,7 +245,7 @@ int halo_topk_f32(const float *values, int rows, int n, int k, float *out_values
  *                             output qkv [B,T,3C] (q|k|v, heads side by side) -> y [B,T,C]  :113-123,90
  *   halo_cross_entropy_fwd    F.cross_entropy(logits, targets, ignore_index, reduction='none')  :231
  * Linear layers, tanh-GELU and the residual adds are halo_gemm_f32 / halo_gemm_split epilogues.
- * head_dim must be 32 or 64 (GPT-2 small: 64). */
+ * halo_attention_causal_fwd is halo_attention_fwd on the packed qkv rows; head_dim in {16, 32, 64} (GPT-2 small: 64). */
 int halo_embed_fwd(const int64_t *ids, const float *wte, const float *wpe, float *x, int n_tokens, int T, int C,
                    int pos0, int vocab, halo_stream_t stream);
 int halo_layernorm_fwd(const float *x, const float *weight, const float *bias, float *y, int rows, int C,
@@ -252,6 +253,58 @@ int halo_layernorm_fwd(const float *x, const float *weight, const float *bias, f
 int halo_attention_causal_fwd(const float *qkv, float *y, int B, int T, int n_head, int C, halo_stream_t stream);
 int halo_cross_entropy_fwd(const float *logits, const int64_t *targets, float *loss, int rows, int V, long ld,
                            long ignore_index, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention operators shared by the GPT path and the encoder-decoder ASR path (ha/transformer.py).
+ *   halo_attention_fwd     F.scaled_dot_product_attention(q, k, v, attn_mask|is_causal)   transformer.py:356, attention.py:90
+ *                          q rows [N, Tq], k/v rows [N, Tk] given by row/batch strides (elements); head h occupies
+ *                          columns [h*head_dim, (h+1)*head_dim) of a row, so the packed q|k|v output of one fused GEMM
+ *                          is consumed in place.  Key j is visible to query i iff j < min(Tk, key_lengths[n]) (the
+ *                          ~memory_mask of transformer.py:476) and, when causal, j <= i + Tk - Tq.
+ *                          lse (optional) [N, heads, Tq] = log-sum-exp of the scaled scores (saved for the backward);
+ *                          entropy (optional) [N, heads, Tq] = -sum_j att*log(att + 1e-8), the monitor of attend()
+ *                          transformer.py:413-430 (its mean over all rows is att_entropy).  head_dim in {16, 32, 64}.
+ *   halo_rope_table /      rotate_interleaved transformer.py:16-31: cos/sin tables [T, head_dim/2] of t * base^(-2i/head_dim);
+ *   halo_rope_interleaved  in-place rotation of the pairs (2i, 2i+1) of every head of x rows (row r sits at position
+ *                          t0 + r % T); inverse != 0 rotates back (the backward of the rotation).
+ *   halo_kv_cache_store    kv_cache[layer, 0|1, alive, :, t0:t0+S, :] = k|v  transformer.py:318-319,333-334: fp32 rows
+ *                          (k at column 0, v at column v_offset of each source row) -> float16 caches [N, heads, cache_len, head_dim]
+ *   halo_attention_decode  one query token per (n, head) against the first n_keys cached keys: the T == 1 branch of
+ *                          MultiHeadAttention.forward transformer.py:313-356; cos/sin tables (optional) rotate the cached
+ *                          keys at positions 0..n_keys-1 (transformer.py:343), q must already be rotated.
+ *   halo_logprob_max       log_softmax(dim=-1).max(dim=-1) per row (+ sum p*logp/log 2)  transformer.py:175-179,116
+ *   halo_greedy_update     the per-step bookkeeping of Decoder.decode transformer.py:179-192 (alive rows only; the entropy
+ *                          increment is the sum over ALL alive rows, as the reference's .sum(dim=(-2,-1)) makes it). */
+int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
+                       long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride,
+                       float *lse, float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal,
+                       const int *key_lengths, halo_stream_t stream);
+int halo_rope_table(float *cos_table, float *sin_table, int T, int head_dim, float base, halo_stream_t stream);
+int halo_rope_interleaved(float *x, long row_stride, int n_rows, int T, int heads, int head_dim, int t0,
+                          const float *cos_table, const float *sin_table, int table_rows, int inverse,
+                          halo_stream_t stream);
+int halo_kv_cache_store(const float *src, long src_row_stride, long v_offset, void *cache_k, void *cache_v, int N,
+                        int S, int heads, int head_dim, int cache_len, int t0, halo_stream_t stream);
+int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k, const void *cache_v, float *y,
+                          long y_row_stride, int N, int heads, int head_dim, int cache_len, int n_keys,
+                          const int *key_lengths, const float *cos_table, const float *sin_table,
+                          halo_stream_t stream);
+int halo_logprob_max(const float *logits, long ld, int rows, int V, float *values, int64_t *indices,
+                     float *neg_entropy_bits, halo_stream_t stream);
+int halo_greedy_update(const float *values, const int64_t *indices, const float *neg_entropy_bits, int64_t *tokens,
+                       long tokens_ld, int t, int plen, int etx, uint8_t *alive, int *output_lengths,
+                       float *log_probs, float *sum_entropies, int N, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutional front-end of AudioEncoder, channels-last.  replaces, in ha/conv.py:
+ *   halo_im2col_cl    the unfold of nn.Conv1d(input_dim, hidden_dim, 3, stride, padding=1) :29; the conv itself is a
+ *                     GEMM of col [N*T', Cin*ks] with weight [Cout, Cin*ks] + bias + HALO_GEMM_GELU_ERF (:46)
+ *   halo_dwconv1d_cl  DWConv1d.depthwise (groups = channels) :15-18; .pointwise :19 is a GEMM over the rows
+ * x [N, T, C] -> [N, T', C] with T' = (T + 2*pad - ks)/stride + 1; no length masking (the reference has none). */
+int halo_im2col_cl(const float *x, float *col, int N, int T, int Cin, int ks, int stride, int pad,
+                   halo_stream_t stream);
+int halo_dwconv1d_cl(const float *x, const float *weight, const float *bias, float *y, int N, int T, int C, int ks,
+                     int stride, int pad, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers.

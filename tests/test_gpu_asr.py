@@ -1,0 +1,201 @@
+"""GPU parity of the encoder-decoder attention ASR path (haloop_amd.transformer / haloop_amd.conv, through the
+C ABI) against the reference-generated goldens (tests/golden/g6_*.npz) and the CPU oracle
+(oracle/transformer_ref.py).  Tolerances (fp32 state; both GEMM modes):
+
+    encoder features <= 2e-4 abs (12 layers; 2e-5 on the tiny nets), lengths exact (int32);
+    teacher-forced losses rel <= 2e-5 (per-token 1e-4 abs); attention-entropy monitors rel 1e-4;
+    greedy decode: token ids and lengths EXACT, accumulated log-probs / entropies <= 2e-3 abs against the oracle
+    (same fp16-cache arithmetic) and <= 5e-2 against the reference's own fp16-autocast run.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from test_oracle_golden import ASR_CASES, asr_case_from_golden, _unpad
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def hal():
+    from haloop_amd import _lib, ops, transformer, conv
+    _lib.lib()
+    _lib.lend_scratch()
+    return dict(ops=ops, tr=transformer, conv=conv, lib=_lib)
+
+
+@pytest.fixture
+def math_mode(request, hal):
+    prev = hal['lib'].get_math_mode()
+    hal['lib'].set_math_mode(request.param)
+    yield request.param
+    hal['lib'].set_math_mode(prev)
+
+
+BOTH_MODES = pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+
+
+def _models(hal, name):
+    g, pe, pd, batch, heads, strides = asr_case_from_golden(name)
+    vocab, hd, heads, el, dl, conv_dim, N, T, S, seed, F_ = (int(v) for v in g['cfg'])
+    tr = hal['tr']
+    enc = tr.AudioEncoder(head_dim=hd, heads=heads, layers=el, p_drop=0.2, input_dim=F_, conv_dim=conv_dim, conv_strides=strides)
+    dec = tr.CTCAttentionDecoder(vocab=vocab, head_dim=hd, heads=heads, p_drop=0.2, layers=dl)
+    enc.load_state_dict(pe, strict=True)
+    dec.load_state_dict(pd, strict=True)
+    return g, pd, batch, heads, enc.to(DEV).eval(), dec.to(DEV).eval()
+
+
+# ---------------------------------------------------------------------------------------- operators
+@pytest.mark.parametrize('hd,heads,N,Tq,Tk,causal,ragged', [
+    (64, 3, 2, 130, 130, True, False), (64, 2, 3, 70, 70, False, True), (32, 4, 2, 9, 100, False, True),
+    (16, 2, 3, 5, 5, True, False), (64, 1, 2, 200, 200, False, False), (32, 2, 2, 65, 65, True, False),
+    (64, 2, 2, 1, 77, False, True)])
+def test_attention_fwd_against_sdpa(hal, hd, heads, N, Tq, Tk, causal, ragged):
+    g = torch.Generator().manual_seed(hd + Tq + Tk)
+    C = heads * hd
+    q = torch.randn(N * Tq, C, generator=g)
+    kv = torch.randn(N * Tk, 2 * C, generator=g)                       # packed k|v rows, like the fused GEMM output
+    lens = torch.tensor([Tk - (7 * n) % Tk for n in range(N)], dtype=torch.int32) if ragged else None
+    y, lse, ent = hal['ops'].attention_fwd(q.to(DEV), kv[:, :C].to(DEV), kv[:, C:].to(DEV), N, heads, hd, Tq, Tk, causal=causal,
+                                           key_lengths=lens.to(DEV) if ragged else None, want_lse=True, want_entropy=True)
+    qh = q.view(N, Tq, heads, hd).transpose(1, 2)
+    kh = kv[:, :C].reshape(N, Tk, heads, hd).transpose(1, 2)
+    vh = kv[:, C:].reshape(N, Tk, heads, hd).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        s = s.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float('-inf'))
+    if ragged:
+        s = s.masked_fill((torch.arange(Tk)[None, :] >= lens[:, None])[:, None, None, :], float('-inf'))
+    att = s.softmax(-1)
+    ref = (att @ vh).transpose(1, 2).reshape(N * Tq, C)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(s, -1).numpy(), atol=1e-5, rtol=1e-6)
+    np.testing.assert_allclose(ent.cpu().numpy(), (-att * torch.log(att + 1e-8)).sum(-1).numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_rope_attend_lengths_match_reference(hal):
+    tr = hal['tr']
+    g = load_golden('g6_asr_parts')
+    for nm in 'abc':
+        y = tr.rotate_interleaved(torch.from_numpy(g[f'rope.{nm}.x']).to(DEV), t0=int(g[f'rope.{nm}.t0']))
+        np.testing.assert_allclose(y.cpu().numpy(), g[f'rope.{nm}.y'], rtol=0, atol=2e-6)
+    q, k, v, mask = (torch.from_numpy(g['attend.' + n]).to(DEV) for n in ('q', 'k', 'v', 'mask'))
+    with pytest.raises(NotImplementedError):
+        tr.attend(q, k, v, mask)                                           # the fixture's mask is not a suffix mask
+    y, ent = tr.attend(q, k, v, None)
+    from oracle import transformer_ref
+    yr, er = transformer_ref.attend(q.cpu(), k.cpu(), v.cpu(), None)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), atol=2e-6)
+    np.testing.assert_allclose(float(ent), float(er), rtol=1e-5)
+    lens = torch.from_numpy(g['lengths.in'])
+    conv = hal['conv']
+    assert np.array_equal(conv.ConvEncoder(input_dim=8, hidden_dim=8, output_dim=8, strides=(2, 2, 2)).subsampled_lengths(lens).numpy(),
+                          g['lengths.s222'])
+    assert np.array_equal(conv.ConvEncoder(input_dim=8, hidden_dim=8, output_dim=8, strides=(2, 2, 1)).subsampled_lengths(lens).numpy(),
+                          g['lengths.s221'])
+
+
+@BOTH_MODES
+def test_conv_frontend_matches_oracle(hal, math_mode):
+    from oracle import transformer_ref
+    pe = transformer_ref.make_encoder_params(64, 8, 0, 80, 256, 3, 5)
+    conv = hal['conv'].ConvEncoder(input_dim=80, hidden_dim=256, output_dim=512, strides=(2, 2, 2))
+    conv.load_state_dict({k[len('conv.'):]: v for k, v in pe.items() if k.startswith('conv.')}, strict=True)
+    conv = conv.to(DEV).eval()
+    x = torch.randn(3, 80, 77, generator=torch.Generator().manual_seed(1))         # [N, F, T] like the reference
+    lens = torch.tensor([77, 60, 9])
+    with torch.no_grad():
+        y, olen = conv(x.to(DEV), lens)
+        ref = transformer_ref.conv_encoder(pe, 'conv.', x, (2, 2, 2))
+    assert y.shape == ref.shape and olen.dtype == torch.int32
+    assert olen.tolist() == transformer_ref.subsampled_lengths(lens, (2, 2, 2)).tolist()
+    # bf16x3 products carry ~2^-16 relative error each; the activations here reach ~10
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5 if math_mode == 'f32' else 1e-4, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- models
+@BOTH_MODES
+@pytest.mark.parametrize('name', ASR_CASES)
+def test_asr_encoder_decoder_matches_reference(hal, name, math_mode):
+    g, pd, (x, il, tg, tl), heads, enc, dec = _models(hal, name)
+    N = x.shape[0]
+    deep = 'transformer32' in name
+    with torch.no_grad():
+        feats, flen, stats = enc(x.to(DEV), il.to(DEV))
+        assert flen.dtype == torch.int32 and np.array_equal(flen.cpu().numpy(), g['feature_lengths'])
+        np.testing.assert_allclose(feats.cpu().numpy(), g['features'], rtol=0, atol=2e-4 if deep else 2e-5)
+        assert all(float(e) == float('-inf') for e in stats['meme_entropy'] + stats['self_entropy'])
+        feats = torch.from_numpy(g['features']).to(DEV)                  # downstream checks start from the reference's features
+        for red in ('mean', 'none', 'sumeach'):
+            loss, _ = dec.decoder(feats, tg.to(DEV), flen, tl.to(DEV), reduction=red, drop_labels=False)
+            np.testing.assert_allclose(loss.cpu().numpy(), g['decoder_loss.' + red], rtol=2e-5, atol=1e-4, err_msg=red)
+        cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1)
+        joint, _ = dec(feats, cond.to(DEV), flen, (tl + 1).to(DEV))
+        np.testing.assert_allclose(float(joint), float(g['joint_loss']), rtol=2e-5)
+        _, stats = dec.decoder(feats, tg.to(DEV), flen, tl.to(DEV), measure_entropy=True, drop_labels=False)
+        np.testing.assert_allclose(np.array([float(e) for e in stats['meme_entropy']]), g['meme_entropy'], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(np.array([float(e) for e in stats['self_entropy']]), g['self_entropy'], rtol=2e-4, atol=1e-5)
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ASR_CASES)
+def test_asr_greedy_decode_matches_reference(hal, name, math_mode):
+    from oracle import transformer_ref
+    g, pd, (x, il, tg, tl), heads, enc, dec = _models(hal, name)
+    feats, flen = torch.from_numpy(g['features']), torch.from_numpy(g['feature_lengths'])
+    with torch.no_grad():
+        outs, olen, ali, lps, ents = dec.decode(feats.to(DEV), flen.to(DEV), tl.to(DEV))
+        o_outs, o_len, o_lps, o_ents, _ = transformer_ref.decoder_decode(pd, feats, flen, tl, heads, pre='decoder.')
+    assert olen.dtype == torch.int32 and ali == [None] * len(tl)
+    assert np.array_equal(olen.cpu().numpy(), g['decode.output_lengths'])
+    assert [o.tolist() for o in outs.unbind()] == _unpad(g['decode.tokens'], g['decode.token_lens'])
+    np.testing.assert_allclose(lps.cpu().numpy(), o_lps.numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(ents.cpu().numpy(), o_ents.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(lps.cpu().numpy(), g['decode.log_probs'], rtol=1e-2, atol=5e-2)
+    np.testing.assert_allclose(ents.cpu().numpy(), g['decode.sum_entropies'], rtol=1e-2, atol=5e-2)
+    with torch.no_grad():
+        outs, olen, _, lps, _ = dec.decode(feats.to(DEV), flen.to(DEV), tl.to(DEV), prompt=torch.tensor([[7, 9]] * len(tl)))
+    assert np.array_equal(olen.cpu().numpy(), g['decode_prompt.output_lengths'])
+    assert [o.tolist() for o in outs.unbind()] == _unpad(g['decode_prompt.tokens'], g['decode_prompt.token_lens'])
+    np.testing.assert_allclose(lps.cpu().numpy(), g['decode_prompt.log_probs'], rtol=1e-2, atol=5e-2)
+
+
+def test_block_and_mha_public_forward(hal):
+    """The module-level call surface (ha/transformer.py:289-300, 464-471): Block / MultiHeadAttention called
+    directly with [N, T, C] tensors, the key-padding mask Block builds, and the refusals."""
+    from oracle import transformer_ref
+    tr = hal['tr']
+    hd, heads, N, T, S = 16, 2, 2, 7, 9
+    C = hd * heads
+    p = {}
+    transformer_ref._block_params(p, torch.Generator().manual_seed(9), '', C, memory=True)
+    blk = tr.Block(head_dim=hd, heads=heads, p_drop=0.1, memory=True)
+    blk.load_state_dict(p, strict=True)
+    blk = blk.to(DEV).eval()
+    g = torch.Generator().manual_seed(10)
+    x, mem = torch.randn(N, T, C, generator=g), torch.randn(N, S, C, generator=g)
+    mlen = torch.tensor([9, 4])
+    ents = []
+    with torch.no_grad():
+        y, (m_ent, t_ent) = blk(x.to(DEV), causal=True, memory=mem.to(DEV), memory_lengths=mlen.to(DEV), measure_entropy=True)
+        ref = transformer_ref.block(p, '', x, heads, causal=True, memory=mem, memory_lengths=mlen, entropies=ents)
+        np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=5e-6, rtol=1e-5)
+        np.testing.assert_allclose([float(m_ent), float(t_ent)], [float(ents[0][0]), float(ents[0][1])], rtol=1e-5)
+        mask = (torch.arange(S)[None, :] >= mlen[:, None])[:, None, None, :]
+        xn = transformer_ref.layer_norm(x, p['ln_time.weight'])
+        m, _ = blk.mix_memory(xn.to(DEV), mem.to(DEV), mask=mask.to(DEV))
+        np.testing.assert_allclose(m.cpu().numpy(), transformer_ref.mha(p, 'mix_memory.', xn, mem, heads, key_mask=mask[:, 0, 0]).numpy(),
+                                   atol=5e-6, rtol=1e-5)
+        with pytest.raises(NotImplementedError):
+            blk(x.to(DEV), memory=mem.to(DEV), memory_lengths=mlen.to(DEV), kv_cache_parts=tr.BlockKVCache(memory=(None,) * 4, time=None))
+    with pytest.raises(NotImplementedError):
+        blk(x.to(DEV), memory=mem.to(DEV), memory_lengths=mlen.to(DEV))       # grad mode: the backward is not built
+    with pytest.raises(hal['lib'].HaloError):
+        with torch.no_grad():
+            blk(x, memory=mem, memory_lengths=mlen)                              # CPU tensors: no fallback
