@@ -68,6 +68,15 @@ SIGNATURES = {
     'halo_attention_decode': (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_logprob_max': (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_greedy_update': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    'halo_attention_bwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _l, _l, _vp, _vp, _l, _l,
+                                _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'halo_layernorm_bwd_workspace_bytes': (_sz, [_i, _i]),
+    'halo_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
+    'halo_gelu_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'halo_cross_entropy_fwd_lse': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _l, _vp]),
+    'halo_cross_entropy_bwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),
+    'halo_embed_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_im2col_cl': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_dwconv1d_cl': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),

@@ -32,6 +32,10 @@ class WeightImages:
         """The split/tiled image of the (concatenated) weight."""
         return self._lookup('split', weights, lambda: ops.split_image(self.dense(weights).contiguous()))
 
+    def split_t(self, weight):
+        """The image of W^T (logical [in, out]) of one weight: the B operand of dx = dy W."""
+        return self._lookup('split_t', (weight,), lambda: ops.split_image(self.dense((weight,)).contiguous(), transposed=True))
+
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
@@ -45,3 +49,26 @@ def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=Fal
         return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
                               accumulate=accumulate)
     return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate)
+
+
+def use_split(M, N, K):
+    return _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64
+
+
+def linear_dx(images, dy2d, weight, out=None, accumulate=False):
+    """dx [M, in] = dy [M, out] W [out, in]  (the input gradient of y = x W^T)."""
+    M, K = dy2d.shape
+    N = weight.shape[1]
+    if use_split(M, N, K):
+        return ops.gemm_split(ops.split_image(dy2d), images.split_t(weight), M, N, K, out=out, accumulate=accumulate)
+    return ops.gemm(dy2d, images.dense((weight,)), True, False, M, N, K, out=out, accumulate=accumulate)
+
+
+def linear_dw(dy2d, x2d, out=None, accumulate=False):
+    """dW [out, in] = dy^T [out, M] x [M, in]  (the weight gradient of y = x W^T)."""
+    K, M = dy2d.shape
+    N = x2d.shape[1]
+    if use_split(M, N, K):
+        return ops.gemm_split(ops.split_image(dy2d, transposed=True), ops.split_image(x2d, transposed=True), M, N, K, out=out,
+                              accumulate=accumulate)
+    return ops.gemm(dy2d, x2d, False, False, M, N, K, out=out, accumulate=accumulate)

@@ -8,8 +8,12 @@ checkpoints load unchanged and ``hap`` (ha/score.py:72-73) can call ``forward_al
 reduction='none')`` as is.  Arithmetic is fp32 state with split-bf16 (bf16x3) or exact-f32 MFMA
 GEMMs per ``halo_set_math_mode``; attention, LayerNorm, softmax and the loss are fp32.
 
-Not built yet (raises NotImplementedError): the backward pass (``hala`` training), the KV-cache
-``past`` argument / ``generate``, ``stable_embedding`` and rotary (flash_attn) blocks.
+Training: with grad enabled ``forward_all`` returns a loss with a ``grad_fn`` (one autograd.Function whose
+backward is the hand-written HIP backward: cross-entropy, lm_head, LayerNorm, GELU, attention and embedding
+gradients), so ``loss.backward()``, ``clip_grad_norm_`` and the optimizers of ha/attention_loop.py work unchanged.
+
+Not built yet (raises NotImplementedError): dropout > 0, the KV-cache ``past`` argument / ``generate``,
+``stable_embedding`` and rotary (flash_attn) blocks.
 """
 import math
 from dataclasses import dataclass, asdict
@@ -18,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from ._linear import WeightImages, linear, linear_dw, linear_dx
 
 
 @dataclass
@@ -84,19 +89,22 @@ class Block(nn.Module):
         self.mlp = MLP(config)
 
 
-class _WeightImages:
-    """Split (bf16 hi/lo, tiled) images of Linear weights, rebuilt only when a weight changes."""
+class _GPTLoss(torch.autograd.Function):
+    """Per-token NLL of GPT.forward_all with its hand-written backward (the autograd graph the reference gets from
+    torch for ha/attention.py:205-232).  The parameters ride along as inputs so that loss.backward() fills their
+    .grad exactly like the reference's, and clip_grad_norm_ / the optimizer of ha/attention_loop.py:203-215 work as is."""
 
-    def __init__(self):
-        self._cache = {}
+    @staticmethod
+    def forward(ctx, model, input_ids, target_ids, *params):
+        per_tok, saved = model._forward_train(input_ids, target_ids)
+        ctx.model, ctx.saved, ctx.params = model, saved, params
+        return per_tok
 
-    def get(self, w):
-        key = id(w)
-        hit = self._cache.get(key)
-        if hit is None or hit[0] != w._version or hit[1] != w.data_ptr():
-            hit = (w._version, w.data_ptr(), ops.split_image(w.detach().contiguous()))
-            self._cache[key] = hit
-        return hit[2]
+    @staticmethod
+    def backward(ctx, grad_per_tok):
+        grads = ctx.model._backward_train(ctx.saved, grad_per_tok.contiguous().float())
+        ctx.saved = None
+        return (None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
 
 
 class GPT(nn.Module):
@@ -119,16 +127,11 @@ class GPT(nn.Module):
             self.transformer.wte.weight.mul_(0.02)
         self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
         self.transformer.wte.weight = self.lm_head.weight       # weight tying
-        self._images = _WeightImages()
+        self._images = WeightImages()
 
     # ---- one Linear: y = x W^T + b, with the epilogue fused ------------------------------------
     def _linear(self, x2d, lin, out=None, gelu=False, accumulate=False):
-        M, K = x2d.shape
-        N = lin.weight.shape[0]
-        if _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64:
-            return ops.gemm_split(ops.split_image(x2d), self._images.get(lin.weight), M, N, K, out=out, bias1=lin.bias,
-                                  gelu=gelu, accumulate=accumulate)
-        return ops.gemm(x2d, lin.weight, True, True, M, N, K, out=out, bias1=lin.bias, gelu=gelu, accumulate=accumulate)
+        return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate)
 
     @torch.no_grad()
     def _trunk(self, input_ids):
@@ -150,15 +153,16 @@ class GPT(nn.Module):
     def forward_all(self, input_ids, target_ids, past=None, reduction='mean'):
         if past is not None:
             raise NotImplementedError('KV-cache continuation is not built yet')
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('haloop_amd.attention.GPT is forward-only so far: call it under torch.no_grad() / '
-                                      'inference_mode (ha/score.py does); training backward is the next row of SURVEY.md 8f')
         if not input_ids.is_cuda:
             raise _lib.HaloError('haloop_amd.attention.GPT runs on the HIP device only (no CPU path)')
         if self.training and self.config.dropout > 0:
-            raise NotImplementedError('dropout in the GPT path is not built; call .eval()')
+            raise NotImplementedError('dropout in the GPT path is not built; train with dropout=0.0 (the GPTConfig default)')
         B, T = input_ids.shape
         V = self.config.vocab_size
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = [p for p in self.parameters() if p.requires_grad]
+            loss = _GPTLoss.apply(self, input_ids, target_ids, *params)          # per-token NLL with a grad_fn
+            return self._reduce(loss, target_ids.reshape(-1), reduction)
         x = self._trunk(input_ids)
         targets = target_ids.reshape(-1)
         # lm_head + cross-entropy in row chunks so the [rows, V] logits stay bounded (206 MB per 1024 rows at V=50304)
@@ -168,14 +172,89 @@ class GPT(nn.Module):
             r1 = min(B * T, r0 + chunk)
             logits = self._linear(x[r0:r1], self.lm_head)
             loss[r0:r1] = ops.cross_entropy_fwd(logits, targets[r0:r1], ignore_index=0)
+        return self._reduce(loss, targets, reduction)
+
+    @staticmethod
+    def _reduce(loss, targets, reduction):
         if reduction == 'none':
             return loss
-        valid = (targets != 0)
         if reduction == 'sum':
             return loss.sum()
         if reduction == 'mean':
-            return loss.sum() / valid.sum()
+            return loss.sum() / (targets != 0).sum()
         raise ValueError(f'unknown reduction {reduction!r}')
+
+    # ---- training: forward that keeps what the backward needs, and the backward itself -------------------------
+    @torch.no_grad()
+    def _forward_train(self, input_ids, target_ids):
+        cfg = self.config
+        B, T = input_ids.shape
+        assert T <= cfg.block_size, f'Cannot forward sequence of length {T}, block size is only {cfg.block_size}'
+        C, H = cfg.n_embd, cfg.n_head
+        tr = self.transformer
+        x = ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, 0)
+        blocks = []
+        for blk in tr.h:
+            x0 = x
+            h1 = ops.layernorm_fwd(x0, blk.ln_1.weight, blk.ln_1.bias)
+            qkv = self._linear(h1, blk.attn.c_attn)
+            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=True, want_lse=True)
+            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True)
+            h2 = ops.layernorm_fwd(x1, blk.ln_2.weight, blk.ln_2.bias)
+            a = self._linear(h2, blk.mlp.c_fc)
+            g = ops.gelu_fwd(a)
+            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True)
+            blocks.append((x0, h1, qkv, y, lse, x1, h2, a, g))
+        xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
+        targets = target_ids.reshape(-1)
+        logits = self._linear(xf, self.lm_head)                              # kept: the backward rewrites it into dlogits
+        loss, row_lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
+        return loss, (input_ids, targets, blocks, x, xf, logits, row_lse)
+
+    @torch.no_grad()
+    def _backward_train(self, saved, grad_per_tok):
+        cfg = self.config
+        input_ids, targets, blocks, x_last, xf, logits, row_lse = saved
+        B, T = input_ids.shape
+        C, H = cfg.n_embd, cfg.n_head
+        tr = self.transformer
+        img = self._images
+        grads = {}
+
+        def put(p, g):
+            if p is not None and p.requires_grad:
+                grads[id(p)] = g if id(p) not in grads else grads[id(p)] + g
+
+        dlogits = ops.cross_entropy_bwd_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
+        dw_head = linear_dw(dlogits, xf)                                     # [V, C]; the tied wte gradient lands here too
+        dxf = linear_dx(img, dlogits, self.lm_head.weight)
+        dx, dw, db = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None)
+        put(tr.ln_f.weight, dw); put(tr.ln_f.bias, db)
+        for blk, (x0, h1, qkv, y, lse, x1, h2, a, g) in zip(reversed(tr.h), reversed(blocks)):
+            # x = x1 + c_proj(gelu(c_fc(ln_2(x1))))
+            put(blk.mlp.c_proj.weight, linear_dw(dx, g))
+            if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dx))
+            da = ops.gelu_bwd(linear_dx(img, dx, blk.mlp.c_proj.weight), a)
+            put(blk.mlp.c_fc.weight, linear_dw(da, h2))
+            if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
+            dx1, dw, db = ops.layernorm_bwd(linear_dx(img, da, blk.mlp.c_fc.weight), x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
+            put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
+            # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
+            put(blk.attn.c_proj.weight, linear_dw(dx1, y))
+            if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dx1))
+            dy = linear_dx(img, dx1, blk.attn.c_proj.weight)
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
+                              B, H, C // H, T, T, causal=True)
+            put(blk.attn.c_attn.weight, linear_dw(dqkv, h1))
+            if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
+            dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight), x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None)
+            put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
+        dwpe = torch.zeros_like(tr.wpe.weight)
+        ops.embed_bwd(input_ids, dx, dw_head, dwpe, 0)                         # tied: embedding rows add into the lm_head gradient
+        put(self.lm_head.weight, dw_head)
+        put(tr.wpe.weight, dwpe)
+        return grads
 
     def forward(self, input_ids, past=None):
         raise NotImplementedError('generation (KV cache) is not built yet; forward_all is')

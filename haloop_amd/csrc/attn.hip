@@ -364,6 +364,252 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float *__restr
     }
 }
 
+// ---- softmax attention backward --------------------------------------------------------------------------
+// Two sweeps, no atomics (bitwise reproducible): attention_bwd_dq_kernel owns 64 query rows and walks the key
+// tiles (dQ), attention_bwd_dkv_kernel owns 64 keys and walks the query tiles (dK, dV).  Both recompute
+// P = exp(scale * q.k - lse) from the forward's log-sum-exp; delta = rowsum(dO * O) comes from attention_delta_kernel.
+//   dV = P^T dO,  dP = dO V^T,  dS = P * (dP - delta),  dQ = scale * dS K,  dK = scale * dS^T Q
+// All four/five products per tile run on v_mfma_f32_16x16x4_f32.  LDS tiles are [row][dim] with stride HD+2; an
+// operand is read either as B[k = dim][col = row] (row = l&15) or as B[k = row][col = dim] (dim = l&15) -- the second
+// pattern is 2-way bank-conflicted, which the 32-cycle f32 MFMA hides.
+struct AttnBwdArgs {
+    const float *q, *k, *v, *dy, *lse, *delta;
+    float *dq, *dk, *dv;
+    long q_rs, q_bs, kv_rs, kv_bs, dy_rs, dy_bs, dq_rs, dq_bs, dkv_rs, dkv_bs;
+    const int *key_len;
+    int Tq, Tk, heads, causal;
+    float scale;
+};
+
+// delta[n, h, t] = sum_d dy[n, t, h*HD + d] * y[n, t, h*HD + d]
+template <int HD>
+__global__ __launch_bounds__(256) void attention_delta_kernel(const float *__restrict__ dy, long dy_rs, const float *__restrict__ y,
+                                                              long y_rs, float *__restrict__ delta, int Tq, int heads) {
+    const long row = blockIdx.x;                              // n * Tq + t
+    const int n = (int)(row / Tq), t = (int)(row % Tq);
+    const int C = heads * HD;
+    for (int c = threadIdx.x; c < ((C + 255) / 256) * 256; c += 256) {
+        float p = c < C ? dy[row * dy_rs + c] * y[row * y_rs + c] : 0.f;
+#pragma unroll
+        for (int o = HD / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (c < C && (c % HD) == 0) delta[((long)n * heads + c / HD) * Tq + t] = p;
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_tile(float *lds, const f32x4 *reg) {
+    constexpr int STRIDE = HD + 2, UNITS = 64 * (HD / 4) / 256;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        const int row = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+        *reinterpret_cast<f32x2 *>(&lds[row * STRIDE + d4]) = f32x2{reg[i][0], reg[i][1]};
+        *reinterpret_cast<f32x2 *>(&lds[row * STRIDE + d4 + 2]) = f32x2{reg[i][2], reg[i][3]};
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void fetch_tile(f32x4 *reg, const float *base, long rs, int row0, int n_rows) {
+    constexpr int UNITS = 64 * (HD / 4) / 256;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        const int row = min(row0 + u / (HD / 4), n_rows - 1), d4 = (u % (HD / 4)) * 4;
+        reg[i] = *reinterpret_cast<const f32x4 *>(base + (long)row * rs + d4);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
+    constexpr int ST = HD + 2, PS = 66, UNITS = 64 * (HD / 4) / 256;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * ST];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * ST];
+    __shared__ float Ps[4][16 * PS];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int q0 = qt * 64 + wave * 16;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+    float qa[HD / 4], doa[HD / 4];
+    {
+        const int qrow = min(q0 + lr, Tq - 1);
+#pragma unroll
+        for (int s = 0; s < HD / 4; ++s) {
+            qa[s] = qb[(long)qrow * a.q_rs + 4 * s + lq] * a.scale;
+            doa[s] = dyb[(long)qrow * a.dy_rs + 4 * s + lq];
+        }
+    }
+    float lse_r[4], del_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long stat = ((long)b * a.heads + h) * Tq + min(q0 + 4 * lq + r, Tq - 1);
+        lse_r[r] = a.lse[stat];
+        del_r[r] = a.delta[stat];
+    }
+    f32x4 dq[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n_ktiles = (klim + 63) / 64;
+    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+    f32x4 kreg[UNITS], vreg[UNITS];
+    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+        __syncthreads();
+        stage_tile<HD>(Ks, kreg);
+        stage_tile<HD>(Vs, vreg);
+        __syncthreads();
+        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+        f32x4 sacc[4], pacc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < HD / 4; ++s) {
+                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
+                pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[s], Vs[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+            }
+        }
+        float *pw = Ps[wave];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
+                const bool hidden = key >= klim || (a.causal && key > qrow + coff);
+                const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
+                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (pacc[n][r] - del_r[r]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float da = pw[lr * PS + 4 * s + lq];
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+                dq[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Ks[(4 * s + lq) * ST + 16 * m + lr], dq[m], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * lq + r;
+        if (qrow >= Tq) continue;
+        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) dp[16 * m + lr] = dq[m][r] * a.scale;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
+    constexpr int ST = HD + 2, PS = 66, UNITS = 64 * (HD / 4) / 256;
+    __shared__ __attribute__((aligned(16))) float Qs[64 * ST];
+    __shared__ __attribute__((aligned(16))) float Os[64 * ST];      // dO tile
+    __shared__ float Ps[4][2][16 * PS];
+    __shared__ float lse_s[64], del_s[64];
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int k0 = kt * 64 + wave * 16;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+    float ka[HD / 4], va[HD / 4];
+    {
+        const int krow = min(k0 + lr, Tk - 1);
+#pragma unroll
+        for (int s = 0; s < HD / 4; ++s) {
+            ka[s] = kb[(long)krow * a.kv_rs + 4 * s + lq] * a.scale;
+            va[s] = vb[(long)krow * a.kv_rs + 4 * s + lq];
+        }
+    }
+    f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int n_qtiles = (Tq + 63) / 64;
+    const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
+    const long stat0 = ((long)b * a.heads + h) * Tq;
+    f32x4 qreg[UNITS], oreg[UNITS];
+    if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
+    for (int qt = qt0; qt < n_qtiles; ++qt) {
+        __syncthreads();
+        stage_tile<HD>(Qs, qreg);
+        stage_tile<HD>(Os, oreg);
+        if (threadIdx.x < 64) {
+            const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
+            lse_s[threadIdx.x] = a.lse[stat0 + qrow];
+            del_s[threadIdx.x] = a.delta[stat0 + qrow];
+        }
+        __syncthreads();
+        if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
+        f32x4 sacc[4], pacc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < HD / 4; ++s) {
+                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], Qs[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
+                pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], Os[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+            }
+        }
+        float *pw = Ps[wave][0], *dw = Ps[wave][1];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int qi = 16 * n + lr, qrow = qt * 64 + qi;
+            const float l = lse_s[qi], dl = del_s[qi];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 4 * lq + r;
+                const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
+                const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
+                pw[(4 * lq + r) * PS + qi] = p;
+                dw[(4 * lq + r) * PS + qi] = p * (pacc[n][r] - dl);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float pa = pw[lr * PS + 4 * s + lq], da = dw[lr * PS + 4 * s + lq];
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                dv[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Os[(4 * s + lq) * ST + 16 * m + lr], dv[m], 0, 0, 0);
+                dk[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Qs[(4 * s + lq) * ST + 16 * m + lr], dk[m], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 4 * lq + r;
+        if (key >= Tk) continue;
+        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) {
+            kp[16 * m + lr] = dk[m][r] * a.scale;
+            vp[16 * m + lr] = dv[m][r];
+        }
+    }
+}
+
+template <int HD>
+int launch_attention_bwd(const AttnBwdArgs &a, const float *y, long y_rs, float *delta, int N, hipStream_t st) {
+    hipLaunchKernelGGL(attention_delta_kernel<HD>, dim3(N * a.Tq), dim3(256), 0, st, a.dy, a.dy_rs, y, y_rs, delta, a.Tq, a.heads);
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<HD>, dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<HD>, dim3((a.Tk + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    return halo_launch_status();
+}
+
 template <int HD>
 int launch_attention(const AttnArgs &a, int N, bool ent, hipStream_t st) {
     dim3 grid((a.Tq + 63) / 64, a.heads, N);
@@ -394,6 +640,32 @@ int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, c
         case 64: return launch_attention<64>(a, N, entropy != nullptr, st);
         case 32: return launch_attention<32>(a, N, entropy != nullptr, st);
         case 16: return launch_attention<16>(a, N, entropy != nullptr, st);
+        default: return HALO_ENOTSUP;
+    }
+}
+
+int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
+                       long kv_batch_stride, const float *y, const float *dy, long y_row_stride, long y_batch_stride, const float *lse,
+                       float *delta, float *dq, long dq_row_stride, long dq_batch_stride, float *dk, float *dv, long dkv_row_stride,
+                       long dkv_batch_stride, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k && v && y && dy && lse && delta && dq && dk && dv && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
+    HALO_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dy) % 16 == 0);
+    HALO_CHECK_ARG(q_row_stride % 4 == 0 && q_batch_stride % 4 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0 &&
+                   y_row_stride % 4 == 0 && y_batch_stride % 4 == 0);
+    HALO_CHECK_ARG(N <= 65535 && heads <= 65535 && y_batch_stride == y_row_stride * Tq);
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.dy = dy; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
+    a.dy_rs = y_row_stride; a.dy_bs = y_batch_stride; a.dq_rs = dq_row_stride; a.dq_bs = dq_batch_stride;
+    a.dkv_rs = dkv_row_stride; a.dkv_bs = dkv_batch_stride; a.key_len = key_lengths;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    switch (head_dim) {
+        case 64: return launch_attention_bwd<64>(a, y, y_row_stride, delta, N, st);
+        case 32: return launch_attention_bwd<32>(a, y, y_row_stride, delta, N, st);
+        case 16: return launch_attention_bwd<16>(a, y, y_row_stride, delta, N, st);
         default: return HALO_ENOTSUP;
     }
 }

@@ -2,6 +2,9 @@
 // LayerNorm): embedding gather, LayerNorm, per-token cross-entropy (the attention kernels live in attn.hip).  The Linear layers run on the GEMMs of gemm_*.hip
 // (bias / tanh-GELU / residual-accumulate epilogues).
 #include "halo_common.h"
+#include "halo_internal.h"
+
+#define HALO_LN_BWD_CHUNKS 128   // row chunks of the LayerNorm weight/bias gradient partial sums
 
 namespace {
 
@@ -40,11 +43,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 // loss[n] = logsumexp(logits[n,:]) - logits[n,target[n]]   (0 where target == ignore_index)
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restrict__ logits, const int64_t *__restrict__ target,
-                                                            float *__restrict__ loss, int V, long ld, long ignore_index) {
+                                                            float *__restrict__ loss, float *__restrict__ lse_out, int V, long ld,
+                                                            long ignore_index) {
     __shared__ float red[4];
     const int n = blockIdx.x;
     const long tgt = target[n];
-    if (tgt == ignore_index) { if (threadIdx.x == 0) loss[n] = 0.f; return; }
+    if (tgt == ignore_index) { if (threadIdx.x == 0) { loss[n] = 0.f; if (lse_out) lse_out[n] = 0.f; } return; }
     const float *row = logits + (long)n * ld;
     float m = -INFINITY;
     for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, row[c]);
@@ -58,7 +62,116 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restr
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) loss[n] = m + logf((red[0] + red[1]) + (red[2] + red[3])) - row[tgt];
+    if (threadIdx.x == 0) {
+        const float l = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+        loss[n] = l - row[tgt];
+        if (lse_out) lse_out[n] = l;
+    }
+}
+
+// ---- backward kernels of the GPT training path -----------------------------------------------------------
+// dx[n,:] = dres[n,:] + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd;
+// stats[n] = (mean, rstd) for the column pass.  One wave per row; the row (<= a few KB) is re-read from L1.
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                               const float *__restrict__ w, const float *__restrict__ dres,
+                                                               float *__restrict__ dx, float *__restrict__ stats, int rows, int C,
+                                                               float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (long)row * C, *dyr = dy + (long)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float g = dyr[c] * w[c];
+        sg += g;
+        sgx += g * (xr[c] - mean) * rstd;
+    }
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+    float *dxr = dx + (long)row * C;
+    const float *rr = dres ? dres + (long)row * C : nullptr;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        const float d = rstd * (dyr[c] * w[c] - mg - xh * mgx);
+        dxr[c] = rr ? rr[c] + d : d;
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// partial_w[chunk, c] = sum over the chunk's rows of dy * xhat, partial_b[chunk, c] = sum dy (fixed order -> reproducible)
+__global__ __launch_bounds__(256) void layernorm_bwd_dw_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                               const float *__restrict__ stats, float *__restrict__ pw,
+                                                               float *__restrict__ pb, int rows, int C, int rows_per_chunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+    if (c >= C) return;
+    const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float aw = 0.f, ab = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float d = dy[(long)r * C + c];
+        aw += d * (x[(long)r * C + c] - stats[2 * r]) * stats[2 * r + 1];
+        ab += d;
+    }
+    pw[(long)chunk * C + c] = aw;
+    pb[(long)chunk * C + c] = ab;
+}
+
+// kind 0: tanh-GELU (ha/attention.py:12-17), kind 1: exact GELU.  fwd: y = gelu(a);  bwd: da = dy * gelu'(a)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float *__restrict__ a, float *__restrict__ y, size_t n, int kind) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = gemm_activation(a[i], kind ? 8 : 2);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ a, float *__restrict__ da,
+                                                       size_t n, int kind) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float d;
+    if (kind) {
+        d = 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+    } else {
+        const float k = 0.7978845608028654f, u = k * (x + 0.044715f * x * x * x), t = tanhf(u);
+        d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    da[i] = dy[i] * d;
+}
+
+// logits[n,:] <- (softmax(logits[n,:]) - onehot(target[n])) * grad[n]   (0 where target == ignore_index), in place
+__global__ __launch_bounds__(256) void cross_entropy_bwd_kernel(float *__restrict__ logits, const int64_t *__restrict__ target,
+                                                                const float *__restrict__ lse, const float *__restrict__ grad,
+                                                                long grad_stride, int V, long ld, long ignore_index) {
+    const int n = blockIdx.x;
+    const long tgt = target[n];
+    float *row = logits + (long)n * ld;
+    if (tgt == ignore_index) {
+        for (int c = threadIdx.x; c < V; c += 256) row[c] = 0.f;
+        return;
+    }
+    const float l = lse[n], g = grad[(long)n * grad_stride];
+    for (int c = threadIdx.x; c < V; c += 256) row[c] = (expf(row[c] - l) - (c == tgt ? 1.0f : 0.f)) * g;
+}
+
+// dwte[ids[n], :] += dx[n, :]  (float atomics: tokens repeat)
+__global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int64_t *__restrict__ ids, const float *__restrict__ dx,
+                                                            float *__restrict__ dwte, int C, int vocab) {
+    const int n = blockIdx.x;
+    long id = ids[n];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dwte + id * C + c, dx[(long)n * C + c]);
+}
+// dwpe[pos0 + t, c] (+)= sum_b dx[b*T + t, c]  (fixed order)
+__global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const float *__restrict__ dx, float *__restrict__ dwpe, int B, int T, int C,
+                                                            int pos0, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)T * C) return;
+    const int t = (int)(idx / C), c = (int)(idx % C);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[((long)b * T + t) * C + c];
+    float *o = dwpe + (long)(pos0 + t) * C + c;
+    *o = accumulate ? *o + s : s;
 }
 
 }  // namespace
@@ -84,8 +197,67 @@ int halo_layernorm_fwd(const float *x, const float *weight, const float *bias, f
 int halo_cross_entropy_fwd(const float *logits, const int64_t *targets, float *loss, int rows, int V, long ld,
                            long ignore_index, halo_stream_t stream) {
     HALO_CHECK_ARG(logits && targets && loss && rows > 0 && V > 0 && ld >= V);
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, targets, loss, V, ld,
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, targets, loss, (float *)nullptr, V,
+                       ld, ignore_index);
+    return halo_launch_status();
+}
+
+int halo_cross_entropy_fwd_lse(const float *logits, const int64_t *targets, float *loss, float *lse, int rows, int V, long ld,
+                               long ignore_index, halo_stream_t stream) {
+    HALO_CHECK_ARG(logits && targets && loss && lse && rows > 0 && V > 0 && ld >= V);
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, targets, loss, lse, V, ld,
                        ignore_index);
+    return halo_launch_status();
+}
+
+int halo_cross_entropy_bwd(float *logits, const int64_t *targets, const float *lse, const float *grad, long grad_stride, int rows,
+                           int V, long ld, long ignore_index, halo_stream_t stream) {
+    HALO_CHECK_ARG(logits && targets && lse && grad && rows > 0 && V > 0 && ld >= V && (grad_stride == 0 || grad_stride == 1));
+    hipLaunchKernelGGL(cross_entropy_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, targets, lse, grad, grad_stride,
+                       V, ld, ignore_index);
+    return halo_launch_status();
+}
+
+size_t halo_layernorm_bwd_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return ((size_t)rows * 2 + (size_t)2 * HALO_LN_BWD_CHUNKS * C) * sizeof(float);
+}
+
+int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx, float *dweight,
+                       float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && x && weight && dx && dweight && workspace && rows > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, weight, dres, dx, stats, rows, C, eps);
+    const int chunks = rows < HALO_LN_BWD_CHUNKS ? rows : HALO_LN_BWD_CHUNKS, rpc = (rows + chunks - 1) / chunks;
+    const int used = (rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(layernorm_bwd_dw_kernel, dim3((C + 255) / 256, used), dim3(256), 0, st, dy, x, stats, pw, pb, rows, C, rpc);
+    if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
+    return halo_colsum2(pw, used, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, used, C, C, dbias, nullptr, st) : HALO_OK);
+}
+
+int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(a && y && n > 0);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, y, n, exact);
+    return halo_launch_status();
+}
+
+int halo_gelu_bwd(const float *dy, const float *a, float *da, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && a && da && n > 0);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, a, da, n, exact);
+    return halo_launch_status();
+}
+
+int halo_embed_bwd(const int64_t *ids, const float *dx, float *dwte, float *dwpe, int B, int T, int C, int pos0, int vocab,
+                   int accumulate_wpe, halo_stream_t stream) {
+    HALO_CHECK_ARG(ids && dx && dwte && B > 0 && T > 0 && C > 0 && pos0 >= 0 && vocab > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(B * T), dim3(256), 0, st, ids, dx, dwte, C, vocab);
+    if (dwpe) {
+        const long n = (long)T * C;
+        hipLaunchKernelGGL(embed_bwd_wpe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dx, dwpe, B, T, C, pos0,
+                           accumulate_wpe);
+    }
     return halo_launch_status();
 }
 

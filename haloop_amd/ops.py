@@ -451,3 +451,74 @@ def dwconv1d_cl(x3d, weight, bias, stride, pad):
     y = torch.empty(N, To, Cn, device=x3d.device, dtype=torch.float32)
     check(lib().halo_dwconv1d_cl(ptr(x3d), ptr(weight), ptr(bias), ptr(y), N, T, Cn, ks, stride, pad, _stream()), 'halo_dwconv1d_cl')
     return y
+
+
+# ---- backward operators of the GPT / transformer training step ----------------------------------------------
+def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None):
+    """Gradients of attention_fwd written into the caller's dq / dk / dv views (row layouts like q / k / v)."""
+    C = heads * head_dim
+    _f32c(y, 'y'); _f32c(dy, 'dy')
+    if k.stride(0) != v.stride(0) or dk.stride(0) != dv.stride(0):
+        raise ValueError('k/v (and dk/dv) must share a row stride')
+    delta = torch.empty(N, heads, Tq, device=q.device, dtype=torch.float32)
+    check(lib().halo_attention_bwd(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), ptr(dy),
+                                   C, C * Tq, ptr(lse), ptr(delta), ptr(dq), dq.stride(0), dq.stride(0) * Tq, ptr(dk), ptr(dv),
+                                   dk.stride(0), dk.stride(0) * Tk, N, heads, head_dim, Tq, Tk, int(causal), ptr(key_lengths),
+                                   _stream()), 'halo_attention_bwd')
+
+
+def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5):
+    """-> (dx = dres + dLN, dweight, dbias or None)"""
+    _f32c(dy, 'dy'); _f32c(x2d, 'x')
+    rows, C = x2d.shape
+    dev = x2d.device
+    dx = torch.empty_like(x2d)
+    dw = torch.empty(C, device=dev, dtype=torch.float32)
+    db = torch.empty(C, device=dev, dtype=torch.float32) if has_bias else None
+    ws = torch.empty(lib().halo_layernorm_bwd_workspace_bytes(rows, C), device=dev, dtype=torch.uint8)
+    check(lib().halo_layernorm_bwd(ptr(dy), ptr(x2d), ptr(weight), ptr(dres), ptr(dx), ptr(dw), ptr(db), ptr(ws), rows, C, eps,
+                                   _stream()), 'halo_layernorm_bwd')
+    return dx, dw, db
+
+
+def gelu_fwd(a, exact=False):
+    _f32c(a, 'a')
+    y = torch.empty_like(a)
+    check(lib().halo_gelu_fwd(ptr(a), ptr(y), a.numel(), int(exact), _stream()), 'halo_gelu_fwd')
+    return y
+
+
+def gelu_bwd(dy, a, exact=False, out=None):
+    _f32c(dy, 'dy'); _f32c(a, 'a')
+    da = out if out is not None else torch.empty_like(a)
+    check(lib().halo_gelu_bwd(ptr(dy), ptr(a), ptr(da), a.numel(), int(exact), _stream()), 'halo_gelu_bwd')
+    return da
+
+
+def cross_entropy_fwd_lse(logits2d, targets, ignore_index=0):
+    _f32c(logits2d, 'logits')
+    tg = _i64c(targets.reshape(-1), 'targets')
+    rows, V = logits2d.shape
+    loss = torch.empty(rows, device=logits2d.device, dtype=torch.float32)
+    lse = torch.empty(rows, device=logits2d.device, dtype=torch.float32)
+    check(lib().halo_cross_entropy_fwd_lse(ptr(logits2d), ptr(tg), ptr(loss), ptr(lse), rows, V, V, ignore_index, _stream()),
+          'halo_cross_entropy_fwd_lse')
+    return loss, lse
+
+
+def cross_entropy_bwd_(logits2d, targets, lse, grad_rows, ignore_index=0):
+    """logits2d <- d loss / d logits in place; grad_rows [rows] (or a 1-element tensor broadcast to all rows)."""
+    _f32c(logits2d, 'logits'); _f32c(grad_rows, 'grad')
+    tg = _i64c(targets.reshape(-1), 'targets')
+    rows, V = logits2d.shape
+    stride = 0 if grad_rows.numel() == 1 else 1
+    check(lib().halo_cross_entropy_bwd(ptr(logits2d), ptr(tg), ptr(lse), ptr(grad_rows), stride, rows, V, V, ignore_index, _stream()),
+          'halo_cross_entropy_bwd')
+    return logits2d
+
+
+def embed_bwd(ids, dx2d, dwte, dwpe, pos0=0, accumulate_wpe=False):
+    ids = _i64c(ids, 'input_ids')
+    Bn, T = ids.shape
+    check(lib().halo_embed_bwd(ptr(ids), ptr(dx2d), ptr(dwte), ptr(dwpe), Bn, T, dx2d.shape[1], pos0, dwte.shape[0],
+                               int(accumulate_wpe), _stream()), 'halo_embed_bwd')

@@ -296,6 +296,39 @@ int halo_greedy_update(const float *values, const int64_t *indices, const float 
                        float *log_probs, float *sum_entropies, int N, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward operators of the GPT / transformer training step (the autograd graph of ha/attention.py:205-232 as
+ * `hal` runs it, ha/attention_loop.py:196-215: loss.backward()).
+ *   halo_attention_bwd         gradient of halo_attention_fwd: dq, dk, dv (same row layouts as q, k, v; written, not
+ *                              accumulated) from dy, the saved y and lse; delta [N, heads, Tq] is scratch.
+ *                              Two sweeps (per query tile, per key tile), no atomics: bitwise reproducible.
+ *   halo_layernorm_bwd         dx = dres + d(layer_norm)/dx . dy (dres: the residual-stream gradient, may be NULL),
+ *                              dweight, dbias (NULL when the LayerNorm has no bias); workspace per *_workspace_bytes.
+ *   halo_gelu_fwd / _bwd       y = gelu(a) keeping the pre-activation; da = dy * gelu'(a); exact != 0 -> erf form
+ *   halo_cross_entropy_fwd_lse halo_cross_entropy_fwd that also returns the row log-sum-exp
+ *   halo_cross_entropy_bwd     logits <- (softmax(logits) - onehot(target)) * grad[n * grad_stride] in place
+ *                              (grad_stride 0: one scalar for all rows; 1: per row); ignored rows -> 0
+ *   halo_embed_bwd             dwte[ids] += dx (float atomics; dwte is the tied lm_head gradient buffer),
+ *                              dwpe[pos0 + t] (+)= sum_b dx  (dwpe may be NULL) */
+int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
+                       long kv_row_stride, long kv_batch_stride, const float *y, const float *dy, long y_row_stride,
+                       long y_batch_stride, const float *lse, float *delta, float *dq, long dq_row_stride,
+                       long dq_batch_stride, float *dk, float *dv, long dkv_row_stride, long dkv_batch_stride, int N,
+                       int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       halo_stream_t stream);
+size_t halo_layernorm_bwd_workspace_bytes(int rows, int C);
+int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx,
+                       float *dweight, float *dbias, void *workspace, int rows, int C, float eps,
+                       halo_stream_t stream);
+int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream);
+int halo_gelu_bwd(const float *dy, const float *a, float *da, size_t n, int exact, halo_stream_t stream);
+int halo_cross_entropy_fwd_lse(const float *logits, const int64_t *targets, float *loss, float *lse, int rows, int V,
+                               long ld, long ignore_index, halo_stream_t stream);
+int halo_cross_entropy_bwd(float *logits, const int64_t *targets, const float *lse, const float *grad,
+                           long grad_stride, int rows, int V, long ld, long ignore_index, halo_stream_t stream);
+int halo_embed_bwd(const int64_t *ids, const float *dx, float *dwte, float *dwpe, int B, int T, int C, int pos0,
+                   int vocab, int accumulate_wpe, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Convolutional front-end of AudioEncoder, channels-last.  replaces, in ha/conv.py:
  *   halo_im2col_cl    the unfold of nn.Conv1d(input_dim, hidden_dim, 3, stride, padding=1) :29; the conv itself is a
  *                     GEMM of col [N*T', Cin*ks] with weight [Cout, Cin*ks] + bias + HALO_GEMM_GELU_ERF (:46)

@@ -261,6 +261,15 @@ def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, stor
         mean = model.forward_all(inputs, targets, reduction='mean')
     d = {'cfg': np.array([vocab, block, n_layer, n_head, n_embd, int(bias), B, T, seed]),
          'inputs': inputs.numpy(), 'targets': targets.numpy(), 'per_token': per_tok.numpy(), 'mean': mean.numpy()}
+    # the training direction (ha/attention_loop.py:203-208): gradients of the mean loss w.r.t. every parameter
+    model.zero_grad()
+    model.forward_all(inputs, targets, reduction='mean').backward()
+    for k, v in model.named_parameters():
+        if store_params:
+            d['grad.' + k] = v.grad.numpy()
+        else:                                     # large model: norms of every gradient and a strided sample of each
+            d['gradnorm.' + k] = np.array(float(v.grad.norm()))
+            d['gradsample.' + k] = v.grad.flatten()[::max(1, v.numel() // 1000)][:1000].numpy().copy()
     if store_params:
         for k, v in params.items():
             d['param.' + k] = v.numpy()

@@ -483,9 +483,13 @@ def test_gpt_refuses_what_is_not_built(hal):
     model = attention.GPT(cfg).to(DEV)
     ids = torch.randint(1, 50, (1, 8), device=DEV)
     with pytest.raises(NotImplementedError):
-        model.forward_all(ids, ids)                      # grad enabled: backward is not built
+        with torch.no_grad():
+            model.forward_all(ids, ids, past=torch.zeros(1))  # KV-cache continuation
     with pytest.raises(NotImplementedError):
         attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))
+    with pytest.raises(NotImplementedError):
+        attention.GPT(attention.GPTConfig(block_size=16, vocab_size=50, n_layer=1, n_head=1, n_embd=64, dropout=0.1)).to(DEV).train() \
+            .forward_all(ids, ids)                       # dropout > 0 is not built
 
 
 # ------------------------------------------------------------------- other shapes of the same path
@@ -543,3 +547,110 @@ def test_hap_scoring_contract(hal):
         assert n == min(block, len(s)) and ln == len(s)
         np.testing.assert_allclose(lpt, r / n, rtol=2e-5)
     assert score.format_lines(got)[0].count('\t') == 2
+
+
+# ------------------------------------------------------------------------------ GPT training direction
+@pytest.mark.parametrize('hd,heads,N,Tq,Tk,causal,ragged', [
+    (64, 2, 2, 130, 130, True, False), (64, 2, 2, 70, 70, False, True), (32, 3, 2, 9, 100, False, True),
+    (16, 2, 3, 5, 5, True, False), (32, 2, 1, 65, 65, True, False), (64, 1, 2, 33, 200, False, False)])
+def test_attention_bwd_against_autograd(hal, hd, heads, N, Tq, Tk, causal, ragged):
+    import math
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(hd + 3 * Tq + Tk)
+    C = heads * hd
+    q = torch.randn(N * Tq, C, generator=g, requires_grad=True)
+    kv = torch.randn(N * Tk, 2 * C, generator=g, requires_grad=True)
+    dy = torch.randn(N * Tq, C, generator=g)
+    lens = torch.tensor([Tk - (7 * n) % Tk for n in range(N)], dtype=torch.int32) if ragged else None
+    qh = q.view(N, Tq, heads, hd).transpose(1, 2)
+    kh = kv[:, :C].reshape(N, Tk, heads, hd).transpose(1, 2)
+    vh = kv[:, C:].reshape(N, Tk, heads, hd).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        s = s.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float('-inf'))
+    if ragged:
+        s = s.masked_fill((torch.arange(Tk)[None, :] >= lens[:, None])[:, None, None, :], float('-inf'))
+    ref = (s.softmax(-1) @ vh).transpose(1, 2).reshape(N * Tq, C)
+    ref.backward(dy)
+    qd, kvd, dyd = q.detach().to(DEV), kv.detach().to(DEV), dy.to(DEV)
+    ld = lens.to(DEV) if ragged else None
+    y, lse, _ = ops.attention_fwd(qd, kvd[:, :C], kvd[:, C:], N, heads, hd, Tq, Tk, causal=causal, key_lengths=ld, want_lse=True)
+    dq = torch.full_like(qd, float('nan'))
+    dkv = torch.full_like(kvd, float('nan'))
+    ops.attention_bwd(qd, kvd[:, :C], kvd[:, C:], y, dyd, lse, dq, dkv[:, :C], dkv[:, C:], N, heads, hd, Tq, Tk, causal=causal,
+                      key_lengths=ld)
+    np.testing.assert_allclose(dq.cpu().numpy(), q.grad.numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(dkv.cpu().numpy(), kv.grad.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_layernorm_gelu_cross_entropy_backward_against_autograd(hal):
+    import torch.nn.functional as Fn
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(11)
+    rows, C = 301, 200
+    x = torch.randn(rows, C, generator=g, requires_grad=True)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy, dres = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    Fn.layer_norm(x, (C,), w, b, 1e-5).backward(dy)
+    dx, dw, db = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), dres.to(DEV), has_bias=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), (x.grad + dres).numpy(), atol=5e-6, rtol=1e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), atol=5e-5, rtol=1e-5)
+    from oracle import gpt_ref
+    for exact in (False, True):
+        a = (3 * torch.randn(1000, generator=g)).requires_grad_(True)
+        (Fn.gelu(a) if exact else gpt_ref.new_gelu(a)).backward(torch.ones(1000))
+        np.testing.assert_allclose(ops.gelu_fwd(a.detach().to(DEV), exact).cpu().numpy(),
+                                   (Fn.gelu(a) if exact else gpt_ref.new_gelu(a)).detach().numpy(), atol=1e-6)
+        np.testing.assert_allclose(ops.gelu_bwd(torch.ones(1000, device=DEV), a.detach().to(DEV), exact).cpu().numpy(), a.grad.numpy(),
+                                   atol=2e-6)
+    logits = torch.randn(50, 333, generator=g, requires_grad=True)
+    tg = torch.randint(0, 333, (50,), generator=g)
+    tg[::7] = 0
+    gr = torch.randn(50, generator=g)
+    (Fn.cross_entropy(logits, tg, ignore_index=0, reduction='none') * gr).sum().backward()
+    ld = logits.detach().to(DEV).clone()
+    loss, lse = ops.cross_entropy_fwd_lse(ld, tg.to(DEV))
+    ops.cross_entropy_bwd_(ld, tg.to(DEV), lse, gr.to(DEV))
+    np.testing.assert_allclose(ld.cpu().numpy(), logits.grad.numpy(), atol=1e-6)
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_tiny_gradients_match_reference(hal, name, math_mode):
+    """loss.backward() through the HIP path vs the reference's own gradients (fixtures): every parameter."""
+    g, model = _gpt_from_golden(hal, name)
+    model.train()
+    inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
+    loss = model.forward_all(inputs, targets, reduction='mean')
+    assert loss.requires_grad
+    np.testing.assert_allclose(loss.item(), float(g['mean']), rtol=1e-5)
+    loss.backward()
+    checked = 0
+    tol = dict(rtol=2e-4, atol=2e-7) if math_mode == 'f32' else dict(rtol=1e-3, atol=2e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g['grad.' + k], err_msg=k, **tol)
+        checked += 1
+    assert checked == sum(1 for k in g if k.startswith('grad.'))
+    # gradient accumulation (ha/attention_loop.py:196-208): a second backward adds up
+    model.forward_all(inputs, targets, reduction='mean').backward()
+    k, p = next(iter(model.named_parameters()))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * g['grad.' + k], rtol=tol['rtol'], atol=2 * tol['atol'])
+
+
+@BOTH_MODES
+def test_gpt2_small_gradients_match_reference(hal, math_mode):
+    """GPT-2 small, one 1024-token sequence: norm and a strided 1000-element sample of every parameter's gradient
+    against the reference's backward (fixture).  Tolerance: 2e-3 of the gradient's own scale (bf16x3: 5e-3)."""
+    g, model = _gpt_from_golden(hal, 'g5_gpt2_small')
+    model.train()
+    inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
+    model.forward_all(inputs, targets, reduction='mean').backward()
+    rel = 2e-3 if math_mode == 'f32' else 5e-3
+    for k, p in model.named_parameters():
+        want_norm = float(g['gradnorm.' + k])
+        assert abs(float(p.grad.norm()) - want_norm) <= rel * want_norm, k
+        sample = p.grad.flatten()[::max(1, p.numel() // 1000)][:1000].cpu().numpy()
+        want = g['gradsample.' + k]
+        assert np.abs(sample - want).max() <= rel * max(np.abs(want).max(), want_norm / p.numel() ** 0.5), k

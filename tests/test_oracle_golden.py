@@ -158,6 +158,24 @@ def test_gpt_forward_all_matches_reference(name):
     assert torch.equal(i2, inputs) and torch.equal(t2, targets)
 
 
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_gradients_match_reference(name):
+    """The training direction: autograd through the restatement == the reference's loss.backward()."""
+    from oracle import gpt_ref
+    g = load_golden(name)
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    params = {k[len('param.'):]: torch.from_numpy(v).requires_grad_(True) for k, v in g.items() if k.startswith('param.')}
+    params['lm_head.weight'] = params['transformer.wte.weight']
+    inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
+    gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean').backward()
+    checked = 0
+    for k, v in g.items():
+        if k.startswith('grad.'):
+            np.testing.assert_allclose(params[k[len('grad.'):]].grad.numpy(), v, rtol=1e-4, atol=1e-7, err_msg=k)
+            checked += 1
+    assert checked >= 10
+
+
 # ------------------------------------------------------------------------------ enc-dec attention ASR (ha/transformer.py)
 ASR_CASES = ['g6_asr_tiny', 'g6_asr_tiny_s221', 'g6_asr_tiny_stop', 'g6_asr_transformer32', 'g6_asr_transformer32_stop']
 
