@@ -32,9 +32,9 @@ class WeightImages:
         """The split/tiled image of the (concatenated) weight."""
         return self._lookup('split', weights, lambda: ops.split_image(self.dense(weights).contiguous()))
 
-    def split_t(self, weight):
-        """The image of W^T (logical [in, out]) of one weight: the B operand of dx = dy W."""
-        return self._lookup('split_t', (weight,), lambda: ops.split_image(self.dense((weight,)).contiguous(), transposed=True))
+    def split_t(self, weights):
+        """The image of W^T (logical [in, sum out]) of the (concatenated) weight: the B operand of dx = dy W."""
+        return self._lookup('split_t', weights, lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False):
@@ -55,13 +55,15 @@ def use_split(M, N, K):
     return _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64
 
 
-def linear_dx(images, dy2d, weight, out=None, accumulate=False):
-    """dx [M, in] = dy [M, out] W [out, in]  (the input gradient of y = x W^T)."""
+def linear_dx(images, dy2d, weights, out=None, accumulate=False):
+    """dx [M, in] = dy [M, sum out] W [sum out, in]  (the input gradient of y = x W^T; ``weights`` as in linear())."""
+    if isinstance(weights, torch.Tensor):
+        weights = (weights,)
     M, K = dy2d.shape
-    N = weight.shape[1]
+    N = weights[0][0].numel()
     if use_split(M, N, K):
-        return ops.gemm_split(ops.split_image(dy2d), images.split_t(weight), M, N, K, out=out, accumulate=accumulate)
-    return ops.gemm(dy2d, images.dense((weight,)), True, False, M, N, K, out=out, accumulate=accumulate)
+        return ops.gemm_split(ops.split_image(dy2d), images.split_t(weights), M, N, K, out=out, accumulate=accumulate)
+    return ops.gemm(dy2d, images.dense(weights), True, False, M, N, K, out=out, accumulate=accumulate)
 
 
 def linear_dw(dy2d, x2d, out=None, accumulate=False):

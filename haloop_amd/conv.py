@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import WeightImages, linear
+from ._linear import WeightImages, linear, linear_dw, linear_dx
 
 
 class DWConv1d(nn.Module):
@@ -40,6 +40,29 @@ class DWConv1d(nn.Module):
     def forward(self, x):
         return self.forward_cl(x.mT.contiguous()).mT
 
+    # training: keep the depthwise output and the pointwise pre-activation
+    def _forward_cl_train(self, x):
+        dw, pw = self.depthwise, self.pointwise
+        y = ops.dwconv1d_cl(x, dw.weight.detach().reshape(dw.weight.shape[0], -1).contiguous(),
+                            dw.bias.detach() if dw.bias is not None else None, dw.stride[0], dw.padding[0])
+        N, To, C = y.shape
+        a = linear(self._images, y.view(N * To, C), pw.weight, bias=pw.bias.detach() if pw.bias is not None else None)
+        out = ops.gelu_fwd(a, exact=True)
+        return out.view(N, To, -1), (x, y, a)
+
+    def _backward_cl(self, saved, dout, put, want_dx=True):
+        x, y, a = saved
+        dw, pw = self.depthwise, self.pointwise
+        N, To, C = y.shape
+        da = ops.gelu_bwd(dout.reshape(N * To, -1), a, exact=True)
+        put(pw.weight, linear_dw(da, y.view(N * To, C)).view_as(pw.weight))
+        put(pw.bias, ops.colsum(da) if pw.bias is not None else None)
+        dy = linear_dx(self._images, da, pw.weight).view(N, To, C)
+        dx, dww, dwb = ops.dwconv1d_cl_bwd(dy, x, dw.weight.detach().reshape(C, -1).contiguous(), dw.stride[0], dw.padding[0],
+                                           want_dx=want_dx, has_bias=dw.bias is not None)
+        put(dw.weight, dww.view_as(dw.weight)); put(dw.bias, dwb)
+        return dx
+
 
 class ConvEncoder(nn.Module):
     def __init__(self, *, input_dim: int, hidden_dim: int, output_dim: int, strides: tuple, kernel_size: int = 3):
@@ -65,13 +88,37 @@ class ConvEncoder(nn.Module):
         if not x.is_cuda:
             raise _lib.HaloError('haloop_amd.conv.ConvEncoder runs on the HIP device only (no CPU path)')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('haloop_amd.conv is forward-only so far: call it under torch.no_grad()')
+            raise NotImplementedError('haloop_amd.conv.ConvEncoder has no autograd of its own: train it through '
+                                      'haloop_amd.transformer.AudioEncoder, or call it under torch.no_grad()')
         first = self.conv[0]
         col, To = ops.im2col_cl(x.float().contiguous(), first.kernel_size[0], first.stride[0], first.padding[0])
         y = linear(self._images, col, first.weight, bias=first.bias.detach(), gelu='erf').view(x.shape[0], To, -1)
         for conv in list(self.conv)[1:]:
             y = conv.forward_cl(y, gelu=True)
         return y
+
+    def _forward_cl_train(self, x):
+        first = self.conv[0]
+        x = x.float().contiguous()
+        col, To = ops.im2col_cl(x, first.kernel_size[0], first.stride[0], first.padding[0])
+        a = linear(self._images, col, first.weight, bias=first.bias.detach())
+        y = ops.gelu_fwd(a, exact=True).view(x.shape[0], To, -1)
+        saved = [(col, a)]
+        for conv in list(self.conv)[1:]:
+            y, sv = conv._forward_cl_train(y)
+            saved.append(sv)
+        return y, saved
+
+    def _backward_cl(self, saved, dout, put):
+        """Parameter gradients only: the input is data (mel features)."""
+        convs = list(self.conv)
+        for i in range(len(convs) - 1, 0, -1):
+            dout = convs[i]._backward_cl(saved[i], dout, put)
+        col, a = saved[0]
+        first = convs[0]
+        da = ops.gelu_bwd(dout.reshape(a.shape), a, exact=True)
+        put(first.weight, linear_dw(da, col).view_as(first.weight))
+        put(first.bias, ops.colsum(da))
 
     def forward(self, x, input_lengths):
         "x [N, F, T] channels-first like the reference"

@@ -47,8 +47,8 @@ def _gemm_flags(relu, gelu, accumulate):
 
 def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, relu=False,
          drop=NO_DROPOUT, stream_id=0, gelu=False, accumulate=False):
-    lda = a.shape[-1]
-    ldb = b.shape[-1]
+    lda = a.stride(0) if a.dim() == 2 else a.shape[-1]          # row-strided views (column slices of packed buffers) are fine
+    ldb = b.stride(0) if b.dim() == 2 else b.shape[-1]
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     check(lib().halo_gemm_f32(int(a_kcontig), int(b_kcontig), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), N,
@@ -59,10 +59,11 @@ def gemm(a, b, a_kcontig, b_kcontig, M, N, K, out=None, bias1=None, bias2=None, 
 
 def split_image(x2d, transposed=False):
     """bf16 hi/lo tiled image of logical X[rows][k]; x2d is [rows,k], or [k,rows] when ``transposed``."""
-    _f32c(x2d, 'x')
+    if x2d.dtype != torch.float32 or not x2d.is_cuda or x2d.dim() != 2 or x2d.stride(1) != 1:
+        raise ValueError('split_image: expected a 2-D float32 HIP tensor with a unit column stride')
     rows, k = (x2d.shape[1], x2d.shape[0]) if transposed else x2d.shape
     img = torch.empty(lib().halo_split_image_bytes(rows, k), device=x2d.device, dtype=torch.uint8)
-    check(lib().halo_split_image(ptr(x2d), rows, k, x2d.shape[1], int(transposed), ptr(img), _stream()), 'halo_split_image')
+    check(lib().halo_split_image(ptr(x2d), rows, k, x2d.stride(0), int(transposed), ptr(img), _stream()), 'halo_split_image')
     return img
 
 
@@ -522,3 +523,18 @@ def embed_bwd(ids, dx2d, dwte, dwpe, pos0=0, accumulate_wpe=False):
     Bn, T = ids.shape
     check(lib().halo_embed_bwd(ptr(ids), ptr(dx2d), ptr(dwte), ptr(dwpe), Bn, T, dx2d.shape[1], pos0, dwte.shape[0],
                                int(accumulate_wpe), _stream()), 'halo_embed_bwd')
+
+
+def dwconv1d_cl_bwd(dy3d, x3d, weight, stride, pad, want_dx=True, has_bias=True):
+    """-> (dx or None, dweight [C, ks], dbias or None)"""
+    _f32c(dy3d, 'dy'); _f32c(x3d, 'x')
+    N, T, Cn = x3d.shape
+    ks = weight.shape[-1]
+    dev = x3d.device
+    dx = torch.empty_like(x3d) if want_dx else None
+    dw = torch.empty(Cn, ks, device=dev, dtype=torch.float32)
+    db = torch.empty(Cn, device=dev, dtype=torch.float32) if has_bias else None
+    ws = torch.empty(lib().halo_dwconv1d_cl_bwd_workspace_bytes(Cn, ks), device=dev, dtype=torch.uint8)
+    check(lib().halo_dwconv1d_cl_bwd(ptr(dy3d), ptr(x3d), ptr(weight), ptr(dx), ptr(dw), ptr(db), ptr(ws), N, T, Cn, ks, stride, pad,
+                                     _stream()), 'halo_dwconv1d_cl_bwd')
+    return dx, dw, db

@@ -12,9 +12,14 @@ Arithmetic: fp32 state; Linear layers on the split-bf16 (bf16x3) or exact-f32 MF
 the reference's float16 cache layout ``[L, 2, N, heads, S|T, head_dim]`` (ha/transformer.py:150-153) -- the
 reference itself only decodes under fp16 autocast -- and computes everything around the caches in fp32.
 
-Not built (raises): backward / training mode (dropout, label dropout), ``kv_cache_parts`` on the public
-Block / MultiHeadAttention.forward (Decoder.decode drives the caches itself), arbitrary attention masks
-(only the key-padding masks Block builds, transformer.py:476).
+Training: with grad enabled ``AudioEncoder.forward`` and ``Decoder.forward`` (hence CTCAttentionDecoder.forward:
+decoder CE + 0.3 CTC) return tensors with a grad_fn whose backward is hand-written end to end (conv front-end,
+blocks with shared-x_norm cross/self attention, inverse rotary, exact-GELU MLP, LayerNorm, embedding, CE), so
+``loss.backward()`` fills ``.grad`` of every parameter like the reference's autograd does.
+
+Not built (raises): dropout (p_drop > 0 in training mode), autograd through a bare Block / MultiHeadAttention
+call, ``kv_cache_parts`` on the public Block / MultiHeadAttention.forward (Decoder.decode drives the caches
+itself), arbitrary attention masks (only the key-padding masks Block builds, transformer.py:476).
 """
 import math
 from collections import namedtuple
@@ -23,7 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import WeightImages, linear
+from ._linear import WeightImages, linear, linear_dw, linear_dx
 from .attention import LayerNorm
 from .conv import ConvEncoder
 from .recognizer import TemporalClassifier
@@ -34,14 +39,67 @@ Stats = namedtuple('Stats', ['meme_entropy', 'self_entropy'])
 STX, ETX = 2, 3
 
 
-def _require_inference(module, x):
+def _wants_grad(module):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+def _check_device_and_dropout(module, x):
     if not x.is_cuda:
         raise _lib.HaloError(f'haloop_amd.transformer.{type(module).__name__} runs on the HIP device only (no CPU path)')
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError('haloop_amd.transformer is forward-only so far: call it under torch.no_grad() / '
-                                  'inference_mode; the training backward is not built')
-    if module.training:
-        raise NotImplementedError('dropout / label dropout of the training mode are not built; call .eval()')
+    if module.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in module.modules()):
+        raise NotImplementedError('dropout (p_drop > 0 in training mode) is not built: construct with p_drop=0.0 or call .eval()')
+
+
+def _require_inference(module, x):
+    """Module-level calls (Block, MultiHeadAttention, attend) have no autograd of their own: gradients flow through
+    AudioEncoder.forward / Decoder.forward, whose backward is hand-written end to end."""
+    _check_device_and_dropout(module, x)
+    if _wants_grad(module):
+        raise NotImplementedError('haloop_amd.transformer.' + type(module).__name__ + ' has no autograd of its own: train through '
+                                  'AudioEncoder / Decoder / CTCAttentionDecoder, or call it under torch.no_grad()')
+
+
+class _GradSink:
+    """Collects parameter gradients of one hand-written backward (summing when a parameter is hit twice)."""
+
+    def __init__(self):
+        self.g = {}
+
+    def __call__(self, p, grad):
+        if p is None or grad is None or not p.requires_grad:
+            return
+        k = id(p)
+        self.g[k] = grad if k not in self.g else self.g[k] + grad
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        out, saved = model._forward_train(x)
+        ctx.model, ctx.saved, ctx.params = model, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sink = _GradSink()
+        ctx.model._backward_train(ctx.saved, dout.contiguous().float(), sink)
+        ctx.saved = None
+        return (None, None) + tuple(sink.g.get(id(p)) for p in ctx.params)
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, features, prompt, tg, mlen, *params):
+        loss, saved = model._forward_train(features, prompt, tg, mlen)
+        ctx.model, ctx.saved, ctx.params = model, saved, params
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        sink = _GradSink()
+        dfeat = ctx.model._backward_train(ctx.saved, grad_rows.contiguous().float(), sink)
+        ctx.saved = None
+        return (None, dfeat if ctx.needs_input_grad[1] else None, None, None, None) + tuple(sink.g.get(id(p)) for p in ctx.params)
 
 
 def _rope_table(cache, T, head_dim, device):
@@ -144,6 +202,54 @@ class MultiHeadAttention(nn.Module):
                                       want_entropy=measure_entropy)
         return y, (ent.mean() if measure_entropy else torch.tensor(float('-inf')))
 
+    # training twins of _attend2d: keep q/k/v (after the rotary), the output and the log-sum-exp
+    def _attend2d_train(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False):
+        C = self.heads * self.head_dim
+        if mem2d is None:
+            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight))
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        else:
+            q = linear(self._images, x2d, self.q.weight)
+            kv = linear(self._images, mem2d, (self.k.weight, self.v.weight))
+            k, v = kv[:, :C], kv[:, C:]
+        table = None
+        if rope:
+            table = _rope_table(self._tables, max(T, S), self.head_dim, x2d.device)
+            ops.rope_(q, T, self.heads, self.head_dim, table)
+            ops.rope_(k, S, self.heads, self.head_dim, table)
+        y, lse, _ = ops.attention_fwd(q, k, v, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths, want_lse=True)
+        return y, (x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S)
+
+    def _attend2d_bwd(self, saved, dy, put, dx_out=None, dmem_out=None):
+        """dy: gradient of the attention output (before proj).  Accumulates the input gradient into dx_out (allocates it
+        when None) and, for cross-attention, the memory gradient into dmem_out.  -> dx"""
+        x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S = saved
+        C = self.heads * self.head_dim
+        dev = x2d.device
+        if mem2d is None:
+            dqkv = torch.empty(N * T, 3 * C, device=dev, dtype=torch.float32)
+            dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+        else:
+            dq = torch.empty(N * T, C, device=dev, dtype=torch.float32)
+            dkv = torch.empty(N * S, 2 * C, device=dev, dtype=torch.float32)
+            dk, dv = dkv[:, :C], dkv[:, C:]
+        ops.attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths)
+        if table is not None:                                   # the rotation is orthogonal: its transpose rotates back
+            ops.rope_(dq, T, self.heads, self.head_dim, table, inverse=True)
+            ops.rope_(dk, S, self.heads, self.head_dim, table, inverse=True)
+        ws = (self.q.weight, self.k.weight, self.v.weight)
+        if mem2d is None:
+            dw = linear_dw(dqkv, x2d)                           # [3C, C]
+            for i, w in enumerate(ws):
+                put(w, dw[i * C:(i + 1) * C])
+            return linear_dx(self._images, dqkv, ws, out=dx_out, accumulate=dx_out is not None)
+        put(self.q.weight, linear_dw(dq, x2d))
+        dwkv = linear_dw(dkv, mem2d)
+        put(self.k.weight, dwkv[:C]); put(self.v.weight, dwkv[C:])
+        if dmem_out is not None:
+            linear_dx(self._images, dkv, ws[1:], out=dmem_out, accumulate=True)
+        return linear_dx(self._images, dq, self.q.weight, out=dx_out, accumulate=dx_out is not None)
+
     def forward(self, x, memory, *, mask=None, causal=False, measure_entropy=False, kv_cache_parts=None, t0=0, rope=False,
                 _key_lengths=None):
         _require_inference(self, x)
@@ -192,6 +298,41 @@ class Block(nn.Module):
         linear(self._images, h, self.mix_chan[2].weight, out=x2d, accumulate=True)
         return m_ent, t_ent
 
+    def _forward2d_train(self, x0, N, T, causal=False, mem2d=None, S=0, memory_lengths=None):
+        x_norm = ops.layernorm_fwd(x0, self.ln_time.weight)
+        xa, sv_m = x0, None
+        if self.mix_memory is not None:
+            mm = self.mix_memory
+            ym, sv_m = mm._attend2d_train(x_norm, mem2d, N, T, S, key_lengths=memory_lengths)
+            xa = linear(mm._images, ym, mm.proj.weight, out=x0.clone(), accumulate=True)
+        mt = self.mix_time
+        yt, sv_t = mt._attend2d_train(x_norm, None, N, T, T, causal=causal, rope=True)
+        xb = linear(mt._images, yt, mt.proj.weight, out=xa.clone(), accumulate=True)
+        hn = ops.layernorm_fwd(xb, self.ln_chan.weight)
+        a = linear(self._images, hn, self.mix_chan[0].weight)
+        g = ops.gelu_fwd(a, exact=True)
+        xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True)
+        return xc, (x0, sv_m, sv_t, xb, hn, a, g)
+
+    def _backward2d(self, saved, dxc, put, dmem_out=None):
+        x0, sv_m, sv_t, xb, hn, a, g = saved
+        w0, w2 = self.mix_chan[0].weight, self.mix_chan[2].weight
+        put(w2, linear_dw(dxc, g))
+        da = ops.gelu_bwd(linear_dx(self._images, dxc, w2), a, exact=True)
+        put(w0, linear_dw(da, hn))
+        dxb, dw, _ = ops.layernorm_bwd(linear_dx(self._images, da, w0), xb, self.ln_chan.weight, dxc)
+        put(self.ln_chan.weight, dw)
+        mt = self.mix_time
+        put(mt.proj.weight, linear_dw(dxb, sv_t[5]))
+        dxn = mt._attend2d_bwd(sv_t, linear_dx(mt._images, dxb, mt.proj.weight), put)
+        if sv_m is not None:
+            mm = self.mix_memory
+            put(mm.proj.weight, linear_dw(dxb, sv_m[5]))
+            mm._attend2d_bwd(sv_m, linear_dx(mm._images, dxb, mm.proj.weight), put, dx_out=dxn, dmem_out=dmem_out)
+        dx0, dw, _ = ops.layernorm_bwd(dxn, x0, self.ln_time.weight, dxb)      # both attentions read the same ln_time(x)
+        put(self.ln_time.weight, dw)
+        return dx0
+
     def forward(self, x, time_mask=None, causal=False, memory=None, memory_lengths=None, measure_entropy=False,
                 kv_cache_parts=BlockKVCache(memory=None, time=None), t0=0):
         _require_inference(self, x)
@@ -222,9 +363,7 @@ class Decoder(nn.Module):
 
     def forward(self, features, targets, input_lengths=None, target_lengths=None, star_penalty=None, measure_entropy=False,
                 drop_labels=None, reduction='mean'):
-        _require_inference(self, features)
-        if drop_labels:
-            raise NotImplementedError('label dropout (training) is not built')
+        _check_device_and_dropout(self, features)
         dev = features.device
         targets = targets.to(dev)
         N, T = targets.shape
@@ -233,9 +372,28 @@ class Decoder(nn.Module):
         tg = nn.functional.pad(targets, (0, 1), value=0)
         tg[torch.arange(N, device=dev), target_lengths.to(dev)] = ETX
         T = T + 1
+        if (drop_labels is None and self.training) or drop_labels:
+            # label dropout (ha/transformer.py:100-103): integer data preparation, drawn from torch's generator like the reference
+            keep = torch.empty_like(prompt).bernoulli_(0.9).bool()
+            prompt = torch.where(keep, prompt, torch.ones_like(prompt))
         S, C = features.shape[1], features.shape[2]
-        mem2d = features.reshape(N * S, C).float().contiguous()
         mlen = input_lengths.to(device=dev, dtype=torch.int32)
+        if _wants_grad(self) or (torch.is_grad_enabled() and features.requires_grad):
+            if measure_entropy or reduction == 'sumeach':
+                raise NotImplementedError("measure_entropy / reduction='sumeach' are inference-only here: call under torch.no_grad()")
+            params = [p for p in self.parameters() if p.requires_grad]
+            per_tok = _DecoderFn.apply(self, features, prompt, tg, mlen, *params)
+            if reduction == 'none':
+                loss = per_tok
+            elif reduction == 'sum':
+                loss = per_tok.sum()
+            elif reduction == 'mean':
+                loss = per_tok.sum() / (tg != 0).sum()
+            else:
+                raise ValueError(f'{reduction} is not a valid value for reduction')
+            ninf = [torch.tensor(float('-inf'))] * len(self.h)
+            return loss, Stats(meme_entropy=list(ninf), self_entropy=list(ninf))._asdict()
+        mem2d = features.reshape(N * S, C).float().contiguous()
         stats = Stats(meme_entropy=[], self_entropy=[])
         y = ops.embed_fwd(prompt, self.wte.weight, None)
         for block in self.h:
@@ -256,6 +414,36 @@ class Decoder(nn.Module):
             else:
                 raise ValueError(f'{reduction} is not a valid value for reduction')
         return loss, stats._asdict()
+
+    @torch.no_grad()
+    def _forward_train(self, features, prompt, tg, mlen):
+        N, T = prompt.shape
+        S, C = features.shape[1], features.shape[2]
+        mem2d = features.detach().reshape(N * S, C).float().contiguous()
+        y = ops.embed_fwd(prompt, self.wte.weight, None)
+        blocks = []
+        for block in self.h:
+            y, sv = block._forward2d_train(y, N, T, True, mem2d, S, mlen)
+            blocks.append(sv)
+        xf = ops.layernorm_fwd(y, self.ln_f.weight)
+        logits = linear(self._images, xf, self.lm_head.weight)
+        loss, row_lse = ops.cross_entropy_fwd_lse(logits, tg.reshape(-1), ignore_index=0)
+        return loss, (prompt, tg.reshape(-1), blocks, y, xf, logits, row_lse, (N, S, C))
+
+    @torch.no_grad()
+    def _backward_train(self, saved, grad_rows, put):
+        prompt, tg, blocks, y_last, xf, logits, row_lse, (N, S, C) = saved
+        dlogits = ops.cross_entropy_bwd_(logits, tg, row_lse, grad_rows, ignore_index=0)
+        put(self.lm_head.weight, linear_dw(dlogits, xf))
+        dy, dw, _ = ops.layernorm_bwd(linear_dx(self._images, dlogits, self.lm_head.weight), y_last, self.ln_f.weight)
+        put(self.ln_f.weight, dw)
+        dmem = torch.zeros(N * S, C, device=xf.device, dtype=torch.float32)
+        for block, sv in zip(reversed(self.h), reversed(blocks)):
+            dy = block._backward2d(sv, dy, put, dmem_out=dmem)
+        dwte = torch.zeros_like(self.wte.weight)
+        ops.embed_bwd(prompt, dy, dwte, None)
+        put(self.wte.weight, dwte)
+        return dmem.view(N, S, C)
 
     @torch.no_grad()
     def decode(self, features, input_lengths, target_lengths, prompt=None):
@@ -353,7 +541,13 @@ class AudioEncoder(nn.Module):
 
     def forward(self, x, input_lengths, measure_entropy=False):
         """x [N, T, F] -> (features [N, T', C], lengths int32, stats); no time mask, like the reference (:245-247)."""
-        _require_inference(self, x)
+        _check_device_and_dropout(self, x)
+        if _wants_grad(self):
+            if measure_entropy:
+                raise NotImplementedError('measure_entropy is inference-only here: call under torch.no_grad()')
+            out = _EncoderFn.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
+            ninf = [torch.tensor(float('-inf'))] * len(self.h)
+            return out, self.conv.subsampled_lengths(input_lengths), Stats(meme_entropy=list(ninf), self_entropy=list(ninf))._asdict()
         y = self.conv.forward_cl(x)                                              # channels-last: no .mT round trip
         input_lengths = self.conv.subsampled_lengths(input_lengths)
         N, T, C = y.shape
@@ -365,3 +559,24 @@ class AudioEncoder(nn.Module):
             stats.self_entropy.append(t_ent)
         out = ops.layernorm_fwd(y2d, self.ln_f.weight).view(N, T, C)
         return out, input_lengths, stats._asdict()
+
+    @torch.no_grad()
+    def _forward_train(self, x):
+        y, conv_saved = self.conv._forward_cl_train(x)
+        N, T, C = y.shape
+        y2d = y.view(N * T, C)
+        blocks = []
+        for block in self.h:
+            y2d, sv = block._forward2d_train(y2d, N, T)
+            blocks.append(sv)
+        out = ops.layernorm_fwd(y2d, self.ln_f.weight)
+        return out.view(N, T, C), (conv_saved, blocks, y2d, (N, T, C))
+
+    @torch.no_grad()
+    def _backward_train(self, saved, dout, put):
+        conv_saved, blocks, y_last, (N, T, C) = saved
+        dy, dw, _ = ops.layernorm_bwd(dout.reshape(N * T, C), y_last, self.ln_f.weight)
+        put(self.ln_f.weight, dw)
+        for block, sv in zip(reversed(self.h), reversed(blocks)):
+            dy = block._backward2d(sv, dy, put)
+        self.conv._backward_cl(conv_saved, dy.view(N, T, C), put)

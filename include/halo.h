@@ -338,6 +338,12 @@ int halo_im2col_cl(const float *x, float *col, int N, int T, int Cin, int ks, in
                    halo_stream_t stream);
 int halo_dwconv1d_cl(const float *x, const float *weight, const float *bias, float *y, int N, int T, int C, int ks,
                      int stride, int pad, halo_stream_t stream);
+/* gradient of halo_dwconv1d_cl: dx [N,T,C] (NULL to skip), dweight [C,ks], dbias [C] (NULL when bias-free); ks <= 8;
+ * fixed-order partial sums through the workspace (bitwise reproducible) */
+size_t halo_dwconv1d_cl_bwd_workspace_bytes(int C, int ks);
+int halo_dwconv1d_cl_bwd(const float *dy, const float *x, const float *weight, float *dx, float *dweight,
+                         float *dbias, void *workspace, int N, int T, int C, int ks, int stride, int pad,
+                         halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers.

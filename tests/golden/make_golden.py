@@ -320,6 +320,20 @@ def asr_case(name, vocab, head_dim, heads, enc_layers, dec_layers, conv_dim, N, 
         o = transformer_ref.decoder_decode(pd, feats, flen, tl, heads, pre='decoder.')
         top2 = o[4].topk(2, dim=-1).values
         d['decode.min_margin'] = (top2[..., 0] - top2[..., 1]).min().numpy()
+    # the training direction (eval mode, so no dropout / label dropout): encoder -> joint loss -> backward, every parameter
+    enc.zero_grad(); dec.zero_grad()
+    feats, flen, _ = enc(x, il)
+    joint, _ = dec(feats, cond, flen, tl + 1)
+    joint.backward()
+    d['train.joint_loss'] = joint.detach().numpy()
+    small = sum(p.numel() for p in list(enc.parameters()) + list(dec.parameters())) < 400000
+    for pre, m in (('encoder.', enc), ('decoder.', dec)):
+        for k, v in m.named_parameters():
+            if small:
+                d['grad.' + pre + k] = v.grad.numpy()
+            else:
+                d['gradnorm.' + pre + k] = np.array(float(v.grad.norm()))
+                d['gradsample.' + pre + k] = v.grad.flatten()[::max(1, v.numel() // 500)][:500].numpy().copy()
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
     print(name, 'flen', flen.tolist(), 'dec loss', float(d['decoder_loss.mean']), 'joint', float(joint), 'decode lens',
           d['decode.output_lengths'].tolist(), 'margin', float(d['decode.min_margin']))

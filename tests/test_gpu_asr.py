@@ -199,3 +199,75 @@ def test_block_and_mha_public_forward(hal):
     with pytest.raises(hal['lib'].HaloError):
         with torch.no_grad():
             blk(x, memory=mem, memory_lengths=mlen)                              # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------ training direction
+def test_dwconv_backward_against_autograd(hal):
+    g = torch.Generator().manual_seed(4)
+    N, T, C, ks = 3, 37, 24, 3
+    for stride in (1, 2, 3):
+        x = torch.randn(N, T, C, generator=g, requires_grad=True)
+        w = torch.randn(C, 1, ks, generator=g, requires_grad=True)
+        b = torch.randn(C, generator=g, requires_grad=True)
+        y = F.conv1d(x.mT, w, b, stride=stride, padding=1, groups=C).mT
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        dx, dw, db = hal['ops'].dwconv1d_cl_bwd(dy.contiguous().to(DEV), x.detach().to(DEV), w.detach().view(C, ks).to(DEV), stride, 1)
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=1e-5)
+        np.testing.assert_allclose(dw.cpu().numpy(), w.grad.view(C, ks).numpy(), atol=5e-5)
+        np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), atol=5e-5)
+
+
+def _joint_backward(hal, name):
+    g, pd, (x, il, tg, tl), heads, enc, dec = _models(hal, name)
+    cond = torch.cat([torch.full((x.shape[0], 1), 5, dtype=torch.long), tg], dim=1)
+    feats, flen, _ = enc(x.to(DEV), il.to(DEV))                    # eval mode + grad: no dropout, like the fixture
+    assert feats.requires_grad
+    joint, _ = dec(feats, cond.to(DEV), flen, (tl + 1).to(DEV))
+    joint.backward()
+    return g, enc, dec, joint
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g6_asr_tiny', 'g6_asr_tiny_s221', 'g6_asr_tiny_stop'])
+def test_asr_tiny_gradients_match_reference(hal, name, math_mode):
+    """loss.backward() of encoder -> (decoder CE + 0.3 CTC) through the HIP path vs the reference's gradients: every parameter."""
+    g, enc, dec, joint = _joint_backward(hal, name)
+    np.testing.assert_allclose(joint.item(), float(g['train.joint_loss']), rtol=2e-5)
+    n = 0
+    for pre, m in (('encoder.', enc), ('decoder.', dec)):
+        for k, p in m.named_parameters():
+            want = g['grad.' + pre + k]
+            scale = max(1.0, float(np.abs(want).max()))
+            tol = dict(rtol=2e-3, atol=2e-5 * scale) if math_mode == 'f32' else dict(rtol=5e-3, atol=1e-4 * scale)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want, err_msg=pre + k, **tol)
+            n += 1
+    assert n == sum(1 for k in g if k.startswith('grad.'))
+
+
+@BOTH_MODES
+def test_asr_transformer32_gradients_match_reference(hal, math_mode):
+    """`transformer:32` (12+12 layers): norm and a strided sample of every parameter's gradient vs the reference's backward."""
+    g, enc, dec, joint = _joint_backward(hal, 'g6_asr_transformer32')
+    np.testing.assert_allclose(joint.item(), float(g['train.joint_loss']), rtol=5e-5)
+    rel = 5e-3 if math_mode == 'f32' else 1e-2
+    for pre, m in (('encoder.', enc), ('decoder.', dec)):
+        for k, p in m.named_parameters():
+            want_norm = float(g['gradnorm.' + pre + k])
+            assert abs(float(p.grad.norm()) - want_norm) <= rel * want_norm + 1e-7, pre + k
+            sample = p.grad.flatten()[::max(1, p.numel() // 500)][:500].cpu().numpy()
+            want = g['gradsample.' + pre + k]
+            assert np.abs(sample - want).max() <= rel * max(np.abs(want).max(), want_norm / p.numel() ** 0.5) + 1e-7, pre + k
+
+
+def test_asr_training_mode_refusals(hal):
+    tr = hal['tr']
+    dec = tr.Decoder(vocab=16, head_dim=16, heads=2, p_drop=0.2, layers=1).to(DEV).train()
+    feats = torch.randn(2, 5, 32, device=DEV)
+    tg = torch.randint(4, 16, (2, 3), device=DEV)
+    with pytest.raises(NotImplementedError):
+        dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))     # dropout 0.2 in training mode
+    dec = tr.Decoder(vocab=16, head_dim=16, heads=2, p_drop=0.0, layers=1).to(DEV).train()
+    loss, _ = dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))  # label dropout on, p_drop 0: trains
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())

@@ -244,3 +244,24 @@ def test_asr_parts_match_reference():
     lens = torch.from_numpy(g['lengths.in'])
     assert np.array_equal(tr.subsampled_lengths(lens, (2, 2, 2)).numpy(), g['lengths.s222'])
     assert np.array_equal(tr.subsampled_lengths(lens, (2, 2, 1)).numpy(), g['lengths.s221'])
+
+
+@pytest.mark.parametrize('name', ['g6_asr_tiny', 'g6_asr_tiny_s221'])
+def test_asr_gradients_match_reference(name):
+    """Training direction: autograd through the restatement (encoder -> decoder CE + 0.3 CTC) == the reference's backward."""
+    from oracle import transformer_ref as tr
+    g, pe, pd, (x, il, tg, tl), heads, strides = asr_case_from_golden(name)
+    pe = {k: v.requires_grad_(True) for k, v in pe.items()}
+    pd = {k: v.requires_grad_(True) for k, v in pd.items()}
+    feats, flen = tr.audio_encoder_forward(pe, x, il, heads, strides)
+    cond = torch.cat([torch.full((x.shape[0], 1), 5, dtype=torch.long), tg], dim=1)
+    joint, _, _ = tr.ctc_attention_forward(pd, feats, cond, flen, tl + 1, heads)
+    np.testing.assert_allclose(float(joint), float(g['train.joint_loss']), rtol=1e-5)
+    joint.backward()
+    n = 0
+    for pre, params in (('encoder.', pe), ('decoder.', pd)):
+        for k, v in params.items():
+            want = g['grad.' + pre + k]
+            np.testing.assert_allclose(v.grad.numpy(), want, rtol=2e-3, atol=1e-5 * max(1.0, float(np.abs(want).max())), err_msg=k)
+            n += 1
+    assert n == sum(1 for k in g if k.startswith('grad.'))
