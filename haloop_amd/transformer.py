@@ -1,6 +1,6 @@
 """Drop-in for the inference/scoring side of ha/transformer.py (encoder-decoder attention ASR, `hala`):
 AudioEncoder, Block, MultiHeadAttention, Decoder (teacher-forced loss and batched greedy decode with fp16
-KV caches), CTCAttentionDecoder, rotate_interleaved, attend, attend_chunked -- forward only, on the HIP
+KV caches), CTCAttentionDecoder, rotate_interleaved, attend, attend_chunked -- on the HIP
 operators of csrc/attn.hip, csrc/conv.hip, csrc/gpt.hip and the GEMMs.
 
 Same constructor arguments, attribute and state-dict names as the reference (``h.{i}.ln_time``,
