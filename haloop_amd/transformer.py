@@ -22,6 +22,7 @@ call, ``kv_cache_parts`` on the public Block / MultiHeadAttention.forward (Decod
 itself), arbitrary attention masks (only the key-padding masks Block builds, transformer.py:476).
 """
 import math
+import os
 from collections import namedtuple
 
 import torch
@@ -360,6 +361,7 @@ class Decoder(nn.Module):
         self.ln_f = LayerNorm(head_dim * heads, bias=False)
         self.lm_head = nn.Linear(head_dim * heads, vocab, bias=False)
         self._images = WeightImages()
+        self._graphs = {}                                                 # captured greedy decodes, see _decode_graph
 
     def forward(self, features, targets, input_lengths=None, target_lengths=None, star_penalty=None, measure_entropy=False,
                 drop_labels=None, reduction='mean'):
@@ -446,28 +448,16 @@ class Decoder(nn.Module):
         return dmem.view(N, S, C)
 
     @torch.no_grad()
-    def decode(self, features, input_lengths, target_lengths, prompt=None):
-        "Perform batched greedy decoding (ha/transformer.py:124-199)."
-        _require_inference(self, features)
-        dev = features.device
-        N, S, C = features.shape
-        T = int(target_lengths.max().item()) + 1
+    def _decode_core(self, mem2d, mlen, tokens_init, plen, N, S, T):
+        """All launches of one batched greedy decode, host-sync free (capturable in a HIP graph).
+        mem2d [N*S, C] fp32 features, mlen [N] int32, tokens_init [N, W] int64 (STX, optional prompt, ETX fill)."""
+        dev = mem2d.device
+        C = mem2d.shape[1]
         L = len(self.h)
         heads, head_dim = self.h[0].heads, self.h[0].head_dim
-        if prompt is None:
-            tokens = torch.full((N, T + 1), ETX, dtype=torch.long, device=dev)
-            tokens[:, 0] = STX
-            plen = 0
-        else:
-            P = prompt.shape[-1]
-            tokens = torch.full((N, T + 1 + P), ETX, dtype=torch.long, device=dev)
-            tokens[:, 0] = STX
-            tokens[:, 1:1 + P] = prompt.to(dev)
-            plen = 1
+        tokens = tokens_init.clone()
         mem_cache = torch.zeros((L, 2, N, heads, S, head_dim), dtype=torch.float16, device=dev)
         time_cache = torch.zeros((L, 2, N, heads, T, head_dim), dtype=torch.float16, device=dev)
-        mlen = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
-        mem2d = features.reshape(N * S, C).float().contiguous()
         for l, block in enumerate(self.h):                                   # cross-attention caches, warmed once (:324-334)
             mm = block.mix_memory
             kv = linear(mm._images, mem2d, (mm.k.weight, mm.v.weight))
@@ -497,6 +487,57 @@ class Decoder(nn.Module):
             logits = linear(self._images, ops.layernorm_fwd(y, self.ln_f.weight), self.lm_head.weight)
             val, idx, negent = ops.logprob_max(logits, want_entropy=True)
             ops.greedy_update(val, idx, negent, tokens, t, plen, ETX, alive, out_len, log_probs, sum_entropies)
+        return tokens, out_len, log_probs, sum_entropies
+
+    def _decode_graph(self, key, mem2d, mlen, tokens, plen, N, S, T):
+        """One HIP graph per (shape, parameter version): ~13 launches x layers x steps become one replay."""
+        stamp = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        entry = self._graphs.get(key)
+        if entry is None or entry['stamp'] != stamp:
+            static = (mem2d.clone(), mlen.clone(), tokens.clone())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._decode_core(*static, plen, N, S, T)               # warm-up: weight images are built outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._decode_core(*static, plen, N, S, T)
+            # the graph reads the cached weight images by address: keep them alive as long as the graph
+            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')]
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = dict(stamp=stamp, graph=graph, static=static, outs=outs, held=held)
+            self._graphs[key] = entry
+        for dst, src in zip(entry['static'], (mem2d, mlen, tokens)):
+            dst.copy_(src)
+        entry['graph'].replay()
+        return tuple(o.clone() for o in entry['outs'])
+
+    @torch.no_grad()
+    def decode(self, features, input_lengths, target_lengths, prompt=None):
+        "Perform batched greedy decoding (ha/transformer.py:124-199)."
+        _require_inference(self, features)
+        dev = features.device
+        N, S, C = features.shape
+        T = int(target_lengths.max().item()) + 1
+        if prompt is None:
+            tokens = torch.full((N, T + 1), ETX, dtype=torch.long, device=dev)
+            tokens[:, 0] = STX
+            plen = 0
+        else:
+            P = prompt.shape[-1]
+            tokens = torch.full((N, T + 1 + P), ETX, dtype=torch.long, device=dev)
+            tokens[:, 0] = STX
+            tokens[:, 1:1 + P] = prompt.to(dev)
+            plen = 1
+        mlen = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        mem2d = features.reshape(N * S, C).float().contiguous()
+        if os.environ.get('HALO_DECODE_GRAPH', '1') != '0':
+            key = (N, S, T, tokens.shape[1], plen, str(dev), _lib.get_math_mode())
+            tokens, out_len, log_probs, sum_entropies = self._decode_graph(key, mem2d, mlen, tokens, plen, N, S, T)
+        else:
+            tokens, out_len, log_probs, sum_entropies = self._decode_core(mem2d, mlen, tokens, plen, N, S, T)
         output_lengths = out_len.to(input_lengths.dtype)
         lens = output_lengths.tolist()
         outputs = torch.nested.nested_tensor([p[1:l] for p, l in zip(tokens, lens)])
