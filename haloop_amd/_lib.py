@@ -62,6 +62,8 @@ SIGNATURES = {
     'halo_attention_causal_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'halo_cross_entropy_fwd': (_i, [_vp, _vp, _vp, _i, _i, _l, _l, _vp]),
     'halo_attention_fwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'halo_attention_fwd_strided': (_i, [_vp, _l, _l, _l, _vp, _vp, _l, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'halo_kv_cache_store_f32': (_i, [_vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_rope_table': (_i, [_vp, _vp, _i, _i, _f, _vp]),
     'halo_rope_interleaved': (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     'halo_kv_cache_store': (_i, [_vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

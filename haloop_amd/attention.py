@@ -12,8 +12,10 @@ Training: with grad enabled ``forward_all`` returns a loss with a ``grad_fn`` (o
 backward is the hand-written HIP backward: cross-entropy, lm_head, LayerNorm, GELU, attention and embedding
 gradients), so ``loss.backward()``, ``clip_grad_norm_`` and the optimizers of ha/attention_loop.py work unchanged.
 
-Not built yet (raises NotImplementedError): dropout > 0, the KV-cache ``past`` argument / ``generate``,
-``stable_embedding`` and rotary (flash_attn) blocks.
+Generation: ``forward(input_ids, past)`` / ``forward_context`` / ``generate`` keep the reference's fp32 KV cache
+layout ``[L, 2, B, nh, T, hs]`` (attend_cached, ha/attention.py:64-93); attention reads the cache in place.
+
+Not built yet (raises NotImplementedError): dropout > 0, ``stable_embedding`` and rotary (flash_attn) blocks.
 """
 import math
 from dataclasses import dataclass, asdict
@@ -134,25 +136,36 @@ class GPT(nn.Module):
         return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate)
 
     @torch.no_grad()
-    def _trunk(self, input_ids):
+    def _trunk(self, input_ids, past=None, want_present=False):
+        """Embedding + blocks + ln_f.  With ``past`` [L, 2, B, nh, T0, hs] (or want_present) keys/values go through a
+        fp32 cache in the reference's layout (attend_cached, ha/attention.py:64-93) and ``present`` is returned."""
         cfg = self.config
         B, T = input_ids.shape
-        assert T <= cfg.block_size, f'Cannot forward sequence of length {T}, block size is only {cfg.block_size}'
+        t0 = 0 if past is None else past.size(-2)
+        assert t0 + T <= cfg.block_size, f'Cannot forward sequence of length {t0 + T}, block size is only {cfg.block_size}'
+        C, H = cfg.n_embd, cfg.n_head
         tr = self.transformer
-        x = ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, 0)                    # [B*T, C], the residual stream
-        for blk in tr.h:
+        x = ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, t0)                   # [B*T, C], the residual stream
+        present = None
+        if past is not None or want_present:
+            present = torch.empty(cfg.n_layer, 2, B, H, t0 + T, C // H, device=x.device, dtype=torch.float32)
+            if t0:
+                present[..., :t0, :] = past
+        for i, blk in enumerate(tr.h):
             h = ops.layernorm_fwd(x, blk.ln_1.weight, blk.ln_1.bias)
             qkv = self._linear(h, blk.attn.c_attn)
-            y = ops.attention_causal_fwd(qkv, B, T, cfg.n_head)
+            if present is not None:
+                ops.kv_cache_store(qkv[:, C:], C, present[i, 0], present[i, 1], B, T, H, C // H, t0)
+                y = ops.attention_cached_fwd(qkv, present[i, 0], present[i, 1], T, t0 + T, causal=True)
+            else:
+                y = ops.attention_causal_fwd(qkv, B, T, cfg.n_head)
             self._linear(y, blk.attn.c_proj, out=x, accumulate=True)                     # x += c_proj(y)
             h = ops.layernorm_fwd(x, blk.ln_2.weight, blk.ln_2.bias)
             h = self._linear(h, blk.mlp.c_fc, gelu=True)
             self._linear(h, blk.mlp.c_proj, out=x, accumulate=True)                      # x += mlp(h)
-        return ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
+        return ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias), present
 
     def forward_all(self, input_ids, target_ids, past=None, reduction='mean'):
-        if past is not None:
-            raise NotImplementedError('KV-cache continuation is not built yet')
         if not input_ids.is_cuda:
             raise _lib.HaloError('haloop_amd.attention.GPT runs on the HIP device only (no CPU path)')
         if self.training and self.config.dropout > 0:
@@ -160,10 +173,12 @@ class GPT(nn.Module):
         B, T = input_ids.shape
         V = self.config.vocab_size
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if past is not None:
+                raise NotImplementedError('training through a KV-cache continuation is not built: call under torch.no_grad()')
             params = [p for p in self.parameters() if p.requires_grad]
             loss = _GPTLoss.apply(self, input_ids, target_ids, *params)          # per-token NLL with a grad_fn
             return self._reduce(loss, target_ids.reshape(-1), reduction)
-        x = self._trunk(input_ids)
+        x, _ = self._trunk(input_ids, past)
         targets = target_ids.reshape(-1)
         # lm_head + cross-entropy in row chunks so the [rows, V] logits stay bounded (206 MB per 1024 rows at V=50304)
         loss = torch.empty(B * T, device=x.device, dtype=torch.float32)
@@ -256,5 +271,48 @@ class GPT(nn.Module):
         put(tr.wpe.weight, dwpe)
         return grads
 
+    def forward_context(self, input_ids):
+        """(ln_f(x) [B, T, C], present [L, 2, B, nh, T, hs]) -- ha/attention.py:234-251"""
+        self._check_inference(input_ids)
+        x, present = self._trunk(input_ids, None, want_present=True)
+        return x.view(*input_ids.shape, -1), present
+
     def forward(self, input_ids, past=None):
-        raise NotImplementedError('generation (KV cache) is not built yet; forward_all is')
+        """(logits of the last position [B, 1, V], present) -- ha/attention.py:253-279"""
+        self._check_inference(input_ids)
+        B, T = input_ids.shape
+        x, present = self._trunk(input_ids, past, want_present=True)
+        last = x.view(B, T, -1)[:, -1, :].contiguous()
+        return self._linear(last, self.lm_head).view(B, 1, -1), present
+
+    def _check_inference(self, input_ids):
+        if not input_ids.is_cuda:
+            raise _lib.HaloError('haloop_amd.attention.GPT runs on the HIP device only (no CPU path)')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('GPT.forward / forward_context (generation) are inference paths: call under torch.no_grad() / '
+                                      'inference_mode; training goes through forward_all')
+
+
+@torch.inference_mode()
+def generate(self, input_ids, max_new_tokens, temperature=1.0, top_k=None, stop_token=50256):
+    """Sampling loop of ha/attention.py:282-321 (same control flow and KV-cache use; the draw itself is torch.multinomial
+    on the device, as in the reference)."""
+    past = None
+    for _ in range(max_new_tokens):
+        if input_ids.size(1) >= self.config.block_size:
+            past = None
+            logits, _ = self(input_ids[:, -self.config.block_size:], past=None)
+        elif past is None:
+            logits, past = self(input_ids, past=None)
+        else:
+            logits, past = self(input_ids[:, [-1]], past=past)
+        logits = logits[:, -1, :] / temperature
+        if top_k is not None:
+            v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+            logits[logits < v[:, [-1]]] = -float('Inf')
+        probs = torch.softmax(logits, dim=-1)
+        input_ids_next = torch.multinomial(probs, num_samples=1)
+        if input_ids_next == stop_token:
+            break
+        input_ids = torch.cat((input_ids, input_ids_next), dim=1)
+        yield input_ids_next

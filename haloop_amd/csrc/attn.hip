@@ -10,7 +10,8 @@ namespace {
 struct AttnArgs {
     const float *q, *k, *v;
     float *y, *lse, *ent;
-    long q_rs, q_bs, kv_rs, kv_bs, y_rs, y_bs;   // row / batch strides in elements; head h sits at column h*HD
+    long q_rs, q_bs, kv_rs, kv_bs, y_rs, y_bs;   // row / batch strides in elements
+    long q_hs, kv_hs;                            // head strides: HD for packed rows, Tc*HD for a [N, heads, Tc, HD] cache
     const int *key_len;                          // [N] keys >= key_len[n] are masked, may be NULL
     int Tq, Tk, heads, causal;
     float scale;
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
     const int q0 = qt * 64 + wave * 16;                   // this wave's first query row
     const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
     const int coff = Tk - Tq;                             // causal: key <= row + coff
@@ -220,8 +221,12 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(float *__restrict__ x, 
 
 // ---- fp16 KV cache (ha/transformer.py:150-153, 315-339) -----------------------------------------------
 // cache[n, h, t0 + s, :] = half(src[n*S + s, h*hd : (h+1)*hd]) for K and V at once; src rows hold k at col 0, v at col v_off
+__device__ __forceinline__ void cache_put(__half *p, float v) { *p = __float2half(v); }
+__device__ __forceinline__ void cache_put(float *p, float v) { *p = v; }
+
+template <typename CT>
 __global__ __launch_bounds__(256) void kv_cache_store_kernel(const float *__restrict__ src, long src_rs, long v_off,
-                                                             __half *__restrict__ ck, __half *__restrict__ cv, int N, int S,
+                                                             CT *__restrict__ ck, CT *__restrict__ cv, int N, int S,
                                                              int heads, int hd, int Tc, int t0) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long C = (long)heads * hd;
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256) void kv_cache_store_kernel(const float *__rest
     const int s = (int)(row % S), n = (int)(row / S), h = c / hd, d = c % hd;
     const float *p = src + row * src_rs + c;
     const long o = (((long)n * heads + h) * Tc + (t0 + s)) * hd + d;
-    ck[o] = __float2half(p[0]);
-    cv[o] = __float2half(p[v_off]);
+    cache_put(ck + o, p[0]);
+    cache_put(cv + o, p[v_off]);
 }
 
 // One wave per (n, head): one query token against n_keys cached keys (fp16), optional rotary on the cached keys
@@ -622,15 +627,17 @@ int launch_attention(const AttnArgs &a, int N, bool ent, hipStream_t st) {
 
 extern "C" {
 
-int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
-                       long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
-                       float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
-                       halo_stream_t stream) {
+int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_stride, long q_head_stride, const float *k,
+                               const float *v, long kv_row_stride, long kv_batch_stride, long kv_head_stride, float *y,
+                               long y_row_stride, long y_batch_stride, float *lse, float *entropy, int N, int heads, int head_dim,
+                               int Tq, int Tk, int causal, const int *key_lengths, halo_stream_t stream) {
     HALO_CHECK_ARG(q && k && v && y && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
-    HALO_CHECK_ARG(((uintptr_t)k | (uintptr_t)v) % 16 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0);
+    HALO_CHECK_ARG(((uintptr_t)k | (uintptr_t)v) % 16 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0 &&
+                   kv_head_stride % 4 == 0);
     HALO_CHECK_ARG(N <= 65535 && heads <= 65535);
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.y = y; a.lse = lse; a.ent = entropy;
+    a.q_hs = q_head_stride; a.kv_hs = kv_head_stride;
     a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
     a.y_rs = y_row_stride; a.y_bs = y_batch_stride; a.key_len = key_lengths;
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
@@ -642,6 +649,15 @@ int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, c
         case 16: return launch_attention<16>(a, N, entropy != nullptr, st);
         default: return HALO_ENOTSUP;
     }
+}
+
+int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
+                       long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
+                       float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       halo_stream_t stream) {
+    return halo_attention_fwd_strided(q, q_row_stride, q_batch_stride, head_dim, k, v, kv_row_stride, kv_batch_stride, head_dim, y,
+                                      y_row_stride, y_batch_stride, lse, entropy, N, heads, head_dim, Tq, Tk, causal, key_lengths,
+                                      stream);
 }
 
 int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
@@ -698,8 +714,17 @@ int halo_kv_cache_store(const float *src, long src_row_stride, long v_offset, vo
                         int head_dim, int cache_len, int t0, halo_stream_t stream) {
     HALO_CHECK_ARG(src && cache_k && cache_v && N > 0 && S > 0 && heads > 0 && head_dim > 0 && t0 >= 0 && t0 + S <= cache_len);
     const long n = (long)N * S * heads * head_dim;
-    hipLaunchKernelGGL(kv_cache_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_row_stride,
-                       v_offset, (__half *)cache_k, (__half *)cache_v, N, S, heads, head_dim, cache_len, t0);
+    hipLaunchKernelGGL(kv_cache_store_kernel<__half>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_row_stride, v_offset, (__half *)cache_k, (__half *)cache_v, N, S, heads, head_dim, cache_len, t0);
+    return halo_launch_status();
+}
+
+int halo_kv_cache_store_f32(const float *src, long src_row_stride, long v_offset, float *cache_k, float *cache_v, int N, int S,
+                            int heads, int head_dim, int cache_len, int t0, halo_stream_t stream) {
+    HALO_CHECK_ARG(src && cache_k && cache_v && N > 0 && S > 0 && heads > 0 && head_dim > 0 && t0 >= 0 && t0 + S <= cache_len);
+    const long n = (long)N * S * heads * head_dim;
+    hipLaunchKernelGGL(kv_cache_store_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_row_stride, v_offset, cache_k, cache_v, N, S, heads, head_dim, cache_len, t0);
     return halo_launch_status();
 }
 

@@ -398,8 +398,24 @@ def rope_(x2d, T, heads, head_dim, table, t0=0, inverse=False):
     return x2d
 
 
+def attention_cached_fwd(q, cache_k, cache_v, Tq, n_keys, causal=True):
+    """q: rows [N*Tq, C] (a column slice is fine); cache_{k,v}: [N, heads, Tc, head_dim] fp32 holding n_keys valid keys.
+    -> y [N*Tq, C]: attend_cached of ha/attention.py:64-93 (queries are the LAST Tq of the n_keys positions)."""
+    N, heads, Tc, hd = cache_k.shape
+    C = heads * hd
+    y = torch.empty(N * Tq, C, device=q.device, dtype=torch.float32)
+    check(lib().halo_attention_fwd_strided(ptr(q), q.stride(0), q.stride(0) * Tq, hd, ptr(cache_k), ptr(cache_v), hd, heads * Tc * hd,
+                                           Tc * hd, ptr(y), C, C * Tq, None, None, N, heads, hd, Tq, n_keys, int(causal), None,
+                                           _stream()), 'halo_attention_fwd_strided')
+    return y
+
+
 def kv_cache_store(src2d, v_offset, cache_k, cache_v, N, S, heads, head_dim, t0):
-    """cache_{k,v} [N, heads, Tc, head_dim] float16 <- rows [N*S] of src2d (k at column 0, v at column v_offset)."""
+    """cache_{k,v} [N, heads, Tc, head_dim] float16 (or float32) <- rows [N*S] of src2d (k at column 0, v at column v_offset)."""
+    if cache_k.dtype == torch.float32:
+        check(lib().halo_kv_cache_store_f32(ptr(src2d), src2d.stride(0), v_offset, ptr(cache_k), ptr(cache_v), N, S, heads, head_dim,
+                                            cache_k.shape[2], t0, _stream()), 'halo_kv_cache_store_f32')
+        return
     check(lib().halo_kv_cache_store(ptr(src2d), src2d.stride(0), v_offset, ptr(cache_k), ptr(cache_v), N, S, heads, head_dim,
                                     cache_k.shape[2], t0, _stream()), 'halo_kv_cache_store')
 

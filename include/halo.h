@@ -279,12 +279,23 @@ int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, c
                        long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride,
                        float *lse, float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal,
                        const int *key_lengths, halo_stream_t stream);
+/* halo_attention_fwd with explicit head strides: q_head_stride / kv_head_stride = head_dim for packed rows, or
+ * cache_len * head_dim (with row stride head_dim, batch stride heads * cache_len * head_dim) to read K/V straight from a
+ * [N, heads, cache_len, head_dim] fp32 cache -- the `past` / `present` layout of ha/attention.py:64-69,232 (attend_cached). */
+int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_stride, long q_head_stride,
+                               const float *k, const float *v, long kv_row_stride, long kv_batch_stride,
+                               long kv_head_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
+                               float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal,
+                               const int *key_lengths, halo_stream_t stream);
 int halo_rope_table(float *cos_table, float *sin_table, int T, int head_dim, float base, halo_stream_t stream);
 int halo_rope_interleaved(float *x, long row_stride, int n_rows, int T, int heads, int head_dim, int t0,
                           const float *cos_table, const float *sin_table, int table_rows, int inverse,
                           halo_stream_t stream);
 int halo_kv_cache_store(const float *src, long src_row_stride, long v_offset, void *cache_k, void *cache_v, int N,
                         int S, int heads, int head_dim, int cache_len, int t0, halo_stream_t stream);
+/* fp32 twin of halo_kv_cache_store: present[layer, 0|1, :, :, t0:t0+S, :] of ha/attention.py:66-67,129 */
+int halo_kv_cache_store_f32(const float *src, long src_row_stride, long v_offset, float *cache_k, float *cache_v,
+                            int N, int S, int heads, int head_dim, int cache_len, int t0, halo_stream_t stream);
 int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k, const void *cache_v, float *y,
                           long y_row_stride, int N, int heads, int head_dim, int cache_len, int n_keys,
                           const int *key_lengths, const float *cos_table, const float *sin_table,

@@ -81,3 +81,30 @@ def synthetic_tokens(B, T, vocab, seed, pad_tail=True):
     eos = min(50256, vocab - 1)
     inputs = torch.cat([torch.full((B, 1), eos, dtype=torch.long), comp[:, :-1]], dim=1)
     return inputs, comp
+
+
+def gpt_forward(p, n_layer, n_head, input_ids, past=None):
+    """GPT.forward (ha/attention.py:253-279): logits of the last position and the present KV cache [L,2,B,nh,T,hs]."""
+    B, T = input_ids.shape
+    C = p['transformer.wte.weight'].shape[1]
+    t0 = 0 if past is None else past.size(-2)
+    x = F.embedding(input_ids, p['transformer.wte.weight']) + p['transformer.wpe.weight'][t0:t0 + T][None]
+    present = []
+    for i in range(n_layer):
+        pre = f'transformer.h.{i}.'
+        h = F.layer_norm(x, (C,), p[pre + 'ln_1.weight'], p.get(pre + 'ln_1.bias'), 1e-5)
+        qkv = F.linear(h, p[pre + 'attn.c_attn.weight'], p.get(pre + 'attn.c_attn.bias'))
+        q, k, v = (t.view(B, T, n_head, C // n_head).transpose(1, 2) for t in qkv.split(C, dim=2))
+        if past is not None:
+            k, v = torch.cat([past[i, 0], k], dim=-2), torch.cat([past[i, 1], v], dim=-2)
+        att = (q @ k.transpose(-2, -1)) * (1.0 / (k.size(-1) ** 0.5))
+        bias = k.new_ones(k.size(-2), k.size(-2)).tril()[-T:]
+        att = att.masked_fill(bias[None, None] == 0, float('-inf')).softmax(dim=-1)
+        y = (att @ v).transpose(1, 2).contiguous().view(B, T, C)
+        present.append(torch.stack([k, v]))
+        x = x + F.linear(y, p[pre + 'attn.c_proj.weight'], p.get(pre + 'attn.c_proj.bias'))
+        h = F.layer_norm(x, (C,), p[pre + 'ln_2.weight'], p.get(pre + 'ln_2.bias'), 1e-5)
+        h = new_gelu(F.linear(h, p[pre + 'mlp.c_fc.weight'], p.get(pre + 'mlp.c_fc.bias')))
+        x = x + F.linear(h, p[pre + 'mlp.c_proj.weight'], p.get(pre + 'mlp.c_proj.bias'))
+    x = F.layer_norm(x, (C,), p['transformer.ln_f.weight'], p.get('transformer.ln_f.bias'), 1e-5)
+    return F.linear(x[:, [-1], :], p['lm_head.weight']), torch.stack(present)

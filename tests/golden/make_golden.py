@@ -273,6 +273,15 @@ def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, stor
     if store_params:
         for k, v in params.items():
             d['param.' + k] = v.numpy()
+        # generation path (ha/attention.py:253-279): prefill, then two single-token continuations through the KV cache
+        with torch.no_grad():
+            split = T // 2
+            logits0, past = model(inputs[:, :split])
+            logits1, past1 = model(inputs[:, split:split + 1], past=past)
+            logits2, past2 = model(inputs[:, split + 1:split + 4], past=past1)
+        d['gen.split'] = np.array(split)
+        d['gen.logits0'], d['gen.logits1'], d['gen.logits2'] = logits0.numpy(), logits1.numpy(), logits2.numpy()
+        d['gen.present2'] = past2.numpy()
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
     print(name, 'mean nats/token', float(mean))
 

@@ -483,8 +483,7 @@ def test_gpt_refuses_what_is_not_built(hal):
     model = attention.GPT(cfg).to(DEV)
     ids = torch.randint(1, 50, (1, 8), device=DEV)
     with pytest.raises(NotImplementedError):
-        with torch.no_grad():
-            model.forward_all(ids, ids, past=torch.zeros(1))  # KV-cache continuation
+        model(ids)                                           # generation path under autograd
     with pytest.raises(NotImplementedError):
         attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))
     with pytest.raises(NotImplementedError):
@@ -654,3 +653,36 @@ def test_gpt2_small_gradients_match_reference(hal, math_mode):
         sample = p.grad.flatten()[::max(1, p.numel() // 1000)][:1000].cpu().numpy()
         want = g['gradsample.' + k]
         assert np.abs(sample - want).max() <= rel * max(np.abs(want).max(), want_norm / p.numel() ** 0.5), k
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_kv_cache_generation_matches_reference(hal, name, math_mode):
+    """GPT.forward(input_ids, past) (ha/attention.py:253-279): prefill + cached continuations vs the reference's logits and
+    its `present` cache; forward_all over a cache prefix; generate() yields greedy (top_k=1) tokens equal to the argmax chain."""
+    from haloop_amd import attention
+    g, model = _gpt_from_golden(hal, name)
+    inputs, split = torch.from_numpy(g['inputs']).to(DEV), int(g['gen.split'])
+    with torch.no_grad():
+        l0, past = model(inputs[:, :split])
+        l1, past1 = model(inputs[:, split:split + 1], past=past)
+        l2, past2 = model(inputs[:, split + 1:split + 4], past=past1)
+        for got, key in ((l0, 'gen.logits0'), (l1, 'gen.logits1'), (l2, 'gen.logits2'), (past2, 'gen.present2')):
+            assert got.shape == g[key].shape
+            # bf16x3 GEMMs: ~2^-16 relative per product on values of order 1
+            np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=2e-5, atol=1e-5 if math_mode == 'f32' else 1e-4, err_msg=key)
+        # per-token loss of a continuation == the same positions of the full pass
+        targets = torch.from_numpy(g['targets']).to(DEV)
+        T = inputs.shape[1]
+        cont = model.forward_all(inputs[:, split:], targets[:, split:], past=past, reduction='none')
+        np.testing.assert_allclose(cont.view(-1, T - split).cpu().numpy(), g['per_token'].reshape(-1, T)[:, split:], rtol=2e-5,
+                                   atol=2e-5 if math_mode == 'f32' else 1e-4)
+        x, present = model.forward_context(inputs)
+        assert x.shape == (*inputs.shape, model.config.n_embd) and present.shape[-2] == T
+        # greedy generation through the cache equals recomputing from scratch each step
+        seq = inputs[:1, :5]
+        out = [int(t) for t in attention.generate(model, seq, 4, top_k=1, stop_token=-1)]
+        for tok in out:
+            logits, _ = model(seq)
+            assert int(logits[0, -1].argmax()) == tok
+            seq = torch.cat([seq, torch.tensor([[tok]], device=DEV)], dim=1)

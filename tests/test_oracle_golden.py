@@ -159,6 +159,21 @@ def test_gpt_forward_all_matches_reference(name):
 
 
 @pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_kv_cache_forward_matches_reference(name):
+    from oracle import gpt_ref
+    g = load_golden(name)
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    inputs, split = torch.from_numpy(g['inputs']), int(g['gen.split'])
+    with torch.no_grad():
+        l0, past = gpt_ref.gpt_forward(params, n_layer, n_head, inputs[:, :split])
+        l1, past = gpt_ref.gpt_forward(params, n_layer, n_head, inputs[:, split:split + 1], past)
+        l2, past = gpt_ref.gpt_forward(params, n_layer, n_head, inputs[:, split + 1:split + 4], past)
+    for got, key in ((l0, 'gen.logits0'), (l1, 'gen.logits1'), (l2, 'gen.logits2'), (past, 'gen.present2')):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=2e-6, err_msg=key)
+
+
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
 def test_gpt_gradients_match_reference(name):
     """The training direction: autograd through the restatement == the reference's loss.backward()."""
     from oracle import gpt_ref
