@@ -21,6 +21,7 @@ HALO_STREAM_LSTM_LAYER0 = 16
 HALO_SUMSQ_PARTS = 1024
 HALO_MATH_F32 = 0
 HALO_MATH_BF16X3 = 1
+HALO_MATH_BF16 = 2
 
 _vp, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 
@@ -117,8 +118,9 @@ def lib():
 
 
 def set_math_mode(mode):
-    """'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16, three MFMAs per product) for the large LSTM GEMMs."""
-    code = {'f32': HALO_MATH_F32, 'bf16x3': HALO_MATH_BF16X3}[mode]
+    """'f32' (exact-f32 MFMA), 'bf16x3' (split-bf16, three MFMAs per product: fp32-grade) or 'bf16' (operands rounded to
+    bf16, one MFMA per product: the reference's bf16-autocast arithmetic) for the dense products (include/halo.h)."""
+    code = {'f32': HALO_MATH_F32, 'bf16x3': HALO_MATH_BF16X3, 'bf16': HALO_MATH_BF16}[mode]
     check(lib().halo_set_math_mode(code), 'halo_set_math_mode')
 
 
@@ -128,7 +130,7 @@ def set_lstm_fusion(on):
 
 
 def get_math_mode():
-    return {HALO_MATH_F32: 'f32', HALO_MATH_BF16X3: 'bf16x3'}[lib().halo_get_math_mode()]
+    return {HALO_MATH_F32: 'f32', HALO_MATH_BF16X3: 'bf16x3', HALO_MATH_BF16: 'bf16'}[lib().halo_get_math_mode()]
 
 
 _scratch = None

@@ -45,14 +45,14 @@ def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=Fal
         weights = (weights,)
     M, K = x2d.shape
     N = sum(w.shape[0] for w in weights)
-    if _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64:
+    if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64:
         return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
                               accumulate=accumulate)
     return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate)
 
 
 def use_split(M, N, K):
-    return _lib.get_math_mode() == 'bf16x3' and K >= 64 and N >= 64
+    return _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64
 
 
 def linear_dx(images, dy2d, weights, out=None, accumulate=False):

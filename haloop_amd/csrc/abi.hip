@@ -37,7 +37,7 @@ int halo_math_mode() { return g_math_mode; }
 extern "C" {
 
 int halo_set_math_mode(int mode) {
-    if (mode != HALO_MATH_F32 && mode != HALO_MATH_BF16X3) return HALO_EINVAL;
+    if (mode != HALO_MATH_F32 && mode != HALO_MATH_BF16X3 && mode != HALO_MATH_BF16) return HALO_EINVAL;
     g_math_mode = mode;
     return HALO_OK;
 }

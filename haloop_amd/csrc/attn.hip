@@ -4,18 +4,11 @@
 // decode attention over them, and the greedy head of Decoder.decode.
 #include <hip/hip_fp16.h>
 #include "halo_common.h"
+#include "halo_internal.h"
+#include "attn_args.h"
 
 namespace {
 
-struct AttnArgs {
-    const float *q, *k, *v;
-    float *y, *lse, *ent;
-    long q_rs, q_bs, kv_rs, kv_bs, y_rs, y_bs;   // row / batch strides in elements
-    long q_hs, kv_hs;                            // head strides: HD for packed rows, Tc*HD for a [N, heads, Tc, HD] cache
-    const int *key_len;                          // [N] keys >= key_len[n] are masked, may be NULL
-    int Tq, Tk, heads, causal;
-    float scale;
-};
 
 // ---- softmax attention forward ---------------------------------------------------------------------
 // One workgroup = 64 query rows of one (batch, head); 4 waves x 16 rows.  Keys/values stream through
@@ -377,14 +370,6 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float *__restr
 // All four/five products per tile run on v_mfma_f32_16x16x4_f32.  LDS tiles are [row][dim] with stride HD+2; an
 // operand is read either as B[k = dim][col = row] (row = l&15) or as B[k = row][col = dim] (dim = l&15) -- the second
 // pattern is 2-way bank-conflicted, which the 32-cycle f32 MFMA hides.
-struct AttnBwdArgs {
-    const float *q, *k, *v, *dy, *lse, *delta;
-    float *dq, *dk, *dv;
-    long q_rs, q_bs, kv_rs, kv_bs, dy_rs, dy_bs, dq_rs, dq_bs, dkv_rs, dkv_bs;
-    const int *key_len;
-    int Tq, Tk, heads, causal;
-    float scale;
-};
 
 // delta[n, h, t] = sum_d dy[n, t, h*HD + d] * y[n, t, h*HD + d]
 template <int HD>
@@ -643,6 +628,10 @@ int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_s
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
     a.scale = 1.0f / sqrtf((float)head_dim);
     hipStream_t st = (hipStream_t)stream;
+    if (halo_math_mode() != HALO_MATH_F32 && !entropy && (head_dim == 64 || head_dim == 32)) {
+        const int rc = halo_attention_fwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
+        if (rc != HALO_ENOTSUP) return rc;           // unaligned operands: the exact-f32 kernel takes them
+    }
     switch (head_dim) {
         case 64: return launch_attention<64>(a, N, entropy != nullptr, st);
         case 32: return launch_attention<32>(a, N, entropy != nullptr, st);
@@ -678,6 +667,13 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
     a.scale = 1.0f / sqrtf((float)head_dim);
     hipStream_t st = (hipStream_t)stream;
+    if (halo_math_mode() != HALO_MATH_F32 && (head_dim == 64 || head_dim == 32)) {
+        if (head_dim == 64)
+            hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
+        else
+            hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
+        return halo_attention_bwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
+    }
     switch (head_dim) {
         case 64: return launch_attention_bwd<64>(a, y, y_row_stride, delta, N, st);
         case 32: return launch_attention_bwd<32>(a, y, y_row_stride, delta, N, st);

@@ -1,0 +1,458 @@
+// Softmax attention forward / backward on the bf16 matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16), same
+// tiling, masks and outputs as the exact-f32 kernels of attn.hip.  Operands are fp32 in HBM; on their way into
+// LDS / registers they are split x = hi + lo (two bf16) and every product is accumulated in fp32 as
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi        (PASSES = 3, ~2^-16 relative error per product)
+// or just a_hi*b_hi (PASSES = 1, plain bf16 operands).  Three 16-cycle bf16 MFMAs replace eight 32-cycle f32
+// MFMAs per 32-deep product: 5.3x the matrix rate at fp32-grade accuracy.
+//
+// LDS images: a 64-row tile is kept ROW-major [row][HD] bf16 (hi image, then lo image), row stride HD*2+16 bytes.
+//   - products that contract over the row's own axis (Q.K^T, dO.V^T, K.Q^T, V.dO^T) read a B fragment as one
+//     ds_read_b128 per lane (8 consecutive dims of one row);
+//   - products that contract over the ROW index (P.V, dS.K, P^T.dO, dS^T.Q) read the same image with
+//     ds_read_b64_tr_b16, the hardware transpose read: no second, transposed copy of V / K / Q / dO is staged.
+// Probabilities and score gradients go from the MFMA D layout to the A layout through a per-wave fp32 LDS patch and
+// are split after the read-back.
+#include "halo_common.h"
+#include "attn_args.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int PS = 68;     // patch row stride in floats: 272 B = 17 x 16 B, so 8-float A fragments are 16-byte aligned
+
+template <int HD>
+struct Img {
+    static constexpr int ROWB = HD * 2 + 16;           // row stride in bytes (multiple of 16)
+    static constexpr int BYTES = 64 * ROWB;            // one image (hi or lo) of a 64-row tile
+    static constexpr int UNITS = 64 * (HD / 4) / 256;  // float4 units per thread and tile
+    static constexpr int KSTEPS = HD / 32;             // 32-deep MFMA steps across the head dimension
+};
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+template <int PASSES>
+__device__ __forceinline__ f32x4 mma(f32x4 acc, const bf16x8 &ah, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bl) {
+    if (PASSES == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// 8 fp32 values of one row (16-byte aligned) -> scaled hi/lo fragments
+__device__ __forceinline__ void load_split8(const float *p, float scale, bf16x8 &hi, bf16x8 &lo) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+    const float x[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+    split8(x, hi, lo);
+}
+
+template <int HD>
+__device__ __forceinline__ void fetch_tile(f32x4 *reg, const float *base, long rs, int row0, int n_rows) {
+#pragma unroll
+    for (int i = 0; i < Img<HD>::UNITS; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        const int row = min(row0 + u / (HD / 4), n_rows - 1), d4 = (u % (HD / 4)) * 4;
+        reg[i] = *reinterpret_cast<const f32x4 *>(base + (long)row * rs + d4);
+    }
+}
+
+// registers (fetch_tile layout) -> hi | lo row-major bf16 images
+template <int HD, int PASSES>
+__device__ __forceinline__ void stage_tile(char *img, const f32x4 *reg) {
+#pragma unroll
+    for (int i = 0; i < Img<HD>::UNITS; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        const int row = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (__bf16)reg[i][e];
+            l[e] = (__bf16)(reg[i][e] - (float)h[e]);
+        }
+        *reinterpret_cast<bf16x4 *>(img + row * Img<HD>::ROWB + d4 * 2) = h;
+        if (PASSES == 3) *reinterpret_cast<bf16x4 *>(img + Img<HD>::BYTES + row * Img<HD>::ROWB + d4 * 2) = l;
+    }
+}
+
+// B (or A) fragment whose k runs along the row: 8 consecutive elements of `row` starting at element k0
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int k0) {
+    return *reinterpret_cast<const bf16x8 *>(img + row * Img<HD>::ROWB + k0 * 2);
+}
+
+// B fragment whose k runs along the ROWS: rows row0 .. row0+7 (this lane's k-group) of column col0 + (lane & 15).
+// ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i
+// receives column i of the 4 rows.  Needs EXEC all ones: call it from wave-uniform code only.
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int row0, int col0, int lr) {
+    const char *p = img + (row0 + (lr >> 2)) * Img<HD>::ROWB + (col0 + 4 * (lr & 3)) * 2;
+    const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)p);
+    const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p + 4 * Img<HD>::ROWB));
+    return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+}
+
+// 8 consecutive floats of a patch row -> hi/lo A fragment
+__device__ __forceinline__ void patch_frag(const float *p, bf16x8 &hi, bf16x8 &lo) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split8(x, hi, lo);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+template <int HD, int PASSES>
+__global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
+    using I = Img<HD>;
+    __shared__ __attribute__((aligned(16))) char Kimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Vimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
+    const int q0 = qt * 64 + wave * 16;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+
+    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS];                       // A[row = lr][k = 32ks + 8lq + e], pre-scaled
+    {
+        const float *qp = qb + (long)min(q0 + lr, Tq - 1) * a.q_rs;
+#pragma unroll
+        for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
+    }
+    f32x4 o[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+
+    int n_ktiles = (klim + 63) / 64;
+    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+    f32x4 kreg[I::UNITS], vreg[I::UNITS];
+    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+        __syncthreads();
+        stage_tile<HD, PASSES>(Kimg, kreg);
+        stage_tile<HD, PASSES>(Vimg, vreg);
+        __syncthreads();
+        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+        f32x4 sacc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                sacc[n] = mma<PASSES>(sacc[n], qh[ks], ql[ks], kh, kl);
+            }
+        }
+        // mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = q0 + 4 * lq + r;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int key = kt * 64 + 16 * n + lr;
+                if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
+                mx = fmaxf(mx, sacc[n][r]);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float mnew = fmaxf(mrow[r], mx);
+            const float msafe = mnew == -INFINITY ? 0.f : mnew;
+            alpha[r] = __expf(mrow[r] - msafe);
+            float ps = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float pv = __expf(sacc[n][r] - msafe);
+                sacc[n][r] = pv;
+                ps += pv;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            lrow[r] = lrow[r] * alpha[r] + ps;
+            mrow[r] = mnew;
+        }
+        float *pw = Ps[wave];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[(4 * lq + r) * PS + 16 * n + lr] = sacc[n][r];
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[m][r] *= alpha[r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // O += P V : two 32-key steps; V fragments come straight from the row-major image through the transpose read
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ph, pl;
+            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, ph, pl);
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                const bf16x8 vh = tr_frag<HD>(Vimg, 32 * kk + 8 * lq, 16 * m, lr);
+                const bf16x8 vl = PASSES == 3 ? tr_frag<HD>(Vimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : vh;
+                o[m] = mma<PASSES>(o[m], ph, pl, vh, vl);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * lq + r;
+        if (qrow >= Tq) continue;
+        const float inv = 1.0f / lrow[r];
+        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) yp[16 * m + lr] = o[m][r] * inv;
+        if (a.lse && lr == 0) a.lse[((long)b * a.heads + h) * Tq + qrow] = mrow[r] + logf(lrow[r]);
+    }
+}
+
+// ---- backward, dQ sweep: one workgroup = 64 query rows, walks the key tiles ----------------------------------
+template <int HD, int PASSES>
+__global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
+    using I = Img<HD>;
+    __shared__ __attribute__((aligned(16))) char Kimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Vimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int q0 = qt * 64 + wave * 16;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];
+    {
+        const int qrow = min(q0 + lr, Tq - 1);
+#pragma unroll
+        for (int ks = 0; ks < I::KSTEPS; ++ks) {
+            load_split8(qb + (long)qrow * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
+            load_split8(dyb + (long)qrow * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
+        }
+    }
+    float lse_r[4], del_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long stat = ((long)b * a.heads + h) * Tq + min(q0 + 4 * lq + r, Tq - 1);
+        lse_r[r] = a.lse[stat];
+        del_r[r] = a.delta[stat];
+    }
+    f32x4 dq[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n_ktiles = (klim + 63) / 64;
+    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+    f32x4 kreg[I::UNITS], vreg[I::UNITS];
+    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+        __syncthreads();
+        stage_tile<HD, PASSES>(Kimg, kreg);
+        stage_tile<HD, PASSES>(Vimg, vreg);
+        __syncthreads();
+        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+        f32x4 sacc[4], pacc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                const bf16x8 vh = row_frag<HD>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 vl = PASSES == 3 ? row_frag<HD>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
+                sacc[n] = mma<PASSES>(sacc[n], qh[ks], ql[ks], kh, kl);
+                pacc[n] = mma<PASSES>(pacc[n], doh[ks], dol[ks], vh, vl);
+            }
+        }
+        float *pw = Ps[wave];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
+                const bool hidden = key >= klim || (a.causal && key > qrow + coff);
+                const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
+                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (pacc[n][r] - del_r[r]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 dh, dl;
+            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, dh, dl);
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                const bf16x8 kh = tr_frag<HD>(Kimg, 32 * kk + 8 * lq, 16 * m, lr);
+                const bf16x8 kl = PASSES == 3 ? tr_frag<HD>(Kimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : kh;
+                dq[m] = mma<PASSES>(dq[m], dh, dl, kh, kl);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * lq + r;
+        if (qrow >= Tq) continue;
+        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) dp[16 * m + lr] = dq[m][r] * a.scale;
+    }
+}
+
+// ---- backward, dK/dV sweep: one workgroup = 64 keys, walks the query tiles -----------------------------------
+template <int HD, int PASSES>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
+    using I = Img<HD>;
+    __shared__ __attribute__((aligned(16))) char Qimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Oimg[2 * I::BYTES];      // dO tile
+    __shared__ __attribute__((aligned(16))) float Ps[4][2][16 * PS];
+    __shared__ float lse_s[64], del_s[64];
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int k0 = kt * 64 + wave * 16;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+    bf16x8 kh[I::KSTEPS], kl[I::KSTEPS], vh[I::KSTEPS], vl[I::KSTEPS];      // A[row = key lr][k = dims]
+    {
+        const int krow = min(k0 + lr, Tk - 1);
+#pragma unroll
+        for (int ks = 0; ks < I::KSTEPS; ++ks) {
+            load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale, kh[ks], kl[ks]);
+            load_split8(vb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, 1.0f, vh[ks], vl[ks]);
+        }
+    }
+    f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int n_qtiles = (Tq + 63) / 64;
+    const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
+    const long stat0 = ((long)b * a.heads + h) * Tq;
+    f32x4 qreg[I::UNITS], oreg[I::UNITS];
+    if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
+    for (int qt = qt0; qt < n_qtiles; ++qt) {
+        __syncthreads();
+        stage_tile<HD, PASSES>(Qimg, qreg);
+        stage_tile<HD, PASSES>(Oimg, oreg);
+        if (threadIdx.x < 64) {
+            const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
+            lse_s[threadIdx.x] = a.lse[stat0 + qrow];
+            del_s[threadIdx.x] = a.delta[stat0 + qrow];
+        }
+        __syncthreads();
+        if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
+        f32x4 sacc[4], pacc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const bf16x8 qfh = row_frag<HD>(Qimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 qfl = PASSES == 3 ? row_frag<HD>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
+                const bf16x8 ofh = row_frag<HD>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 ofl = PASSES == 3 ? row_frag<HD>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
+                sacc[n] = mma<PASSES>(sacc[n], kh[ks], kl[ks], qfh, qfl);       // S^T: rows = keys, cols = queries
+                pacc[n] = mma<PASSES>(pacc[n], vh[ks], vl[ks], ofh, ofl);       // dP^T
+            }
+        }
+        float *pw = Ps[wave][0], *dw = Ps[wave][1];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int qi = 16 * n + lr, qrow = qt * 64 + qi;
+            const float l = lse_s[qi], dl = del_s[qi];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 4 * lq + r;
+                const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
+                const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
+                pw[(4 * lq + r) * PS + qi] = p;
+                dw[(4 * lq + r) * PS + qi] = p * (pacc[n][r] - dl);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ph, pl, dh, dl;
+            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, ph, pl);
+            patch_frag(dw + lr * PS + 32 * kk + 8 * lq, dh, dl);
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                const bf16x8 oth = tr_frag<HD>(Oimg, 32 * kk + 8 * lq, 16 * m, lr);
+                const bf16x8 otl = PASSES == 3 ? tr_frag<HD>(Oimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : oth;
+                const bf16x8 qth = tr_frag<HD>(Qimg, 32 * kk + 8 * lq, 16 * m, lr);
+                const bf16x8 qtl = PASSES == 3 ? tr_frag<HD>(Qimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : qth;
+                dv[m] = mma<PASSES>(dv[m], ph, pl, oth, otl);
+                dk[m] = mma<PASSES>(dk[m], dh, dl, qth, qtl);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 4 * lq + r;
+        if (key >= Tk) continue;
+        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) {
+            kp[16 * m + lr] = dk[m][r] * a.scale;
+            vp[16 * m + lr] = dv[m][r];
+        }
+    }
+}
+
+template <int HD, int PASSES>
+int launch_fwd(const AttnArgs &a, int N, hipStream_t st) {
+    hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES>), dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    return halo_launch_status();
+}
+
+template <int HD, int PASSES>
+int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
+    hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES>), dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES>), dim3((a.Tk + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    return halo_launch_status();
+}
+
+}  // namespace
+
+// the fragment loads are 16-byte vector loads: row strides and head offsets must keep them aligned
+static bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
+
+int halo_attention_fwd_mx(const AttnArgs &a, int N, int head_dim, int passes, hipStream_t st) {
+    if (!aligned16(a.q) || a.q_rs % 4 || a.q_bs % 4 || a.q_hs % 4) return HALO_ENOTSUP;
+    if (head_dim == 64) return passes == 1 ? launch_fwd<64, 1>(a, N, st) : launch_fwd<64, 3>(a, N, st);
+    if (head_dim == 32) return passes == 1 ? launch_fwd<32, 1>(a, N, st) : launch_fwd<32, 3>(a, N, st);
+    return HALO_ENOTSUP;
+}
+
+int halo_attention_bwd_mx(const AttnBwdArgs &a, int N, int head_dim, int passes, hipStream_t st) {
+    if (head_dim == 64) return passes == 1 ? launch_bwd<64, 1>(a, N, st) : launch_bwd<64, 3>(a, N, st);
+    if (head_dim == 32) return passes == 1 ? launch_bwd<32, 1>(a, N, st) : launch_bwd<32, 3>(a, N, st);
+    return HALO_ENOTSUP;
+}

@@ -116,10 +116,11 @@ struct TiledGemmArgs {
     float *slab;
 };
 
+template <int PASSES>
 __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int wave, int lane) {
-    // 16 KiB block = 16 wave-instructions of 1 KiB; each of the 4 waves issues 4
+    // 16 KiB block = 16 wave-instructions of 1 KiB; each of the 4 waves issues 4 (PASSES == 1: only the hi part, 2 each)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (PASSES == 3 ? 4 : 2); ++i) {
         const int piece = i * 4 + wave;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gblk + piece * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
@@ -127,7 +128,7 @@ __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int
 }
 
 constexpr int STAGE_BYTES = 2 * BLOCK_BYTES;    // one ring slot: A block | B block = 32 KiB
-constexpr int LOADS_PER_STAGE = 8;              // global_load_lds per thread and stage
+constexpr int LOADS_PER_STAGE = 8;              // global_load_lds per thread and stage (hi + lo; half of it when only hi is staged)
 
 template <int N>
 __device__ __forceinline__ void wait_vm_and_barrier() {
@@ -145,8 +146,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int NSTAGE>
+// PASSES == 3: split-bf16 (hi*hi + hi*lo + lo*hi);  PASSES == 1: plain bf16 operands (hi parts only: HALO_MATH_BF16)
+template <int NSTAGE, int PASSES>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
+    constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int kslice = blockIdx.x / p.ntiles;
     // within an XCD's contiguous run, walk the tiles in groups of 8 tile rows, column by column: the
@@ -191,17 +194,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
         const int t = min(s, nkt - 1);
-        stage_block(Ablk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES, wave, lane);
-        stage_block(Bblk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES + BLOCK_BYTES, wave, lane);
+        stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES, wave, lane);
+        stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES + BLOCK_BYTES, wave, lane);
     }
     for (int t = 0; t < nkt; ++t) {
         // tile t is complete once all but the newest (NSTAGE-2) stages have landed
-        wait_vm_and_barrier<(NSTAGE - 2) * LOADS_PER_STAGE>();
+        wait_vm_and_barrier<(NSTAGE - 2) * LOADS>();
         {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
             const int tn = min(t + NSTAGE - 1, nkt - 1);
             char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * STAGE_BYTES;
-            stage_block(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
-            stage_block(Bblk + (long)tn * BLOCK_BYTES, slot + BLOCK_BYTES, wave, lane);
+            stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
+            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, slot + BLOCK_BYTES, wave, lane);
         }
         const char *cur = lds + (t % NSTAGE) * STAGE_BYTES;
         const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + BLOCK_BYTES, *bl = cur + BLOCK_BYTES + PART_BYTES;
@@ -212,9 +215,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 fah[ks][i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
-                fal[ks][i] = *reinterpret_cast<const bf16x8 *>(al + aoff[i][ks]);
                 fbh[ks][i] = *reinterpret_cast<const bf16x8 *>(bh + boff[i][ks]);
-                fbl[ks][i] = *reinterpret_cast<const bf16x8 *>(bl + boff[i][ks]);
+                if (PASSES == 3) {
+                    fal[ks][i] = *reinterpret_cast<const bf16x8 *>(al + aoff[i][ks]);
+                    fbl[ks][i] = *reinterpret_cast<const bf16x8 *>(bl + boff[i][ks]);
+                }
             }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -222,8 +227,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbl[ks][j], acc[i][j], 0, 0, 0);
+                    if (PASSES == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbl[ks][j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[ks][i], fbh[ks][j], acc[i][j], 0, 0, 0);
                 }
     }
@@ -286,9 +293,13 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
         // ring depth: 2 slots = 64 KiB (two workgroups per CU), 4 slots = 128 KiB (one); opt in to the LDS size once
         const char *e = getenv("HALO_GEMM_STAGES");
         const int want = e ? atoi(e) : 2;
-        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
         nstage = want == 4 ? 4 : 2;
@@ -306,10 +317,12 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
     void *scratch; size_t bytes;
     halo_get_scratch(&scratch, &bytes);
     p.slab = (float *)scratch;
-    if (nstage == 4)
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 4 * STAGE_BYTES, st, p);
-    else
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3((unsigned)(p.ntiles * p.ksplit)), dim3(256), 2 * STAGE_BYTES, st, p);
+    const dim3 grid((unsigned)(p.ntiles * p.ksplit));
+    const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
+    if (nstage == 4 && one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    else if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
     if (rc != HALO_OK || p.ksplit == 1) return rc;
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);

@@ -736,7 +736,8 @@ inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
     return lb;
 }
 
-inline bool use_x3(int H) { return halo_math_mode() == HALO_MATH_BF16X3 && H % 32 == 0; }
+// HALO_MATH_BF16 only narrows the GEMM / attention operands; the recurrent step keeps the split (hi + lo) form
+inline bool use_x3(int H) { return halo_math_mode() != HALO_MATH_F32 && H % 32 == 0; }
 
 // waves = (gate, k-slice): the slice count must divide the number of k-blocks
 inline int pick_fwd_ks(int H, bool x3) {
@@ -828,7 +829,7 @@ inline int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st) {
 
 // ---- layer-diagonal fused path: eligibility, extra buffers, drivers ------------------------------
 inline bool fused_ok(int H, int L) {
-    return halo_lstm_fusion() && L >= 2 && L <= MAXL && halo_math_mode() == HALO_MATH_BF16X3 && H % 64 == 0;
+    return halo_lstm_fusion() && L >= 2 && L <= MAXL && halo_math_mode() != HALO_MATH_F32 && H % 64 == 0;
 }
 // appended to the reserve: packed forward weights of every layer (all layers are live at once) and the
 // packed y_{l,t} images of the non-top layers
@@ -1041,7 +1042,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             in_dim = H;
         }
         // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
-        if (halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64) {
+        if (halo_math_mode() != HALO_MATH_F32 && in_dim >= 64) {
             HALO_TRY(halo_prep_tiles(in, T * B, in_dim, in_dim, 0, img_in, st));
             HALO_TRY(halo_prep_tiles(w_ih[l], 4 * H, in_dim, in_dim, 0, img_w, st));
             HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, lb.gates, 4 * H, b_ih[l], b_hh[l], 0,
@@ -1163,7 +1164,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         float *din_out = l > 0 ? din : dx;
         const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
                                               offset, offset_dev);
-        const bool tiled = halo_math_mode() == HALO_MATH_BF16X3 && in_dim >= 64;
+        const bool tiled = halo_math_mode() != HALO_MATH_F32 && in_dim >= 64;
         // (1) critical path, main stream: the gradient w.r.t. this layer's input feeds layer l-1's steps
         if (need_din) {
             if (tiled) {

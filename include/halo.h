@@ -40,13 +40,17 @@ const char *halo_strerror(int code);
 /* Device sanity for the loader: returns HALO_OK and fills arch (e.g. "gfx950") and CU count. */
 int halo_device_info(int device, char *arch, int arch_len, int *cu_count);
 
-/* Arithmetic of the large LSTM GEMMs (input projections, weight/input gradients):
+/* Arithmetic of the dense products (large GEMMs, the recurrent LSTM GEMM, attention Q.K^T / P.V and their gradients):
  *   HALO_MATH_F32     exact-f32 MFMA (default)
  *   HALO_MATH_BF16X3  operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
- *                     (~2^-16 relative error per product; 5.3x the f32 matrix rate)
+ *                     (~2^-16 relative error per product; 5.3x the f32 matrix rate): fp32-grade results
+ *   HALO_MATH_BF16    operands rounded to bf16, one MFMA per product, fp32 accumulate -- the arithmetic of the reference's
+ *                     `torch.autocast(dtype=bfloat16)` runs (ha/attention_loop.py:87); GEMMs and attention only, the
+ *                     recurrent LSTM step keeps the split form.  State, softmax, LayerNorm, losses stay fp32 in every mode.
  * Process-wide; set it before the first call / graph capture. */
 #define HALO_MATH_F32 0
 #define HALO_MATH_BF16X3 1
+#define HALO_MATH_BF16 2
 int halo_set_math_mode(int mode);
 int halo_get_math_mode(void);
 
