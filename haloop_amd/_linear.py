@@ -30,11 +30,13 @@ class WeightImages:
 
     def split(self, weights):
         """The split/tiled image of the (concatenated) weight."""
-        return self._lookup('split', weights, lambda: ops.split_image(self.dense(weights).contiguous()))
+        # bf16 mode writes only the hi part of an image: keep the images of different modes apart
+        return self._lookup('split:' + _lib.get_math_mode(), weights, lambda: ops.split_image(self.dense(weights).contiguous()))
 
     def split_t(self, weights):
         """The image of W^T (logical [in, sum out]) of the (concatenated) weight: the B operand of dx = dy W."""
-        return self._lookup('split_t', weights, lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
+        return self._lookup('split_t:' + _lib.get_math_mode(), weights,
+                            lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False):

@@ -36,7 +36,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &
 
 // src row-major [R][K] (leading dimension ld): one workgroup writes one (rt, kt) block
 __global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restrict__ src, int R, int K, int ld,
-                                                            char *__restrict__ img, int KT) {
+                                                            char *__restrict__ img, int KT, int with_lo) {
     const int kt = blockIdx.x, rt = blockIdx.y;
     char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
     const bool vec = (ld % 4 == 0) && ((uintptr_t)src % 16 == 0);
@@ -61,13 +61,13 @@ __global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restr
         split8(x, hi, lo);
         const int off = swz_byte(row, c);
         *reinterpret_cast<bf16x8 *>(blk + off) = hi;
-        *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;   // HALO_MATH_BF16 never reads the lo part
     }
 }
 
 // src stored transposed: memory [K][R] (leading dimension ld, R contiguous); logical X[r][k] = src[k*ld + r]
 __global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__restrict__ src, int R, int K, int ld,
-                                                              char *__restrict__ img, int KT) {
+                                                              char *__restrict__ img, int KT, int with_lo) {
     __shared__ float tile[TK][TR + 1];
     const int kt = blockIdx.x, rt = blockIdx.y;
     char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__res
         split8(x, hi, lo);
         const int off = swz_byte(row, c);
         *reinterpret_cast<bf16x8 *>(blk + off) = hi;
-        *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;   // HALO_MATH_BF16 never reads the lo part
     }
 }
 
@@ -150,6 +150,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 template <int NSTAGE, int PASSES>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
     constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
+    // ring slot: [A block | B block]; with one pass only the hi parts are staged, so a slot is half the size and the
+    // same LDS holds a ring twice as deep (the single-pass loop is bound by LDS-DMA latency, not by the MFMAs)
+    constexpr int OPER = PASSES == 3 ? BLOCK_BYTES : PART_BYTES, SLOT = 2 * OPER;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int kslice = blockIdx.x / p.ntiles;
     // within an XCD's contiguous run, walk the tiles in groups of 8 tile rows, column by column: the
@@ -194,20 +197,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
         const int t = min(s, nkt - 1);
-        stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES, wave, lane);
-        stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * STAGE_BYTES + BLOCK_BYTES, wave, lane);
+        stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * SLOT, wave, lane);
+        stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * SLOT + OPER, wave, lane);
     }
     for (int t = 0; t < nkt; ++t) {
         // tile t is complete once all but the newest (NSTAGE-2) stages have landed
         wait_vm_and_barrier<(NSTAGE - 2) * LOADS>();
         {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
             const int tn = min(t + NSTAGE - 1, nkt - 1);
-            char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * STAGE_BYTES;
+            char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * SLOT;
             stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
-            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, slot + BLOCK_BYTES, wave, lane);
+            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, slot + OPER, wave, lane);
         }
-        const char *cur = lds + (t % NSTAGE) * STAGE_BYTES;
-        const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + BLOCK_BYTES, *bl = cur + BLOCK_BYTES + PART_BYTES;
+        const char *cur = lds + (t % NSTAGE) * SLOT;
+        const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + OPER, *bl = cur + OPER + PART_BYTES;
         // both k-steps' fragments are requested up front: the second set lands under the first set's MFMAs
         bf16x8 fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];
 #pragma unroll
@@ -278,17 +281,18 @@ size_t halo_tiled_image_bytes(int R, int K) {
 }
 
 int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, void *image, hipStream_t st) {
+    const int with_lo = halo_math_mode() != HALO_MATH_BF16;   // images made in bf16 mode must be remade after a mode switch
     const int KT = (K + TK - 1) / TK, RT = (R + TR - 1) / TR;
     if (src_transposed)
-        hipLaunchKernelGGL(prep_transposed_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT);
+        hipLaunchKernelGGL(prep_transposed_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT, with_lo);
     else
-        hipLaunchKernelGGL(prep_rowmajor_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT);
+        hipLaunchKernelGGL(prep_rowmajor_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT, with_lo);
     return halo_launch_status();
 }
 
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
-    static int nstage = 0;
+    static int nstage = 0, nstage1 = 0;
     if (!nstage) {
         // ring depth: 2 slots = 64 KiB (two workgroups per CU), 4 slots = 128 KiB (one); opt in to the LDS size once
         const char *e = getenv("HALO_GEMM_STAGES");
@@ -297,12 +301,15 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
                                 2 * STAGE_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * STAGE_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * STAGE_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
         nstage = want == 4 ? 4 : 2;
+        // single pass: 4 half-size slots = 64 KiB (two workgroups per CU) or 8 = 128 KiB (one)
+        const char *e1 = getenv("HALO_GEMM_STAGES_BF16");
+        nstage1 = e1 && atoi(e1) == 8 ? 8 : 4;
     }
     TiledGemmArgs p;
     p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.bias1 = bias1; p.bias2 = bias2;
@@ -319,9 +326,9 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
     p.slab = (float *)scratch;
     const dim3 grid((unsigned)(p.ntiles * p.ksplit));
     const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
-    if (nstage == 4 && one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    if (one_pass && nstage1 == 8) hipLaunchKernelGGL((gemm_bf16x3_kernel<8, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    else if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
-    else if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
     if (rc != HALO_OK || p.ksplit == 1) return rc;
