@@ -63,7 +63,8 @@ SIGNATURES = {
     'halo_attention_causal_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'halo_cross_entropy_fwd': (_i, [_vp, _vp, _vp, _i, _i, _l, _l, _vp]),
     'halo_attention_fwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    'halo_attention_fwd_strided': (_i, [_vp, _l, _l, _l, _vp, _vp, _l, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'halo_attention_fwd_strided': (_i, [_vp, _l, _l, _l, _vp, _vp, _l, _l, _l, _vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp,
+                                        _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_kv_cache_store_f32': (_i, [_vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_rope_table': (_i, [_vp, _vp, _i, _i, _f, _vp]),
     'halo_rope_interleaved': (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
@@ -72,7 +73,7 @@ SIGNATURES = {
     'halo_logprob_max': (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_greedy_update': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'halo_attention_bwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _l, _l, _vp, _vp, _l, _l,
-                                _i, _i, _i, _i, _i, _i, _vp, _vp]),
+                                _i, _i, _i, _i, _i, _i, _vp, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_layernorm_bwd_workspace_bytes': (_sz, [_i, _i]),
     'halo_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),

@@ -39,18 +39,19 @@ class WeightImages:
                             lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
 
 
-def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False):
+def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
     ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
-    and version), not views made per call."""
+    and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add)."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
     M, K = x2d.shape
     N = sum(w.shape[0] for w in weights)
     if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64:
         return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
-                              accumulate=accumulate)
-    return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate)
+                              accumulate=accumulate, drop=drop, stream_id=stream_id)
+    return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate,
+                    drop=drop, stream_id=stream_id)
 
 
 def use_split(M, N, K):
@@ -76,3 +77,25 @@ def linear_dw(dy2d, x2d, out=None, accumulate=False):
         return ops.gemm_split(ops.split_image(dy2d, transposed=True), ops.split_image(x2d, transposed=True), M, N, K, out=out,
                               accumulate=accumulate)
     return ops.gemm(dy2d, x2d, False, False, M, N, K, out=out, accumulate=accumulate)
+
+
+class DropSites:
+    """Dropout of one training forward: (p, seed, offset) from the module's DropoutStream plus a running stream id, one per
+    dropout site in forward order (the backward replays the same ids).  p == 0 hands out NO_DROPOUT."""
+    BASE = 64
+
+    def __init__(self, drop):
+        self.drop, self.n = drop, 0
+
+    def next(self):
+        self.n += 1
+        return self.drop, self.BASE + self.n - 1
+
+
+NO_SITES = DropSites(ops.NO_DROPOUT)
+
+
+def drop_rows(x2d, site):
+    """x2d * mask of a dropout site (elementwise kernel); the same call gives the backward of that site."""
+    drop, sid = site
+    return ops.dropout_fwd(x2d, drop, sid) if drop.p > 0 else x2d

@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
                 for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
                 lrow[r] = lrow[r] * alpha[r] + ps;
                 mrow[r] = mnew;
+                if (a.use_drop) {                          // the normaliser keeps the undropped sum (dropout acts on softmax's output)
+                    const f32x4 dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
+                }
             }
             // P from the D layout to the A layout through this wave's LDS patch
             float *pw = Ps[wave];
@@ -474,7 +479,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
                 const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
                 const bool hidden = key >= klim || (a.causal && key > qrow + coff);
                 const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
-                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (pacc[n][r] - del_r[r]);
+                float dp = pacc[n][r];
+                if (a.use_drop)
+                    dp *= dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + n);
+                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (dp - del_r[r]);
             }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -562,8 +570,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
                 const int key = k0 + 4 * lq + r;
                 const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
                 const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
-                pw[(4 * lq + r) * PS + qi] = p;
-                dw[(4 * lq + r) * PS + qi] = p * (pacc[n][r] - dl);
+                float dm = 1.0f;
+                if (a.use_drop)
+                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) +
+                                                  4 * (4 * lq + r) + wave);
+                pw[(4 * lq + r) * PS + qi] = p * dm;
+                dw[(4 * lq + r) * PS + qi] = p * (dm * pacc[n][r] - dl);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -615,7 +627,8 @@ extern "C" {
 int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_stride, long q_head_stride, const float *k,
                                const float *v, long kv_row_stride, long kv_batch_stride, long kv_head_stride, float *y,
                                long y_row_stride, long y_batch_stride, float *lse, float *entropy, int N, int heads, int head_dim,
-                               int Tq, int Tk, int causal, const int *key_lengths, halo_stream_t stream) {
+                               int Tq, int Tk, int causal, const int *key_lengths, float p_drop, uint64_t seed, uint32_t stream_id,
+                               uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
     HALO_CHECK_ARG(q && k && v && y && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
     HALO_CHECK_ARG(((uintptr_t)k | (uintptr_t)v) % 16 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0 &&
                    kv_head_stride % 4 == 0);
@@ -627,6 +640,9 @@ int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_s
     a.y_rs = y_row_stride; a.y_bs = y_batch_stride; a.key_len = key_lengths;
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
     a.scale = 1.0f / sqrtf((float)head_dim);
+    a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    a.use_drop = p_drop > 0.f;
+    HALO_CHECK_ARG(!(a.use_drop && entropy));       // the entropy monitor is an eval-time measurement
     hipStream_t st = (hipStream_t)stream;
     if (halo_math_mode() != HALO_MATH_F32 && !entropy && (head_dim == 64 || head_dim == 32)) {
         const int rc = halo_attention_fwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
@@ -646,13 +662,14 @@ int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, c
                        halo_stream_t stream) {
     return halo_attention_fwd_strided(q, q_row_stride, q_batch_stride, head_dim, k, v, kv_row_stride, kv_batch_stride, head_dim, y,
                                       y_row_stride, y_batch_stride, lse, entropy, N, heads, head_dim, Tq, Tk, causal, key_lengths,
-                                      stream);
+                                      0.f, 0, 0, 0, nullptr, stream);
 }
 
 int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
                        long kv_batch_stride, const float *y, const float *dy, long y_row_stride, long y_batch_stride, const float *lse,
                        float *delta, float *dq, long dq_row_stride, long dq_batch_stride, float *dk, float *dv, long dkv_row_stride,
                        long dkv_batch_stride, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev,
                        halo_stream_t stream) {
     HALO_CHECK_ARG(q && k && v && y && dy && lse && delta && dq && dk && dv && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
     HALO_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dy) % 16 == 0);
@@ -666,6 +683,8 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
     a.dkv_rs = dkv_row_stride; a.dkv_bs = dkv_batch_stride; a.key_len = key_lengths;
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
     a.scale = 1.0f / sqrtf((float)head_dim);
+    a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    a.use_drop = p_drop > 0.f;
     hipStream_t st = (hipStream_t)stream;
     if (halo_math_mode() != HALO_MATH_F32 && (head_dim == 64 || head_dim == 32)) {
         if (head_dim == 64)

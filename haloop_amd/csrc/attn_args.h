@@ -1,6 +1,7 @@
 // Argument blocks shared by the attention kernels of attn.hip (exact-f32 MFMA) and attn_mx.hip (split-bf16 MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "halo_common.h"
 
 struct AttnArgs {
     const float *q, *k, *v;
@@ -10,7 +11,17 @@ struct AttnArgs {
     const int *key_len;                          // [N] keys >= key_len[n] are masked, may be NULL
     int Tq, Tk, heads, causal;
     float scale;
+    DropoutCfg drop;                             // dropout on the attention probabilities (training), see attn_drop_index
+    int use_drop;
 };
+
+// Philox element index of attention probability (n, h, i, j): the four 16-key sub-tiles (j%64)/16 = 0..3 that one lane holds
+// for a query row sit in ONE Philox group, so a 64-key tile costs a lane one Philox call per row:
+//     e = ((((n*H + h)*Tq + i) * ceil(Tk/64) + j/64) * 64 + 4*(j%16) + (j%64)/16
+// (oracle/transformer_ref.py: attention_dropout_mask restates it)
+__device__ __forceinline__ uint64_t attn_drop_tile_base(int n, int H, int h, int Tq, int i, int KT, int kt) {
+    return ((((uint64_t)n * H + h) * Tq + i) * KT + kt) * 64;
+}
 
 struct AttnBwdArgs {
     const float *q, *k, *v, *dy, *lse, *delta;
@@ -19,6 +30,8 @@ struct AttnBwdArgs {
     const int *key_len;
     int Tq, Tk, heads, causal;
     float scale;
+    DropoutCfg drop;
+    int use_drop;
 };
 
 // attn_mx.hip: the same products on v_mfma_f32_16x16x32_bf16 with operands split hi + lo (passes = 3) or rounded to bf16 (passes = 1)

@@ -187,6 +187,11 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
             for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
             lrow[r] = lrow[r] * alpha[r] + ps;
             mrow[r] = mnew;
+            if (a.use_drop) {                              // the normaliser keeps the undropped sum
+                const f32x4 dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
+            }
         }
         float *pw = Ps[wave];
 #pragma unroll
@@ -293,7 +298,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
                 const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
                 const bool hidden = key >= klim || (a.causal && key > qrow + coff);
                 const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
-                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (pacc[n][r] - del_r[r]);
+                float dp = pacc[n][r];
+                if (a.use_drop)
+                    dp *= dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + n);
+                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (dp - del_r[r]);
             }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -390,8 +398,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
                 const int key = k0 + 4 * lq + r;
                 const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
                 const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
-                pw[(4 * lq + r) * PS + qi] = p;
-                dw[(4 * lq + r) * PS + qi] = p * (pacc[n][r] - dl);
+                float dm = 1.0f;
+                if (a.use_drop)
+                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) +
+                                                  4 * (4 * lq + r) + wave);
+                pw[(4 * lq + r) * PS + qi] = p * dm;
+                dw[(4 * lq + r) * PS + qi] = p * (dm * pacc[n][r] - dl);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -358,9 +358,10 @@ def cross_entropy_fwd(logits2d, targets, ignore_index=0):
 
 
 # ---- attention / rotary / KV-cache operators (GPT and the enc-dec ASR path) ------------------------------
-def attention_fwd(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, want_lse=False, want_entropy=False):
+def attention_fwd(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, want_lse=False, want_entropy=False,
+                  drop=NO_DROPOUT, stream_id=0):
     """q: rows [N*Tq, >=C] (a column slice of a packed GEMM output is fine), k/v: rows [N*Tk, ...] sharing one row stride.
-    -> y [N*Tq, C] (+ lse / entropy [N, heads, Tq] when asked)."""
+    -> y [N*Tq, C] (+ lse / entropy [N, heads, Tq] when asked).  ``drop``: dropout on the attention probabilities."""
     C = heads * head_dim
     for t in (q, k, v):
         if t.dtype != torch.float32 or not t.is_cuda or t.stride(-1) != 1:
@@ -373,9 +374,10 @@ def attention_fwd(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths
     ent = torch.empty(N, heads, Tq, device=dev, dtype=torch.float32) if want_entropy else None
     if key_lengths is not None:
         key_lengths = key_lengths.to(device=dev, dtype=torch.int32).contiguous()
-    check(lib().halo_attention_fwd(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), C,
-                                   C * Tq, ptr(lse), ptr(ent), N, heads, head_dim, Tq, Tk, int(causal), ptr(key_lengths), _stream()),
-          'halo_attention_fwd')
+    check(lib().halo_attention_fwd_strided(ptr(q), q.stride(0), q.stride(0) * Tq, head_dim, ptr(k), ptr(v), k.stride(0),
+                                           k.stride(0) * Tk, head_dim, ptr(y), C, C * Tq, ptr(lse), ptr(ent), N, heads, head_dim, Tq, Tk,
+                                           int(causal), ptr(key_lengths), drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr,
+                                           _stream()), 'halo_attention_fwd')
     return y, lse, ent
 
 
@@ -406,7 +408,7 @@ def attention_cached_fwd(q, cache_k, cache_v, Tq, n_keys, causal=True):
     y = torch.empty(N * Tq, C, device=q.device, dtype=torch.float32)
     check(lib().halo_attention_fwd_strided(ptr(q), q.stride(0), q.stride(0) * Tq, hd, ptr(cache_k), ptr(cache_v), hd, heads * Tc * hd,
                                            Tc * hd, ptr(y), C, C * Tq, None, None, N, heads, hd, Tq, n_keys, int(causal), None,
-                                           _stream()), 'halo_attention_fwd_strided')
+                                           0.0, 0, 0, 0, None, _stream()), 'halo_attention_fwd_strided')
     return y
 
 
@@ -471,7 +473,8 @@ def dwconv1d_cl(x3d, weight, bias, stride, pad):
 
 
 # ---- backward operators of the GPT / transformer training step ----------------------------------------------
-def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None):
+def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT,
+                  stream_id=0):
     """Gradients of attention_fwd written into the caller's dq / dk / dv views (row layouts like q / k / v)."""
     C = heads * head_dim
     _f32c(y, 'y'); _f32c(dy, 'dy')
@@ -481,7 +484,7 @@ def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, c
     check(lib().halo_attention_bwd(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), ptr(dy),
                                    C, C * Tq, ptr(lse), ptr(delta), ptr(dq), dq.stride(0), dq.stride(0) * Tq, ptr(dk), ptr(dv),
                                    dk.stride(0), dk.stride(0) * Tk, N, heads, head_dim, Tq, Tk, int(causal), ptr(key_lengths),
-                                   _stream()), 'halo_attention_bwd')
+                                   drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_attention_bwd')
 
 
 def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5):

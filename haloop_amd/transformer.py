@@ -17,8 +17,12 @@ decoder CE + 0.3 CTC) return tensors with a grad_fn whose backward is hand-writt
 blocks with shared-x_norm cross/self attention, inverse rotary, exact-GELU MLP, LayerNorm, embedding, CE), so
 ``loss.backward()`` fills ``.grad`` of every parameter like the reference's autograd does.
 
-Not built (raises): dropout (p_drop > 0 in training mode), autograd through a bare Block / MultiHeadAttention
-call, ``kv_cache_parts`` on the public Block / MultiHeadAttention.forward (Decoder.decode drives the caches
+Training-mode dropout (p_drop > 0): every site of the reference (encoder input, attention probabilities, both
+proj outputs, MLP output) draws from a Philox stream keyed by torch.initial_seed() -- statistically the reference's
+dropout, not torch's bit stream; the output dropouts are GEMM epilogues, the probability dropout lives inside the
+attention kernels (forward and both backward sweeps recompute the same mask).
+
+Not built (raises): autograd through a bare Block / MultiHeadAttention call, ``kv_cache_parts`` on the public Block / MultiHeadAttention.forward (Decoder.decode drives the caches
 itself), arbitrary attention masks (only the key-padding masks Block builds, transformer.py:476).
 """
 import math
@@ -29,10 +33,11 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import WeightImages, linear, linear_dw, linear_dx
+from ._linear import NO_SITES, DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx
 from .attention import LayerNorm
 from .conv import ConvEncoder
 from .recognizer import TemporalClassifier
+from .rnn import DropoutStream
 
 BlockKVCache = namedtuple('BlockKVCache', ['memory', 'time'])
 Stats = namedtuple('Stats', ['meme_entropy', 'self_entropy'])
@@ -47,14 +52,26 @@ def _wants_grad(module):
 def _check_device_and_dropout(module, x):
     if not x.is_cuda:
         raise _lib.HaloError(f'haloop_amd.transformer.{type(module).__name__} runs on the HIP device only (no CPU path)')
-    if module.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in module.modules()):
-        raise NotImplementedError('dropout (p_drop > 0 in training mode) is not built: construct with p_drop=0.0 or call .eval()')
+    if module.training and not _wants_grad(module) and _p_drop(module) > 0:
+        raise NotImplementedError('training-mode dropout is built into the autograd path only: enable grad, or call .eval()')
+
+
+def _p_drop(module):
+    """The model's dropout probability (the reference builds every site from one p_drop)."""
+    ps = {float(m.p) for m in module.modules() if isinstance(m, nn.Dropout)}
+    ps |= {float(m.p_drop) for m in module.modules() if hasattr(m, 'p_drop')}
+    if len(ps) > 1:
+        raise NotImplementedError(f'one dropout probability per model is built, found {sorted(ps)}')
+    return ps.pop() if ps else 0.0
 
 
 def _require_inference(module, x):
     """Module-level calls (Block, MultiHeadAttention, attend) have no autograd of their own: gradients flow through
     AudioEncoder.forward / Decoder.forward, whose backward is hand-written end to end."""
-    _check_device_and_dropout(module, x)
+    if not x.is_cuda:
+        raise _lib.HaloError(f'haloop_amd.transformer.{type(module).__name__} runs on the HIP device only (no CPU path)')
+    if module.training and _p_drop(module) > 0:
+        raise NotImplementedError('training-mode dropout is built into the AudioEncoder / Decoder autograd path only: call .eval()')
     if _wants_grad(module):
         raise NotImplementedError('haloop_amd.transformer.' + type(module).__name__ + ' has no autograd of its own: train through '
                                   'AudioEncoder / Decoder / CTCAttentionDecoder, or call it under torch.no_grad()')
@@ -204,7 +221,7 @@ class MultiHeadAttention(nn.Module):
         return y, (ent.mean() if measure_entropy else torch.tensor(float('-inf')))
 
     # training twins of _attend2d: keep q/k/v (after the rotary), the output and the log-sum-exp
-    def _attend2d_train(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False):
+    def _attend2d_train(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, site=(ops.NO_DROPOUT, 0)):
         C = self.heads * self.head_dim
         if mem2d is None:
             qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight))
@@ -218,13 +235,14 @@ class MultiHeadAttention(nn.Module):
             table = _rope_table(self._tables, max(T, S), self.head_dim, x2d.device)
             ops.rope_(q, T, self.heads, self.head_dim, table)
             ops.rope_(k, S, self.heads, self.head_dim, table)
-        y, lse, _ = ops.attention_fwd(q, k, v, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths, want_lse=True)
-        return y, (x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S)
+        y, lse, _ = ops.attention_fwd(q, k, v, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths, want_lse=True,
+                                      drop=site[0], stream_id=site[1])
+        return y, (x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S, site)
 
     def _attend2d_bwd(self, saved, dy, put, dx_out=None, dmem_out=None):
         """dy: gradient of the attention output (before proj).  Accumulates the input gradient into dx_out (allocates it
         when None) and, for cross-attention, the memory gradient into dmem_out.  -> dx"""
-        x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S = saved
+        x2d, mem2d, q, k, v, y, lse, key_lengths, causal, table, N, T, S, site = saved
         C = self.heads * self.head_dim
         dev = x2d.device
         if mem2d is None:
@@ -234,7 +252,8 @@ class MultiHeadAttention(nn.Module):
             dq = torch.empty(N * T, C, device=dev, dtype=torch.float32)
             dkv = torch.empty(N * S, 2 * C, device=dev, dtype=torch.float32)
             dk, dv = dkv[:, :C], dkv[:, C:]
-        ops.attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths)
+        ops.attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, self.heads, self.head_dim, T, S, causal=causal, key_lengths=key_lengths,
+                          drop=site[0], stream_id=site[1])
         if table is not None:                                   # the rotation is orthogonal: its transpose rotates back
             ops.rope_(dq, T, self.heads, self.head_dim, table, inverse=True)
             ops.rope_(dk, S, self.heads, self.head_dim, table, inverse=True)
@@ -299,37 +318,45 @@ class Block(nn.Module):
         linear(self._images, h, self.mix_chan[2].weight, out=x2d, accumulate=True)
         return m_ent, t_ent
 
-    def _forward2d_train(self, x0, N, T, causal=False, mem2d=None, S=0, memory_lengths=None):
+    def _forward2d_train(self, x0, N, T, causal=False, mem2d=None, S=0, memory_lengths=None, sites=NO_SITES):
+        """Dropout sites in forward order: [cross-attention probabilities, cross proj output,] self-attention probabilities,
+        self proj output, MLP output (ha/transformer.py:356,371,457); each output dropout is the GEMM's epilogue."""
         x_norm = ops.layernorm_fwd(x0, self.ln_time.weight)
-        xa, sv_m = x0, None
+        xa, sv_m, s_mo = x0, None, None
         if self.mix_memory is not None:
             mm = self.mix_memory
-            ym, sv_m = mm._attend2d_train(x_norm, mem2d, N, T, S, key_lengths=memory_lengths)
-            xa = linear(mm._images, ym, mm.proj.weight, out=x0.clone(), accumulate=True)
+            ym, sv_m = mm._attend2d_train(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, site=sites.next())
+            s_mo = sites.next()
+            xa = linear(mm._images, ym, mm.proj.weight, out=x0.clone(), accumulate=True, drop=s_mo[0], stream_id=s_mo[1])
         mt = self.mix_time
-        yt, sv_t = mt._attend2d_train(x_norm, None, N, T, T, causal=causal, rope=True)
-        xb = linear(mt._images, yt, mt.proj.weight, out=xa.clone(), accumulate=True)
+        yt, sv_t = mt._attend2d_train(x_norm, None, N, T, T, causal=causal, rope=True, site=sites.next())
+        s_to = sites.next()
+        xb = linear(mt._images, yt, mt.proj.weight, out=xa.clone(), accumulate=True, drop=s_to[0], stream_id=s_to[1])
         hn = ops.layernorm_fwd(xb, self.ln_chan.weight)
         a = linear(self._images, hn, self.mix_chan[0].weight)
         g = ops.gelu_fwd(a, exact=True)
-        xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True)
-        return xc, (x0, sv_m, sv_t, xb, hn, a, g)
+        s_co = sites.next()
+        xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True, drop=s_co[0], stream_id=s_co[1])
+        return xc, (x0, sv_m, sv_t, xb, hn, a, g, s_mo, s_to, s_co)
 
     def _backward2d(self, saved, dxc, put, dmem_out=None):
-        x0, sv_m, sv_t, xb, hn, a, g = saved
+        x0, sv_m, sv_t, xb, hn, a, g, s_mo, s_to, s_co = saved
         w0, w2 = self.mix_chan[0].weight, self.mix_chan[2].weight
-        put(w2, linear_dw(dxc, g))
-        da = ops.gelu_bwd(linear_dx(self._images, dxc, w2), a, exact=True)
+        dmlp = drop_rows(dxc, s_co)                                             # gradient at the MLP output, before its dropout
+        put(w2, linear_dw(dmlp, g))
+        da = ops.gelu_bwd(linear_dx(self._images, dmlp, w2), a, exact=True)
         put(w0, linear_dw(da, hn))
         dxb, dw, _ = ops.layernorm_bwd(linear_dx(self._images, da, w0), xb, self.ln_chan.weight, dxc)
         put(self.ln_chan.weight, dw)
         mt = self.mix_time
-        put(mt.proj.weight, linear_dw(dxb, sv_t[5]))
-        dxn = mt._attend2d_bwd(sv_t, linear_dx(mt._images, dxb, mt.proj.weight), put)
+        dto = drop_rows(dxb, s_to)
+        put(mt.proj.weight, linear_dw(dto, sv_t[5]))
+        dxn = mt._attend2d_bwd(sv_t, linear_dx(mt._images, dto, mt.proj.weight), put)
         if sv_m is not None:
             mm = self.mix_memory
-            put(mm.proj.weight, linear_dw(dxb, sv_m[5]))
-            mm._attend2d_bwd(sv_m, linear_dx(mm._images, dxb, mm.proj.weight), put, dx_out=dxn, dmem_out=dmem_out)
+            dmo = drop_rows(dxb, s_mo)
+            put(mm.proj.weight, linear_dw(dmo, sv_m[5]))
+            mm._attend2d_bwd(sv_m, linear_dx(mm._images, dmo, mm.proj.weight), put, dx_out=dxn, dmem_out=dmem_out)
         dx0, dw, _ = ops.layernorm_bwd(dxn, x0, self.ln_time.weight, dxb)      # both attentions read the same ln_time(x)
         put(self.ln_time.weight, dw)
         return dx0
@@ -362,6 +389,7 @@ class Decoder(nn.Module):
         self.lm_head = nn.Linear(head_dim * heads, vocab, bias=False)
         self._images = WeightImages()
         self._graphs = {}                                                 # captured greedy decodes, see _decode_graph
+        self.dropout_stream = DropoutStream()                             # Philox (seed, offset) per training forward
 
     def forward(self, features, targets, input_lengths=None, target_lengths=None, star_penalty=None, measure_entropy=False,
                 drop_labels=None, reduction='mean'):
@@ -423,9 +451,10 @@ class Decoder(nn.Module):
         S, C = features.shape[1], features.shape[2]
         mem2d = features.detach().reshape(N * S, C).float().contiguous()
         y = ops.embed_fwd(prompt, self.wte.weight, None)
+        sites = DropSites(self.dropout_stream.next(_p_drop(self), self.training))
         blocks = []
         for block in self.h:
-            y, sv = block._forward2d_train(y, N, T, True, mem2d, S, mlen)
+            y, sv = block._forward2d_train(y, N, T, True, mem2d, S, mlen, sites)
             blocks.append(sv)
         xf = ops.layernorm_fwd(y, self.ln_f.weight)
         logits = linear(self._images, xf, self.lm_head.weight)
@@ -576,6 +605,7 @@ class AudioEncoder(nn.Module):
         self.drop = nn.Dropout(p_drop)
         self.h = nn.ModuleList([Block(head_dim=head_dim, heads=heads, p_drop=p_drop) for _ in range(layers)])
         self.ln_f = LayerNorm(head_dim * heads, bias=False)
+        self.dropout_stream = DropoutStream()
 
     def subsampled_lengths(self, input_lengths):
         return self.conv.subsampled_lengths(input_lengths)
@@ -605,19 +635,21 @@ class AudioEncoder(nn.Module):
     def _forward_train(self, x):
         y, conv_saved = self.conv._forward_cl_train(x)
         N, T, C = y.shape
-        y2d = y.view(N * T, C)
+        sites = DropSites(self.dropout_stream.next(_p_drop(self), self.training))
+        s_in = sites.next()
+        y2d = drop_rows(y.view(N * T, C), s_in)                                    # self.drop(x), ha/transformer.py:239
         blocks = []
         for block in self.h:
-            y2d, sv = block._forward2d_train(y2d, N, T)
+            y2d, sv = block._forward2d_train(y2d, N, T, sites=sites)
             blocks.append(sv)
         out = ops.layernorm_fwd(y2d, self.ln_f.weight)
-        return out.view(N, T, C), (conv_saved, blocks, y2d, (N, T, C))
+        return out.view(N, T, C), (conv_saved, blocks, y2d, (N, T, C), s_in)
 
     @torch.no_grad()
     def _backward_train(self, saved, dout, put):
-        conv_saved, blocks, y_last, (N, T, C) = saved
+        conv_saved, blocks, y_last, (N, T, C), s_in = saved
         dy, dw, _ = ops.layernorm_bwd(dout.reshape(N * T, C), y_last, self.ln_f.weight)
         put(self.ln_f.weight, dw)
         for block, sv in zip(reversed(self.h), reversed(blocks)):
             dy = block._backward2d(sv, dy, put)
-        self.conv._backward_cl(conv_saved, dy.view(N, T, C), put)
+        self.conv._backward_cl(conv_saved, drop_rows(dy, s_in).view(N, T, C), put)

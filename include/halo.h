@@ -285,12 +285,17 @@ int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, c
                        const int *key_lengths, halo_stream_t stream);
 /* halo_attention_fwd with explicit head strides: q_head_stride / kv_head_stride = head_dim for packed rows, or
  * cache_len * head_dim (with row stride head_dim, batch stride heads * cache_len * head_dim) to read K/V straight from a
- * [N, heads, cache_len, head_dim] fp32 cache -- the `past` / `present` layout of ha/attention.py:64-69,232 (attend_cached). */
+ * [N, heads, cache_len, head_dim] fp32 cache -- the `past` / `present` layout of ha/attention.py:64-69,232 (attend_cached).
+ * p_drop > 0: inverted dropout on the attention probabilities (the dropout_p of SDPA, ha/transformer.py:356,
+ * ha/attention.py:90) from the Philox stream (seed, stream_id, offset [+ *offset_dev]); probability (n, h, i, j) uses element
+ *   e = ((((n*heads + h)*Tq + i) * ceil(Tk/64) + j/64) * 64 + 4*(j%16) + (j%64)/16
+ * of the stream; halo_attention_bwd must be given the same five values. */
 int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_stride, long q_head_stride,
                                const float *k, const float *v, long kv_row_stride, long kv_batch_stride,
                                long kv_head_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
                                float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal,
-                               const int *key_lengths, halo_stream_t stream);
+                               const int *key_lengths, float p_drop, uint64_t seed, uint32_t stream_id,
+                               uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
 int halo_rope_table(float *cos_table, float *sin_table, int T, int head_dim, float base, halo_stream_t stream);
 int halo_rope_interleaved(float *x, long row_stride, int n_rows, int T, int heads, int head_dim, int t0,
                           const float *cos_table, const float *sin_table, int table_rows, int inverse,
@@ -328,7 +333,8 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
                        long kv_row_stride, long kv_batch_stride, const float *y, const float *dy, long y_row_stride,
                        long y_batch_stride, const float *lse, float *delta, float *dq, long dq_row_stride,
                        long dq_batch_stride, float *dk, float *dv, long dkv_row_stride, long dkv_batch_stride, int N,
-                       int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,
+                       int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths, float p_drop,
+                       uint64_t seed, uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev,
                        halo_stream_t stream);
 size_t halo_layernorm_bwd_workspace_bytes(int rows, int C);
 int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx,

@@ -66,3 +66,12 @@ def dropout_mask(n, p, seed, stream_id, offset):
     rr = np.choose(sel, r)
     keep = rr >= dropout_threshold(p)
     return np.where(keep, dropout_scale(p), np.float32(0.0)).astype(np.float32)
+
+
+def attention_dropout_mask(N, H, Tq, Tk, p, seed, stream_id, offset):
+    """Multipliers [N, H, Tq, Tk] of the attention-probability dropout of halo_attention_fwd (include/halo.h):
+    probability (n, h, i, j) uses stream element ((((n*H + h)*Tq + i) * ceil(Tk/64) + j/64) * 64 + 4*(j%16) + (j%64)/16."""
+    KT = (Tk + 63) // 64
+    flat = dropout_mask(N * H * Tq * KT * 64, p, seed, stream_id, offset).reshape(N, H, Tq, KT, 64)
+    j = np.arange(Tk)
+    return flat[:, :, :, j // 64, 4 * (j % 16) + (j % 64) // 16]

@@ -76,9 +76,11 @@ def attend(q, k, v, mask):
     return att @ v, ent
 
 
-def mha(p, pre, x, memory, heads, key_mask=None, causal=False, rope=False, t0=0, measure_entropy=False):
+def mha(p, pre, x, memory, heads, key_mask=None, causal=False, rope=False, t0=0, measure_entropy=False, att_mult=None,
+        out_mult=None):
     """MultiHeadAttention.forward without caches (transformer.py:289-371).  key_mask [N,S] True = masked.
-    With measure_entropy returns (y, entropy) through attend()."""
+    With measure_entropy returns (y, entropy) through attend().  att_mult [N,H,T,S] / out_mult [N,T,C]: explicit
+    inverted-dropout multipliers of the attention probabilities / of the proj output (training-mode parity)."""
     N, T, C = x.shape
     q = _heads(F.linear(x, p[pre + 'q.weight']), heads)
     k = _heads(F.linear(memory, p[pre + 'k.weight']), heads)
@@ -92,33 +94,47 @@ def mha(p, pre, x, memory, heads, key_mask=None, causal=False, rope=False, t0=0,
         if causal and mask is None:
             mask = ~torch.ones(k.size(-2), k.size(-2), dtype=torch.bool).tril()[-T:]
         y, ent = attend(q, k, v, mask)
+    elif att_mult is not None:
+        sc = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(k.shape[-1])
+        if key_mask is not None:
+            sc = sc.masked_fill(key_mask[:, None, None, :], float('-inf'))
+        elif causal:
+            sc = sc.masked_fill(~torch.ones(T, k.size(-2), dtype=torch.bool).tril(), float('-inf'))
+        y = (sc.softmax(dim=-1) * att_mult) @ v
     elif key_mask is not None:
         y = F.scaled_dot_product_attention(q, k, v, attn_mask=~key_mask[:, None, None, :])
     else:
         y = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
     y = F.linear(y.transpose(1, 2).reshape(N, T, C), p[pre + 'proj.weight'])
+    if out_mult is not None:
+        y = y * out_mult
     return (y, ent) if measure_entropy else y
 
 
-def block(p, pre, x, heads, causal=False, memory=None, memory_lengths=None, entropies=None):
+def block(p, pre, x, heads, causal=False, memory=None, memory_lengths=None, entropies=None, masks=None):
     """Block.forward (transformer.py:464-496): cross- and self-attention both read the SAME ln_time(x).
-    ``entropies``: a list that receives (memory_entropy, self_entropy) -> the measure_entropy=True path."""
+    ``entropies``: a list that receives (memory_entropy, self_entropy) -> the measure_entropy=True path.
+    ``masks``: dropout multipliers {'cross_att','cross_out','self_att','self_out','mlp_out'} (training mode)."""
     me = entropies is not None
+    mk = masks or {}
     x_norm = layer_norm(x, p[pre + 'ln_time.weight'])
     m_ent = None
     if memory is not None:
         mask = torch.arange(memory.shape[-2])[None, :] >= memory_lengths[:, None]
-        m = mha(p, pre + 'mix_memory.', x_norm, memory, heads, key_mask=mask, measure_entropy=me)
+        m = mha(p, pre + 'mix_memory.', x_norm, memory, heads, key_mask=mask, measure_entropy=me, att_mult=mk.get('cross_att'),
+                out_mult=mk.get('cross_out'))
         if me:
             m, m_ent = m
         x = x + m
-    t = mha(p, pre + 'mix_time.', x_norm, x_norm, heads, causal=causal, rope=True, measure_entropy=me)
+    t = mha(p, pre + 'mix_time.', x_norm, x_norm, heads, causal=causal, rope=True, measure_entropy=me, att_mult=mk.get('self_att'),
+            out_mult=mk.get('self_out'))
     if me:
         t, t_ent = t
         entropies.append((m_ent, t_ent))
     x = x + t
     h = F.gelu(F.linear(layer_norm(x, p[pre + 'ln_chan.weight']), p[pre + 'mix_chan.0.weight']))
-    return x + F.linear(h, p[pre + 'mix_chan.2.weight'])
+    h = F.linear(h, p[pre + 'mix_chan.2.weight'])
+    return x + (h * mk['mlp_out'] if 'mlp_out' in mk else h)
 
 
 def n_layers(p, pre=''):
@@ -128,28 +144,33 @@ def n_layers(p, pre=''):
     return i
 
 
-def audio_encoder_forward(p, x, input_lengths, heads, strides=(2, 2, 2)):
-    """AudioEncoder.forward in eval mode (transformer.py:234-258): x [N,T,F] -> (features [N,T',C], lengths int32)."""
+def audio_encoder_forward(p, x, input_lengths, heads, strides=(2, 2, 2), in_mult=None, block_masks=None):
+    """AudioEncoder.forward (transformer.py:234-258): x [N,T,F] -> (features [N,T',C], lengths int32); eval mode unless the
+    dropout multipliers in_mult [N,T',C] / block_masks (one dict per block) are given."""
     y = conv_encoder(p, 'conv.', x.mT, strides).mT
+    if in_mult is not None:
+        y = y * in_mult
     for i in range(n_layers(p)):
-        y = block(p, f'h.{i}.', y, heads)
+        y = block(p, f'h.{i}.', y, heads, masks=block_masks[i] if block_masks else None)
     return layer_norm(y, p['ln_f.weight']), subsampled_lengths(input_lengths, strides)
 
 
-def decoder_logits(p, features, prompt, input_lengths, heads, pre='', entropies=None):
+def decoder_logits(p, features, prompt, input_lengths, heads, pre='', entropies=None, block_masks=None):
     y = F.embedding(prompt, p[pre + 'wte.weight'])
     for i in range(n_layers(p, pre)):
-        y = block(p, f'{pre}h.{i}.', y, heads, causal=True, memory=features, memory_lengths=input_lengths, entropies=entropies)
+        y = block(p, f'{pre}h.{i}.', y, heads, causal=True, memory=features, memory_lengths=input_lengths, entropies=entropies,
+                  masks=block_masks[i] if block_masks else None)
     return F.linear(layer_norm(y, p[pre + 'ln_f.weight']), p[pre + 'lm_head.weight'])
 
 
-def decoder_forward(p, features, targets, input_lengths, target_lengths, heads, reduction='mean', pre='', entropies=None):
+def decoder_forward(p, features, targets, input_lengths, target_lengths, heads, reduction='mean', pre='', entropies=None,
+                    block_masks=None):
     """Decoder.forward without label dropout (transformer.py:73-122)."""
     N, T = targets.shape
     prompt = F.pad(targets, (1, 0), value=STX)
     tg = F.pad(targets, (0, 1), value=0)
     tg[torch.arange(N), target_lengths] = ETX
-    logits = decoder_logits(p, features, prompt, input_lengths, heads, pre, entropies)
+    logits = decoder_logits(p, features, prompt, input_lengths, heads, pre, entropies, block_masks)
     if reduction == 'sumeach':
         return logits.log_softmax(dim=-1).max(dim=-1).values.sum(dim=-1)
     return F.cross_entropy(logits.view(-1, logits.size(-1)), tg.view(-1), ignore_index=0, reduction=reduction)

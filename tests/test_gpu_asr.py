@@ -273,8 +273,84 @@ def test_asr_training_mode_refusals(hal):
     feats = torch.randn(2, 5, 32, device=DEV)
     tg = torch.randint(4, 16, (2, 3), device=DEV)
     with pytest.raises(NotImplementedError):
-        dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))     # dropout 0.2 in training mode
-    dec = tr.Decoder(vocab=16, head_dim=16, heads=2, p_drop=0.0, layers=1).to(DEV).train()
-    loss, _ = dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))  # label dropout on, p_drop 0: trains
+        with torch.no_grad():
+            dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))  # train-mode dropout without autograd
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            dec.h[0](feats, memory=feats, memory_lengths=torch.tensor([5, 4], device=DEV))       # bare Block in training mode
+    loss, _ = dec(feats, tg, torch.tensor([5, 4], device=DEV), torch.tensor([3, 2], device=DEV))  # label dropout + dropout: trains
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())
+
+
+def _block_masks(philox, seed, offset, p, first_site, N, heads, T, S, C, memory):
+    """The multipliers of one Block's dropout sites (forward order, see Block._forward2d_train) for the CPU oracle."""
+    sid, mk = first_site, {}
+    def rows(n_rows):
+        nonlocal sid
+        m = torch.from_numpy(philox.dropout_mask(n_rows * C, p, seed, sid, offset)).view(N, n_rows // N, C)
+        sid += 1
+        return m
+    def att(Tq, Tk):
+        nonlocal sid
+        m = torch.from_numpy(philox.attention_dropout_mask(N, heads, Tq, Tk, p, seed, sid, offset).copy())
+        sid += 1
+        return m
+    if memory:
+        mk['cross_att'] = att(T, S)
+        mk['cross_out'] = rows(N * T)
+    mk['self_att'] = att(T, T)
+    mk['self_out'] = rows(N * T)
+    mk['mlp_out'] = rows(N * T)
+    return mk, sid
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g6_asr_tiny', 'g6_asr_tiny_s221'])
+def test_asr_training_mode_dropout_matches_oracle_with_same_masks(hal, name, math_mode):
+    """model.train() with p_drop = 0.2: the Philox masks of every dropout site (encoder input, attention probabilities in the
+    kernels, proj / MLP outputs in the GEMM epilogues) are restated on the CPU and fed to the oracle; loss and every
+    gradient must agree like in eval mode."""
+    from oracle import philox, transformer_ref
+    g, pe, pd, (x, il, tg, tl), heads, strides = asr_case_from_golden(name)
+    vocab, hd, heads, el, dl, conv_dim, N, T, S_t, seed0, F_ = (int(v) for v in g['cfg'])
+    tr = hal['tr']
+    P, SEED = 0.2, 0x1234567890ABCDEF
+    enc = tr.AudioEncoder(head_dim=hd, heads=heads, layers=el, p_drop=P, input_dim=F_, conv_dim=conv_dim, conv_strides=strides)
+    dec = tr.Decoder(vocab=vocab, head_dim=hd, heads=heads, p_drop=P, layers=dl)
+    enc.load_state_dict(pe, strict=True)
+    dec.load_state_dict({k[len('decoder.'):]: v for k, v in pd.items() if k.startswith('decoder.')}, strict=True)
+    enc, dec = enc.to(DEV).train(), dec.to(DEV).train()
+    enc.dropout_stream.seed = dec.dropout_stream.seed = SEED
+    feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+    loss, _ = dec(feats, tg.to(DEV), flen, tl.to(DEV), drop_labels=False)
+    loss.backward()
+    # CPU oracle with the same masks
+    C = hd * heads
+    Tp = feats.shape[1]
+    pe_r = {k: v.clone().requires_grad_(True) for k, v in pe.items()}
+    pd_r = {k[len('decoder.'):]: v.clone().requires_grad_(True) for k, v in pd.items() if k.startswith('decoder.')}
+    in_mult = torch.from_numpy(philox.dropout_mask(N * Tp * C, P, SEED, 64, 0)).view(N, Tp, C)
+    sid, enc_masks = 65, []
+    for _ in range(el):
+        mk, sid = _block_masks(philox, SEED, 0, P, sid, N, heads, Tp, 0, C, memory=False)
+        enc_masks.append(mk)
+    Td = tg.shape[1] + 1
+    sid, dec_masks = 64, []
+    for _ in range(dl):
+        mk, sid = _block_masks(philox, SEED, 0, P, sid, N, heads, Td, Tp, C, memory=True)
+        dec_masks.append(mk)
+    f_ref, fl_ref = transformer_ref.audio_encoder_forward(pe_r, x, il, heads, strides, in_mult=in_mult, block_masks=enc_masks)
+    l_ref = transformer_ref.decoder_forward(pd_r, f_ref, tg, fl_ref, tl, heads, block_masks=dec_masks)
+    l_ref.backward()
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), f_ref.detach().numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), l_ref.item(), rtol=5e-5)
+    for m, params in ((enc, pe_r), (dec, pd_r)):
+        for k, p in m.named_parameters():
+            want = params[k].grad.numpy()
+            scale = max(1.0, float(np.abs(want).max()))
+            tol = dict(rtol=2e-3, atol=2e-5 * scale) if math_mode == 'f32' else dict(rtol=5e-3, atol=1e-4 * scale)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want, err_msg=k, **tol)
+    # a second forward draws new masks (the stream offset advanced)
+    feats2, _, _ = enc(x.to(DEV), il.to(DEV))
+    assert not torch.allclose(feats2, feats)
