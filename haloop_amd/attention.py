@@ -15,7 +15,10 @@ gradients), so ``loss.backward()``, ``clip_grad_norm_`` and the optimizers of ha
 Generation: ``forward(input_ids, past)`` / ``forward_context`` / ``generate`` keep the reference's fp32 KV cache
 layout ``[L, 2, B, nh, T, hs]`` (attend_cached, ha/attention.py:64-93); attention reads the cache in place.
 
-Not built yet (raises NotImplementedError): dropout > 0, ``stable_embedding`` and rotary (flash_attn) blocks.
+Training-mode dropout (config.dropout > 0): Philox masks at the reference's four kinds of site (embeddings, attention
+probabilities inside the attention kernels, c_proj and MLP outputs as GEMM epilogues), see haloop_amd/transformer.py.
+
+Not built yet (raises NotImplementedError): ``stable_embedding`` and rotary (flash_attn) blocks.
 """
 import math
 from dataclasses import dataclass, asdict
@@ -24,7 +27,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import WeightImages, linear, linear_dw, linear_dx
+from ._linear import DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx
+from .rnn import DropoutStream
 
 
 @dataclass
@@ -130,10 +134,12 @@ class GPT(nn.Module):
         self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
         self.transformer.wte.weight = self.lm_head.weight       # weight tying
         self._images = WeightImages()
+        self.dropout_stream = DropoutStream()                   # Philox (seed, offset) per training forward
 
     # ---- one Linear: y = x W^T + b, with the epilogue fused ------------------------------------
-    def _linear(self, x2d, lin, out=None, gelu=False, accumulate=False):
-        return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate)
+    def _linear(self, x2d, lin, out=None, gelu=False, accumulate=False, site=(ops.NO_DROPOUT, 0)):
+        return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate, drop=site[0],
+                      stream_id=site[1])
 
     @torch.no_grad()
     def _trunk(self, input_ids, past=None, want_present=False):
@@ -168,8 +174,6 @@ class GPT(nn.Module):
     def forward_all(self, input_ids, target_ids, past=None, reduction='mean'):
         if not input_ids.is_cuda:
             raise _lib.HaloError('haloop_amd.attention.GPT runs on the HIP device only (no CPU path)')
-        if self.training and self.config.dropout > 0:
-            raise NotImplementedError('dropout in the GPT path is not built; train with dropout=0.0 (the GPTConfig default)')
         B, T = input_ids.shape
         V = self.config.vocab_size
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -178,6 +182,8 @@ class GPT(nn.Module):
             params = [p for p in self.parameters() if p.requires_grad]
             loss = _GPTLoss.apply(self, input_ids, target_ids, *params)          # per-token NLL with a grad_fn
             return self._reduce(loss, target_ids.reshape(-1), reduction)
+        if self.training and self.config.dropout > 0:
+            raise NotImplementedError('training-mode dropout is built into the autograd path only: enable grad, or call .eval()')
         x, _ = self._trunk(input_ids, past)
         targets = target_ids.reshape(-1)
         # lm_head + cross-entropy in row chunks so the [rows, V] logits stay bounded (206 MB per 1024 rows at V=50304)
@@ -207,29 +213,35 @@ class GPT(nn.Module):
         assert T <= cfg.block_size, f'Cannot forward sequence of length {T}, block size is only {cfg.block_size}'
         C, H = cfg.n_embd, cfg.n_head
         tr = self.transformer
-        x = ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, 0)
+        # dropout sites in forward order (ha/attention.py:224,90,127,141): embeddings, then per block the attention
+        # probabilities, the c_proj output and the MLP output; output dropouts are GEMM epilogues
+        sites = DropSites(self.dropout_stream.next(cfg.dropout, self.training))
+        s_emb = sites.next()
+        x = drop_rows(ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, 0), s_emb)
         blocks = []
         for blk in tr.h:
             x0 = x
             h1 = ops.layernorm_fwd(x0, blk.ln_1.weight, blk.ln_1.bias)
             qkv = self._linear(h1, blk.attn.c_attn)
-            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=True, want_lse=True)
-            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True)
+            s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
+            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=True, want_lse=True,
+                                          drop=s_att[0], stream_id=s_att[1])
+            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res)
             h2 = ops.layernorm_fwd(x1, blk.ln_2.weight, blk.ln_2.bias)
             a = self._linear(h2, blk.mlp.c_fc)
             g = ops.gelu_fwd(a)
-            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True)
-            blocks.append((x0, h1, qkv, y, lse, x1, h2, a, g))
+            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True, site=s_mlp)
+            blocks.append((x0, h1, qkv, y, lse, x1, h2, a, g, s_att, s_res, s_mlp))
         xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
         logits = self._linear(xf, self.lm_head)                              # kept: the backward rewrites it into dlogits
         loss, row_lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
-        return loss, (input_ids, targets, blocks, x, xf, logits, row_lse)
+        return loss, (input_ids, targets, blocks, x, xf, logits, row_lse, s_emb)
 
     @torch.no_grad()
     def _backward_train(self, saved, grad_per_tok):
         cfg = self.config
-        input_ids, targets, blocks, x_last, xf, logits, row_lse = saved
+        input_ids, targets, blocks, x_last, xf, logits, row_lse, s_emb = saved
         B, T = input_ids.shape
         C, H = cfg.n_embd, cfg.n_head
         tr = self.transformer
@@ -245,27 +257,30 @@ class GPT(nn.Module):
         dxf = linear_dx(img, dlogits, self.lm_head.weight)
         dx, dw, db = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None)
         put(tr.ln_f.weight, dw); put(tr.ln_f.bias, db)
-        for blk, (x0, h1, qkv, y, lse, x1, h2, a, g) in zip(reversed(tr.h), reversed(blocks)):
-            # x = x1 + c_proj(gelu(c_fc(ln_2(x1))))
-            put(blk.mlp.c_proj.weight, linear_dw(dx, g))
-            if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dx))
-            da = ops.gelu_bwd(linear_dx(img, dx, blk.mlp.c_proj.weight), a)
+        for blk, (x0, h1, qkv, y, lse, x1, h2, a, g, s_att, s_res, s_mlp) in zip(reversed(tr.h), reversed(blocks)):
+            # x = x1 + drop(c_proj(gelu(c_fc(ln_2(x1)))))
+            dm = drop_rows(dx, s_mlp)
+            put(blk.mlp.c_proj.weight, linear_dw(dm, g))
+            if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dm))
+            da = ops.gelu_bwd(linear_dx(img, dm, blk.mlp.c_proj.weight), a)
             put(blk.mlp.c_fc.weight, linear_dw(da, h2))
             if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
             dx1, dw, db = ops.layernorm_bwd(linear_dx(img, da, blk.mlp.c_fc.weight), x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
             put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
-            # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
-            put(blk.attn.c_proj.weight, linear_dw(dx1, y))
-            if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dx1))
-            dy = linear_dx(img, dx1, blk.attn.c_proj.weight)
+            # x1 = x0 + drop(c_proj(attention(c_attn(ln_1(x0)))))
+            dr = drop_rows(dx1, s_res)
+            put(blk.attn.c_proj.weight, linear_dw(dr, y))
+            if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dr))
+            dy = linear_dx(img, dr, blk.attn.c_proj.weight)
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
-                              B, H, C // H, T, T, causal=True)
+                              B, H, C // H, T, T, causal=True, drop=s_att[0], stream_id=s_att[1])
             put(blk.attn.c_attn.weight, linear_dw(dqkv, h1))
             if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
             dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight), x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None)
             put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
         dwpe = torch.zeros_like(tr.wpe.weight)
+        dx = drop_rows(dx, s_emb)
         ops.embed_bwd(input_ids, dx, dw_head, dwpe, 0)                         # tied: embedding rows add into the lm_head gradient
         put(self.lm_head.weight, dw_head)
         put(tr.wpe.weight, dwpe)

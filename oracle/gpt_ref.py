@@ -50,21 +50,32 @@ def make_gpt_params(vocab_size, block_size, n_layer, n_head, n_embd, bias, seed)
     return p
 
 
-def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean'):
+def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean', masks=None):
+    """masks (training-mode parity): {'emb': [B,T,C], 'att': [per layer [B,H,T,T]], 'res': [...[B,T,C]], 'mlp': [...]} inverted-dropout
+    multipliers at the sites of ha/attention.py:224,90,127,141."""
     B, T = input_ids.shape
     C = p['transformer.wte.weight'].shape[1]
     x = F.embedding(input_ids, p['transformer.wte.weight']) + p['transformer.wpe.weight'][:T][None]
+    if masks:
+        x = x * masks['emb']
     for i in range(n_layer):
         pre = f'transformer.h.{i}.'
         h = F.layer_norm(x, (C,), p[pre + 'ln_1.weight'], p.get(pre + 'ln_1.bias'), 1e-5)
         qkv = F.linear(h, p[pre + 'attn.c_attn.weight'], p.get(pre + 'attn.c_attn.bias'))
         q, k, v = (t.view(B, T, n_head, C // n_head).transpose(1, 2) for t in qkv.split(C, dim=2))
-        y = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        if masks:
+            sc = (q @ k.transpose(-2, -1)) / math.sqrt(k.shape[-1])
+            sc = sc.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float('-inf'))
+            y = (sc.softmax(-1) * masks['att'][i]) @ v
+        else:
+            y = F.scaled_dot_product_attention(q, k, v, is_causal=True)
         y = y.transpose(1, 2).contiguous().view(B, T, C)
-        x = x + F.linear(y, p[pre + 'attn.c_proj.weight'], p.get(pre + 'attn.c_proj.bias'))
+        r = F.linear(y, p[pre + 'attn.c_proj.weight'], p.get(pre + 'attn.c_proj.bias'))
+        x = x + (r * masks['res'][i] if masks else r)
         h = F.layer_norm(x, (C,), p[pre + 'ln_2.weight'], p.get(pre + 'ln_2.bias'), 1e-5)
         h = new_gelu(F.linear(h, p[pre + 'mlp.c_fc.weight'], p.get(pre + 'mlp.c_fc.bias')))
-        x = x + F.linear(h, p[pre + 'mlp.c_proj.weight'], p.get(pre + 'mlp.c_proj.bias'))
+        m = F.linear(h, p[pre + 'mlp.c_proj.weight'], p.get(pre + 'mlp.c_proj.bias'))
+        x = x + (m * masks['mlp'][i] if masks else m)
     x = F.layer_norm(x, (C,), p['transformer.ln_f.weight'], p.get('transformer.ln_f.bias'), 1e-5)
     logits = F.linear(x, p['lm_head.weight'])
     return F.cross_entropy(logits.view(-1, logits.size(-1)), target_ids.reshape(-1), ignore_index=0, reduction=reduction)

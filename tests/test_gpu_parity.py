@@ -487,8 +487,9 @@ def test_gpt_refuses_what_is_not_built(hal):
     with pytest.raises(NotImplementedError):
         attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))
     with pytest.raises(NotImplementedError):
-        attention.GPT(attention.GPTConfig(block_size=16, vocab_size=50, n_layer=1, n_head=1, n_embd=64, dropout=0.1)).to(DEV).train() \
-            .forward_all(ids, ids)                       # dropout > 0 is not built
+        with torch.no_grad():
+            attention.GPT(attention.GPTConfig(block_size=16, vocab_size=50, n_layer=1, n_head=1, n_embd=64, dropout=0.1)).to(DEV).train() \
+                .forward_all(ids, ids)                   # training-mode dropout only exists on the autograd path
 
 
 # ------------------------------------------------------------------- other shapes of the same path
@@ -710,3 +711,38 @@ def test_gpt_bf16_mode_nats_per_token(hal):
             assert abs(float(p.grad.norm()) - want) <= 0.05 * want, k
     finally:
         hal['lib'].set_math_mode(prev)
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+def test_gpt_training_mode_dropout_matches_oracle_with_same_masks(hal, name, math_mode):
+    """config.dropout = 0.1, model.train(): the Philox masks of every site are restated on the CPU and fed to the oracle."""
+    from haloop_amd import attention
+    from oracle import gpt_ref, philox
+    g = load_golden(name)
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    P, SEED = 0.1, 0xFEEDFACE12345
+    model = attention.GPT(attention.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head, n_embd=n_embd,
+                                              bias=bool(bias), dropout=P))
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).train()
+    model.dropout_stream.seed = SEED
+    inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
+    loss = model.forward_all(inputs.to(DEV), targets.to(DEV))
+    loss.backward()
+    C = n_embd
+    rows = lambda sid: torch.from_numpy(philox.dropout_mask(B * T * C, P, SEED, sid, 0)).view(B, T, C)
+    masks = {'emb': rows(64), 'att': [], 'res': [], 'mlp': []}
+    for i in range(n_layer):
+        masks['att'].append(torch.from_numpy(philox.attention_dropout_mask(B, n_head, T, T, P, SEED, 65 + 3 * i, 0).copy()))
+        masks['res'].append(rows(66 + 3 * i))
+        masks['mlp'].append(rows(67 + 3 * i))
+    pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    pr['lm_head.weight'] = pr['transformer.wte.weight']
+    ref = gpt_ref.gpt_forward_all(pr, n_layer, n_head, inputs, targets, masks=masks)
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    tol = dict(rtol=5e-4, atol=5e-7) if math_mode == 'f32' else dict(rtol=2e-3, atol=4e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), pr[k].grad.numpy(), err_msg=k, **tol)
