@@ -81,6 +81,7 @@ SIGNATURES = {
     'halo_cross_entropy_fwd_lse': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _l, _vp]),
     'halo_cross_entropy_bwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),
     'halo_embed_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'halo_add_rows_bcast': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'halo_im2col_cl': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_dwconv1d_cl': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_dwconv1d_cl_bwd_workspace_bytes': (_sz, [_i, _i]),

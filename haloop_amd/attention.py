@@ -18,7 +18,10 @@ layout ``[L, 2, B, nh, T, hs]`` (attend_cached, ha/attention.py:64-93); attentio
 Training-mode dropout (config.dropout > 0): Philox masks at the reference's four kinds of site (embeddings, attention
 probabilities inside the attention kernels, c_proj and MLP outputs as GEMM epilogues), see haloop_amd/transformer.py.
 
-Not built yet (raises NotImplementedError): ``stable_embedding`` and rotary (flash_attn) blocks.
+``stable_embedding`` (ha/attention.py:30-61: each embedding followed by its own LayerNorm) is built, forward and backward.
+
+Not built (raises NotImplementedError): rotary (flash_attn) blocks -- the reference itself cannot construct them without
+flash_attn.
 """
 import math
 from dataclasses import dataclass, asdict
@@ -64,6 +67,18 @@ class LayerNorm(nn.Module):
     def forward(self, input):
         shp = input.shape
         return ops.layernorm_fwd(input.reshape(-1, shp[-1]).contiguous(), self.weight, self.bias, 1e-5).view(shp)
+
+
+class StableEmbedding(nn.Embedding):
+    """nn.Embedding followed by its own LayerNorm (ha/attention.py:30-61); GPT runs the gather and the norm on the HIP ops."""
+
+    def __init__(self, num_embeddings, embedding_dim, **kw):
+        super().__init__(num_embeddings, embedding_dim, **kw)
+        self.norm = nn.LayerNorm(embedding_dim)
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight)
+        self._fill_padding_idx_with_zero()
 
 
 class MonitoredSelfAttention(nn.Module):
@@ -117,13 +132,11 @@ class GPT(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if config.stable_embedding:
-            raise NotImplementedError('stable_embedding (LayerNorm-ed embeddings) is not built yet')
         if not config.causal:
             raise NotImplementedError('only the causal LM configuration is built')
         self.transformer = nn.ModuleDict(dict(
-            wte=nn.Embedding(config.vocab_size, config.n_embd),
-            wpe=nn.Embedding(config.block_size, config.n_embd),
+            wte=(StableEmbedding if config.stable_embedding else nn.Embedding)(config.vocab_size, config.n_embd),
+            wpe=(StableEmbedding if config.stable_embedding else nn.Embedding)(config.block_size, config.n_embd),
             drop=nn.Dropout(config.dropout),
             h=nn.ModuleList([Block(config) for _ in range(config.n_layer)]),
             ln_f=LayerNorm(config.n_embd, bias=config.bias),
@@ -141,6 +154,19 @@ class GPT(nn.Module):
         return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate, drop=site[0],
                       stream_id=site[1])
 
+    def _embed(self, input_ids, t0=0, keep=False):
+        """tok_emb + pos_emb [B*T, C]; with stable_embedding each goes through its own LayerNorm first.  keep: also return
+        what the backward needs (raw token rows, raw position rows)."""
+        tr = self.transformer
+        if not self.config.stable_embedding:
+            return ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, t0), None
+        T = input_ids.shape[1]
+        et = ops.embed_fwd(input_ids, tr.wte.weight, None)
+        ep = tr.wpe.weight.detach()[t0:t0 + T].contiguous()
+        x = ops.layernorm_fwd(et, tr.wte.norm.weight, tr.wte.norm.bias)
+        ops.add_rows_bcast_(x, ops.layernorm_fwd(ep, tr.wpe.norm.weight, tr.wpe.norm.bias), T)
+        return x, ((et, ep) if keep else None)
+
     @torch.no_grad()
     def _trunk(self, input_ids, past=None, want_present=False):
         """Embedding + blocks + ln_f.  With ``past`` [L, 2, B, nh, T0, hs] (or want_present) keys/values go through a
@@ -151,7 +177,7 @@ class GPT(nn.Module):
         assert t0 + T <= cfg.block_size, f'Cannot forward sequence of length {t0 + T}, block size is only {cfg.block_size}'
         C, H = cfg.n_embd, cfg.n_head
         tr = self.transformer
-        x = ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, t0)                   # [B*T, C], the residual stream
+        x, _ = self._embed(input_ids, t0)                                                # [B*T, C], the residual stream
         present = None
         if past is not None or want_present:
             present = torch.empty(cfg.n_layer, 2, B, H, t0 + T, C // H, device=x.device, dtype=torch.float32)
@@ -217,7 +243,8 @@ class GPT(nn.Module):
         # probabilities, the c_proj output and the MLP output; output dropouts are GEMM epilogues
         sites = DropSites(self.dropout_stream.next(cfg.dropout, self.training))
         s_emb = sites.next()
-        x = drop_rows(ops.embed_fwd(input_ids, tr.wte.weight, tr.wpe.weight, 0), s_emb)
+        x, emb_saved = self._embed(input_ids, 0, keep=True)
+        x = drop_rows(x, s_emb)
         blocks = []
         for blk in tr.h:
             x0 = x
@@ -236,12 +263,12 @@ class GPT(nn.Module):
         targets = target_ids.reshape(-1)
         logits = self._linear(xf, self.lm_head)                              # kept: the backward rewrites it into dlogits
         loss, row_lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
-        return loss, (input_ids, targets, blocks, x, xf, logits, row_lse, s_emb)
+        return loss, (input_ids, targets, blocks, x, xf, logits, row_lse, s_emb, emb_saved)
 
     @torch.no_grad()
     def _backward_train(self, saved, grad_per_tok):
         cfg = self.config
-        input_ids, targets, blocks, x_last, xf, logits, row_lse, s_emb = saved
+        input_ids, targets, blocks, x_last, xf, logits, row_lse, s_emb, emb_saved = saved
         B, T = input_ids.shape
         C, H = cfg.n_embd, cfg.n_head
         tr = self.transformer
@@ -281,7 +308,18 @@ class GPT(nn.Module):
             put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
         dwpe = torch.zeros_like(tr.wpe.weight)
         dx = drop_rows(dx, s_emb)
-        ops.embed_bwd(input_ids, dx, dw_head, dwpe, 0)                         # tied: embedding rows add into the lm_head gradient
+        if emb_saved is not None:                                                # StableEmbedding: through the two LayerNorms first
+            et, ep = emb_saved
+            dpos = torch.empty_like(ep)
+            ops.embed_bwd(input_ids, dx, None, dpos, 0)                          # dpos[t] = sum_b dx[b, t]
+            dx, dw, db = ops.layernorm_bwd(dx, et, tr.wte.norm.weight, None, True)
+            put(tr.wte.norm.weight, dw); put(tr.wte.norm.bias, db)
+            dep, dw, db = ops.layernorm_bwd(dpos, ep, tr.wpe.norm.weight, None, True)
+            put(tr.wpe.norm.weight, dw); put(tr.wpe.norm.bias, db)
+            dwpe[:T] = dep
+            ops.embed_bwd(input_ids, dx, dw_head, None, 0)                       # tied: token rows add into the lm_head gradient
+        else:
+            ops.embed_bwd(input_ids, dx, dw_head, dwpe, 0)
         put(self.lm_head.weight, dw_head)
         put(tr.wpe.weight, dwpe)
         return grads

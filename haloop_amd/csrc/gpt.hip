@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int64_t *__res
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dwte + id * C + c, dx[(long)n * C + c]);
 }
+// x[n, :] += p[n % T, :]   (StableEmbedding: the normalised position rows are shared by the batch, ha/attention.py:222-224)
+__global__ __launch_bounds__(256) void add_rows_bcast_kernel(float *__restrict__ x, const float *__restrict__ p, long n_elem, int T, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_elem) return;
+    const long row = idx / C;
+    x[idx] += p[(row % T) * C + idx % C];
+}
+
 // dwpe[pos0 + t, c] (+)= sum_b dx[b*T + t, c]  (fixed order)
 __global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const float *__restrict__ dx, float *__restrict__ dwpe, int B, int T, int C,
                                                             int pos0, int accumulate) {
@@ -248,11 +256,18 @@ int halo_gelu_bwd(const float *dy, const float *a, float *da, size_t n, int exac
     return halo_launch_status();
 }
 
+int halo_add_rows_bcast(float *x, const float *p, int rows, int T, int C, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && p && rows > 0 && T > 0 && C > 0);
+    const long n = (long)rows * C;
+    hipLaunchKernelGGL(add_rows_bcast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, p, n, T, C);
+    return halo_launch_status();
+}
+
 int halo_embed_bwd(const int64_t *ids, const float *dx, float *dwte, float *dwpe, int B, int T, int C, int pos0, int vocab,
                    int accumulate_wpe, halo_stream_t stream) {
-    HALO_CHECK_ARG(ids && dx && dwte && B > 0 && T > 0 && C > 0 && pos0 >= 0 && vocab > 0);
+    HALO_CHECK_ARG(ids && dx && (dwte || dwpe) && B > 0 && T > 0 && C > 0 && pos0 >= 0 && vocab > 0);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(B * T), dim3(256), 0, st, ids, dx, dwte, C, vocab);
+    if (dwte) hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3(B * T), dim3(256), 0, st, ids, dx, dwte, C, vocab);
     if (dwpe) {
         const long n = (long)T * C;
         hipLaunchKernelGGL(embed_bwd_wpe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dx, dwpe, B, T, C, pos0,

@@ -540,7 +540,8 @@ def cross_entropy_bwd_(logits2d, targets, lse, grad_rows, ignore_index=0):
 def embed_bwd(ids, dx2d, dwte, dwpe, pos0=0, accumulate_wpe=False):
     ids = _i64c(ids, 'input_ids')
     Bn, T = ids.shape
-    check(lib().halo_embed_bwd(ptr(ids), ptr(dx2d), ptr(dwte), ptr(dwpe), Bn, T, dx2d.shape[1], pos0, dwte.shape[0],
+    vocab = dwte.shape[0] if dwte is not None else 1
+    check(lib().halo_embed_bwd(ptr(ids), ptr(dx2d), ptr(dwte), ptr(dwpe), Bn, T, dx2d.shape[1], pos0, vocab,
                                int(accumulate_wpe), _stream()), 'halo_embed_bwd')
 
 
@@ -557,3 +558,10 @@ def dwconv1d_cl_bwd(dy3d, x3d, weight, stride, pad, want_dx=True, has_bias=True)
     check(lib().halo_dwconv1d_cl_bwd(ptr(dy3d), ptr(x3d), ptr(weight), ptr(dx), ptr(dw), ptr(db), ptr(ws), N, T, Cn, ks, stride, pad,
                                      _stream()), 'halo_dwconv1d_cl_bwd')
     return dx, dw, db
+
+
+def add_rows_bcast_(x2d, p2d, T):
+    """x2d[n] += p2d[n % T] in place."""
+    _f32c(x2d, 'x'); _f32c(p2d, 'p')
+    check(lib().halo_add_rows_bcast(ptr(x2d), ptr(p2d), x2d.shape[0], T, x2d.shape[1], _stream()), 'halo_add_rows_bcast')
+    return x2d

@@ -328,7 +328,7 @@ int halo_greedy_update(const float *values, const int64_t *indices, const float 
  *   halo_cross_entropy_bwd     logits <- (softmax(logits) - onehot(target)) * grad[n * grad_stride] in place
  *                              (grad_stride 0: one scalar for all rows; 1: per row); ignored rows -> 0
  *   halo_embed_bwd             dwte[ids] += dx (float atomics; dwte is the tied lm_head gradient buffer),
- *                              dwpe[pos0 + t] (+)= sum_b dx  (dwpe may be NULL) */
+ *                              dwpe[pos0 + t] (+)= sum_b dx  (either of dwte / dwpe may be NULL) */
 int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
                        long kv_row_stride, long kv_batch_stride, const float *y, const float *dy, long y_row_stride,
                        long y_batch_stride, const float *lse, float *delta, float *dq, long dq_row_stride,
@@ -348,6 +348,8 @@ int halo_cross_entropy_bwd(float *logits, const int64_t *targets, const float *l
                            long grad_stride, int rows, int V, long ld, long ignore_index, halo_stream_t stream);
 int halo_embed_bwd(const int64_t *ids, const float *dx, float *dwte, float *dwpe, int B, int T, int C, int pos0,
                    int vocab, int accumulate_wpe, halo_stream_t stream);
+/* x[n, :] += p[n % T, :]: tok_emb + pos_emb when both went through StableEmbedding's LayerNorm first (ha/attention.py:30-61,224) */
+int halo_add_rows_bcast(float *x, const float *p, int rows, int T, int C, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolutional front-end of AudioEncoder, channels-last.  replaces, in ha/conv.py:

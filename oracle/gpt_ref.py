@@ -19,7 +19,7 @@ def new_gelu(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x * x * x)))
 
 
-def make_gpt_params(vocab_size, block_size, n_layer, n_head, n_embd, bias, seed):
+def make_gpt_params(vocab_size, block_size, n_layer, n_head, n_embd, bias, seed, stable=False):
     """Deterministic, non-degenerate parameters (the reference's own init zeroes wpe)."""
     g = torch.Generator().manual_seed(seed)
     C = n_embd
@@ -30,6 +30,10 @@ def make_gpt_params(vocab_size, block_size, n_layer, n_head, n_embd, bias, seed)
     p = OrderedDict()
     p['transformer.wte.weight'] = n((vocab_size, C), 0.05)
     p['transformer.wpe.weight'] = n((block_size, C), 0.05)
+    if stable:                                            # StableEmbedding's own LayerNorms (ha/attention.py:41)
+        for e in ('wte', 'wpe'):
+            p[f'transformer.{e}.norm.weight'] = 1.0 + n((C,), 0.1)
+            p[f'transformer.{e}.norm.bias'] = n((C,), 0.05)
     for i in range(n_layer):
         pre = f'transformer.h.{i}.'
         p[pre + 'ln_1.weight'] = 1.0 + n((C,), 0.1)
@@ -55,7 +59,11 @@ def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean',
     multipliers at the sites of ha/attention.py:224,90,127,141."""
     B, T = input_ids.shape
     C = p['transformer.wte.weight'].shape[1]
-    x = F.embedding(input_ids, p['transformer.wte.weight']) + p['transformer.wpe.weight'][:T][None]
+    tok, pos = F.embedding(input_ids, p['transformer.wte.weight']), p['transformer.wpe.weight'][:T][None]
+    if 'transformer.wte.norm.weight' in p:                # stable_embedding: each embedding through its own LayerNorm
+        tok = F.layer_norm(tok, (C,), p['transformer.wte.norm.weight'], p['transformer.wte.norm.bias'], 1e-5)
+        pos = F.layer_norm(pos, (C,), p['transformer.wpe.norm.weight'], p['transformer.wpe.norm.bias'], 1e-5)
+    x = tok + pos
     if masks:
         x = x * masks['emb']
     for i in range(n_layer):

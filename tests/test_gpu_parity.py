@@ -445,14 +445,14 @@ def _gpt_from_golden(hal, name):
     else:
         params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
     model = attention.GPT(attention.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head,
-                                              n_embd=n_embd, bias=bool(bias)))
+                                              n_embd=n_embd, bias=bool(bias), stable_embedding=bool(g.get('stable', 0))))
     model.load_state_dict(params, strict=True)
     assert model.transformer.wte.weight is model.lm_head.weight
     return g, model.to(DEV).eval()
 
 
 @BOTH_MODES
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
 def test_gpt_tiny_forward_all_matches_reference(hal, name, math_mode):
     g, model = _gpt_from_golden(hal, name)
     inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
@@ -485,7 +485,7 @@ def test_gpt_refuses_what_is_not_built(hal):
     with pytest.raises(NotImplementedError):
         model(ids)                                           # generation path under autograd
     with pytest.raises(NotImplementedError):
-        attention.GPT(attention.GPTConfig(stable_embedding=True, n_layer=1))
+        attention.GPT(attention.GPTConfig(rotary_emb_dim=32, n_layer=1))   # flash_attn rotary blocks
     with pytest.raises(NotImplementedError):
         with torch.no_grad():
             attention.GPT(attention.GPTConfig(block_size=16, vocab_size=50, n_layer=1, n_head=1, n_embd=64, dropout=0.1)).to(DEV).train() \
@@ -619,7 +619,7 @@ def test_layernorm_gelu_cross_entropy_backward_against_autograd(hal):
 
 
 @BOTH_MODES
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
 def test_gpt_tiny_gradients_match_reference(hal, name, math_mode):
     """loss.backward() through the HIP path vs the reference's own gradients (fixtures): every parameter."""
     g, model = _gpt_from_golden(hal, name)

@@ -139,7 +139,7 @@ def test_philox_known_answers():
     assert set(np.unique(m)) == {np.float32(0), np.float32(1.25)}
 
 
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt2_small'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt2_small'])
 def test_gpt_forward_all_matches_reference(name):
     from oracle import gpt_ref
     g = load_golden(name)
@@ -173,7 +173,7 @@ def test_gpt_kv_cache_forward_matches_reference(name):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=2e-6, err_msg=key)
 
 
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
 def test_gpt_gradients_match_reference(name):
     """The training direction: autograd through the restatement == the reference's loss.backward()."""
     from oracle import gpt_ref
