@@ -82,47 +82,56 @@ struct Frag3 {
     bf16x8 ah, al, wh, wl;
 };
 
+// ONE: single-pass bf16 (HALO_MATH_BF16): only the hi halves of the packed blocks are fetched and multiplied
+template <bool ONE>
 __device__ __forceinline__ void load_chunk3(Frag3 (&f)[CHUNK3], const char *ap, const char *bp, int blk0) {
 #pragma unroll
     for (int i = 0; i < CHUNK3; ++i) {
         const char *a = ap + (long)(blk0 + i) * 2048, *w = bp + (long)(blk0 + i) * 2048;
         f[i].ah = *reinterpret_cast<const bf16x8 *>(a);
-        f[i].al = *reinterpret_cast<const bf16x8 *>(a + 1024);
         f[i].wh = *reinterpret_cast<const bf16x8 *>(w);
-        f[i].wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
+        if (!ONE) {
+            f[i].al = *reinterpret_cast<const bf16x8 *>(a + 1024);
+            f[i].wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
+        }
     }
 }
 
+template <bool ONE>
 __device__ __forceinline__ void mma_chunk3(const Frag3 (&f)[CHUNK3], f32x4 &acc0, f32x4 &acc1) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].al, f[0].wh, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].al, f[1].wh, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].ah, f[0].wl, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].ah, f[1].wl, acc1, 0, 0, 0);
+    if (!ONE) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].al, f[0].wh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].al, f[1].wh, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].ah, f[0].wl, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].ah, f[1].wl, acc1, 0, 0, 0);
+    }
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0].ah, f[0].wh, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1].ah, f[1].wh, acc1, 0, 0, 0);
 }
 
 // sum over k-blocks [0, nblk) of A-block x B-block; ap/bp point at this lane's 16 bytes of block 0
-template <bool X3>
+template <bool X3, bool ONE = false>
 __device__ __forceinline__ f32x4 packed_dot(const char *ap, const char *bp, int nblk) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (X3) {
         if (nblk % (2 * CHUNK3) == 0) {
             Frag3 f0[CHUNK3], f1[CHUNK3];
-            load_chunk3(f0, ap, bp, 0);
+            load_chunk3<ONE>(f0, ap, bp, 0);
             for (int c = 0; c < nblk; c += 2 * CHUNK3) {
-                load_chunk3(f1, ap, bp, c + CHUNK3);
-                mma_chunk3(f0, acc0, acc1);
-                load_chunk3(f0, ap, bp, min(c + 2 * CHUNK3, nblk - CHUNK3));   // last pass: harmless re-read
-                mma_chunk3(f1, acc0, acc1);
+                load_chunk3<ONE>(f1, ap, bp, c + CHUNK3);
+                mma_chunk3<ONE>(f0, acc0, acc1);
+                load_chunk3<ONE>(f0, ap, bp, min(c + 2 * CHUNK3, nblk - CHUNK3));   // last pass: harmless re-read
+                mma_chunk3<ONE>(f1, acc0, acc1);
             }
         } else {
             for (int blk = 0; blk < nblk; ++blk) {
                 const char *a = ap + (long)blk * 2048, *w = bp + (long)blk * 2048;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(a), al = *reinterpret_cast<const bf16x8 *>(a + 1024);
-                const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(w), wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc0, 0, 0, 0);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(a), wh = *reinterpret_cast<const bf16x8 *>(w);
+                if (!ONE) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(a + 1024), wl = *reinterpret_cast<const bf16x8 *>(w + 1024);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc0, 0, 0, 0);
+                }
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc0, 0, 0, 0);
             }
         }
@@ -163,10 +172,13 @@ struct ATileStage {      // what to copy into LDS before the first fragment read
     char *dst;           // LDS
     int pieces;          // 1 KiB pieces
     int wave, nwaves, lane;
+    int hi_only;         // single-pass bf16: skip the lo half (odd 1 KiB pieces) of every 2 KiB block
     __device__ __forceinline__ void issue() const {
-        for (int pc = wave; pc < pieces; pc += nwaves)
+        for (int pc = wave; pc < pieces; pc += nwaves) {
+            if (hi_only && (pc & 1)) continue;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)pc * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+        }
         asm volatile("" ::: "memory");        // nothing below may be issued ahead of the LDS-DMA requests
     }
     // wait for the tile while the NEWER loads (the first W stage, N of them per lane) stay in flight:
@@ -177,7 +189,7 @@ struct ATileStage {      // what to copy into LDS before the first fragment read
     }
 };
 
-template <bool X3>
+template <bool X3, bool ONE = false>
 __device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a_lds, const char *bp, int nblk) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (X3) {
@@ -186,7 +198,7 @@ __device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a
 #pragma unroll
             for (int i = 0; i < WCH; ++i) {
                 wh[i] = *reinterpret_cast<const bf16x8 *>(bp + (long)(blk0 + i) * 2048);
-                wl[i] = *reinterpret_cast<const bf16x8 *>(bp + (long)(blk0 + i) * 2048 + 1024);
+                if (!ONE) wl[i] = *reinterpret_cast<const bf16x8 *>(bp + (long)(blk0 + i) * 2048 + 1024);
             }
         };
         auto mma = [&](const bf16x8 (&wh)[WCH], const bf16x8 (&wl)[WCH], int blk0) {
@@ -194,17 +206,19 @@ __device__ __forceinline__ f32x4 dot_lds_a(const ATileStage &stage, lds_cchar *a
             for (int i = 0; i < WCH; ++i) {
                 typedef __attribute__((address_space(3))) const bf16x8 lds_frag;
                 const bf16x8 ah = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 2048);
-                const bf16x8 al = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 2048 + 1024);
                 f32x4 &acc = (i & 1) ? acc1 : acc0;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[i], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[i], acc, 0, 0, 0);
+                if (!ONE) {
+                    const bf16x8 al = *reinterpret_cast<lds_frag *>(a_lds + (blk0 + i) * 2048 + 1024);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[i], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[i], acc, 0, 0, 0);
+                }
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[i], acc, 0, 0, 0);
             }
         };
         stage.issue();
         loadw(wh0, wl0, 0);
         asm volatile("" ::: "memory");
-        stage.wait_keeping<2 * WCH>();
+        stage.wait_keeping<(ONE ? 1 : 2) * WCH>();
         for (int c = 0; c < nblk; c += 2 * WCH) {
             loadw(wh1, wl1, c + WCH);
             mma(wh0, wl0, c);
@@ -257,7 +271,7 @@ struct StepFwdArgs {
     int B, H;
 };
 
-template <int KS, bool X3, bool ALDS>
+template <int KS, bool X3, bool ALDS, bool ONE = false>
 __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdArgs p) {
     constexpr int NW = 4 * KS;
     using PK = Packed<X3>;
@@ -287,12 +301,12 @@ __global__ __launch_bounds__(256 * KS) void lstm_step_fwd_kernel(const StepFwdAr
         // stage this batch tile's packed h_{t-1} (nkb blocks, contiguous) into LDS, 1 KiB per wave instruction
         char *a_tile = dyn_lds + NW * 256 * sizeof(float);
         const char *a_src = (const char *)p.hp_prev + (long)bt * nkb * PK::BLOCK_BYTES;
-        const ATileStage stage = {a_src, a_tile, nkb * PK::BLOCK_BYTES / 1024, __builtin_amdgcn_readfirstlane(wave), NW, lane};
+        const ATileStage stage = {a_src, a_tile, nkb * PK::BLOCK_BYTES / 1024, __builtin_amdgcn_readfirstlane(wave), NW, lane, ONE};
         lds_cchar *a_lds = (lds_cchar *)(a_tile + (long)ks * nblk * PK::BLOCK_BYTES + lane * 16);
-        acc = dot_lds_a<X3>(stage, a_lds, bp, nblk);
+        acc = dot_lds_a<X3, ONE>(stage, a_lds, bp, nblk);
     } else {
         const char *ap = (const char *)p.hp_prev + ((long)bt * nkb + ks * nblk) * PK::BLOCK_BYTES + lane * 16;
-        acc = packed_dot<X3>(ap, bp, nblk);
+        acc = packed_dot<X3, ONE>(ap, bp, nblk);
     }
     // D layout: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch)
     {
@@ -349,7 +363,7 @@ struct StepBwdArgs {
     int B, H;
 };
 
-template <int NW, bool X3>
+template <int NW, bool X3, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArgs p) {
     using PK = Packed<X3>;
     __shared__ float red[NW][256];
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArg
         const int nblk = nkb4 / NW;
         const char *ap = (const char *)p.dgp_next + ((long)bt * nkb4 + wave * nblk) * PK::BLOCK_BYTES + lane * 16;
         const char *bp = (const char *)p.wpT + ((long)jt * nkb4 + wave * nblk) * PK::BLOCK_BYTES + lane * 16;
-        const f32x4 acc = packed_dot<X3>(ap, bp, nblk);
+        const f32x4 acc = packed_dot<X3, ONE>(ap, bp, nblk);
         const int r = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) red[wave][(4 * q + e2) * 16 + r] = acc[e2];
@@ -736,7 +750,7 @@ inline LayerBufs layer_bufs(float *reserve, int l, int T, int B, int H) {
     return lb;
 }
 
-// HALO_MATH_BF16 only narrows the GEMM / attention operands; the recurrent step keeps the split (hi + lo) form
+// HALO_MATH_BF16 keeps the split packed images and skips their lo halves in the step kernels (launch_step_*)
 inline bool use_x3(int H) { return halo_math_mode() != HALO_MATH_F32 && H % 32 == 0; }
 
 // waves = (gate, k-slice): the slice count must divide the number of k-blocks
@@ -750,7 +764,7 @@ inline int pick_bwd_nw(int H, bool x3) {
     return (nkb4 % 16 == 0) ? 16 : (nkb4 % 8 == 0) ? 8 : 4;
 }
 
-template <int KS, bool X3>
+template <int KS, bool X3, bool ONE>
 int launch_step_fwd_ks(const StepFwdArgs &a, hipStream_t st) {
     dim3 grid(a.H / 16, (a.B + 15) / 16);
     const int nkb = a.H / (X3 ? 32 : 16);
@@ -762,42 +776,46 @@ int launch_step_fwd_ks(const StepFwdArgs &a, hipStream_t st) {
     if (alds) {
         static bool attr = false;
         if (!attr) {
-            if (hipFuncSetAttribute((const void *)lstm_step_fwd_kernel<KS, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void *)lstm_step_fwd_kernel<KS, X3, true, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     128 * 1024) != hipSuccess)
                 return HALO_ELAUNCH;
             attr = true;
         }
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, true>), grid, dim3(256 * KS), red_bytes + tile_bytes, st, a);
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, true, ONE>), grid, dim3(256 * KS), red_bytes + tile_bytes, st, a);
     } else {
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, false>), grid, dim3(256 * KS), red_bytes, st, a);
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<KS, X3, false, ONE>), grid, dim3(256 * KS), red_bytes, st, a);
     }
     return halo_launch_status();
 }
 
-template <bool X3>
+template <bool X3, bool ONE>
 int launch_step_fwd_t(const StepFwdArgs &a, hipStream_t st) {
     switch (pick_fwd_ks(a.H, X3)) {
-        case 4: return launch_step_fwd_ks<4, X3>(a, st);
-        case 2: return launch_step_fwd_ks<2, X3>(a, st);
-        default: return launch_step_fwd_ks<1, X3>(a, st);
+        case 4: return launch_step_fwd_ks<4, X3, ONE>(a, st);
+        case 2: return launch_step_fwd_ks<2, X3, ONE>(a, st);
+        default: return launch_step_fwd_ks<1, X3, ONE>(a, st);
     }
 }
+// HALO_MATH_BF16: the split (hi|lo) packed images are kept, the kernels fetch and multiply only their hi halves
+inline bool one_pass() { return halo_math_mode() == HALO_MATH_BF16; }
 int launch_step_fwd(const StepFwdArgs &a, bool x3, hipStream_t st) {
-    return x3 ? launch_step_fwd_t<true>(a, st) : launch_step_fwd_t<false>(a, st);
+    if (x3 && one_pass()) return launch_step_fwd_t<true, true>(a, st);
+    return x3 ? launch_step_fwd_t<true, false>(a, st) : launch_step_fwd_t<false, false>(a, st);
 }
 
-template <bool X3>
+template <bool X3, bool ONE>
 int launch_step_bwd_t(const StepBwdArgs &a, hipStream_t st) {
     dim3 grid(a.H / 16, (a.B + 15) / 16);
     switch (pick_bwd_nw(a.H, X3)) {
-        case 16: hipLaunchKernelGGL((lstm_step_bwd_kernel<16, X3>), grid, dim3(1024), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((lstm_step_bwd_kernel<8, X3>), grid, dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL((lstm_step_bwd_kernel<4, X3>), grid, dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((lstm_step_bwd_kernel<16, X3, ONE>), grid, dim3(1024), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((lstm_step_bwd_kernel<8, X3, ONE>), grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((lstm_step_bwd_kernel<4, X3, ONE>), grid, dim3(256), 0, st, a); break;
     }
     return halo_launch_status();
 }
 int launch_step_bwd(const StepBwdArgs &a, bool x3, hipStream_t st) {
-    return x3 ? launch_step_bwd_t<true>(a, st) : launch_step_bwd_t<false>(a, st);
+    if (x3 && one_pass()) return launch_step_bwd_t<true, true>(a, st);
+    return x3 ? launch_step_bwd_t<true, false>(a, st) : launch_step_bwd_t<false, false>(a, st);
 }
 
 // MODE 0: W_hh for the forward, 1: W_hh^T for the backward, 2: row-major [B,W] rows (initial state)
