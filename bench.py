@@ -222,6 +222,25 @@ def main():
         }
         if world == 1:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
+        if world == 1 and args.math != 'bf16':
+            # the same step with every dense operand rounded to bf16 (the reference's autocast arithmetic on GPUs,
+            # ha/loop.py:125); parity at the bf16-MFMA tolerance of SURVEY.md 8d (loss rel <= 2e-2, tests/test_gpu_parity.py)
+            _lib.set_math_mode('bf16')
+            enc2, rec2, _ = build_model(device)
+            tr2 = LstmCtcTrainer(enc2, rec2, seed=1337, use_graph=not args.no_graph)
+            for _ in range(args.warmup):
+                tr2.step(x, il, tg, tl)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = max(20, args.steps // 2)
+            for _ in range(n2):
+                tr2.step(x, il, tg, tl)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out['bf16_mode'] = {'value': round(B_PER_GPU * n2 / dt2, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt2 / n2, 4),
+                                'dtype': 'bf16', 'final_loss': round(tr2.loss.item(), 5),
+                                'note': 'same step, operands of the dense products rounded to bf16 (--math bf16)'}
+            _lib.set_math_mode(args.math)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(params)
         print(json.dumps(out), flush=True)
