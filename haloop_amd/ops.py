@@ -314,8 +314,11 @@ def clip_coef(partials, count, max_norm, coef, norm):
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    """In-place AdamW on flat views.  Pass views that share the parameter's version counter (``param.detach().view(-1)``,
+    not ``param.data``): the update bumps it so that cached operand images of the weight (haloop_amd/_linear.py) are rebuilt."""
     check(lib().halo_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            ptr(grad_scale), _stream()), 'halo_adamw')
+    torch.autograd.graph.increment_version(p)
 
 
 def counter_inc(counter):

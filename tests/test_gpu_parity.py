@@ -783,3 +783,43 @@ def test_gpt_training_mode_dropout_matches_oracle_with_same_masks(hal, name, mat
     tol = dict(rtol=5e-4, atol=5e-7) if math_mode == 'f32' else dict(rtol=2e-3, atol=4e-6)
     for k, p in model.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), pr[k].grad.numpy(), err_msg=k, **tol)
+
+
+@BOTH_MODES
+def test_gpt_three_adamw_steps_match_cpu(hal, math_mode):
+    """Three optimizer steps (forward_all + backward + halo_adamw) vs the CPU oracle with torch.optim.AdamW: the weight
+    operand images cached per parameter version must be rebuilt after every update (a stale image would freeze the
+    forward), and the trajectory must follow the reference's."""
+    from oracle import gpt_ref
+    g, model = _gpt_from_golden(hal, 'g5_gpt_tiny_nobias')
+    model.train()
+    vocab, block, n_layer, n_head, n_embd, bias, B, T, seed = (int(v) for v in g['cfg'])
+    inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
+    ref = {k[len('param.'):]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith('param.')}
+    ref['lm_head.weight'] = ref['transformer.wte.weight']
+    uniq = [p for k, p in ref.items() if k != 'lm_head.weight']
+    opt = torch.optim.AdamW([{'params': [p for p in uniq if p.dim() >= 2], 'weight_decay': 0.1},
+                             {'params': [p for p in uniq if p.dim() < 2], 'weight_decay': 0.0}], lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    params = list(model.parameters())
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    losses, ref_losses = [], []
+    for step in range(1, 4):
+        for p in params: p.grad = None
+        loss = model.forward_all(inputs.to(DEV), targets.to(DEV))
+        loss.backward()
+        losses.append(loss.item())
+        for p, (m, v) in zip(params, state):
+            hal['ops'].adamw(p.detach().view(-1), p.grad.view(-1), m.view(-1), v.view(-1), 1e-2, 0.9, 0.95, 1e-8,
+                             0.1 if p.dim() >= 2 else 0.0, step)
+        opt.zero_grad()
+        rl = gpt_ref.gpt_forward_all(ref, n_layer, n_head, inputs, targets)
+        rl.backward()
+        ref_losses.append(rl.item())
+        opt.step()
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
+    assert losses[2] < losses[0] - 0.05                    # the forward sees the updated weights
+    # Adam normalises each element by its own gradient scale: an element whose gradient is ~0 can take a +-lr step of either
+    # sign under last-bit differences, so allow 0.1 % outliers (bounded by 3 steps of lr) on top of the elementwise tolerance
+    for k, p in model.named_parameters():
+        d = np.abs(p.detach().cpu().numpy() - ref[k].detach().numpy())
+        assert (d > (2e-4 if math_mode == 'f32' else 5e-4)).mean() <= 1e-3 and d.max() <= 3.5e-2, k

@@ -1,41 +1,127 @@
 #!/usr/bin/env python3
-"""GPT-2 small scoring throughput (BASELINE config 3 shape): tokens/s of forward_all(reduction='none')."""
-import os, sys, time
+"""BASELINE config 3: GPT-2 small (124 M), seq_len 1024, on one MI355X -- tokens/s of scoring (`hap`: forward_all,
+reduction='none') and of the full training step (`hal`: forward_all + loss.backward() + AdamW on the HIP kernels),
+nats/token against the CPU oracle, the dominant kernel against the MFMA roof, and the CPU oracle timed on the host
+cores.  Prints human-readable lines and ONE JSON line (last).
+
+    HALO_MATH=bf16x3|bf16|f32  B=8  python tools/bench_gpt.py [--no-cpu-baseline]
+"""
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from haloop_amd import _lib, attention
+
+from haloop_amd import _lib, attention, ops
 from oracle import gpt_ref
 
+MFMA_BF16_PEAK = 2500.0     # TFLOP/s dense bf16, MI355X_MICROARCH.md
 _lib.lib(); _lib.lend_scratch(256 << 20)
-math = os.environ.get('HALO_MATH', 'bf16x3'); _lib.set_math_mode(math)
+math_mode = os.environ.get('HALO_MATH', 'bf16x3'); _lib.set_math_mode(math_mode)
 B = int(os.environ.get('B', '8')); T = 1024
 cfg = attention.GPTConfig()
+torch.manual_seed(0)
 model = attention.GPT(cfg).cuda().eval()
+with torch.no_grad():                                     # the reference's init zeroes wpe; give it content
+    model.transformer.wpe.weight.normal_(0, 0.02)
 inputs, targets = gpt_ref.synthetic_tokens(B, T, cfg.vocab_size, 3, pad_tail=False)
-inputs, targets = inputs.cuda(), targets.cuda()
-with torch.inference_mode():
-    for _ in range(2): model.forward_all(inputs, targets, reduction='none')
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 5
-    for _ in range(n): out = model.forward_all(inputs, targets, reduction='none')
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f'GPT-2 small forward_all B={B} T={T} math={math}: {dt*1e3:.2f} ms  {B*T/dt:,.0f} tokens/s  mean nats/token {out.mean().item():.4f}')
+inputs_d, targets_d = inputs.cuda(), targets.cuda()
 
-# training direction: forward_all + loss.backward() (ha/attention_loop.py:196-208) and an AdamW step on the HIP kernels
-from haloop_amd import ops
+
+def timed(fn, n=5, warm=2):
+    for _ in range(warm): out = fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): out = fn()
+    torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) / n
+
+
+def event_us(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
+with torch.inference_mode():
+    per_tok, t_fwd = timed(lambda: model.forward_all(inputs_d, targets_d, reduction='none'))
+print(f'GPT-2 small forward_all B={B} T={T} math={math_mode}: {t_fwd*1e3:.2f} ms  {B*T/t_fwd:,.0f} tokens/s  '
+      f'mean nats/token {per_tok.mean().item():.4f}')
+
 model.train()
-params = [p for p in model.parameters()]
+params = list(model.parameters())
 state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
-def train_step(step):
+step_no = [0]
+
+
+def train_step():
+    step_no[0] += 1
     for p in params: p.grad = None
-    loss = model.forward_all(inputs, targets)
+    loss = model.forward_all(inputs_d, targets_d)
     loss.backward()
     for p, (m, v) in zip(params, state):
-        ops.adamw(p.data.view(-1), p.grad.view(-1), m.view(-1), v.view(-1), 3e-4, 0.9, 0.95, 1e-8, 0.1 if p.dim() >= 2 else 0.0, step)
+        ops.adamw(p.detach().view(-1), p.grad.view(-1), m.view(-1), v.view(-1), 3e-4, 0.9, 0.95, 1e-8, 0.1 if p.dim() >= 2 else 0.0, step_no[0])
     return loss
-for i in range(2): train_step(i + 1)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 5
-for i in range(n): loss = train_step(i + 3)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f'GPT-2 small train step (fwd+bwd+AdamW) B={B} T={T} math={math}: {dt*1e3:.2f} ms  {B*T/dt:,.0f} tokens/s  loss {loss.item():.4f}')
+
+
+loss, t_train = timed(train_step)
+print(f'GPT-2 small train step (fwd+bwd+AdamW) B={B} T={T} math={math_mode}: {t_train*1e3:.2f} ms  {B*T/t_train:,.0f} tokens/s  '
+      f'loss {loss.item():.4f}')
+
+# algorithmic FLOPs: 2 * P_nonemb per token, causal attention 4*T^2*d*L/2 per sequence, lm_head 2*d*V per token
+C, L, V = cfg.n_embd, cfg.n_layer, cfg.vocab_size
+p_nonemb = sum(p.numel() for n, p in model.named_parameters() if 'wte' not in n and 'wpe' not in n and 'lm_head' not in n)
+fwd_flops = B * (2 * p_nonemb * T + 4 * T * T * C * L // 2 + 2 * C * V * T)
+train_flops = 3 * fwd_flops
+# dominant kernel: the split GEMM on the MLP up-projection shape [B*T, 768] x [3072, 768]^T, timed with HIP events on the launch stream
+M, N, K = B * T, 4 * C, C
+a_img = ops.split_image(torch.randn(M, K, device='cuda'))
+b_img = ops.split_image(torch.randn(N, K, device='cuda'))
+out = torch.empty(M, N, device='cuda')
+gemm_us = event_us(lambda: ops.gemm_split(a_img, b_img, M, N, K, out=out))
+passes = 1 if math_mode == 'bf16' else 3
+gemm_tflops = passes * 2.0 * M * N * K / (gemm_us * 1e-6) / 1e12
+res = {
+    'metric': 'tokens/sec, GPT-2 small LM seq_len 1024 (BASELINE config 3): train step (fwd + bwd + AdamW) and scoring',
+    'value': round(B * T / t_train, 1), 'unit': 'tokens/s', 'n_gpus': 1, 'ms_per_step': round(t_train * 1e3, 3),
+    'scoring': {'value': round(B * T / t_fwd, 1), 'unit': 'tokens/s', 'ms_per_batch': round(t_fwd * 1e3, 3)},
+    'dtype': 'bf16' if math_mode == 'bf16' else 'f32', 'data': 'synthetic',
+    'config': {'workload': 'GPT-2 small 12L/12h/768, vocab 50304, tied lm_head, random init', 'batch': B, 'seq_len': T, 'math': math_mode},
+    'step_mfma': {'algorithmic_tflop_per_train_step': round(train_flops / 1e12, 3),
+                  'achieved_tflops': round(train_flops / t_train / 1e12, 1),
+                  'mfma_tflops_issued': round(passes * train_flops / t_train / 1e12, 1), 'peak': MFMA_BF16_PEAK},
+    'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16x3_kernel ({passes} bf16 MFMA pass(es)), M={M} N={N} K={K}',
+                 'achieved': round(gemm_tflops, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(gemm_tflops / MFMA_BF16_PEAK, 4),
+                 'traffic': None, 'avg_launch_us': round(gemm_us, 1)},
+}
+
+if '--no-cpu-baseline' not in sys.argv:
+    # nats/token parity and the CPU baseline on ONE sequence (the oracle = stock torch CPU ops = what the reference runs on CPU)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cpu_p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref_tok = gpt_ref.gpt_forward_all(cpu_p, L, cfg.n_head, inputs[:1], targets[:1], reduction='none')
+        t_cpu_fwd = time.perf_counter() - t0
+    model.eval()
+    with torch.inference_mode():
+        gpu_tok = model.forward_all(inputs_d[:1], targets_d[:1], reduction='none').cpu()
+    err = (gpu_tok - ref_tok).abs()
+    cpu_r = {k: v.requires_grad_(True) for k, v in cpu_p.items()}
+    cpu_r['lm_head.weight'] = cpu_r['transformer.wte.weight']
+    t0 = time.perf_counter()
+    gpt_ref.gpt_forward_all(cpu_r, L, cfg.n_head, inputs[:1], targets[:1]).backward()
+    t_cpu_train = time.perf_counter() - t0
+    res['nats_per_token'] = {'hip_mean': round(gpu_tok.mean().item(), 5), 'cpu_mean': round(ref_tok.mean().item(), 5),
+                             'max_abs_diff': round(err.max().item(), 6), 'mean_abs_diff': round(err.mean().item(), 7)}
+    res['cpu_baseline'] = {'value': round(T / t_cpu_train, 1), 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                           'sample': f'one 1024-token sequence: forward {t_cpu_fwd:.2f} s, forward+backward {t_cpu_train:.2f} s (no optimizer)',
+                           'scoring_tokens_per_s': round(T / t_cpu_fwd, 1)}
+    print(f"nats/token HIP {res['nats_per_token']['hip_mean']} vs CPU {res['nats_per_token']['cpu_mean']} "
+          f"(max abs diff {res['nats_per_token']['max_abs_diff']}); CPU {res['cpu_baseline']['value']} tokens/s train, "
+          f"{res['cpu_baseline']['scoring_tokens_per_s']} tokens/s scoring on {res['cpu_baseline']['cores']} threads")
+print(json.dumps(res), flush=True)
