@@ -3,7 +3,7 @@
 on 80-frame x 80-mel utterances: encoder forward, CTC-head beam decode (beam 16, ha.beam semantics), attention greedy
 decode (fp16 KV caches).  Prints utterances/s per stage and the WER of the HIP hypotheses against the CPU oracle's
 (own edit distance) on a small sample, with the oracle timed on the host cores."""
-import os, sys, time
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from haloop_amd import _lib, transformer, beam
@@ -71,3 +71,17 @@ print(f'feature max-abs diff vs oracle {float((feats[:NCPU].cpu() - f_ref).abs()
       f'beam-16 top hypothesis WER vs CPU oracle {berrs}/{bwords}')
 print(f'CPU oracle ({torch.get_num_threads()} threads, {NCPU} utt): encoder {NCPU/t_cpu_enc:.1f} utt/s, greedy decode {NCPU/t_cpu_dec:.1f} utt/s, '
       f'beam16 {NCPU/t_cpu_beam:.1f} utt/s')
+
+print(json.dumps({
+    'metric': 'utterances/sec, encoder-decoder attention ASR `transformer:32` (BASELINE config 5): encoder, CTC beam-16, greedy attention decode',
+    'value': round(N / (t_enc + t_dec), 1), 'unit': 'utterances/s', 'n_gpus': 1, 'dtype': 'bf16' if math_mode == 'bf16' else 'f32',
+    'data': 'synthetic', 'config': {'workload': 'AudioEncoder 12L + CTCAttentionDecoder 12L, 8x64 heads, vocab 32, 80 frames x 80 mels',
+                                    'batch': N, 'decode_steps': int(tl.max()) + 1, 'beam': 16, 'math': math_mode},
+    'stages': {'encoder_utt_per_s': round(N / t_enc, 1), 'ctc_beam16_utt_per_s': round(N / t_beam, 1),
+               'greedy_decode_utt_per_s': round(N / t_dec, 1), 'encoder_ms': round(t_enc * 1e3, 3), 'beam_ms': round(t_beam * 1e3, 3),
+               'decode_ms': round(t_dec * 1e3, 3)},
+    'wer_vs_cpu_oracle': {'greedy_errors': errs, 'greedy_words': words, 'beam_errors': berrs, 'beam_words': bwords,
+                          'feature_max_abs_diff': float((feats[:NCPU].cpu() - f_ref).abs().max())},
+    'cpu_baseline': {'value': round(NCPU / (t_cpu_enc + t_cpu_dec), 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                     'sample': f'{NCPU} utterances: encoder {t_cpu_enc:.2f} s, greedy decode {t_cpu_dec:.2f} s, beam-16 {t_cpu_beam:.2f} s'},
+}), flush=True)
