@@ -6,6 +6,9 @@ import torch
 from . import _lib, ops
 
 
+SMALL_M = int(__import__('os').environ.get('HALO_SMALL_M', '64'))
+
+
 class WeightImages:
     """Per-module cache of GEMM-ready weight operands, rebuilt only when a weight changes."""
 
@@ -47,7 +50,9 @@ def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=Fal
         weights = (weights,)
     M, K = x2d.shape
     N = sum(w.shape[0] for w in weights)
-    if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64:
+    # a handful of rows (one decode step): the operand-image pass would cost more than the product; the exact-f32 kernel
+    # reads x and W where they lie
+    if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64 and M > SMALL_M:
         return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
                               accumulate=accumulate, drop=drop, stream_id=stream_id)
     return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate,
