@@ -97,3 +97,77 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph):
         tr.step(x.cuda(), il.cuda(), tg.cuda(), tl.cuda())
     np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=1e-4)
     np.testing.assert_allclose(params2, tr.flat.params.cpu().numpy(), atol=5e-6)
+
+
+# ---- the reference's own multi-process path: DistributedDataParallel around GPT (ha/attention_loop.py:152-155,203) ----
+def _gpt_worker(rank, world, port, out):
+    import datetime
+    import traceback
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from haloop_amd import attention
+        from oracle import gpt_ref
+        torch.cuda.set_device(0)
+        torch.manual_seed(100 + rank)                       # different init per rank: DDP broadcasts rank 0's
+        model = attention.GPT(attention.GPTConfig(block_size=32, vocab_size=61, n_layer=2, n_head=2, n_embd=64)).to('cuda:0').train()
+        class LM(torch.nn.Module):                          # DDP only hooks what runs under its own forward()
+            def __init__(self, gpt):
+                super().__init__()
+                self.gpt = gpt
+
+            def forward(self, x, y):
+                return self.gpt.forward_all(x, y)
+
+        ddp = DDP(LM(model), device_ids=[0])
+        inputs, targets = gpt_ref.synthetic_tokens(4, 24, 61, 9, pad_tail=False)
+        sl = slice(rank * 2, rank * 2 + 2)
+        loss = ddp(inputs[sl].cuda(), targets[sl].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        if rank == 0:
+            out.put(('ok', {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()},
+                     {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
+    except Exception:
+        out.put(('error', rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gpt_under_torch_ddp_averages_gradients():
+    """The hand-written GPT backward hands its gradients to autograd like any Function, so torch's DDP (what `hala` wraps the
+    model in) all-reduces them: two ranks on half batches == one process on the whole batch."""
+    from haloop_amd import attention
+    from oracle import gpt_ref
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpt_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import time
+    deadline, msg = time.time() + 150, None
+    while msg is None and time.time() < deadline:
+        if not out.empty():
+            msg = out.get()
+        elif not any(p.is_alive() for p in procs):
+            break
+        else:
+            time.sleep(0.2)
+    for p in procs:
+        p.join(20)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, 'workers produced no result'
+    assert msg[0] == 'ok', msg
+    _, state, grads2 = msg
+    model = attention.GPT(attention.GPTConfig(block_size=32, vocab_size=61, n_layer=2, n_head=2, n_embd=64))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to('cuda:0').train()
+    inputs, targets = gpt_ref.synthetic_tokens(4, 24, 61, 9, pad_tail=False)
+    model.forward_all(inputs.cuda(), targets.cuda()).backward()
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(grads2[k], p.grad.cpu().numpy(), rtol=2e-4, atol=2e-7, err_msg=k)
