@@ -369,6 +369,21 @@ int halo_dwconv1d_cl_bwd(const float *dy, const float *x, const float *weight, f
                          halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Token-tape batching (the data formats either side of the LM paths).  Integer gathers on
+ * HBM-resident tapes, bit-exact.
+ *   halo_tape_batch    SymbolTapeNoPad.__getitem__(i)  ha/symbol_tape.py:239-279: out [rows, batch_size] (row-major, same
+ *                      element type as the tape: elem_bytes 1/2/4/8), out[t, b] = data[b*(tape_len-1) + i*bptt_len + t] with
+ *                      tape_len = ceil(n_tokens / batch_size); positions past the tape get pad_value.  rows = bptt_len, or
+ *                      the trailing token count for the last part.
+ *   halo_lm_batch_u16  get_batch of ha/attention_loop.py:98-125 on a uint16 tape (np.memmap dtype uint16 :90): x[b, :] =
+ *                      data[offsets[b] : offsets[b] + T] as int64, y = x shifted left with a 0 in the last column
+ *                      (objective "lm"); objective_cond != 0 keeps only column (#non-zero x) - 2 of y ("cond"). */
+int halo_tape_batch(const void *data, int elem_bytes, long n_tokens, int batch_size, int bptt_len, long part_index,
+                    int rows, long pad_value, void *out, halo_stream_t stream);
+int halo_lm_batch_u16(const uint16_t *data, long n_tokens, const int64_t *offsets, int B, int T, int objective_cond,
+                      int64_t *x, int64_t *y, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers.
  * replaces: clip_grad_norm_ ha/loop.py:184 and torch.optim.AdamW(fused) ha/optim.py:137-139
  *   halo_sumsq: partials[0..HALO_SUMSQ_PARTS) = per-workgroup sums of x^2 (fixed order, so the

@@ -823,3 +823,38 @@ def test_gpt_three_adamw_steps_match_cpu(hal, math_mode):
     for k, p in model.named_parameters():
         d = np.abs(p.detach().cpu().numpy() - ref[k].detach().numpy())
         assert (d > (2e-4 if math_mode == 'f32' else 5e-4)).mean() <= 1e-3 and d.max() <= 3.5e-2, k
+
+
+# ------------------------------------------------------------------------------ token-tape batching (data formats)
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.int16, torch.int32, torch.int64])
+@pytest.mark.parametrize('n,batch,bptt', [(48, 2, 8), (50, 3, 5), (1000, 7, 33), (5, 8, 4), (4096, 64, 16)])
+def test_symbol_tape_batches_bit_exact(hal, dtype, n, batch, bptt):
+    from haloop_amd import symbol_tape
+    from oracle import tape_ref
+    g = torch.Generator().manual_seed(n + batch)
+    data = torch.randint(1, 120, (n,), generator=g).to(dtype)
+    ref = tape_ref.SymbolTapeNoPad(data.numpy(), batch, bptt)
+    tape = symbol_tape.SymbolTapeNoPad(data.to(DEV), batch, bptt)
+    assert (len(tape), tape.tape_len, tape.tape_parts, tape.trailing_tokens) == (len(ref), ref.tape_len, ref.tape_parts, ref.trailing_tokens)
+    for i in range(len(tape)):
+        got = tape[i]
+        assert got.dtype == dtype and np.array_equal(got.cpu().numpy(), ref[i]), i
+    with pytest.raises(hal['lib'].HaloError):
+        symbol_tape.SymbolTapeNoPad(data, batch, bptt)[0]                    # host tape: no CPU path
+
+
+def test_lm_get_batch_u16_bit_exact(hal, tmp_path):
+    from haloop_amd import symbol_tape
+    from oracle import tape_ref
+    rng = np.random.default_rng(5)
+    tokens = rng.integers(0, 50257, size=20000).astype(np.uint16)
+    tokens[rng.integers(0, 20000, size=3000)] = 0                            # zeros matter to the "cond" objective
+    path = tmp_path / 'tokens.u16'
+    tokens.tofile(path)                                                      # the flat u16 file format of ha/spm_encode.py:45-47
+    data = symbol_tape.load_u16(path, DEV)
+    assert data.numel() == 20000
+    offsets = torch.tensor([0, 17, 19000, 19999 - 64, 4242])
+    for objective in ('lm', 'cond'):
+        x, y = symbol_tape.get_batch(data, offsets, 64, objective)
+        xr, yr = tape_ref.get_batch(tokens, offsets.tolist(), 64, objective)
+        assert x.dtype == torch.int64 and np.array_equal(x.cpu().numpy(), xr) and np.array_equal(y.cpu().numpy(), yr), objective

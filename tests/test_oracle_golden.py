@@ -280,3 +280,23 @@ def test_asr_gradients_match_reference(name):
             np.testing.assert_allclose(v.grad.numpy(), want, rtol=2e-3, atol=1e-5 * max(1.0, float(np.abs(want).max())), err_msg=k)
             n += 1
     assert n == sum(1 for k in g if k.startswith('grad.'))
+
+
+def test_symbol_tape_restatement_on_the_reference_demo():
+    """ha/symbol_tape.py:311-313 (`__main__`): the 48-letter tape, batch_size 2, bptt_len 8.  tape_len = 24, three parts, no
+    trailing part; column b of part i is data[b*23 + 8i : b*23 + 8i + 8] (worked out by hand from :252-277)."""
+    from oracle import tape_ref
+    data = np.frombuffer(b'ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuv', dtype=np.uint8)
+    tape = tape_ref.SymbolTapeNoPad(data, batch_size=2, bptt_len=8)
+    assert (tape.tape_len, tape.tape_parts, tape.trailing_tokens, len(tape)) == (24, 3, 0, 3)
+    assert tape[0].shape == (8, 2)
+    assert tape[0].T.tobytes() == b'ABCDEFGHXYZabcde'
+    assert tape[1].T.tobytes() == b'IJKLMNOPfghijklm'
+    assert tape[2].T.tobytes() == b'QRSTUVWXnopqrstu'
+    # a ragged tape: 50 tokens, 3 columns -> tape_len 17, parts of 5 with 2 trailing rows; the last column runs off the end
+    tape = tape_ref.SymbolTapeNoPad(np.arange(1, 51, dtype=np.int16), batch_size=3, bptt_len=5)
+    assert (tape.tape_len, tape.tape_parts, tape.trailing_tokens, len(tape)) == (17, 3, 2, 4)
+    assert tape[3].tolist() == [[16, 32, 48], [17, 33, 49]]
+    assert tape[2][:, 2].tolist() == [43, 44, 45, 46, 47]
+    x, y = tape_ref.get_batch(np.arange(100, 200, dtype=np.uint16), [0, 90], 8)
+    assert x[1].tolist() == list(range(190, 198)) and y[1].tolist() == list(range(191, 198)) + [0]
