@@ -104,6 +104,9 @@ def lib():
     """The loaded library; raises (never falls back) when it is missing or mismatched."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64: it must be in the process BEFORE libhalo.so resolves the same soname, or the
+        # library binds a second HIP runtime and every launch on torch's streams fails (HALO_ELAUNCH)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise HaloError(f'{LIB_PATH} not found: build it with `make -C haloop_amd/csrc` '
                             '(or __graft_entry__.build()); haloop_amd has no CPU fallback')
