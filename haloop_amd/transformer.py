@@ -606,6 +606,7 @@ class AudioEncoder(nn.Module):
         self.h = nn.ModuleList([Block(head_dim=head_dim, heads=heads, p_drop=p_drop) for _ in range(layers)])
         self.ln_f = LayerNorm(head_dim * heads, bias=False)
         self.dropout_stream = DropoutStream()
+        self._graphs = {}                                                 # captured inference forwards, see _forward_graph
 
     def subsampled_lengths(self, input_lengths):
         return self.conv.subsampled_lengths(input_lengths)
@@ -619,8 +620,17 @@ class AudioEncoder(nn.Module):
             out = _EncoderFn.apply(self, x, *[p for p in self.parameters() if p.requires_grad])
             ninf = [torch.tensor(float('-inf'))] * len(self.h)
             return out, self.conv.subsampled_lengths(input_lengths), Stats(meme_entropy=list(ninf), self_entropy=list(ninf))._asdict()
+        out_lengths = self.conv.subsampled_lengths(input_lengths)
+        if not measure_entropy and os.environ.get('HALO_ENCODER_GRAPH', '1') != '0':
+            out = self._forward_graph(x.float().contiguous())
+            ninf = [torch.tensor(float('-inf'))] * len(self.h)
+            return out, out_lengths, Stats(meme_entropy=list(ninf), self_entropy=list(ninf))._asdict()
+        out, stats = self._forward_core(x, measure_entropy)
+        return out, out_lengths, stats._asdict()
+
+    @torch.no_grad()
+    def _forward_core(self, x, measure_entropy=False):
         y = self.conv.forward_cl(x)                                              # channels-last: no .mT round trip
-        input_lengths = self.conv.subsampled_lengths(input_lengths)
         N, T, C = y.shape
         y2d = y.view(N * T, C)
         stats = Stats(meme_entropy=[], self_entropy=[])
@@ -628,8 +638,32 @@ class AudioEncoder(nn.Module):
             m_ent, t_ent = block._forward2d(y2d, N, T, measure_entropy=measure_entropy)
             stats.meme_entropy.append(m_ent)
             stats.self_entropy.append(t_ent)
-        out = ops.layernorm_fwd(y2d, self.ln_f.weight).view(N, T, C)
-        return out, input_lengths, stats._asdict()
+        return ops.layernorm_fwd(y2d, self.ln_f.weight).view(N, T, C), stats
+
+    def _forward_graph(self, x):
+        """Inference forward replayed from one HIP graph per (input shape, arithmetic mode, parameter version): the ~17 small
+        launches per block are host-launch bound when issued eagerly."""
+        key = (tuple(x.shape), str(x.device), _lib.get_math_mode())
+        stamp = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        entry = self._graphs.get(key)
+        if entry is None or entry['stamp'] != stamp:
+            static = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._forward_core(static)                              # warm-up: weight images are built outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, _ = self._forward_core(static)
+            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')]
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = dict(stamp=stamp, graph=graph, static=static, out=out, held=held)
+            self._graphs[key] = entry
+        entry['static'].copy_(x)
+        entry['graph'].replay()
+        return entry['out'].clone()
 
     @torch.no_grad()
     def _forward_train(self, x):
