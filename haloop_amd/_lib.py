@@ -70,6 +70,7 @@ SIGNATURES = {
     'halo_rope_interleaved': (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     'halo_kv_cache_store': (_i, [_vp, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_attention_decode': (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'halo_attention_decode_step': (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'halo_logprob_max': (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_greedy_update': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'halo_attention_bwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _l, _l, _vp, _vp, _l, _l,

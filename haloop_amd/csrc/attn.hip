@@ -240,27 +240,52 @@ __global__ __launch_bounds__(256) void kv_cache_store_kernel(const float *__rest
 
 // One wave per (n, head): one query token against n_keys cached keys (fp16), optional rotary on the cached keys
 // (positions 0..n_keys-1, rotated from the fp16 bytes exactly like transformer.py:341-343), optional key-length mask.
+// knew / vnew (optional, rows like q): this step's key / value.  They are rounded to fp16, stored at cache position n_keys - 1
+// (kv_cache[layer, :, alive, :, t0:t0+1, :] = k, v) and used from LDS, so the store, the query rotation (rope_q: by position
+// n_keys - 1) and the attention of one decode step are ONE launch instead of three.
 template <int MAXK>
-__global__ __launch_bounds__(64) void attention_decode_kernel(const float *__restrict__ q, long q_rs, const __half *__restrict__ ck,
-                                                              const __half *__restrict__ cv, float *__restrict__ y, long y_rs,
+__global__ __launch_bounds__(64) void attention_decode_kernel(const float *__restrict__ q, long q_rs, __half *__restrict__ ck,
+                                                              __half *__restrict__ cv, float *__restrict__ y, long y_rs,
                                                               int heads, int hd, int Tc, int n_keys, const int *__restrict__ key_len,
-                                                              const float *__restrict__ cs, const float *__restrict__ sn, float scale) {
-    __shared__ float qs[128];
+                                                              const float *__restrict__ cs, const float *__restrict__ sn, float scale,
+                                                              const float *__restrict__ knew, const float *__restrict__ vnew, int rope_q) {
+    __shared__ float qs[128], kn[128], vn[128];
     __shared__ float ps[MAXK];
     const int h = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
     const int half = hd / 2;
     const float *qp = q + (long)n * q_rs + (long)h * hd;
-    for (int d = lane; d < hd; d += 64) qs[d] = qp[d] * scale;
+    const int tq = n_keys - 1;                                   // the query's own position
+    for (int i = lane; i < half; i += 64) {
+        float q0 = qp[2 * i], q1 = qp[2 * i + 1];
+        if (rope_q && cs) {
+            const float c = cs[(long)tq * half + i], sv = sn[(long)tq * half + i];
+            const float r0 = q0 * c + (-q1) * sv, r1 = q1 * c + q0 * sv;
+            q0 = r0; q1 = r1;
+        }
+        qs[2 * i] = q0 * scale;
+        qs[2 * i + 1] = q1 * scale;
+    }
+    __half *kb = ck + ((long)n * heads + h) * Tc * hd;
+    __half *vb = cv + ((long)n * heads + h) * Tc * hd;
+    if (knew) {
+        const float *kp = knew + (long)n * q_rs + (long)h * hd, *vp = vnew + (long)n * q_rs + (long)h * hd;
+        for (int d = lane; d < hd; d += 64) {
+            const __half kh = __float2half(kp[d]), vh = __float2half(vp[d]);
+            kb[(long)tq * hd + d] = kh;
+            vb[(long)tq * hd + d] = vh;
+            kn[d] = __half2float(kh);
+            vn[d] = __half2float(vh);
+        }
+    }
     __syncthreads();
     const int klim = key_len ? max(0, min(n_keys, key_len[n])) : n_keys;
-    const __half *kb = ck + ((long)n * heads + h) * Tc * hd;
-    const __half *vb = cv + ((long)n * heads + h) * Tc * hd;
     float mx = -INFINITY;
     for (int j = lane; j < klim; j += 64) {
         const __half2 *kr = reinterpret_cast<const __half2 *>(kb + (long)j * hd);
+        const bool fresh = knew && j == tq;                      // this step's row: from LDS, not from the store just issued
         float s = 0.f;
         for (int i = 0; i < half; ++i) {
-            const float2 kk = __half22float2(kr[i]);
+            const float2 kk = fresh ? float2{kn[2 * i], kn[2 * i + 1]} : __half22float2(kr[i]);
             float k0 = kk.x, k1 = kk.y;
             if (cs) {
                 const float c = cs[(long)j * half + i], sv = sn[(long)j * half + i];
@@ -285,7 +310,9 @@ __global__ __launch_bounds__(64) void attention_decode_kernel(const float *__res
     const float inv = 1.0f / sum;
     for (int d = lane; d < hd; d += 64) {
         float acc = 0.f;
-        for (int j = 0; j < klim; ++j) acc = fmaf(ps[j], __half2float(vb[(long)j * hd + d]), acc);
+        const int jcache = (knew && tq < klim) ? tq : klim;      // cached rows; the fresh row (always the last one) comes from LDS
+        for (int j = 0; j < jcache; ++j) acc = fmaf(ps[j], __half2float(vb[(long)j * hd + d]), acc);
+        if (knew && tq < klim) acc = fmaf(ps[tq], vn[d], acc);
         y[(long)n * y_rs + (long)h * hd + d] = acc * inv;
     }
 }
@@ -743,6 +770,26 @@ int halo_kv_cache_store_f32(const float *src, long src_row_stride, long v_offset
     return halo_launch_status();
 }
 
+int halo_attention_decode_step(const float *q, const float *k_new, const float *v_new, long row_stride, void *cache_k, void *cache_v,
+                               float *y, long y_row_stride, int N, int heads, int head_dim, int cache_len, int n_keys,
+                               const float *cos_table, const float *sin_table, halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k_new && v_new && cache_k && cache_v && y && N > 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0 &&
+                   head_dim <= 128);
+    HALO_CHECK_ARG(n_keys > 0 && n_keys <= cache_len && n_keys <= 8192 && N <= 65535 && (cos_table == nullptr) == (sin_table == nullptr));
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    dim3 grid(heads, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_keys <= 1024)
+        hipLaunchKernelGGL(attention_decode_kernel<1024>, grid, dim3(64), 0, st, q, row_stride, (__half *)cache_k, (__half *)cache_v, y,
+                           y_row_stride, heads, head_dim, cache_len, n_keys, (const int *)nullptr, cos_table, sin_table, scale, k_new,
+                           v_new, 1);
+    else
+        hipLaunchKernelGGL(attention_decode_kernel<8192>, grid, dim3(64), 0, st, q, row_stride, (__half *)cache_k, (__half *)cache_v, y,
+                           y_row_stride, heads, head_dim, cache_len, n_keys, (const int *)nullptr, cos_table, sin_table, scale, k_new,
+                           v_new, 1);
+    return halo_launch_status();
+}
+
 int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k, const void *cache_v, float *y, long y_row_stride,
                           int N, int heads, int head_dim, int cache_len, int n_keys, const int *key_lengths, const float *cos_table,
                           const float *sin_table, halo_stream_t stream) {
@@ -752,13 +799,13 @@ int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k
     dim3 grid(heads, N);
     hipStream_t st = (hipStream_t)stream;
     if (n_keys <= 1024)
-        hipLaunchKernelGGL(attention_decode_kernel<1024>, grid, dim3(64), 0, st, q, q_row_stride, (const __half *)cache_k,
-                           (const __half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
-                           scale);
+        hipLaunchKernelGGL(attention_decode_kernel<1024>, grid, dim3(64), 0, st, q, q_row_stride, (__half *)cache_k,
+                           (__half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
+                           scale, (const float *)nullptr, (const float *)nullptr, 0);
     else if (n_keys <= 8192)
-        hipLaunchKernelGGL(attention_decode_kernel<8192>, grid, dim3(64), 0, st, q, q_row_stride, (const __half *)cache_k,
-                           (const __half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
-                           scale);
+        hipLaunchKernelGGL(attention_decode_kernel<8192>, grid, dim3(64), 0, st, q, q_row_stride, (__half *)cache_k,
+                           (__half *)cache_v, y, y_row_stride, heads, head_dim, cache_len, n_keys, key_lengths, cos_table, sin_table,
+                           scale, (const float *)nullptr, (const float *)nullptr, 0);
     else return HALO_ENOTSUP;
     return halo_launch_status();
 }

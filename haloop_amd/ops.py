@@ -435,6 +435,19 @@ def attention_decode(q2d, cache_k, cache_v, n_keys, key_lengths=None, table=None
     return out
 
 
+def attention_decode_step(q2d, k2d, v2d, cache_k, cache_v, n_keys, table=None):
+    """Self-attention of one decode step in one launch: stores k2d / v2d (fp16) at cache position n_keys - 1, rotates q and the
+    cached keys (table), attends over n_keys positions.  q2d / k2d / v2d: column slices of one packed row buffer."""
+    N, heads, Tc, hd = cache_k.shape
+    if not (q2d.stride(0) == k2d.stride(0) == v2d.stride(0)):
+        raise ValueError('q, k, v must share a row stride')
+    out = torch.empty(N, heads * hd, device=q2d.device, dtype=torch.float32)
+    check(lib().halo_attention_decode_step(ptr(q2d), ptr(k2d), ptr(v2d), q2d.stride(0), ptr(cache_k), ptr(cache_v), ptr(out),
+                                           out.stride(0), N, heads, hd, Tc, n_keys, ptr(table.cos) if table else None,
+                                           ptr(table.sin) if table else None, _stream()), 'halo_attention_decode_step')
+    return out
+
+
 def logprob_max(logits2d, want_entropy=False):
     _f32c(logits2d, 'logits')
     rows, V = logits2d.shape

@@ -503,13 +503,13 @@ class Decoder(nn.Module):
             for l, block in enumerate(self.h):
                 mm, mt = block.mix_memory, block.mix_time
                 xn = ops.layernorm_fwd(y, block.ln_time.weight)
-                q = linear(mm._images, xn, mm.q.weight)
-                m = ops.attention_decode(q, mem_cache[l, 0], mem_cache[l, 1], S, key_lengths=mlen)
+                # both attentions read the same ln_time(x) (:476-494): one GEMM gives the cross query and the self q | k | v
+                a = linear(mt._images, xn, (mm.q.weight, mt.q.weight, mt.k.weight, mt.v.weight))      # [N, 4C]
+                m = ops.attention_decode(a, mem_cache[l, 0], mem_cache[l, 1], S, key_lengths=mlen)
                 linear(mm._images, m, mm.proj.weight, out=y, accumulate=True)
-                qkv = linear(mt._images, xn, (mt.q.weight, mt.k.weight, mt.v.weight))
-                ops.kv_cache_store(qkv[:, C:], C, time_cache[l, 0], time_cache[l, 1], N, 1, heads, head_dim, t)
-                ops.rope_(qkv, 1, heads, head_dim, table, t0=t)                  # q columns only
-                s = ops.attention_decode(qkv, time_cache[l, 0], time_cache[l, 1], t + 1, table=table)
+                # cache store (fp16) + rotary + attention over the t + 1 cached positions in one launch
+                s = ops.attention_decode_step(a[:, C:2 * C], a[:, 2 * C:3 * C], a[:, 3 * C:], time_cache[l, 0], time_cache[l, 1], t + 1,
+                                              table=table)
                 linear(mt._images, s, mt.proj.weight, out=y, accumulate=True)
                 h = linear(block._images, ops.layernorm_fwd(y, block.ln_chan.weight), block.mix_chan[0].weight, gelu='erf')
                 linear(block._images, h, block.mix_chan[2].weight, out=y, accumulate=True)

@@ -309,6 +309,12 @@ int halo_attention_decode(const float *q, long q_row_stride, const void *cache_k
                           long y_row_stride, int N, int heads, int head_dim, int cache_len, int n_keys,
                           const int *key_lengths, const float *cos_table, const float *sin_table,
                           halo_stream_t stream);
+/* One self-attention decode step in ONE launch: k_new / v_new (rows like q, same row stride) are rounded to float16 and stored
+ * at cache position n_keys - 1, q is rotated by that position (when tables are given), the cached keys by theirs, and the
+ * token attends to all n_keys positions: halo_kv_cache_store + halo_rope_interleaved + halo_attention_decode fused. */
+int halo_attention_decode_step(const float *q, const float *k_new, const float *v_new, long row_stride, void *cache_k,
+                               void *cache_v, float *y, long y_row_stride, int N, int heads, int head_dim, int cache_len,
+                               int n_keys, const float *cos_table, const float *sin_table, halo_stream_t stream);
 int halo_logprob_max(const float *logits, long ld, int rows, int V, float *values, int64_t *indices,
                      float *neg_entropy_bits, halo_stream_t stream);
 int halo_greedy_update(const float *values, const int64_t *indices, const float *neg_entropy_bits, int64_t *tokens,
