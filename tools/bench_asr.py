@@ -47,6 +47,19 @@ with torch.inference_mode():
 print(f'transformer:32 N={N} math={math_mode}: encoder {t_enc*1e3:.2f} ms ({N/t_enc:,.0f} utt/s) | CTC beam16 {t_beam*1e3:.2f} ms '
       f'({N/t_beam:,.0f} utt/s) | greedy decode T={int(tl.max())+1} {t_dec*1e3:.2f} ms ({N/t_dec:,.0f} utt/s)')
 
+# training direction (`hala`): encoder -> decoder CE + 0.3 CTC -> backward, dropout 0.2 on, every parameter's gradient
+enc.train(); dec.train()
+cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1).cuda()
+def train_fwd_bwd():
+    for p in list(enc.parameters()) + list(dec.parameters()): p.grad = None
+    f, fl, _ = enc(xd, ild)
+    loss, _ = dec(f, cond, fl, (tl + 1).cuda())
+    loss.backward()
+    return loss
+loss, t_train = timed(train_fwd_bwd)
+enc.eval(); dec.eval()
+print(f'transformer:32 N={N} joint-loss forward+backward (dropout 0.2): {t_train*1e3:.2f} ms ({N/t_train:,.0f} utt/s), loss {loss.item():.4f}')
+
 # CPU oracle on the first NCPU utterances: same hypotheses?
 torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))   # the box share; os.cpu_count() reports the whole host
 with torch.no_grad():
@@ -79,7 +92,8 @@ print(json.dumps({
                                     'batch': N, 'decode_steps': int(tl.max()) + 1, 'beam': 16, 'math': math_mode},
     'stages': {'encoder_utt_per_s': round(N / t_enc, 1), 'ctc_beam16_utt_per_s': round(N / t_beam, 1),
                'greedy_decode_utt_per_s': round(N / t_dec, 1), 'encoder_ms': round(t_enc * 1e3, 3), 'beam_ms': round(t_beam * 1e3, 3),
-               'decode_ms': round(t_dec * 1e3, 3)},
+               'decode_ms': round(t_dec * 1e3, 3), 'train_fwd_bwd_ms': round(t_train * 1e3, 3),
+               'train_fwd_bwd_utt_per_s': round(N / t_train, 1)},
     'wer_vs_cpu_oracle': {'greedy_errors': errs, 'greedy_words': words, 'beam_errors': berrs, 'beam_words': bwords,
                           'feature_max_abs_diff': float((feats[:NCPU].cpu() - f_ref).abs().max())},
     'cpu_baseline': {'value': round(NCPU / (t_cpu_enc + t_cpu_dec), 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
