@@ -42,28 +42,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // loss[n] = logsumexp(logits[n,:]) - logits[n,target[n]]   (0 where target == ignore_index)
+// One sweep over the row: every thread keeps a running (max, sum of exp relative to it) over its 16-byte pieces and the
+// pairs are merged at the end (online softmax), so the 200 KB row of a 50k vocabulary is read once, not twice.
+__device__ __forceinline__ void lse_merge(float &m, float &s, float om, float os) {
+    const float nm = fmaxf(m, om);
+    if (nm == -INFINITY) return;
+    s = s * __expf(m - nm) + os * __expf(om - nm);
+    m = nm;
+}
+
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restrict__ logits, const int64_t *__restrict__ target,
                                                             float *__restrict__ loss, float *__restrict__ lse_out, int V, long ld,
                                                             long ignore_index) {
-    __shared__ float red[4];
+    __shared__ float redm[4], reds[4];
     const int n = blockIdx.x;
     const long tgt = target[n];
     if (tgt == ignore_index) { if (threadIdx.x == 0) { loss[n] = 0.f; if (lse_out) lse_out[n] = 0.f; } return; }
     const float *row = logits + (long)n * ld;
-    float m = -INFINITY;
-    for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, row[c]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] - m);
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    float m = -INFINITY, s = 0.f;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)logits % 16 == 0);
+    const int V4 = vec ? V / 4 : 0;
+    for (int c = threadIdx.x; c < V4; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * c);
+        const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (vm > m) { s *= __expf(m - vm); m = vm; }
+        s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
+    }
+    for (int c = 4 * V4 + threadIdx.x; c < V; c += 256) {
+        const float v = row[c];
+        if (v > m) { s *= __expf(m - v); m = v; }
+        s += __expf(v - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lse_merge(m, s, __shfl_xor(m, o, 64), __shfl_xor(s, o, 64));
+    if ((threadIdx.x & 63) == 0) { redm[threadIdx.x >> 6] = m; reds[threadIdx.x >> 6] = s; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float l = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+        m = redm[0]; s = reds[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) lse_merge(m, s, redm[w], reds[w]);
+        const float l = m + logf(s);
         loss[n] = l - row[tgt];
         if (lse_out) lse_out[n] = l;
     }
