@@ -89,6 +89,7 @@ SIGNATURES = {
     'halo_dwconv1d_cl_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_tape_batch': (_i, [_vp, _i, _l, _i, _i, _l, _i, _l, _vp, _vp]),
     'halo_lm_batch_u16': (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'halo_scale_add': (_i, [_vp, _vp, _f, _f, _sz, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -93,7 +93,31 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
 
 }  // namespace
 
+namespace {
+// y = alpha * y + beta * x : gradient accumulation over micro-batches (ha/loop.py:176-181: loss / accumulate, backward, ...)
+__global__ __launch_bounds__(256) void scale_add_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha, float beta, size_t n4,
+                                                        size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        f32x4 a = reinterpret_cast<f32x4 *>(y)[i];
+        const f32x4 b = reinterpret_cast<const f32x4 *>(x)[i];
+        a = alpha * a + beta * b;
+        reinterpret_cast<f32x4 *>(y)[i] = a;
+    } else if (i == n4) {
+        for (size_t e = 4 * n4; e < n; ++e) y[e] = alpha * y[e] + beta * x[e];
+    }
+}
+}  // namespace
+
 extern "C" {
+
+int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, halo_stream_t stream) {
+    HALO_CHECK_ARG(y && x && ((uintptr_t)y % 16 == 0) && ((uintptr_t)x % 16 == 0));
+    if (n == 0) return HALO_OK;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(scale_add_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n4, n);
+    return halo_launch_status();
+}
 
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream) {
     HALO_CHECK_ARG(x && partials && ((uintptr_t)x % 16 == 0));

@@ -321,6 +321,12 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None
     torch.autograd.graph.increment_version(p)
 
 
+def scale_add_(y, x, alpha, beta):
+    """y <- alpha*y + beta*x in place (flat fp32 buffers)."""
+    check(lib().halo_scale_add(ptr(y), ptr(x), float(alpha), float(beta), y.numel(), _stream()), 'halo_scale_add')
+    return y
+
+
 def counter_inc(counter):
     check(lib().halo_counter_inc(ptr(counter), _stream()), 'halo_counter_inc')
 

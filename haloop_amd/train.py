@@ -87,8 +87,12 @@ class FlatParams:
 
 class LstmCtcTrainer:
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
-                 clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None):
+                 clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1):
+        """accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
+        forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call."""
         self.encoder, self.recognizer = encoder, recognizer
+        self.accumulate = int(accumulate)
+        self._micro = 0
         self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip_grad_norm
         self.flat = FlatParams(encoder, recognizer)
         dev = self.flat.params.device
@@ -110,6 +114,7 @@ class LstmCtcTrainer:
         self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range)
         self._graphs = None
         self._static = None
+        self._accum = torch.zeros_like(self.flat.grads) if self.accumulate > 1 else None
 
     # ---- pieces -------------------------------------------------------------------------------
     def _dropout(self):
@@ -191,7 +196,10 @@ class LstmCtcTrainer:
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):
-        """One optimizer step.  Returns the (device) loss tensor; nothing here synchronises."""
+        """One optimizer step (one micro-step of it when accumulate > 1).  Returns the (device) loss tensor of this batch;
+        nothing here synchronises."""
+        if self.accumulate > 1:
+            return self._accumulating_step(x, input_lengths, targets, target_lengths)
         self.step_count += 1
         if not self.use_graph:
             st = self._forward_backward_top(x, input_lengths, targets, target_lengths)
@@ -204,13 +212,53 @@ class LstmCtcTrainer:
             return self.loss
         return self._graph_step(x, input_lengths, targets, target_lengths)
 
+    def _accumulating_step(self, x, il, tg, tl):
+        # forward/backward writes this micro-batch's gradients into the flat buffer; they are folded into the running sum
+        # scaled by 1/accumulate; the last micro-step hands the sum back and runs the (averaged, clipped) update
+        if self.use_graph:
+            self._replay_forward_backward(x, il, tg, tl)
+        else:
+            self._forward_backward(x, il, tg, tl)
+        self._micro += 1
+        first, last = self._micro == 1, self._micro == self.accumulate
+        ops.scale_add_(self._accum, self.flat.grads, 0.0 if first else 1.0, 1.0 / self.accumulate)
+        if not last:
+            ops.counter_inc(self.counter)                        # the next micro-batch draws fresh dropout masks
+            return self.loss
+        self._micro = 0
+        self.flat.grads.copy_(self._accum)
+        self._all_reduce()                                   # only on the last micro-step (attention_loop.py:203)
+        self.step_count += 1
+        self._optimizer(self.step_count)
+        return self.loss
+
+    def _replay_forward_backward(self, x, il, tg, tl):
+        if self._graphs is None or len(self._graphs) != 1 or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
+            # private buffers: refilling them for the next batch must never write into a tensor the caller still owns
+            self._static = tuple(t.contiguous().clone() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
+            sx, sil, stg, stl = self._static
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._forward_backward(sx, sil, stg, stl)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward_backward(sx, sil, stg, stl)
+            self._graphs = (g,)
+        for dst, src in zip(self._static, (x, il, tg, tl)):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
+        self._graphs[0].replay()
+
     def _graph_step(self, x, il, tg, tl):
         # AdamW's bias corrections depend on the step number (a host scalar in the kernel arguments), so
         # forward/backward are captured and the 7-launch optimizer runs eagerly.  With data parallelism
         # backward is captured as TWO graphs so that the first gradient bucket's all-reduce (eager, on
         # RCCL's stream) runs beside the second graph.
         if self._graphs is None or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
-            self._static = tuple(t.contiguous() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
+            # private buffers: refilling them for the next batch must never write into a tensor the caller still owns
+            self._static = tuple(t.contiguous().clone() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
             sx, sil, stg, stl = self._static
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -247,5 +295,6 @@ class LstmCtcTrainer:
         return self.loss
 
     def static_inputs(self):
-        """The graph's input buffers (fill these in place to avoid the per-step copy)."""
+        """The graph's own input buffers (x, input_lengths, targets, target_lengths), available after the first step: fill
+        them in place (e.g. as the destination of the host-to-device copy) and pass them to step() to avoid a device copy."""
         return self._static

@@ -402,6 +402,8 @@ int halo_lm_batch_u16(const uint16_t *data, long n_tokens, const int64_t *offset
  *   (device scalar, may be NULL) before use.  step >= 1 is the 1-based update count.
  * ------------------------------------------------------------------------------------------ */
 #define HALO_SUMSQ_PARTS 1024
+/* y = alpha*y + beta*x on flat buffers: accumulates micro-batch gradients (loss / accumulate; ha/loop.py:176-181) */
+int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, halo_stream_t stream);
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
 int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                    halo_stream_t stream);

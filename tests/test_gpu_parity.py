@@ -859,3 +859,33 @@ def test_lm_get_batch_u16_bit_exact(hal, tmp_path):
         x, y = symbol_tape.get_batch(data, offsets, 64, objective)
         xr, yr = tape_ref.get_batch(tokens, offsets.tolist(), 64, objective)
         assert x.dtype == torch.int64 and np.array_equal(x.cpu().numpy(), xr) and np.array_equal(y.cpu().numpy(), yr), objective
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_gradient_accumulation_equals_one_large_batch(hal, use_graph):
+    """--accumulate (ha/loop.py:176-181): two half-batch micro-steps of loss / 2 == one step on the whole batch (dropout off,
+    equal halves so the mean-reduced CTC loss is the mean of the halves' means)."""
+    from haloop_amd.train import LstmCtcTrainer
+    from oracle import cpu_ref
+    F_, C, H, L, V, B, T, S = 12, 16, 32, 2, 9, 4, 41, 4
+    x, il, tg, tl = (t.to(DEV) for t in cpu_ref.synthetic_batch(B, T, F_, V, S, 7))
+
+    def build():
+        enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 100)
+        enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+        enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+        return enc.to(DEV).eval(), rec.to(DEV).eval()
+
+    enc, rec = build()
+    whole = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=False)
+    for _ in range(2):
+        whole.step(x, il, tg, tl)
+    enc2, rec2 = build()
+    acc = LstmCtcTrainer(enc2, rec2, lr=3e-3, use_graph=use_graph, accumulate=2)
+    for _ in range(2):
+        acc.step(x[:2], il[:2], tg[:2], tl[:2])
+        assert acc.step_count == _                                  # no update after the first micro-step
+        acc.step(x[2:], il[2:], tg[2:], tl[2:])
+    assert acc.step_count == 2
+    np.testing.assert_allclose(acc.grad_norm.item(), whole.grad_norm.item(), rtol=1e-4)
+    np.testing.assert_allclose(acc.flat.params.cpu().numpy(), whole.flat.params.cpu().numpy(), atol=5e-6)
