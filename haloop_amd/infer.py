@@ -35,7 +35,7 @@ class LstmCtcRecognizer:
         if not self.use_graph:
             return self._run(x.contiguous())
         if self._graph is None or self._static.shape != x.shape:
-            self._static = x.contiguous()
+            self._static = x.contiguous().clone()        # private: refilling it must not write into the caller's tensor
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
