@@ -29,6 +29,10 @@ class LstmCtcRecognizer:
         lp = ops.log_softmax_fwd(logits).view(B, Tp, V)
         return ops.ctc_greedy(lp)          # alignments, scores, hyp (padded), hyp_len
 
+    def static_input(self):
+        """The graph's own input buffer (after the first call): fill it in place and pass it to recognize() to skip the copy."""
+        return self._static
+
     @torch.no_grad()
     def recognize(self, x):
         """x [B,T,F] on the HIP device -> (alignments [B,T'], scores [B,T'], hyp [B,T'] padded, hyp_len [B])."""
