@@ -1,8 +1,8 @@
 """torch.autograd glue: each Function is one forward/backward pair of C-ABI calls."""
 import torch
 
-from . import _lib, ops
-from .ops import Dropout, NO_DROPOUT
+from . import ops
+from .ops import NO_DROPOUT
 
 
 def _lstm_lists(lstm_params, L):

@@ -12,7 +12,6 @@ gradients averaged with one RCCL all-reduce per step over the flat gradient buff
 semantics of DistributedDataParallel in ha/attention_loop.py:154.
 """
 import torch
-import torch.distributed as dist
 
 from . import _lib, dp, ops
 from .ops import Dropout, NO_DROPOUT

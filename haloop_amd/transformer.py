@@ -25,7 +25,6 @@ attention kernels (forward and both backward sweeps recompute the same mask).
 Not built (raises): autograd through a bare Block / MultiHeadAttention call, ``kv_cache_parts`` on the public Block / MultiHeadAttention.forward (Decoder.decode drives the caches
 itself), arbitrary attention masks (only the key-padding masks Block builds, transformer.py:476).
 """
-import math
 import os
 from collections import namedtuple
 

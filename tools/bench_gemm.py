@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the GEMM kernels on the LSTM's shapes (run on the GPU box)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from haloop_amd import _lib, ops
