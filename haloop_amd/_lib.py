@@ -39,6 +39,7 @@ SIGNATURES = {
     'halo_gemm_f32': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_split_image_bytes': (_sz, [_i, _i]),
     'halo_split_image': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'halo_layernorm_image': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_gemm_split': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_subsample_col_bytes': (_sz, [_i] * 6),
     'halo_subsample_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),

@@ -42,10 +42,11 @@ class WeightImages:
                             lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
 
 
-def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0):
+def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
     ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
-    and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add)."""
+    and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add).
+    ``a_image``: the split image of x2d when the caller already has it (normed_image), used if the split GEMM runs."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
     M, K = x2d.shape
@@ -53,8 +54,8 @@ def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=Fal
     # a handful of rows (one decode step): the operand-image pass would cost more than the product; the exact-f32 kernel
     # reads x and W where they lie
     if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64 and M > SMALL_M:
-        return ops.gemm_split(ops.split_image(x2d), images.split(weights), M, N, K, out=out, bias1=bias, gelu=gelu,
-                              accumulate=accumulate, drop=drop, stream_id=stream_id)
+        return ops.gemm_split(a_image if a_image is not None else ops.split_image(x2d), images.split(weights), M, N, K, out=out,
+                              bias1=bias, gelu=gelu, accumulate=accumulate, drop=drop, stream_id=stream_id)
     return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate,
                     drop=drop, stream_id=stream_id)
 
@@ -104,3 +105,27 @@ def drop_rows(x2d, site):
     """x2d * mask of a dropout site (elementwise kernel); the same call gives the backward of that site."""
     drop, sid = site
     return ops.dropout_fwd(x2d, drop, sid) if drop.p > 0 else x2d
+
+
+def ln_linear(images, x2d, ln_weight, ln_bias, weights, bias=None, gelu=False, want_normed=False, eps=1e-5):
+    """linear(layer_norm(x2d), weights) with the normalisation written straight into the GEMM's operand image when the split
+    GEMM will run (saves the pass that re-reads the normalised rows to split them).  -> (out, normed fp32 rows or None)"""
+    if isinstance(weights, torch.Tensor):
+        weights = (weights,)
+    M, K = x2d.shape
+    N = sum(w.shape[0] for w in weights)
+    if use_split(M, N, K) and M > SMALL_M and K % 32 == 0:
+        a_img, h = ops.layernorm_image(x2d, ln_weight, ln_bias, eps, want_y=want_normed)
+        return ops.gemm_split(a_img, images.split(weights), M, N, K, bias1=bias, gelu=gelu), h
+    h = ops.layernorm_fwd(x2d, ln_weight, ln_bias, eps)
+    return linear(images, h, weights, bias=bias, gelu=gelu), (h if want_normed else None)
+
+
+def normed_image(x2d, ln_weight, ln_bias=None, n_out=64, want_normed=True, eps=1e-5):
+    """layer_norm(x2d) for Linear layers with n_out outputs: (normed fp32 rows or None, their split image or None).  The image
+    comes straight out of the LayerNorm kernel when the split GEMM will consume it; otherwise only the fp32 rows exist."""
+    M, K = x2d.shape
+    if use_split(M, n_out, K) and M > SMALL_M and K % 32 == 0:
+        img, h = ops.layernorm_image(x2d, ln_weight, ln_bias, eps, want_y=want_normed)
+        return h, img
+    return ops.layernorm_fwd(x2d, ln_weight, ln_bias, eps), None

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx
+from ._linear import DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx, ln_linear
 from .rnn import DropoutStream
 
 
@@ -184,16 +184,14 @@ class GPT(nn.Module):
             if t0:
                 present[..., :t0, :] = past
         for i, blk in enumerate(tr.h):
-            h = ops.layernorm_fwd(x, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = self._linear(h, blk.attn.c_attn)
+            qkv, _ = ln_linear(self._images, x, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias)
             if present is not None:
                 ops.kv_cache_store(qkv[:, C:], C, present[i, 0], present[i, 1], B, T, H, C // H, t0)
                 y = ops.attention_cached_fwd(qkv, present[i, 0], present[i, 1], T, t0 + T, causal=True)
             else:
                 y = ops.attention_causal_fwd(qkv, B, T, cfg.n_head)
             self._linear(y, blk.attn.c_proj, out=x, accumulate=True)                     # x += c_proj(y)
-            h = ops.layernorm_fwd(x, blk.ln_2.weight, blk.ln_2.bias)
-            h = self._linear(h, blk.mlp.c_fc, gelu=True)
+            h, _ = ln_linear(self._images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True)
             self._linear(h, blk.mlp.c_proj, out=x, accumulate=True)                      # x += mlp(h)
         return ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias), present
 
@@ -248,14 +246,13 @@ class GPT(nn.Module):
         blocks = []
         for blk in tr.h:
             x0 = x
-            h1 = ops.layernorm_fwd(x0, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = self._linear(h1, blk.attn.c_attn)
+            qkv, h1 = ln_linear(self._images, x0, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias,
+                                want_normed=True)
             s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
             y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=True, want_lse=True,
                                           drop=s_att[0], stream_id=s_att[1])
             x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res)
-            h2 = ops.layernorm_fwd(x1, blk.ln_2.weight, blk.ln_2.bias)
-            a = self._linear(h2, blk.mlp.c_fc)
+            a, h2 = ln_linear(self._images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
             g = ops.gelu_fwd(a)
             x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True, site=s_mlp)
             blocks.append((x0, h1, qkv, y, lse, x1, h2, a, g, s_att, s_res, s_mlp))

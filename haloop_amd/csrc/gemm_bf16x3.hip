@@ -274,6 +274,53 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     }
 }
 
+
+// F.layer_norm fused with the operand-image pass of the GEMM that consumes it: one wave per row normalises the row (fp32,
+// biased variance) and writes it straight into the tiled hi|lo image (and, optionally, as fp32 rows for the backward), so the
+// normalised activations are not written and re-read once more just to be split.  C % 32 == 0 (whole k-tiles).
+__global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ b, float *__restrict__ y, char *__restrict__ img,
+                                                              int rows, int C, float eps, int with_lo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (long)row * C;
+    const int groups = C / 8, KT = C / TK;
+    float s = 0.f;
+    for (int g = lane; g < groups; g += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 8 * g), c = *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4);
+        s += (a[0] + a[1]) + (a[2] + a[3]) + (c[0] + c[1]) + (c[2] + c[3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int g = lane; g < groups; g += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 8 * g), c = *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d0 = a[e] - mean, d1 = c[e] - mean; v += d0 * d0 + d1 * d1; }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    const int rt = row / TR, rin = row % TR;
+    for (int g = lane; g < groups; g += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 8 * g), c = *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (a[e] - mean) * rstd * w[8 * g + e];
+            o[4 + e] = (c[e] - mean) * rstd * w[8 * g + 4 + e];
+            if (b) { o[e] += b[8 * g + e]; o[4 + e] += b[8 * g + 4 + e]; }
+        }
+        if (y) {
+            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+        bf16x8 hi, lo;
+        split8(o, hi, lo);
+        char *blk = img + ((long)rt * KT + (8 * g) / TK) * BLOCK_BYTES;
+        const int off = swz_byte(rin, ((8 * g) % TK) / 8);
+        *reinterpret_cast<bf16x8 *>(blk + off) = hi;
+        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+    }
+}
+
 }  // namespace
 
 size_t halo_tiled_image_bytes(int R, int K) {
@@ -349,6 +396,15 @@ int halo_split_image(const float *src, int rows, int k, int ld, int src_transpos
     HALO_CHECK_ARG(ld >= (src_transposed ? rows : k));
     HALO_CHECK_ARG((uintptr_t)image % 16 == 0);
     return halo_prep_tiles(src, rows, k, ld, src_transposed, image, (hipStream_t)stream);
+}
+
+int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C, float eps,
+                         halo_stream_t stream) {
+    HALO_CHECK_ARG(x && weight && image && rows > 0 && C > 0 && C % TK == 0);
+    HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)image | (uintptr_t)y) % 16 == 0);
+    hipLaunchKernelGGL(layernorm_image_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image,
+                       rows, C, eps, halo_math_mode() != HALO_MATH_BF16);
+    return halo_launch_status();
 }
 
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *bias1,

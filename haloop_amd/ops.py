@@ -67,6 +67,17 @@ def split_image(x2d, transposed=False):
     return img
 
 
+def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
+    """LayerNorm of the rows written directly as the split operand image of the Linear that follows (C % 32 == 0).
+    -> (image, y fp32 or None)"""
+    _f32c(x2d, 'x')
+    rows, Cn = x2d.shape
+    img = torch.empty(lib().halo_split_image_bytes(rows, Cn), device=x2d.device, dtype=torch.uint8)
+    y = torch.empty_like(x2d) if want_y else None
+    check(lib().halo_layernorm_image(ptr(x2d), ptr(weight), ptr(bias), ptr(y), ptr(img), rows, Cn, eps, _stream()), 'halo_layernorm_image')
+    return img, y
+
+
 def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0,
                gelu=False, accumulate=False):
     """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate)."""

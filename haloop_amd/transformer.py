@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import NO_SITES, DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx
+from ._linear import NO_SITES, DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx, ln_linear, normed_image
 from .attention import LayerNorm
 from .conv import ConvEncoder
 from .recognizer import TemporalClassifier
@@ -202,13 +202,13 @@ class MultiHeadAttention(nn.Module):
                 v.reshape(N, S, self.heads, self.head_dim).transpose(-3, -2))
 
     # x2d [N*T, C] (already normalised), mem2d [N*S, C] or None for self-attention -> attention output [N*T, C] (before proj)
-    def _attend2d(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, t0=0, measure_entropy=False):
+    def _attend2d(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, t0=0, measure_entropy=False, x_img=None):
         C = self.heads * self.head_dim
         if mem2d is None:
-            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight))       # one GEMM, [N*T, 3C]
+            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight), a_image=x_img)   # one GEMM, [N*T, 3C]
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         else:
-            q = linear(self._images, x2d, self.q.weight)
+            q = linear(self._images, x2d, self.q.weight, a_image=x_img)
             kv = linear(self._images, mem2d, (self.k.weight, self.v.weight))
             k, v = kv[:, :C], kv[:, C:]
         if rope:
@@ -220,13 +220,13 @@ class MultiHeadAttention(nn.Module):
         return y, (ent.mean() if measure_entropy else torch.tensor(float('-inf')))
 
     # training twins of _attend2d: keep q/k/v (after the rotary), the output and the log-sum-exp
-    def _attend2d_train(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, site=(ops.NO_DROPOUT, 0)):
+    def _attend2d_train(self, x2d, mem2d, N, T, S, key_lengths=None, causal=False, rope=False, site=(ops.NO_DROPOUT, 0), x_img=None):
         C = self.heads * self.head_dim
         if mem2d is None:
-            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight))
+            qkv = linear(self._images, x2d, (self.q.weight, self.k.weight, self.v.weight), a_image=x_img)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         else:
-            q = linear(self._images, x2d, self.q.weight)
+            q = linear(self._images, x2d, self.q.weight, a_image=x_img)
             kv = linear(self._images, mem2d, (self.k.weight, self.v.weight))
             k, v = kv[:, :C], kv[:, C:]
         table = None
@@ -303,36 +303,36 @@ class Block(nn.Module):
 
     # x2d [N*T, C] is updated IN PLACE (the caller owns it); memory rows [N*S, C]
     def _forward2d(self, x2d, N, T, causal=False, mem2d=None, S=0, memory_lengths=None, measure_entropy=False, time_lengths=None):
-        x_norm = ops.layernorm_fwd(x2d, self.ln_time.weight)
+        # ln_time(x) feeds up to two GEMMs (cross query, self q|k|v): one LayerNorm pass writes their shared operand image
+        x_norm, x_img = normed_image(x2d, self.ln_time.weight, n_out=x2d.shape[1])
         m_ent = torch.tensor(float('-inf'))
         if self.mix_memory is not None:
             mm = self.mix_memory
-            m, m_ent = mm._attend2d(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, measure_entropy=measure_entropy)
+            m, m_ent = mm._attend2d(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, measure_entropy=measure_entropy, x_img=x_img)
             linear(mm._images, m, mm.proj.weight, out=x2d, accumulate=True)                      # x += cross(ln(x), memory)
         mt = self.mix_time
         t, t_ent = mt._attend2d(x_norm, None, N, T, T, key_lengths=time_lengths, causal=causal and time_lengths is None, rope=True,
-                                measure_entropy=measure_entropy)                                 # the SAME x_norm (:476-494)
+                                measure_entropy=measure_entropy, x_img=x_img)                    # the SAME x_norm (:476-494)
         linear(mt._images, t, mt.proj.weight, out=x2d, accumulate=True)
-        h = linear(self._images, ops.layernorm_fwd(x2d, self.ln_chan.weight), self.mix_chan[0].weight, gelu='erf')
+        h, _ = ln_linear(self._images, x2d, self.ln_chan.weight, None, self.mix_chan[0].weight, gelu='erf')
         linear(self._images, h, self.mix_chan[2].weight, out=x2d, accumulate=True)
         return m_ent, t_ent
 
     def _forward2d_train(self, x0, N, T, causal=False, mem2d=None, S=0, memory_lengths=None, sites=NO_SITES):
         """Dropout sites in forward order: [cross-attention probabilities, cross proj output,] self-attention probabilities,
         self proj output, MLP output (ha/transformer.py:356,371,457); each output dropout is the GEMM's epilogue."""
-        x_norm = ops.layernorm_fwd(x0, self.ln_time.weight)
+        x_norm, x_img = normed_image(x0, self.ln_time.weight, n_out=x0.shape[1])
         xa, sv_m, s_mo = x0, None, None
         if self.mix_memory is not None:
             mm = self.mix_memory
-            ym, sv_m = mm._attend2d_train(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, site=sites.next())
+            ym, sv_m = mm._attend2d_train(x_norm, mem2d, N, T, S, key_lengths=memory_lengths, site=sites.next(), x_img=x_img)
             s_mo = sites.next()
             xa = linear(mm._images, ym, mm.proj.weight, out=x0.clone(), accumulate=True, drop=s_mo[0], stream_id=s_mo[1])
         mt = self.mix_time
-        yt, sv_t = mt._attend2d_train(x_norm, None, N, T, T, causal=causal, rope=True, site=sites.next())
+        yt, sv_t = mt._attend2d_train(x_norm, None, N, T, T, causal=causal, rope=True, site=sites.next(), x_img=x_img)
         s_to = sites.next()
         xb = linear(mt._images, yt, mt.proj.weight, out=xa.clone(), accumulate=True, drop=s_to[0], stream_id=s_to[1])
-        hn = ops.layernorm_fwd(xb, self.ln_chan.weight)
-        a = linear(self._images, hn, self.mix_chan[0].weight)
+        a, hn = ln_linear(self._images, xb, self.ln_chan.weight, None, self.mix_chan[0].weight, want_normed=True)
         g = ops.gelu_fwd(a, exact=True)
         s_co = sites.next()
         xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True, drop=s_co[0], stream_id=s_co[1])

@@ -117,6 +117,11 @@ int halo_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float
 size_t halo_split_image_bytes(int rows, int k);
 int halo_split_image(const float *src, int rows, int k, int ld, int src_transposed, void *image,
                      halo_stream_t stream);
+/* F.layer_norm(x, (C,), weight, bias|NULL, eps) written straight into the split image of its rows (the A operand of the Linear
+ * that follows: ln_1 -> c_attn, ln_2 -> c_fc, ha/attention.py:175-179; ln_time / ln_chan, ha/transformer.py:476,495), and
+ * optionally as fp32 rows y (NULL to skip).  C % 32 == 0. */
+int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C,
+                         float eps, halo_stream_t stream);
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc,
                     const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                     uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
