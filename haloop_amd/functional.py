@@ -102,6 +102,28 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _Embedding(torch.autograd.Function):
+    """nn.Embedding lookup (ha/rnn.py:38,45) on the HIP gather; the backward scatter-adds rows with float atomics."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        flat = ids.reshape(1, -1)
+        ctx.save_for_backward(flat)
+        ctx.shape = weight.shape
+        return ops.embed_fwd(flat, weight, None).view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (flat,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, device=dy.device, dtype=torch.float32)
+        ops.embed_bwd(flat, dy.reshape(-1, ctx.shape[1]).contiguous().float(), dw, None)
+        return None, dw
+
+
+def embedding(ids, weight):
+    return _Embedding.apply(ids, weight)
+
+
 def linear(x, w, b):
     shp = x.shape
     y = _Linear.apply(x.reshape(-1, shp[-1]), w, b)

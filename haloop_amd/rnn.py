@@ -101,12 +101,12 @@ class Decoder(nn.Module):
         return HF.linear(y, self.out_layer.weight, self.out_layer.bias), (hn, cn)
 
     def forward(self, input, state):
-        emb = self.embedding(input)                          # (T, N, E)
+        emb = HF.embedding(input, self.embedding.weight)     # (T, N, E)
         output, state = self._run(emb, state)
         return output.view(-1, self.num_classes), state
 
     def forward_batch_first(self, input, state):
-        emb = self.embedding(input).transpose(0, 1)          # (T, N, E)
+        emb = HF.embedding(input, self.embedding.weight).transpose(0, 1)   # (T, N, E)
         output, state = self._run(emb, state)
         return output.transpose(0, 1), state
 

@@ -389,7 +389,7 @@ def test_decoder_lm_matches_torch_lstm(hal, math_mode, fusion, E):
     dec = hal['rnn'].Decoder(V, E, E, L)
     ref = torch.nn.LSTM(E, E, L)
     ref.load_state_dict({k: v for k, v in dec.rnn.state_dict().items()})
-    emb_w, out_b = dec.embedding.weight.detach().clone(), dec.out_layer.bias.detach().clone()
+    emb_w, out_b = dec.embedding.weight.detach().clone().requires_grad_(True), dec.out_layer.bias.detach().clone()
     tokens = torch.randint(0, V, (T, N))
     h0, c0 = torch.randn(L, N, E) * 0.1, torch.randn(L, N, E) * 0.1
     out_ref, (hn_ref, cn_ref) = ref(torch.nn.functional.embedding(tokens, emb_w), (h0, c0))
@@ -403,6 +403,8 @@ def test_decoder_lm_matches_torch_lstm(hal, math_mode, fusion, E):
     logits_ref.square().mean().backward()
     for k, p in dec.rnn.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), getattr(ref, k).grad.numpy(), rtol=1e-3, atol=1e-6, err_msg=k)
+    # tied embedding / output weight (ha/rnn.py:42): the HIP gather's scatter-add backward plus the output layer's dW
+    np.testing.assert_allclose(dec.embedding.weight.grad.cpu().numpy(), emb_w.grad.numpy(), rtol=1e-3, atol=2e-6)
     lbf, _ = dec.forward_batch_first(tokens.t().to(DEV), (h0.to(DEV), c0.to(DEV)))
     np.testing.assert_allclose(lbf.detach().cpu().numpy(), logits_ref.detach().view(T, N, V).transpose(0, 1).numpy(), atol=1e-5)
 
