@@ -354,3 +354,45 @@ def test_asr_training_mode_dropout_matches_oracle_with_same_masks(hal, name, mat
     # a second forward draws new masks (the stream offset advanced)
     feats2, _, _ = enc(x.to(DEV), il.to(DEV))
     assert not torch.allclose(feats2, feats)
+
+
+# ------------------------------------------------------------------------------------- other shapes of the same path
+@BOTH_MODES
+@pytest.mark.parametrize('hd,heads,el,dl,conv_dim,N,T,S,strides,F_', [
+    (16, 5, 1, 1, 40, 1, 300, 20, (2, 2, 1), 23),      # C = 80: not a multiple of 32 (LayerNorm-image fallback, ragged k-tiles), N = 1
+    (64, 2, 2, 1, 64, 5, 531, 70, (2, 2, 2), 80),      # 67 encoder frames and 71 decoder positions: more than one 64-row attention tile
+    (32, 3, 1, 2, 96, 2, 97, 3, (2, 1), 17),           # two convs only, C = 96
+])
+def test_asr_shape_robustness_against_oracle(hal, math_mode, hd, heads, el, dl, conv_dim, N, T, S, strides, F_):
+    """Forward, losses and every gradient against the CPU oracle at sizes the goldens do not cover (no fixture: the oracle is
+    pinned to the reference by tests/test_oracle_golden.py)."""
+    from oracle import transformer_ref
+    vocab = 29
+    pe = transformer_ref.make_encoder_params(hd, heads, el, F_, conv_dim, len(strides), 3)
+    pd = transformer_ref.make_decoder_params(vocab, hd, heads, dl, 4)
+    x, il, tg, tl = transformer_ref.synthetic_asr_batch(N, T, F_, vocab, S, 5)
+    tr = hal['tr']
+    enc = tr.AudioEncoder(head_dim=hd, heads=heads, layers=el, p_drop=0.1, input_dim=F_, conv_dim=conv_dim, conv_strides=strides)
+    dec = tr.CTCAttentionDecoder(vocab=vocab, head_dim=hd, heads=heads, p_drop=0.1, layers=dl)
+    enc.load_state_dict(pe, strict=True); dec.load_state_dict(pd, strict=True)
+    enc, dec = enc.to(DEV).eval(), dec.to(DEV).eval()
+    feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+    loss, _ = dec.decoder(feats, tg.to(DEV), flen, tl.to(DEV), drop_labels=False)
+    loss.backward()
+    pe_r = {k: v.clone().requires_grad_(True) for k, v in pe.items()}
+    pd_r = {k[len('decoder.'):]: v.clone().requires_grad_(True) for k, v in pd.items() if k.startswith('decoder.')}
+    f_ref, fl_ref = transformer_ref.audio_encoder_forward(pe_r, x, il, heads, strides)
+    l_ref = transformer_ref.decoder_forward(pd_r, f_ref, tg, fl_ref, tl, heads)
+    l_ref.backward()
+    assert np.array_equal(flen.cpu().numpy(), fl_ref.numpy())
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), f_ref.detach().numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), l_ref.item(), rtol=5e-5)
+    for m, params in ((enc, pe_r), (dec.decoder, pd_r)):
+        for k, p in m.named_parameters():
+            want = params[k].grad.numpy()
+            scale = max(1.0, float(np.abs(want).max()))
+            tol = dict(rtol=2e-3, atol=3e-5 * scale) if math_mode == 'f32' else dict(rtol=5e-3, atol=2e-4 * scale)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want, err_msg=k, **tol)
+    with torch.no_grad():                                      # greedy decode runs at these sizes and stops within the step budget
+        outs, olen, _, lps, _ = dec.decode(feats.detach(), flen, tl.to(DEV))
+    assert olen.shape == (N,) and int(olen.max()) <= int(tl.max()) + 1 and torch.isfinite(lps).all()
