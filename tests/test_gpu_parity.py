@@ -891,3 +891,28 @@ def test_gradient_accumulation_equals_one_large_batch(hal, use_graph):
     assert acc.step_count == 2
     np.testing.assert_allclose(acc.grad_norm.item(), whole.grad_norm.item(), rtol=1e-4)
     np.testing.assert_allclose(acc.flat.params.cpu().numpy(), whole.flat.params.cpu().numpy(), atol=5e-6)
+
+
+@BOTH_MODES
+@pytest.mark.parametrize('vocab,block,n_layer,n_head,n_embd,bias,B,T', [(131, 80, 2, 3, 96, True, 3, 77), (53, 200, 1, 2, 128, False, 1, 193)])
+def test_gpt_shape_robustness_against_oracle(hal, math_mode, vocab, block, n_layer, n_head, n_embd, bias, B, T):
+    """Sizes the fixtures do not cover (T across several 64-row attention tiles and not a multiple of anything, 3 heads of 32,
+    odd vocabulary, B = 1): per-token loss and every gradient against the CPU oracle."""
+    from haloop_amd import attention
+    from oracle import gpt_ref
+    params = gpt_ref.make_gpt_params(vocab, block, n_layer, n_head, n_embd, bias, 11)
+    inputs, targets = gpt_ref.synthetic_tokens(B, T, vocab, 12)
+    model = attention.GPT(attention.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head, n_embd=n_embd, bias=bias))
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).train()
+    per_tok = model.forward_all(inputs.to(DEV), targets.to(DEV), reduction='none')
+    loss = per_tok.sum() / (targets != 0).sum().to(DEV)
+    loss.backward()
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref['lm_head.weight'] = ref['transformer.wte.weight']
+    ref_tok = gpt_ref.gpt_forward_all(ref, n_layer, n_head, inputs, targets, reduction='none')
+    (ref_tok.sum() / (targets != 0).sum()).backward()
+    np.testing.assert_allclose(per_tok.detach().cpu().numpy(), ref_tok.detach().numpy(), rtol=2e-5, atol=5e-5)
+    tol = dict(rtol=5e-4, atol=5e-7) if math_mode == 'f32' else dict(rtol=2e-3, atol=4e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].grad.numpy(), err_msg=k, **tol)
