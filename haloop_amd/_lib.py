@@ -130,8 +130,10 @@ def lib():
 def set_math_mode(mode):
     """'f32' (exact-f32 MFMA), 'bf16x3' (split-bf16, three MFMAs per product: fp32-grade) or 'bf16' (operands rounded to
     bf16, one MFMA per product: the reference's bf16-autocast arithmetic) for the dense products (include/halo.h)."""
+    global _mode
     code = {'f32': HALO_MATH_F32, 'bf16x3': HALO_MATH_BF16X3, 'bf16': HALO_MATH_BF16}[mode]
     check(lib().halo_set_math_mode(code), 'halo_set_math_mode')
+    _mode = mode
 
 
 def set_lstm_fusion(on):
@@ -139,8 +141,15 @@ def set_lstm_fusion(on):
     check(lib().halo_set_lstm_fusion(int(bool(on))), 'halo_set_lstm_fusion')
 
 
+_mode = None       # the library's arithmetic mode, mirrored here: it only changes through set_math_mode, and the Linear helpers
+                   # ask for it on every call
+
+
 def get_math_mode():
-    return {HALO_MATH_F32: 'f32', HALO_MATH_BF16X3: 'bf16x3', HALO_MATH_BF16: 'bf16'}[lib().halo_get_math_mode()]
+    global _mode
+    if _mode is None:
+        _mode = {HALO_MATH_F32: 'f32', HALO_MATH_BF16X3: 'bf16x3', HALO_MATH_BF16: 'bf16'}[lib().halo_get_math_mode()]
+    return _mode
 
 
 _scratch = None
