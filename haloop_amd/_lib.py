@@ -93,6 +93,7 @@ SIGNATURES = {
     'halo_scale_add': (_i, [_vp, _vp, _f, _f, _sz, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
+    'halo_adamw_ranges': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 

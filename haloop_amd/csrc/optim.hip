@@ -91,6 +91,50 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     }
 }
 
+
+// AdamW over several contiguous ranges of the same flat buffers in ONE launch (each range has its own weight decay and
+// gradient scale: clipped encoder / unclipped recognizer, decayed weights / undecayed biases), plus the dropout step counter's
+// increment: the per-step optimizer was 4 AdamW launches + 1 counter launch, three of them over a few hundred elements.
+constexpr int ADAM_MAX_RANGES = 8;
+struct AdamRangesArgs {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    size_t begin4[ADAM_MAX_RANGES], end4[ADAM_MAX_RANGES];      // in float4 units
+    float decay_mul[ADAM_MAX_RANGES];
+    const float *grad_scale[ADAM_MAX_RANGES];
+    int n_ranges;
+    float beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps;
+    uint32_t *counter;
+};
+
+__global__ __launch_bounds__(256) void adamw_ranges_kernel(const AdamRangesArgs a) {
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);
+    for (int r = 0; r < a.n_ranges; ++r) {
+        const float gs = a.grad_scale[r] ? *a.grad_scale[r] : 1.0f;
+        if (gs != gs) continue;                                   // NaN scale: this range's update is skipped
+        const float decay_mul = a.decay_mul[r];
+        for (size_t i = a.begin4[r] + blockIdx.x * (size_t)256 + threadIdx.x; i < a.end4[r]; i += (size_t)gridDim.x * 256) {
+            f32x4 p = p4[i], m = m4[i], v = v4[i];
+            const f32x4 g = g4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = a.grad_scale[r] ? g[e] * gs : g[e];
+                float pe = p[e] * decay_mul;
+                const float me = m[e] + (ge - m[e]) * a.beta1_w;
+                const float ve = v[e] * a.beta2 + a.beta2_w * ge * ge;
+                const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
+                pe -= a.step_size * (me / denom);
+                p[e] = pe; m[e] = me; v[e] = ve;
+            }
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+    }
+    if (a.counter && blockIdx.x == 0 && threadIdx.x == 0) *a.counter += 1u;
+}
+
 }  // namespace
 
 namespace {
@@ -156,6 +200,37 @@ int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr,
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return halo_launch_status();
+}
+
+int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+                      const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                      uint32_t *counter, halo_stream_t stream) {
+    HALO_CHECK_ARG(p && g && m && v && begin && end && weight_decay && grad_scale && n_ranges > 0 && n_ranges <= ADAM_MAX_RANGES &&
+                   step >= 1);
+    HALO_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0));
+    AdamRangesArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n_ranges = n_ranges; a.counter = counter;
+    size_t biggest = 0;
+    for (int r = 0; r < n_ranges; ++r) {
+        HALO_CHECK_ARG(begin[r] % 4 == 0 && end[r] % 4 == 0 && begin[r] <= end[r]);
+        a.begin4[r] = begin[r] / 4; a.end4[r] = end[r] / 4;
+        a.decay_mul[r] = (float)(1.0 - (double)lr * (double)weight_decay[r]);
+        a.grad_scale[r] = grad_scale[r];
+        if (a.end4[r] - a.begin4[r] > biggest) biggest = a.end4[r] - a.begin4[r];
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.beta1_w = (float)(1.0 - (double)beta1);
+    a.beta2 = beta2;
+    a.beta2_w = (float)(1.0 - (double)beta2);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = eps;
+    size_t blocks = (biggest + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return halo_launch_status();
 }
 

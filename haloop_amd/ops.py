@@ -334,6 +334,18 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None
     torch.autograd.graph.increment_version(p)
 
 
+def adamw_ranges(p, g, m, v, ranges, lr, beta1, beta2, eps, step, counter=None):
+    """One-launch AdamW over ``ranges`` = [(begin, end, weight_decay, grad_scale tensor or None), ...] of flat buffers."""
+    n = len(ranges)
+    begin = (C.c_size_t * n)(*[r[0] for r in ranges])
+    end = (C.c_size_t * n)(*[r[1] for r in ranges])
+    wd = (C.c_float * n)(*[float(r[2]) for r in ranges])
+    gs = (C.c_void_p * n)(*[ptr(r[3]) for r in ranges])
+    check(lib().halo_adamw_ranges(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, step, ptr(counter),
+                                  _stream()), 'halo_adamw_ranges')
+    torch.autograd.graph.increment_version(p)
+
+
 def scale_add_(y, x, alpha, beta):
     """y <- alpha*y + beta*x in place (flat fp32 buffers)."""
     check(lib().halo_scale_add(ptr(y), ptr(x), float(alpha), float(beta), y.numel(), _stream()), 'halo_scale_add')

@@ -185,13 +185,11 @@ class LstmCtcTrainer:
         e0, e1 = f.encoder_range
         ops.sumsq_partials(f.grads[e0:e1], self.partials)
         ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm)
-        for a, b, decays, clipped in f.ranges:
-            if b == a:
-                continue
-            scale = self.coef[0:1] if clipped else self.coef[1:2]
-            ops.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay if decays else 0.0, step, scale)
-        ops.counter_inc(self.counter)
+        # all (decay, clip) ranges and the dropout step counter in one launch
+        ranges = [(a, b, self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
+                  for a, b, decays, clipped in f.ranges if b > a]
+        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self.lr, self.betas[0], self.betas[1], self.eps, step,
+                         counter=self.counter)
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):

@@ -414,6 +414,12 @@ int halo_clip_coef(const float *partials, int count, float max_norm, float *coef
                    halo_stream_t stream);
 int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, const float *grad_scale, halo_stream_t stream);
+/* halo_adamw over n_ranges (<= 8) contiguous element ranges [begin[r], end[r]) of the same flat buffers in ONE launch (host
+ * arrays; offsets multiples of 4): range r has its own weight_decay[r] and device gradient scale grad_scale[r] (NULL: 1).
+ * counter (optional, device): incremented once -- the dropout step counter of halo_counter_inc rides along. */
+int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+                      const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2,
+                      float eps, int step, uint32_t *counter, halo_stream_t stream);
 
 #ifdef __cplusplus
 }
