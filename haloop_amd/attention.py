@@ -132,8 +132,6 @@ class GPT(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if not config.causal:
-            raise NotImplementedError('only the causal LM configuration is built')
         self.transformer = nn.ModuleDict(dict(
             wte=(StableEmbedding if config.stable_embedding else nn.Embedding)(config.vocab_size, config.n_embd),
             wpe=(StableEmbedding if config.stable_embedding else nn.Embedding)(config.block_size, config.n_embd),
@@ -187,9 +185,9 @@ class GPT(nn.Module):
             qkv, _ = ln_linear(self._images, x, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias)
             if present is not None:
                 ops.kv_cache_store(qkv[:, C:], C, present[i, 0], present[i, 1], B, T, H, C // H, t0)
-                y = ops.attention_cached_fwd(qkv, present[i, 0], present[i, 1], T, t0 + T, causal=True)
+                y = ops.attention_cached_fwd(qkv, present[i, 0], present[i, 1], T, t0 + T, causal=cfg.causal)
             else:
-                y = ops.attention_causal_fwd(qkv, B, T, cfg.n_head)
+                y, _, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
             self._linear(y, blk.attn.c_proj, out=x, accumulate=True)                     # x += c_proj(y)
             h, _ = ln_linear(self._images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True)
             self._linear(h, blk.mlp.c_proj, out=x, accumulate=True)                      # x += mlp(h)
@@ -249,7 +247,7 @@ class GPT(nn.Module):
             qkv, h1 = ln_linear(self._images, x0, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias,
                                 want_normed=True)
             s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
-            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=True, want_lse=True,
+            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
                                           drop=s_att[0], stream_id=s_att[1])
             x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res)
             a, h2 = ln_linear(self._images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
@@ -298,7 +296,7 @@ class GPT(nn.Module):
             dy = linear_dx(img, dr, blk.attn.c_proj.weight)
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
-                              B, H, C // H, T, T, causal=True, drop=s_att[0], stream_id=s_att[1])
+                              B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
             put(blk.attn.c_attn.weight, linear_dw(dqkv, h1))
             if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
             dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight), x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None)

@@ -54,7 +54,7 @@ def make_gpt_params(vocab_size, block_size, n_layer, n_head, n_embd, bias, seed,
     return p
 
 
-def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean', masks=None):
+def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean', masks=None, causal=True):
     """masks (training-mode parity): {'emb': [B,T,C], 'att': [per layer [B,H,T,T]], 'res': [...[B,T,C]], 'mlp': [...]} inverted-dropout
     multipliers at the sites of ha/attention.py:224,90,127,141."""
     B, T = input_ids.shape
@@ -73,10 +73,11 @@ def gpt_forward_all(p, n_layer, n_head, input_ids, target_ids, reduction='mean',
         q, k, v = (t.view(B, T, n_head, C // n_head).transpose(1, 2) for t in qkv.split(C, dim=2))
         if masks:
             sc = (q @ k.transpose(-2, -1)) / math.sqrt(k.shape[-1])
-            sc = sc.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float('-inf'))
+            if causal:
+                sc = sc.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float('-inf'))
             y = (sc.softmax(-1) * masks['att'][i]) @ v
         else:
-            y = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+            y = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
         y = y.transpose(1, 2).contiguous().view(B, T, C)
         r = F.linear(y, p[pre + 'attn.c_proj.weight'], p.get(pre + 'attn.c_proj.bias'))
         x = x + (r * masks['res'][i] if masks else r)

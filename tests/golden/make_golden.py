@@ -250,9 +250,9 @@ def save_beam():
     print('g3_beam onehot', d['onehot.seqs'].tolist(), d['onehot.scores'], 'r6x4b4', d['r6x4b4.seqs'][0], d['r6x4b4.scores'][0])
 
 
-def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, store_params, stable=False):
+def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, store_params, stable=False, causal=True):
     cfg = ha.init.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head, n_embd=n_embd, bias=bias,
-                            stable_embedding=stable)
+                            stable_embedding=stable, causal=causal)
     model = ha.attention.GPT(cfg).eval()
     params = gpt_ref.make_gpt_params(vocab, block, n_layer, n_head, n_embd, bias, seed, stable=stable)
     missing = model.load_state_dict(params, strict=True)
@@ -261,6 +261,7 @@ def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, stor
         per_tok = model.forward_all(inputs, targets, reduction='none')
         mean = model.forward_all(inputs, targets, reduction='mean')
     d = {'cfg': np.array([vocab, block, n_layer, n_head, n_embd, int(bias), B, T, seed]), 'stable': np.array(int(stable)),
+         'causal': np.array(int(causal)),
          'inputs': inputs.numpy(), 'targets': targets.numpy(), 'per_token': per_tok.numpy(), 'mean': mean.numpy()}
     # the training direction (ha/attention_loop.py:203-208): gradients of the mean loss w.r.t. every parameter
     model.zero_grad()
@@ -275,7 +276,7 @@ def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, stor
         for k, v in params.items():
             d['param.' + k] = v.numpy()
         # generation path (ha/attention.py:253-279): prefill, then two single-token continuations through the KV cache
-        with torch.no_grad():
+        with torch.no_grad() if causal else torch.no_grad():
             split = T // 2
             logits0, past = model(inputs[:, :split])
             logits1, past1 = model(inputs[:, split:split + 1], past=past)
@@ -291,6 +292,7 @@ def save_gpt():
     gpt_case('g5_gpt_tiny_nobias', 97, 32, 2, 2, 64, False, 3, 20, 5, True)
     gpt_case('g5_gpt_tiny_bias', 97, 48, 3, 1, 64, True, 2, 40, 6, True)
     gpt_case('g5_gpt_tiny_stable', 61, 32, 2, 2, 64, False, 3, 24, 8, True, stable=True)
+    gpt_case('g5_gpt_tiny_bidir', 71, 40, 2, 2, 64, True, 2, 33, 9, True, causal=False)     # MLM / audio-encoder blocks
     gpt_case('g5_gpt2_small', 50304, 1024, 12, 12, 768, False, 1, 1024, 7, False)   # params rebuilt from the seed
 
 def asr_case(name, vocab, head_dim, heads, enc_layers, dec_layers, conv_dim, N, T, S, seed, strides=(2, 2, 2), F_=80):

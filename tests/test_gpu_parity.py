@@ -485,14 +485,15 @@ def _gpt_from_golden(hal, name):
     else:
         params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
     model = attention.GPT(attention.GPTConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head,
-                                              n_embd=n_embd, bias=bool(bias), stable_embedding=bool(g.get('stable', 0))))
+                                              n_embd=n_embd, bias=bool(bias), stable_embedding=bool(g.get('stable', 0)),
+                                              causal=bool(g.get('causal', 1))))
     model.load_state_dict(params, strict=True)
     assert model.transformer.wte.weight is model.lm_head.weight
     return g, model.to(DEV).eval()
 
 
 @BOTH_MODES
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt_tiny_bidir'])
 def test_gpt_tiny_forward_all_matches_reference(hal, name, math_mode):
     g, model = _gpt_from_golden(hal, name)
     inputs, targets = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['targets']).to(DEV)
@@ -659,7 +660,7 @@ def test_layernorm_gelu_cross_entropy_backward_against_autograd(hal):
 
 
 @BOTH_MODES
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt_tiny_bidir'])
 def test_gpt_tiny_gradients_match_reference(hal, name, math_mode):
     """loss.backward() through the HIP path vs the reference's own gradients (fixtures): every parameter."""
     g, model = _gpt_from_golden(hal, name)

@@ -139,7 +139,7 @@ def test_philox_known_answers():
     assert set(np.unique(m)) == {np.float32(0), np.float32(1.25)}
 
 
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt2_small'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt_tiny_bidir', 'g5_gpt2_small'])
 def test_gpt_forward_all_matches_reference(name):
     from oracle import gpt_ref
     g = load_golden(name)
@@ -150,8 +150,9 @@ def test_gpt_forward_all_matches_reference(name):
         params = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
     inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
     with torch.no_grad():
-        per_tok = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='none')
-        mean = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean')
+        causal = bool(g.get('causal', 1))
+        per_tok = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='none', causal=causal)
+        mean = gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean', causal=causal)
     np.testing.assert_allclose(per_tok.numpy(), g['per_token'], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(float(mean), float(g['mean']), rtol=1e-6)
     i2, t2 = gpt_ref.synthetic_tokens(B, T, vocab, seed + 1)
@@ -173,7 +174,7 @@ def test_gpt_kv_cache_forward_matches_reference(name):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=2e-6, err_msg=key)
 
 
-@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable'])
+@pytest.mark.parametrize('name', ['g5_gpt_tiny_nobias', 'g5_gpt_tiny_bias', 'g5_gpt_tiny_stable', 'g5_gpt_tiny_bidir'])
 def test_gpt_gradients_match_reference(name):
     """The training direction: autograd through the restatement == the reference's loss.backward()."""
     from oracle import gpt_ref
@@ -182,7 +183,7 @@ def test_gpt_gradients_match_reference(name):
     params = {k[len('param.'):]: torch.from_numpy(v).requires_grad_(True) for k, v in g.items() if k.startswith('param.')}
     params['lm_head.weight'] = params['transformer.wte.weight']
     inputs, targets = torch.from_numpy(g['inputs']), torch.from_numpy(g['targets'])
-    gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean').backward()
+    gpt_ref.gpt_forward_all(params, n_layer, n_head, inputs, targets, reduction='mean', causal=bool(g.get('causal', 1))).backward()
     checked = 0
     for k, v in g.items():
         if k.startswith('grad.'):
