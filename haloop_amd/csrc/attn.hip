@@ -123,8 +123,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
                     if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
                     mx = fmaxf(mx, sacc[n][r]);
                 }
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                mx = row16_max(mx);
                 const float mnew = fmaxf(mrow[r], mx);
                 const float msafe = mnew == -INFINITY ? 0.f : mnew;
                 alpha[r] = __expf(mrow[r] - msafe);       // exp(-inf) = 0 on the first tile (hardware exp2: ~1e-7 rel.)
@@ -135,8 +134,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
                     sacc[n][r] = pv;
                     ps += pv;
                 }
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+                ps = row16_sum(ps);
                 lrow[r] = lrow[r] * alpha[r] + ps;
                 mrow[r] = mnew;
                 if (a.use_drop) {                          // the normaliser keeps the undropped sum (dropout acts on softmax's output)
@@ -180,8 +178,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         if (a.lse && lr == 0) a.lse[stat] = mrow[r] + logf(lrow[r]);
         if (ENT) {
             float e = erow[r];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+            e = row16_sum(e);
             if (lr == 0) a.ent[stat] = e;
         }
     }

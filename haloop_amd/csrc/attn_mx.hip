@@ -112,8 +112,8 @@ __device__ __forceinline__ void patch_frag(const float *p, bf16x8 &hi, bf16x8 &l
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
     using I = Img<HD>;
-    __shared__ __attribute__((aligned(16))) char Kimg[2 * I::BYTES];
-    __shared__ __attribute__((aligned(16))) char Vimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
+    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -171,8 +171,7 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
                 if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
                 mx = fmaxf(mx, sacc[n][r]);
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            mx = row16_max(mx);
             const float mnew = fmaxf(mrow[r], mx);
             const float msafe = mnew == -INFINITY ? 0.f : mnew;
             alpha[r] = __expf(mrow[r] - msafe);
@@ -183,8 +182,7 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
                 sacc[n][r] = pv;
                 ps += pv;
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            ps = row16_sum(ps);
             lrow[r] = lrow[r] * alpha[r] + ps;
             mrow[r] = mnew;
             if (a.use_drop) {                              // the normaliser keeps the undropped sum
@@ -233,8 +231,8 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
-    __shared__ __attribute__((aligned(16))) char Kimg[2 * I::BYTES];
-    __shared__ __attribute__((aligned(16))) char Vimg[2 * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
+    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -331,8 +329,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
-    __shared__ __attribute__((aligned(16))) char Qimg[2 * I::BYTES];
-    __shared__ __attribute__((aligned(16))) char Oimg[2 * I::BYTES];      // dO tile
+    __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
+    __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)      // dO tile
     __shared__ __attribute__((aligned(16))) float Ps[4][2][16 * PS];
     __shared__ float lse_s[64], del_s[64];
     const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;

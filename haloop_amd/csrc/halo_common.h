@@ -110,6 +110,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// All-reduce over the 16 lanes of a DPP row (lanes 16g .. 16g+15) on the VALU: row_ror:8,4,2,1 folds the row in four
+// v_*_dpp instructions, no trip through the LDS crossbar that a ds_bpermute-based __shfl_xor takes.  Every lane of the
+// row ends with the same bits (after the shift-s step the values are s-periodic, so each step adds one commutative pair).
+template <int N>
+__device__ __forceinline__ float row_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 | N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
+
 // GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result,
 // bit 3 exact (erf) GELU (nn.GELU() / F.gelu: ha/transformer.py:456, ha/conv.py:46)
 __device__ __forceinline__ float gemm_activation(float v, int flags) {
