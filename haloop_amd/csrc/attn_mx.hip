@@ -109,34 +109,72 @@ __device__ __forceinline__ void patch_frag(const float *p, bf16x8 &hi, bf16x8 &l
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------
+// The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the MFMA D layout a lane holds 16 keys of ONE query
+// (query = lane & 15): the running max / sum / rescale are lane-local scalars, the only cross-lane traffic per tile
+// is one max over the four 16-lane rows (two v_permlane*_swap), and the probabilities are already laid out as the B
+// operand of O^T = V^T P^T -- no trip through LDS.  The contraction slot (lq, e) of a 32-deep P.V step stands for key
+// 16*(2kk + e/4) + 4*lq + e%4; the transpose read fetches V's rows in the same order.
+
+// all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48).  v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
+// lower half of the second; fed the same value twice they leave (x_r, x_r^1) resp. (x_lo, x_hi) in every lane.
+// Issued as inline asm: through __builtin_amdgcn_permlane*_swap this compiler (ROCm 7.2) folds the second result into
+// the first (the ISA showed max(s0, s0)).  The s_nop covers the VALU-write -> permlane-swap read hazard the compiler
+// would otherwise schedule around.
+__device__ __forceinline__ void swap_rows16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows4_max(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    a = b = fmaxf(a, b);
+    swap_rows32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    a = b = a + b;
+    swap_rows32(a, b);
+    return a + b;
+}
+
+// A fragment of V^T (or any row-major image read across its rows): rows rowA .. rowA+3 and rowB .. rowB+3 of column
+// col0 + (lane & 15), through the hardware transpose read (see tr_frag)
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, int col0, int lr) {
+    const int off = (lr >> 2) * Img<HD>::ROWB + (col0 + 4 * (lr & 3)) * 2;
+    const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowA * Img<HD>::ROWB + off));
+    const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowB * Img<HD>::ROWB + off));
+    return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+}
+
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
-    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
-    __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
+    // causal: the long (late) query tiles are dispatched first so the short ones fill the tail
+    const int qt = a.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int Tq = a.Tq, Tk = a.Tk;
     const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
     const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
     const int q0 = qt * 64 + wave * 16;
+    const int qrow = q0 + lr;                                  // this lane's query
     const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
     const int coff = Tk - Tq;
 
-    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS];                       // A[row = lr][k = 32ks + 8lq + e], pre-scaled
+    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS];                       // B[k = 32ks + 8lq + e][col = query lr], pre-scaled
     {
-        const float *qp = qb + (long)min(q0 + lr, Tq - 1) * a.q_rs;
+        const float *qp = qb + (long)min(qrow, Tq - 1) * a.q_rs;
 #pragma unroll
         for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
     }
-    f32x4 o[HD / 16];
+    f32x4 o[HD / 16];                                          // O^T[dim = 16m + 4lq + r][query lr]
 #pragma unroll
     for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+    float mrow = -INFINITY, lsum = 0.f;                        // lsum: this lane's share (its 16 keys per tile) of the normaliser
 
     int n_ktiles = (klim + 63) / 64;
     if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
@@ -148,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
         stage_tile<HD, PASSES>(Vimg, vreg);
         __syncthreads();
         if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-        f32x4 sacc[4];
+        f32x4 sacc[4];                                         // S^T[key = 64kt + 16n + 4lq + r][query lr]
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -156,74 +194,70 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
             for (int ks = 0; ks < I::KSTEPS; ++ks) {
                 const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
                 const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
-                sacc[n] = mma<PASSES>(sacc[n], qh[ks], ql[ks], kh, kl);
+                sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
             }
         }
-        // mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
-        float alpha[4];
+        // masks only where the tile can need them (wave-uniform): the key-length edge and the causal diagonal
+        if (kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff)) {
+            const int kmax = a.causal ? min(klim - 1, qrow + coff) : klim - 1;    // last visible key of this query
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qrow = q0 + 4 * lq + r;
-            float mx = -INFINITY;
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int key = kt * 64 + 16 * n + lr;
-                if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
-                mx = fmaxf(mx, sacc[n][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 64 + 16 * n + 4 * lq + r > kmax) sacc[n][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+#pragma unroll
+        for (int n = 1; n < 4; ++n) mx = fmaxf(mx, fmaxf(fmaxf(sacc[n][0], sacc[n][1]), fmaxf(sacc[n][2], sacc[n][3])));
+        mx = rows4_max(mx);
+        const float mnew = fmaxf(mrow, mx);
+        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+        const float alpha = __expf(mrow - msafe);              // exp(-inf) = 0 on the first tile
+        mrow = mnew;
+        float ps = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sacc[n][r] = __expf(sacc[n][r] - msafe);
+                ps += sacc[n][r];
             }
-            mx = row16_max(mx);
-            const float mnew = fmaxf(mrow[r], mx);
-            const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            alpha[r] = __expf(mrow[r] - msafe);
-            float ps = 0.f;
+        lsum = lsum * alpha + ps;                              // the normaliser keeps the undropped sum
+        if (a.use_drop) {
+            const uint64_t base = attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const float pv = __expf(sacc[n][r] - msafe);
-                sacc[n][r] = pv;
-                ps += pv;
-            }
-            ps = row16_sum(ps);
-            lrow[r] = lrow[r] * alpha[r] + ps;
-            mrow[r] = mnew;
-            if (a.use_drop) {                              // the normaliser keeps the undropped sum
-                const f32x4 dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr);
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 dm = dropout_mult4(a.drop, base + 4 * (4 * lq + r));
 #pragma unroll
                 for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
             }
         }
-        float *pw = Ps[wave];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pw[(4 * lq + r) * PS + 16 * n + lr] = sacc[n][r];
 #pragma unroll
         for (int m = 0; m < HD / 16; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[m][r] *= alpha[r];
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // O += P V : two 32-key steps; V fragments come straight from the row-major image through the transpose read
+            for (int r = 0; r < 4; ++r) o[m][r] *= alpha;
+        // O^T += V^T P^T : two 32-slot steps; V^T fragments come from the row-major image through the transpose read
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            const float pf[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
+                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
             bf16x8 ph, pl;
-            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, ph, pl);
+            split8(pf, ph, pl);
 #pragma unroll
             for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 vh = tr_frag<HD>(Vimg, 32 * kk + 8 * lq, 16 * m, lr);
-                const bf16x8 vl = PASSES == 3 ? tr_frag<HD>(Vimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : vh;
-                o[m] = mma<PASSES>(o[m], ph, pl, vh, vl);
+                const bf16x8 vh = tr_frag2<HD>(Vimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                const bf16x8 vl = PASSES == 3 ? tr_frag2<HD>(Vimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : vh;
+                o[m] = mma<PASSES>(o[m], vh, vl, ph, pl);
             }
         }
     }
+    const float lrow = rows4_sum(lsum);
+    if (qrow < Tq) {
+        const float inv = 1.0f / lrow;
+        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD + 4 * lq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * lq + r;
-        if (qrow >= Tq) continue;
-        const float inv = 1.0f / lrow[r];
-        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) yp[16 * m + lr] = o[m][r] * inv;
-        if (a.lse && lr == 0) a.lse[((long)b * a.heads + h) * Tq + qrow] = mrow[r] + logf(lrow[r]);
+        for (int m = 0; m < HD / 16; ++m) *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[m][0] * inv, o[m][1] * inv, o[m][2] * inv, o[m][3] * inv};
+        if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow] = mrow + logf(lrow);
     }
 }
 
@@ -456,6 +490,7 @@ static bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
 
 int halo_attention_fwd_mx(const AttnArgs &a, int N, int head_dim, int passes, hipStream_t st) {
     if (!aligned16(a.q) || a.q_rs % 4 || a.q_bs % 4 || a.q_hs % 4) return HALO_ENOTSUP;
+    if (!aligned16(a.y) || a.y_rs % 4 || a.y_bs % 4) return HALO_ENOTSUP;          // the output goes out as 16-byte stores
     if (head_dim == 64) return passes == 1 ? launch_fwd<64, 1>(a, N, st) : launch_fwd<64, 3>(a, N, st);
     if (head_dim == 32) return passes == 1 ? launch_fwd<32, 1>(a, N, st) : launch_fwd<32, 3>(a, N, st);
     return HALO_ENOTSUP;
