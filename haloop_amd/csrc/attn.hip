@@ -715,7 +715,8 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
             hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
         else
             hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
-        return halo_attention_bwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
+        const int rc = halo_attention_bwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
+        if (rc != HALO_ENOTSUP) return rc;           // unaligned gradient views: the exact-f32 kernels take them
     }
     switch (head_dim) {
         case 64: return launch_attention_bwd<64>(a, y, y_row_stride, delta, N, st);

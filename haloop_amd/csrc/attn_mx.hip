@@ -10,8 +10,9 @@
 //     ds_read_b128 per lane (8 consecutive dims of one row);
 //   - products that contract over the ROW index (P.V, dS.K, P^T.dO, dS^T.Q) read the same image with
 //     ds_read_b64_tr_b16, the hardware transpose read: no second, transposed copy of V / K / Q / dO is staged.
-// Probabilities and score gradients go from the MFMA D layout to the A layout through a per-wave fp32 LDS patch and
-// are split after the read-back.
+// Score tiles are computed transposed so that the lane-fixed index of the MFMA D layout is the row a workgroup owns
+// (the query in the forward / dQ sweeps, the key in the dK/dV sweep): softmax statistics are lane scalars and the
+// probabilities / score gradients are, as they sit in registers, the B operand of the second product.
 #include "halo_common.h"
 #include "attn_args.h"
 
@@ -20,8 +21,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-constexpr int PS = 68;     // patch row stride in floats: 272 B = 17 x 16 B, so 8-float A fragments are 16-byte aligned
 
 template <int HD>
 struct Img {
@@ -90,24 +89,6 @@ __device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int k0) {
     return *reinterpret_cast<const bf16x8 *>(img + row * Img<HD>::ROWB + k0 * 2);
 }
 
-// B fragment whose k runs along the ROWS: rows row0 .. row0+7 (this lane's k-group) of column col0 + (lane & 15).
-// ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i
-// receives column i of the 4 rows.  Needs EXEC all ones: call it from wave-uniform code only.
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag(const char *img, int row0, int col0, int lr) {
-    const char *p = img + (row0 + (lr >> 2)) * Img<HD>::ROWB + (col0 + 4 * (lr & 3)) * 2;
-    const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)p);
-    const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p + 4 * Img<HD>::ROWB));
-    return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-}
-
-// 8 consecutive floats of a patch row -> hi/lo A fragment
-__device__ __forceinline__ void patch_frag(const float *p, bf16x8 &hi, bf16x8 &lo) {
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
-    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    split8(x, hi, lo);
-}
-
 // ---- forward ---------------------------------------------------------------------------------------------
 // The score tile is computed TRANSPOSED, S^T = K Q^T, so that in the MFMA D layout a lane holds 16 keys of ONE query
 // (query = lane & 15): the running max / sum / rescale are lane-local scalars, the only cross-lane traffic per tile
@@ -139,7 +120,9 @@ __device__ __forceinline__ float rows4_sum(float x) {
 }
 
 // A fragment of V^T (or any row-major image read across its rows): rows rowA .. rowA+3 and rowB .. rowB+3 of column
-// col0 + (lane & 15), through the hardware transpose read (see tr_frag)
+// col0 + (lane & 15), through the hardware transpose read.  ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p
+// addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i receives column i of the 4 rows.  Needs EXEC all
+// ones: call it from wave-uniform code only.
 template <int HD>
 __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, int col0, int lr) {
     const int off = (lr >> 2) * Img<HD>::ROWB + (col0 + 4 * (lr & 3)) * 2;
@@ -262,13 +245,14 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
 }
 
 // ---- backward, dQ sweep: one workgroup = 64 query rows, walks the key tiles ----------------------------------
+// Same transposed formulation as the forward: S^T = K Q^T and dP^T = V dO^T leave a lane with 16 keys of ONE query, so
+// lse / delta are lane scalars and dS^T is already the B operand of dQ^T = K^T dS^T (K^T through the transpose read).
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
-    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
-    __shared__ __attribute__((aligned(16))) float Ps[4][16 * PS];
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
+    const int qt = a.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x, h = blockIdx.y, b = blockIdx.z;   // causal: long tiles first
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int Tq = a.Tq, Tk = a.Tk;
     const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
@@ -276,25 +260,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
     const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
     const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
     const int q0 = qt * 64 + wave * 16;
+    const int qrow = q0 + lr, qsafe = min(qrow, Tq - 1);       // this lane's query
     const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
     const int coff = Tk - Tq;
-    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];
-    {
-        const int qrow = min(q0 + lr, Tq - 1);
+    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];      // B[k = dims][col = query lr]
 #pragma unroll
-        for (int ks = 0; ks < I::KSTEPS; ++ks) {
-            load_split8(qb + (long)qrow * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
-            load_split8(dyb + (long)qrow * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
-        }
+    for (int ks = 0; ks < I::KSTEPS; ++ks) {
+        load_split8(qb + (long)qsafe * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
+        load_split8(dyb + (long)qsafe * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
     }
-    float lse_r[4], del_r[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long stat = ((long)b * a.heads + h) * Tq + min(q0 + 4 * lq + r, Tq - 1);
-        lse_r[r] = a.lse[stat];
-        del_r[r] = a.delta[stat];
-    }
-    f32x4 dq[HD / 16];
+    const long stat = ((long)b * a.heads + h) * Tq + qsafe;
+    const float lse = a.lse[stat], delta = a.delta[stat];
+    f32x4 dq[HD / 16];                                         // dQ^T[dim = 16m + 4lq + r][query lr]
 #pragma unroll
     for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     int n_ktiles = (klim + 63) / 64;
@@ -307,7 +284,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
         stage_tile<HD, PASSES>(Vimg, vreg);
         __syncthreads();
         if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-        f32x4 sacc[4], pacc[4];
+        f32x4 sacc[4], pacc[4];                                // S^T, dP^T [key = 64kt + 16n + 4lq + r][query lr]
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -318,56 +295,57 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
                 const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
                 const bf16x8 vh = row_frag<HD>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
                 const bf16x8 vl = PASSES == 3 ? row_frag<HD>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
-                sacc[n] = mma<PASSES>(sacc[n], qh[ks], ql[ks], kh, kl);
-                pacc[n] = mma<PASSES>(pacc[n], doh[ks], dol[ks], vh, vl);
+                sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
+                pacc[n] = mma<PASSES>(pacc[n], vh, vl, doh[ks], dol[ks]);
             }
         }
-        float *pw = Ps[wave];
+        // dS^T = P^T (dP^T . dropout - delta), in place in sacc
+        const bool edge = kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff);      // wave-uniform
+        const int kmax = a.causal ? min(klim - 1, qrow + coff) : klim - 1;                     // last visible key of this query
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int r = 0; r < 4; ++r) {
+            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (a.use_drop)
+                dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe, (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
-                const bool hidden = key >= klim || (a.causal && key > qrow + coff);
-                const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
-                float dp = pacc[n][r];
-                if (a.use_drop)
-                    dp *= dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + n);
-                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (dp - del_r[r]);
+            for (int n = 0; n < 4; ++n) {
+                float p = __expf(sacc[n][r] - lse);
+                if (edge && kt * 64 + 16 * n + 4 * lq + r > kmax) p = 0.f;
+                sacc[n][r] = p * (pacc[n][r] * dm[n] - delta);
             }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
+                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
             bf16x8 dh, dl;
-            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, dh, dl);
+            split8(df, dh, dl);
 #pragma unroll
             for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 kh = tr_frag<HD>(Kimg, 32 * kk + 8 * lq, 16 * m, lr);
-                const bf16x8 kl = PASSES == 3 ? tr_frag<HD>(Kimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : kh;
-                dq[m] = mma<PASSES>(dq[m], dh, dl, kh, kl);
+                const bf16x8 kh = tr_frag2<HD>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                const bf16x8 kl = PASSES == 3 ? tr_frag2<HD>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
+                dq[m] = mma<PASSES>(dq[m], kh, kl, dh, dl);
             }
         }
     }
+    if (qrow < Tq) {
+        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD + 4 * lq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * lq + r;
-        if (qrow >= Tq) continue;
-        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) dp[16 * m + lr] = dq[m][r] * a.scale;
+        for (int m = 0; m < HD / 16; ++m)
+            *reinterpret_cast<f32x4 *>(dp + 16 * m) = f32x4{dq[m][0] * a.scale, dq[m][1] * a.scale, dq[m][2] * a.scale, dq[m][3] * a.scale};
     }
 }
 
 // ---- backward, dK/dV sweep: one workgroup = 64 keys, walks the query tiles -----------------------------------
+// Here the lane-fixed index is the KEY: S = Q K^T and dP = dO V^T (this wave's 16 keys as the B operand, from registers)
+// leave a lane with 16 queries of one key, and P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
 template <int HD, int PASSES>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
-    __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)      // dO tile
-    __shared__ __attribute__((aligned(16))) float Ps[4][2][16 * PS];
-    __shared__ float lse_s[64], del_s[64];
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // dO tile
+    __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;       // causal: key tile 0 sees every query tile, so the long ones already go first
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int Tq = a.Tq, Tk = a.Tk;
     const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
@@ -375,18 +353,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
     const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
     const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
     const int k0 = kt * 64 + wave * 16;
+    const int key = k0 + lr;                                    // this lane's key
     const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
     const int coff = Tk - Tq;
-    bf16x8 kh[I::KSTEPS], kl[I::KSTEPS], vh[I::KSTEPS], vl[I::KSTEPS];      // A[row = key lr][k = dims]
+    bf16x8 kh[I::KSTEPS], kl[I::KSTEPS], vh[I::KSTEPS], vl[I::KSTEPS];      // B[k = dims][col = key lr]
     {
-        const int krow = min(k0 + lr, Tk - 1);
+        const int krow = min(key, Tk - 1);
 #pragma unroll
         for (int ks = 0; ks < I::KSTEPS; ++ks) {
             load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale, kh[ks], kl[ks]);
             load_split8(vb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, 1.0f, vh[ks], vl[ks]);
         }
     }
-    f32x4 dk[HD / 16], dv[HD / 16];
+    f32x4 dk[HD / 16], dv[HD / 16];                            // dK^T, dV^T [dim = 16m + 4lq + r][key lr]
 #pragma unroll
     for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int n_qtiles = (Tq + 63) / 64;
@@ -405,7 +384,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
         }
         __syncthreads();
         if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
-        f32x4 sacc[4], pacc[4];
+        f32x4 sacc[4], pacc[4];                                // S, dP [query = 64qt + 16n + 4lq + r][key lr]
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -416,56 +395,55 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
                 const bf16x8 qfl = PASSES == 3 ? row_frag<HD>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
                 const bf16x8 ofh = row_frag<HD>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
                 const bf16x8 ofl = PASSES == 3 ? row_frag<HD>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
-                sacc[n] = mma<PASSES>(sacc[n], kh[ks], kl[ks], qfh, qfl);       // S^T: rows = keys, cols = queries
-                pacc[n] = mma<PASSES>(pacc[n], vh[ks], vl[ks], ofh, ofl);       // dP^T
+                sacc[n] = mma<PASSES>(sacc[n], qfh, qfl, kh[ks], kl[ks]);
+                pacc[n] = mma<PASSES>(pacc[n], ofh, ofl, vh[ks], vl[ks]);
             }
         }
-        float *pw = Ps[wave][0], *dw = Ps[wave][1];
+        // P (dropped) stays in pacc's place, dS in sacc's: both in place
+        const bool edge = k0 + 15 >= klim || qt * 64 + 63 >= Tq || (a.causal && k0 + 15 > qt * 64 + coff);   // wave-uniform
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int qi = 16 * n + lr, qrow = qt * 64 + qi;
-            const float l = lse_s[qi], dl = del_s[qi];
+            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[16 * n + 4 * lq]);
+            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&del_s[16 * n + 4 * lq]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 4 * lq + r;
-                const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
-                const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
+                const int qrow = qt * 64 + 16 * n + 4 * lq + r;
+                float p = __expf(sacc[n][r] - l4[r]);
+                if (edge && (key >= klim || qrow >= Tq || (a.causal && key > qrow + coff))) p = 0.f;
                 float dm = 1.0f;
                 if (a.use_drop)
-                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) +
-                                                  4 * (4 * lq + r) + wave);
-                pw[(4 * lq + r) * PS + qi] = p * dm;
-                dw[(4 * lq + r) * PS + qi] = p * (dm * pacc[n][r] - dl);
+                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + wave);
+                sacc[n][r] = p * (dm * pacc[n][r] - d4[r]);
+                pacc[n][r] = p * dm;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            const float pf[8] = {pacc[2 * kk][0], pacc[2 * kk][1], pacc[2 * kk][2], pacc[2 * kk][3],
+                                 pacc[2 * kk + 1][0], pacc[2 * kk + 1][1], pacc[2 * kk + 1][2], pacc[2 * kk + 1][3]};
+            const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
+                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
             bf16x8 ph, pl, dh, dl;
-            patch_frag(pw + lr * PS + 32 * kk + 8 * lq, ph, pl);
-            patch_frag(dw + lr * PS + 32 * kk + 8 * lq, dh, dl);
+            split8(pf, ph, pl);
+            split8(df, dh, dl);
 #pragma unroll
             for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 oth = tr_frag<HD>(Oimg, 32 * kk + 8 * lq, 16 * m, lr);
-                const bf16x8 otl = PASSES == 3 ? tr_frag<HD>(Oimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : oth;
-                const bf16x8 qth = tr_frag<HD>(Qimg, 32 * kk + 8 * lq, 16 * m, lr);
-                const bf16x8 qtl = PASSES == 3 ? tr_frag<HD>(Qimg + I::BYTES, 32 * kk + 8 * lq, 16 * m, lr) : qth;
-                dv[m] = mma<PASSES>(dv[m], ph, pl, oth, otl);
-                dk[m] = mma<PASSES>(dk[m], dh, dl, qth, qtl);
+                const bf16x8 oth = tr_frag2<HD>(Oimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                const bf16x8 otl = PASSES == 3 ? tr_frag2<HD>(Oimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : oth;
+                const bf16x8 qth = tr_frag2<HD>(Qimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                const bf16x8 qtl = PASSES == 3 ? tr_frag2<HD>(Qimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : qth;
+                dv[m] = mma<PASSES>(dv[m], oth, otl, ph, pl);
+                dk[m] = mma<PASSES>(dk[m], qth, qtl, dh, dl);
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 4 * lq + r;
-        if (key >= Tk) continue;
-        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
-        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+    if (key < Tk) {
+        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
+        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
 #pragma unroll
         for (int m = 0; m < HD / 16; ++m) {
-            kp[16 * m + lr] = dk[m][r] * a.scale;
-            vp[16 * m + lr] = dv[m][r];
+            *reinterpret_cast<f32x4 *>(kp + 16 * m) = f32x4{dk[m][0] * a.scale, dk[m][1] * a.scale, dk[m][2] * a.scale, dk[m][3] * a.scale};
+            *reinterpret_cast<f32x4 *>(vp + 16 * m) = dv[m];
         }
     }
 }
@@ -497,6 +475,8 @@ int halo_attention_fwd_mx(const AttnArgs &a, int N, int head_dim, int passes, hi
 }
 
 int halo_attention_bwd_mx(const AttnBwdArgs &a, int N, int head_dim, int passes, hipStream_t st) {
+    // gradients go out as 16-byte stores
+    if (!aligned16(a.dq) || !aligned16(a.dk) || !aligned16(a.dv) || a.dq_rs % 4 || a.dq_bs % 4 || a.dkv_rs % 4 || a.dkv_bs % 4) return HALO_ENOTSUP;
     if (head_dim == 64) return passes == 1 ? launch_bwd<64, 1>(a, N, st) : launch_bwd<64, 3>(a, N, st);
     if (head_dim == 32) return passes == 1 ? launch_bwd<32, 1>(a, N, st) : launch_bwd<32, 3>(a, N, st);
     return HALO_ENOTSUP;
