@@ -42,14 +42,16 @@ class WeightImages:
                             lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
 
 
-def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None):
+def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None,
+           shape=None):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
     ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
     and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add).
-    ``a_image``: the split image of x2d when the caller already has it (normed_image), used if the split GEMM runs."""
+    ``a_image``: the split image of x2d when the caller already has it (normed_image, forward_images), used if the split GEMM
+    runs; x2d may then be None with ``shape`` = its shape."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
-    M, K = x2d.shape
+    M, K = x2d.shape if x2d is not None else shape
     N = sum(w.shape[0] for w in weights)
     # a handful of rows (one decode step): the operand-image pass would cost more than the product; the exact-f32 kernel
     # reads x and W where they lie
@@ -64,25 +66,48 @@ def use_split(M, N, K):
     return _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64
 
 
-def linear_dx(images, dy2d, weights, out=None, accumulate=False):
-    """dx [M, in] = dy [M, sum out] W [sum out, in]  (the input gradient of y = x W^T; ``weights`` as in linear())."""
+def linear_dx(images, dy2d, weights, out=None, accumulate=False, dy_image=None, shape=None):
+    """dx [M, in] = dy [M, sum out] W [sum out, in]  (the input gradient of y = x W^T; ``weights`` as in linear()).
+    ``dy_image``: the split image of dy when the caller already has it (grad_images); then dy2d may be None with ``shape`` = dy's."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
-    M, K = dy2d.shape
+    M, K = dy2d.shape if dy2d is not None else shape
     N = weights[0][0].numel()
     if use_split(M, N, K):
-        return ops.gemm_split(ops.split_image(dy2d), images.split_t(weights), M, N, K, out=out, accumulate=accumulate)
+        return ops.gemm_split(dy_image if dy_image is not None else ops.split_image(dy2d), images.split_t(weights), M, N, K, out=out,
+                              accumulate=accumulate)
     return ops.gemm(dy2d, images.dense(weights), True, False, M, N, K, out=out, accumulate=accumulate)
 
 
-def linear_dw(dy2d, x2d, out=None, accumulate=False):
-    """dW [out, in] = dy^T [out, M] x [M, in]  (the weight gradient of y = x W^T)."""
-    K, M = dy2d.shape
-    N = x2d.shape[1]
+def linear_dw(dy2d, x2d, out=None, accumulate=False, dy_image_t=None, x_image_t=None, shapes=None):
+    """dW [out, in] = dy^T [out, M] x [M, in]  (the weight gradient of y = x W^T).  ``dy_image_t`` / ``x_image_t``: the split
+    images of dy^T / x^T when the caller already has them; the fp32 tensor may then be None with ``shapes`` = (dy.shape, x.shape)."""
+    K, M = dy2d.shape if dy2d is not None else shapes[0]
+    N = x2d.shape[1] if x2d is not None else shapes[1][1]
     if use_split(M, N, K):
-        return ops.gemm_split(ops.split_image(dy2d, transposed=True), ops.split_image(x2d, transposed=True), M, N, K, out=out,
+        return ops.gemm_split(dy_image_t if dy_image_t is not None else ops.split_image(dy2d, transposed=True),
+                              x_image_t if x_image_t is not None else ops.split_image(x2d, transposed=True), M, N, K, out=out,
                               accumulate=accumulate)
     return ops.gemm(dy2d, x2d, False, False, M, N, K, out=out, accumulate=accumulate)
+
+
+def forward_images(x2d, n_out, op=ops.PAIR_COPY):
+    """(image of v, image of v^T) for v = op(x2d) [M, K], the input of a Linear with n_out outputs: the forward GEMM reads the first,
+    the weight-gradient GEMM of the backward the second, and v itself is never written in fp32.  (None, None) when the split GEMM
+    would not run (the caller then materialises v as before)."""
+    M, K = x2d.shape
+    if use_split(M, n_out, K) and M > SMALL_M and use_split(n_out, K, M):
+        return ops.image_pair(x2d, op)
+    return None, None
+
+
+def grad_images(dy2d, n_in, op=ops.PAIR_COPY, x2=None):
+    """(image of dy, image of dy^T) from ONE read of dy [M, out] -- what linear_dx and linear_dw of the same Linear (n_in inputs)
+    each want -- or (None, None) when the split GEMM would not run for it (the callers then pass the fp32 tensor as before)."""
+    M, K = dy2d.shape
+    if use_split(M, n_in, K) and use_split(K, n_in, M):
+        return ops.image_pair(dy2d, op, x2)
+    return None, None
 
 
 class DropSites:

@@ -30,7 +30,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx, ln_linear
+from ._linear import (DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
+                      use_split)
 from .rnn import DropoutStream
 
 
@@ -148,9 +149,9 @@ class GPT(nn.Module):
         self.dropout_stream = DropoutStream()                   # Philox (seed, offset) per training forward
 
     # ---- one Linear: y = x W^T + b, with the epilogue fused ------------------------------------
-    def _linear(self, x2d, lin, out=None, gelu=False, accumulate=False, site=(ops.NO_DROPOUT, 0)):
+    def _linear(self, x2d, lin, out=None, gelu=False, accumulate=False, site=(ops.NO_DROPOUT, 0), a_image=None, shape=None):
         return linear(self._images, x2d, lin.weight, bias=lin.bias, out=out, gelu=gelu, accumulate=accumulate, drop=site[0],
-                      stream_id=site[1])
+                      stream_id=site[1], a_image=a_image, shape=shape)
 
     def _embed(self, input_ids, t0=0, keep=False):
         """tok_emb + pos_emb [B*T, C]; with stable_embedding each goes through its own LayerNorm first.  keep: also return
@@ -249,11 +250,15 @@ class GPT(nn.Module):
             s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
             y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
                                           drop=s_att[0], stream_id=s_att[1])
-            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res)
+            # y and gelu(a) each feed one Linear now and its weight gradient later: both operand images come out of one read, and
+            # gelu(a) is never written in fp32
+            y_img, y_img_t = forward_images(y, C)
+            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res, a_image=y_img)
             a, h2 = ln_linear(self._images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
-            g = ops.gelu_fwd(a)
-            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True, site=s_mlp)
-            blocks.append((x0, h1, qkv, y, lse, x1, h2, a, g, s_att, s_res, s_mlp))
+            g_img, g_img_t = forward_images(a, C, ops.PAIR_GELU)
+            g = ops.gelu_fwd(a) if g_img is None else None
+            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True, site=s_mlp, a_image=g_img, shape=a.shape)
+            blocks.append((x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp))
         xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
         logits = self._linear(xf, self.lm_head)                              # kept: the backward rewrites it into dlogits
@@ -274,32 +279,53 @@ class GPT(nn.Module):
             if p is not None and p.requires_grad:
                 grads[id(p)] = g if id(p) not in grads else grads[id(p)] + g
 
-        dlogits = ops.cross_entropy_bwd_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
-        dw_head = linear_dw(dlogits, xf)                                     # [V, C]; the tied wte gradient lands here too
-        dxf = linear_dx(img, dlogits, self.lm_head.weight)
+        M, V = logits.shape
+        if use_split(M, C, V) and use_split(V, C, M):
+            # d loss / d logits goes straight into the two operand images of the lm_head's backward products
+            dl_img, dl_img_t = ops.cross_entropy_bwd_images(logits, targets, row_lse, grad_per_tok, ignore_index=0)
+            dw_head = linear_dw(None, xf, dy_image_t=dl_img_t, shapes=((M, V), xf.shape))    # [V, C]; the tied wte gradient lands here too
+            dxf = linear_dx(img, None, self.lm_head.weight, dy_image=dl_img, shape=(M, V))
+            del dl_img, dl_img_t
+        else:
+            dlogits = ops.cross_entropy_bwd_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
+            dw_head = linear_dw(dlogits, xf)
+            dxf = linear_dx(img, dlogits, self.lm_head.weight)
         dx, dw, db = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None)
         put(tr.ln_f.weight, dw); put(tr.ln_f.bias, db)
-        for blk, (x0, h1, qkv, y, lse, x1, h2, a, g, s_att, s_res, s_mlp) in zip(reversed(tr.h), reversed(blocks)):
+        for blk, (x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp) in zip(reversed(tr.h), reversed(blocks)):
             # x = x1 + drop(c_proj(gelu(c_fc(ln_2(x1)))))
             dm = drop_rows(dx, s_mlp)
-            put(blk.mlp.c_proj.weight, linear_dw(dm, g))
+            dm_img, dm_img_t = grad_images(dm, 4 * C)
+            put(blk.mlp.c_proj.weight, linear_dw(dm, g, dy_image_t=dm_img_t, x_image_t=g_img_t, shapes=(dm.shape, a.shape)))
             if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dm))
-            da = ops.gelu_bwd(linear_dx(img, dm, blk.mlp.c_proj.weight), a)
-            put(blk.mlp.c_fc.weight, linear_dw(da, h2))
-            if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
-            dx1, dw, db = ops.layernorm_bwd(linear_dx(img, da, blk.mlp.c_fc.weight), x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
+            dg = linear_dx(img, dm, blk.mlp.c_proj.weight, dy_image=dm_img)
+            if blk.mlp.c_fc.bias is None and use_split(M, C, 4 * C) and use_split(4 * C, C, M):
+                # da = dg * gelu'(a) is only ever a GEMM operand: write its two images, not the fp32 matrix
+                da_img, da_img_t = ops.image_pair(dg, ops.PAIR_GELU_BWD, a)
+                put(blk.mlp.c_fc.weight, linear_dw(None, h2, dy_image_t=da_img_t, shapes=(a.shape, h2.shape)))
+                d_ln2 = linear_dx(img, None, blk.mlp.c_fc.weight, dy_image=da_img, shape=a.shape)
+                del da_img, da_img_t
+            else:
+                da = ops.gelu_bwd(dg, a)
+                put(blk.mlp.c_fc.weight, linear_dw(da, h2))
+                if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
+                d_ln2 = linear_dx(img, da, blk.mlp.c_fc.weight)
+            dx1, dw, db = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
             put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
             # x1 = x0 + drop(c_proj(attention(c_attn(ln_1(x0)))))
             dr = drop_rows(dx1, s_res)
-            put(blk.attn.c_proj.weight, linear_dw(dr, y))
+            dr_img, dr_img_t = grad_images(dr, C)
+            put(blk.attn.c_proj.weight, linear_dw(dr, y, dy_image_t=dr_img_t, x_image_t=y_img_t))
             if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dr))
-            dy = linear_dx(img, dr, blk.attn.c_proj.weight)
+            dy = linear_dx(img, dr, blk.attn.c_proj.weight, dy_image=dr_img)
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
                               B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
-            put(blk.attn.c_attn.weight, linear_dw(dqkv, h1))
+            dq_img, dq_img_t = grad_images(dqkv, C)
+            put(blk.attn.c_attn.weight, linear_dw(dqkv, h1, dy_image_t=dq_img_t))
             if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
-            dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight), x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None)
+            dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight, dy_image=dq_img), x0, blk.ln_1.weight, dx1,
+                                           blk.ln_1.bias is not None)
             put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
         dwpe = torch.zeros_like(tr.wpe.weight)
         dx = drop_rows(dx, s_emb)

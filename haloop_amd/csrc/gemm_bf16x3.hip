@@ -100,6 +100,100 @@ __global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__res
     }
 }
 
+// One read of a [R][C] fp32 source (optionally through an elementwise operator) -> BOTH operand images a Linear's backward wants:
+// the row-major image (rows R, k = C: the A operand of dx = dy W) and the transposed one (rows C, k = R: the A / B operand of
+// dW = dy^T x).  A workgroup owns a 128 x 32 source tile: it is one whole block of the row-major image and a 32-row quarter of
+// four blocks of the transposed image (tile rows 32q..32q+31 are k-tile 4*rt + q), turned through LDS.
+enum PairOp { PAIR_COPY = 0, PAIR_GELU_TANH = 1, PAIR_GELU_ERF = 2, PAIR_GELU_TANH_BWD = 3, PAIR_GELU_ERF_BWD = 4, PAIR_CE_BWD = 5 };
+
+struct PairArgs {
+    const float *src, *src2;       // src2: the pre-activation of the GELU backward (src = dy)
+    long ld, ld2;
+    int R, C;
+    char *img_rm, *img_tr;         // either may be NULL
+    int KT_rm, KT_tr, with_lo;
+    // PAIR_CE_BWD: src = logits [R][C]; value = (softmax - onehot(target)) * grad, 0 on ignored rows
+    const int64_t *target;
+    const float *lse, *grad;
+    long grad_stride, ignore_index;
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void image_pair_kernel(const PairArgs p) {
+    __shared__ float tile[TR][TK + 1];
+    const int kt = blockIdx.x, rt = blockIdx.y;
+    const bool vec = (p.ld % 4 == 0) && ((uintptr_t)p.src % 16 == 0) &&
+                     (!(OP == PAIR_GELU_TANH_BWD || OP == PAIR_GELU_ERF_BWD) || ((p.ld2 % 4 == 0) && ((uintptr_t)p.src2 % 16 == 0)));
+    const bool write_rm = p.img_rm && kt < p.KT_rm;
+    char *blk = p.img_rm + ((long)rt * p.KT_rm + kt) * BLOCK_BYTES;
+#pragma unroll
+    for (int u = threadIdx.x; u < TR * 4; u += 256) {
+        const int row = u >> 2, c = u & 3;
+        const int gr = rt * TR + row, gk = kt * TK + c * 8;
+        float x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = 0.f; y[j] = 0.f; }
+        if (gr < p.R && gk < p.C) {
+            const float *s = p.src + (long)gr * p.ld + gk;
+            const float *s2 = (OP == PAIR_GELU_TANH_BWD || OP == PAIR_GELU_ERF_BWD) ? p.src2 + (long)gr * p.ld2 + gk : nullptr;
+            if (vec && gk + 7 < p.C) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(s), b = *reinterpret_cast<const f32x4 *>(s + 4);
+                x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+                if (s2) {
+                    const f32x4 e = *reinterpret_cast<const f32x4 *>(s2), f = *reinterpret_cast<const f32x4 *>(s2 + 4);
+                    y[0] = e[0]; y[1] = e[1]; y[2] = e[2]; y[3] = e[3]; y[4] = f[0]; y[5] = f[1]; y[6] = f[2]; y[7] = f[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (gk + j < p.C) { x[j] = s[j]; if (s2) y[j] = s2[j]; }
+            }
+            if (OP == PAIR_GELU_TANH || OP == PAIR_GELU_ERF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = gemm_activation(x[j], OP == PAIR_GELU_ERF ? 8 : 2);       // gelu(0) = 0: the padding stays 0
+            } else if (OP == PAIR_GELU_TANH_BWD || OP == PAIR_GELU_ERF_BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = x[j] * gelu_grad(y[j], OP == PAIR_GELU_ERF_BWD);
+            } else if (OP == PAIR_CE_BWD) {
+                const long tgt = p.target[gr];
+                const float l = p.lse[gr], g = p.grad[(long)gr * p.grad_stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = (tgt == p.ignore_index || gk + j >= p.C) ? 0.f : (expf(x[j] - l) - (gk + j == tgt ? 1.0f : 0.f)) * g;
+            }
+        }
+        if (write_rm) {
+            bf16x8 hi, lo;
+            split8(x, hi, lo);
+            const int off = swz_byte(row, c);
+            *reinterpret_cast<bf16x8 *>(blk + off) = hi;
+            if (p.with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+        }
+        if (p.img_tr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[row][c * 8 + j] = x[j];
+        }
+    }
+    if (!p.img_tr) return;
+    __syncthreads();
+    // transposed image: its rows are the source columns kt*32 + cc, its k runs over the source rows
+#pragma unroll
+    for (int u = threadIdx.x; u < 4 * TK * 4; u += 256) {
+        const int c = u & 3, cc = (u >> 2) & 31, q = u >> 7;
+        const int tkt = rt * 4 + q;
+        if (tkt >= p.KT_tr) continue;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = tile[q * 32 + c * 8 + j][cc];
+        bf16x8 hi, lo;
+        split8(x, hi, lo);
+        char *tb = p.img_tr + ((long)(kt >> 2) * p.KT_tr + tkt) * BLOCK_BYTES;
+        const int off = swz_byte((kt & 3) * 32 + cc, c);
+        *reinterpret_cast<bf16x8 *>(tb + off) = hi;
+        if (p.with_lo) *reinterpret_cast<bf16x8 *>(tb + PART_BYTES + off) = lo;
+    }
+}
+
 struct TiledGemmArgs {
     const char *A;     // image of A [M][K]
     const char *B;     // image of B [N][K]
@@ -337,6 +431,25 @@ int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, 
     return halo_launch_status();
 }
 
+static int launch_image_pair(PairArgs &p, int op, hipStream_t st) {
+    p.with_lo = halo_math_mode() != HALO_MATH_BF16;
+    p.KT_rm = (p.C + TK - 1) / TK;
+    p.KT_tr = (p.R + TK - 1) / TK;
+    // the transposed image is zero padded to whole 128-row tiles: cover the source columns in groups of four k-tiles
+    const int kts = p.img_tr ? 4 * ((p.C + TR - 1) / TR) : p.KT_rm;
+    const dim3 grid(kts, (p.R + TR - 1) / TR);
+    switch (op) {
+        case PAIR_COPY: hipLaunchKernelGGL(image_pair_kernel<PAIR_COPY>, grid, dim3(256), 0, st, p); break;
+        case PAIR_GELU_TANH: hipLaunchKernelGGL(image_pair_kernel<PAIR_GELU_TANH>, grid, dim3(256), 0, st, p); break;
+        case PAIR_GELU_ERF: hipLaunchKernelGGL(image_pair_kernel<PAIR_GELU_ERF>, grid, dim3(256), 0, st, p); break;
+        case PAIR_GELU_TANH_BWD: hipLaunchKernelGGL(image_pair_kernel<PAIR_GELU_TANH_BWD>, grid, dim3(256), 0, st, p); break;
+        case PAIR_GELU_ERF_BWD: hipLaunchKernelGGL(image_pair_kernel<PAIR_GELU_ERF_BWD>, grid, dim3(256), 0, st, p); break;
+        case PAIR_CE_BWD: hipLaunchKernelGGL(image_pair_kernel<PAIR_CE_BWD>, grid, dim3(256), 0, st, p); break;
+        default: return HALO_EINVAL;
+    }
+    return halo_launch_status();
+}
+
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
     static int nstage = 0, nstage1 = 0;
@@ -396,6 +509,31 @@ int halo_split_image(const float *src, int rows, int k, int ld, int src_transpos
     HALO_CHECK_ARG(ld >= (src_transposed ? rows : k));
     HALO_CHECK_ARG((uintptr_t)image % 16 == 0);
     return halo_prep_tiles(src, rows, k, ld, src_transposed, image, (hipStream_t)stream);
+}
+
+int halo_image_pair(const float *src, const float *src2, int rows, int cols, long ld, long ld2, int op, void *image_rows,
+                    void *image_cols, halo_stream_t stream) {
+    HALO_CHECK_ARG(src && rows > 0 && cols > 0 && ld >= cols && (image_rows || image_cols));
+    HALO_CHECK_ARG(op >= HALO_PAIR_COPY && op <= HALO_PAIR_GELU_ERF_BWD);
+    const bool two = op == HALO_PAIR_GELU_TANH_BWD || op == HALO_PAIR_GELU_ERF_BWD;
+    HALO_CHECK_ARG(!two || (src2 && ld2 >= cols));
+    HALO_CHECK_ARG(((uintptr_t)image_rows | (uintptr_t)image_cols) % 16 == 0);
+    PairArgs p = {};
+    p.src = src; p.src2 = two ? src2 : nullptr; p.ld = ld; p.ld2 = ld2; p.R = rows; p.C = cols;
+    p.img_rm = (char *)image_rows; p.img_tr = (char *)image_cols;
+    return launch_image_pair(p, op, (hipStream_t)stream);
+}
+
+int halo_cross_entropy_bwd_images(const float *logits, const int64_t *targets, const float *lse, const float *grad, long grad_stride,
+                                  int rows, int V, long ld, long ignore_index, void *image_rows, void *image_cols,
+                                  halo_stream_t stream) {
+    HALO_CHECK_ARG(logits && targets && lse && grad && rows > 0 && V > 0 && ld >= V && (grad_stride == 0 || grad_stride == 1));
+    HALO_CHECK_ARG((image_rows || image_cols) && ((uintptr_t)image_rows | (uintptr_t)image_cols) % 16 == 0);
+    PairArgs p = {};
+    p.src = logits; p.ld = ld; p.R = rows; p.C = V;
+    p.img_rm = (char *)image_rows; p.img_tr = (char *)image_cols;
+    p.target = targets; p.lse = lse; p.grad = grad; p.grad_stride = grad_stride; p.ignore_index = ignore_index;
+    return launch_image_pair(p, PAIR_CE_BWD, (hipStream_t)stream);
 }
 
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C, float eps,

@@ -146,15 +146,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float *__restrict__
                                                        size_t n, int kind) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float x = a[i];
-    float d;
-    if (kind) {
-        d = 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
-    } else {
-        const float k = 0.7978845608028654f, u = k * (x + 0.044715f * x * x * x), t = tanhf(u);
-        d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x * x);
-    }
-    da[i] = dy[i] * d;
+    da[i] = dy[i] * gelu_grad(a[i], kind);
 }
 
 // logits[n,:] <- (softmax(logits[n,:]) - onehot(target[n])) * grad[n]   (0 where target == ignore_index), in place

@@ -110,6 +110,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// d gelu(x) / dx: kind 0 tanh-GELU (ha/attention.py:12-17), kind 1 exact (erf) GELU
+__device__ __forceinline__ float gelu_grad(float x, int kind) {
+    if (kind) return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+    const float k = 0.7978845608028654f, u = k * (x + 0.044715f * x * x * x), t = tanhf(u);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
 // All-reduce over the 16 lanes of a DPP row (lanes 16g .. 16g+15) on the VALU: row_ror:8,4,2,1 folds the row in four
 // v_*_dpp instructions, no trip through the LDS crossbar that a ds_bpermute-based __shfl_xor takes.  Every lane of the
 // row ends with the same bits (after the shift-s step the values are s-periodic, so each step adds one commutative pair).

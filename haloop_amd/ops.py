@@ -69,6 +69,26 @@ def split_image(x2d, transposed=False):
     return img
 
 
+PAIR_COPY, PAIR_GELU, PAIR_GELU_ERF, PAIR_GELU_BWD, PAIR_GELU_ERF_BWD = range(5)
+
+
+def image_pair(x2d, op=PAIR_COPY, x2=None, rows_image=True, cols_image=True):
+    """One read of x2d [rows, cols] (through ``op``) -> (split image of value [rows][cols], split image of value^T [cols][rows]):
+    the two operand images a Linear's backward wants of the same matrix (dx = dy W and dW = dy^T x); either can be skipped (None).
+    ops: PAIR_COPY value = x2d; PAIR_GELU(_ERF) value = gelu(x2d); PAIR_GELU(_ERF)_BWD value = x2d * gelu'(x2) (x2d = dy)."""
+    for t in (x2d, x2):
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1):
+            raise ValueError('image_pair: expected 2-D float32 HIP tensors with a unit column stride')
+    if op in (PAIR_GELU_BWD, PAIR_GELU_ERF_BWD) and (x2 is None or x2.shape != x2d.shape):
+        raise ValueError('image_pair: the GELU backward needs the pre-activation, shaped like dy')
+    rows, cols = x2d.shape
+    rm = torch.empty(lib().halo_split_image_bytes(rows, cols), device=x2d.device, dtype=torch.uint8) if rows_image else None
+    tr = torch.empty(lib().halo_split_image_bytes(cols, rows), device=x2d.device, dtype=torch.uint8) if cols_image else None
+    check(lib().halo_image_pair(ptr(x2d), ptr(x2), rows, cols, x2d.stride(0), x2.stride(0) if x2 is not None else 0, op, ptr(rm), ptr(tr),
+                                _stream()), 'halo_image_pair')
+    return rm, tr
+
+
 def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
     """LayerNorm of the rows written directly as the split operand image of the Linear that follows (C % 32 == 0).
     -> (image, y fp32 or None)"""
@@ -582,6 +602,20 @@ def cross_entropy_bwd_(logits2d, targets, lse, grad_rows, ignore_index=0):
     check(lib().halo_cross_entropy_bwd(ptr(logits2d), ptr(tg), ptr(lse), ptr(grad_rows), stride, rows, V, V, ignore_index, _stream()),
           'halo_cross_entropy_bwd')
     return logits2d
+
+
+def cross_entropy_bwd_images(logits2d, targets, lse, grad_rows, ignore_index=0):
+    """d loss / d logits (as cross_entropy_bwd_ computes it) written as the two split images the lm_head's backward
+    products read -- (image of [rows][V], image of [V][rows]) -- without materialising it in fp32; logits2d is not modified."""
+    _f32c(logits2d, 'logits'); _f32c(grad_rows, 'grad')
+    tg = _i64c(targets.reshape(-1), 'targets')
+    rows, V = logits2d.shape
+    stride = 0 if grad_rows.numel() == 1 else 1
+    rm = torch.empty(lib().halo_split_image_bytes(rows, V), device=logits2d.device, dtype=torch.uint8)
+    tr = torch.empty(lib().halo_split_image_bytes(V, rows), device=logits2d.device, dtype=torch.uint8)
+    check(lib().halo_cross_entropy_bwd_images(ptr(logits2d), ptr(tg), ptr(lse), ptr(grad_rows), stride, rows, V, V, ignore_index,
+                                              ptr(rm), ptr(tr), _stream()), 'halo_cross_entropy_bwd_images')
+    return rm, tr
 
 
 def embed_bwd(ids, dx2d, dwte, dwpe, pos0=0, accumulate_wpe=False):

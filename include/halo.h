@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 3
+#define HALO_ABI_VERSION 4
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -122,6 +122,25 @@ int halo_split_image(const float *src, int rows, int k, int ld, int src_transpos
  * optionally as fp32 rows y (NULL to skip).  C % 32 == 0. */
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C,
                          float eps, halo_stream_t stream);
+/* One read of an fp32 matrix src [rows][cols] (leading dimension ld), optionally through an elementwise operator, written as
+ * BOTH split images a Linear's backward consumes: image_rows = halo_split_image(value [rows][cols]) (the A operand of
+ * dx = dy W, ha/attention.py:117-129,141) and image_cols = halo_split_image(value^T [cols][rows]) (the operand of dW = dy^T x);
+ * either may be NULL.  The fp32 value itself is never written.  op:
+ *   HALO_PAIR_COPY            value = src
+ *   HALO_PAIR_GELU_TANH/_ERF  value = gelu(src)                (forward of new_gelu ha/attention.py:12-17 / nn.GELU())
+ *   HALO_PAIR_GELU_*_BWD      value = src * gelu'(src2)        (src = dy, src2 = the pre-activation [rows][cols], ld2)
+ * halo_cross_entropy_bwd_images: value = d loss / d logits as halo_cross_entropy_bwd writes it (same arguments), as images of
+ *   [rows][V] and [V][rows] for the lm_head's two backward products (ha/attention.py:266-269); logits are left untouched. */
+#define HALO_PAIR_COPY 0
+#define HALO_PAIR_GELU_TANH 1
+#define HALO_PAIR_GELU_ERF 2
+#define HALO_PAIR_GELU_TANH_BWD 3
+#define HALO_PAIR_GELU_ERF_BWD 4
+int halo_image_pair(const float *src, const float *src2, int rows, int cols, long ld, long ld2, int op, void *image_rows,
+                    void *image_cols, halo_stream_t stream);
+int halo_cross_entropy_bwd_images(const float *logits, const int64_t *targets, const float *lse, const float *grad,
+                                  long grad_stride, int rows, int V, long ld, long ignore_index, void *image_rows,
+                                  void *image_cols, halo_stream_t stream);
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc,
                     const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                     uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);

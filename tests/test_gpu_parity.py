@@ -917,3 +917,63 @@ def test_gpt_shape_robustness_against_oracle(hal, math_mode, vocab, block, n_lay
     tol = dict(rtol=5e-4, atol=5e-7) if math_mode == 'f32' else dict(rtol=2e-3, atol=4e-6)
     for k, p in model.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].grad.numpy(), err_msg=k, **tol)
+
+
+# ---- one-read operand image pairs (halo_image_pair / halo_cross_entropy_bwd_images) -------------------------------------
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('R,Cc,pad', [(130, 70, 0), (257, 200, 8), (128, 128, 0), (64, 96, 4)])
+def test_image_pair_matches_the_two_single_image_passes(mode, R, Cc, pad):
+    """image_pair(x, op) must produce exactly the images split_image makes of op(x) and of op(x)^T: GEMMs fed either way agree
+    bit for bit (compared through GEMMs so that the unwritten lo parts of bf16-mode images do not matter)."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(R * 1000 + Cc)
+        buf = torch.randn(R, Cc + pad, generator=g).cuda()
+        x = buf[:, :Cc]                                                     # row stride > cols when pad
+        a = torch.randn(R, Cc, generator=g).cuda()
+        wb = torch.randn(72, Cc, generator=g).cuda()                        # B operand for the row-major image: [N, K = Cc]
+        wc = torch.randn(80, R, generator=g).cuda()                         # B operand for the transposed image: [N, K = R]
+        wb_img, wc_img = ops.split_image(wb), ops.split_image(wc)
+        cases = [(ops.PAIR_COPY, None, x.contiguous()),
+                 (ops.PAIR_GELU, None, ops.gelu_fwd(x.contiguous())),
+                 (ops.PAIR_GELU_ERF, None, ops.gelu_fwd(x.contiguous(), exact=True)),
+                 (ops.PAIR_GELU_BWD, a, ops.gelu_bwd(x.contiguous(), a)),
+                 (ops.PAIR_GELU_ERF_BWD, a, ops.gelu_bwd(x.contiguous(), a, exact=True))]
+        for op, x2, value in cases:
+            rm, tr = ops.image_pair(x, op, x2)
+            ref_rm = ops.gemm_split(ops.split_image(value), wb_img, R, 72, Cc)
+            ref_tr = ops.gemm_split(ops.split_image(value, transposed=True), wc_img, Cc, 80, R)
+            assert torch.equal(ops.gemm_split(rm, wb_img, R, 72, Cc), ref_rm), op
+            assert torch.equal(ops.gemm_split(tr, wc_img, Cc, 80, R), ref_tr), op
+            only_rm, none = ops.image_pair(x, op, x2, cols_image=False)
+            assert none is None and torch.equal(ops.gemm_split(only_rm, wb_img, R, 72, Cc), ref_rm)
+    finally:
+        _lib.set_math_mode(prev)
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+def test_cross_entropy_bwd_images_match_the_in_place_gradient(mode):
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(5)
+        rows, V, C = 150, 333, 64
+        logits = torch.randn(rows, V, generator=g).cuda()
+        targets = torch.randint(0, V, (rows,), generator=g).cuda()
+        targets[::7] = 0                                                    # ignored rows
+        grad = torch.rand(rows, generator=g).cuda()
+        loss, lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
+        w = torch.randn(C, V, generator=g).cuda(); xf = torch.randn(C, rows, generator=g).cuda()
+        w_img, xf_img = ops.split_image(w), ops.split_image(xf)
+        for gr in (grad, torch.full((1,), 0.25).cuda()):
+            rm, tr = ops.cross_entropy_bwd_images(logits, targets, lse, gr, ignore_index=0)
+            d = ops.cross_entropy_bwd_(logits.clone(), targets, lse, gr, ignore_index=0)
+            assert torch.equal(ops.gemm_split(rm, w_img, rows, C, V), ops.gemm_split(ops.split_image(d), w_img, rows, C, V))
+            assert torch.equal(ops.gemm_split(tr, xf_img, V, C, rows), ops.gemm_split(ops.split_image(d, transposed=True), xf_img, V, C, rows))
+    finally:
+        _lib.set_math_mode(prev)
