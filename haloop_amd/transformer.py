@@ -32,7 +32,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import NO_SITES, DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx, ln_linear, normed_image
+from ._linear import (NO_SITES, DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
+                      normed_image, use_split)
 from .attention import LayerNorm
 from .conv import ConvEncoder
 from .recognizer import TemporalClassifier
@@ -257,17 +258,21 @@ class MultiHeadAttention(nn.Module):
             ops.rope_(dq, T, self.heads, self.head_dim, table, inverse=True)
             ops.rope_(dk, S, self.heads, self.head_dim, table, inverse=True)
         ws = (self.q.weight, self.k.weight, self.v.weight)
+        # each projection gradient feeds a weight-gradient and an input-gradient GEMM: both operand images from one read
         if mem2d is None:
-            dw = linear_dw(dqkv, x2d)                           # [3C, C]
+            im, im_t = grad_images(dqkv, C)
+            dw = linear_dw(dqkv, x2d, dy_image_t=im_t)          # [3C, C]
             for i, w in enumerate(ws):
                 put(w, dw[i * C:(i + 1) * C])
-            return linear_dx(self._images, dqkv, ws, out=dx_out, accumulate=dx_out is not None)
-        put(self.q.weight, linear_dw(dq, x2d))
-        dwkv = linear_dw(dkv, mem2d)
+            return linear_dx(self._images, dqkv, ws, out=dx_out, accumulate=dx_out is not None, dy_image=im)
+        im, im_t = grad_images(dq, C)
+        put(self.q.weight, linear_dw(dq, x2d, dy_image_t=im_t))
+        km, km_t = grad_images(dkv, C) if dmem_out is not None else (None, None)
+        dwkv = linear_dw(dkv, mem2d, dy_image_t=km_t)
         put(self.k.weight, dwkv[:C]); put(self.v.weight, dwkv[C:])
         if dmem_out is not None:
-            linear_dx(self._images, dkv, ws[1:], out=dmem_out, accumulate=True)
-        return linear_dx(self._images, dq, self.q.weight, out=dx_out, accumulate=dx_out is not None)
+            linear_dx(self._images, dkv, ws[1:], out=dmem_out, accumulate=True, dy_image=km)
+        return linear_dx(self._images, dq, self.q.weight, out=dx_out, accumulate=dx_out is not None, dy_image=im)
 
     def forward(self, x, memory, *, mask=None, causal=False, measure_entropy=False, kv_cache_parts=None, t0=0, rope=False,
                 _key_lengths=None):
@@ -333,29 +338,43 @@ class Block(nn.Module):
         s_to = sites.next()
         xb = linear(mt._images, yt, mt.proj.weight, out=xa.clone(), accumulate=True, drop=s_to[0], stream_id=s_to[1])
         a, hn = ln_linear(self._images, xb, self.ln_chan.weight, None, self.mix_chan[0].weight, want_normed=True)
-        g = ops.gelu_fwd(a, exact=True)
+        # gelu(a) is only ever a GEMM operand (mix_chan[2] now, its weight gradient later): write its two images, not the matrix
+        g_img, g_img_t = forward_images(a, x0.shape[1], ops.PAIR_GELU_ERF)
+        g = ops.gelu_fwd(a, exact=True) if g_img is None else None
         s_co = sites.next()
-        xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True, drop=s_co[0], stream_id=s_co[1])
-        return xc, (x0, sv_m, sv_t, xb, hn, a, g, s_mo, s_to, s_co)
+        xc = linear(self._images, g, self.mix_chan[2].weight, out=xb.clone(), accumulate=True, drop=s_co[0], stream_id=s_co[1],
+                    a_image=g_img, shape=a.shape)
+        return xc, (x0, sv_m, sv_t, xb, hn, a, g, g_img_t, s_mo, s_to, s_co)
 
     def _backward2d(self, saved, dxc, put, dmem_out=None):
-        x0, sv_m, sv_t, xb, hn, a, g, s_mo, s_to, s_co = saved
+        x0, sv_m, sv_t, xb, hn, a, g, g_img_t, s_mo, s_to, s_co = saved
         w0, w2 = self.mix_chan[0].weight, self.mix_chan[2].weight
+        C, M = x0.shape[1], x0.shape[0]
         dmlp = drop_rows(dxc, s_co)                                             # gradient at the MLP output, before its dropout
-        put(w2, linear_dw(dmlp, g))
-        da = ops.gelu_bwd(linear_dx(self._images, dmlp, w2), a, exact=True)
-        put(w0, linear_dw(da, hn))
-        dxb, dw, _ = ops.layernorm_bwd(linear_dx(self._images, da, w0), xb, self.ln_chan.weight, dxc)
+        dm_img, dm_img_t = grad_images(dmlp, a.shape[1])
+        put(w2, linear_dw(dmlp, g, dy_image_t=dm_img_t, x_image_t=g_img_t, shapes=(dmlp.shape, a.shape)))
+        dg = linear_dx(self._images, dmlp, w2, dy_image=dm_img)
+        if use_split(M, C, a.shape[1]) and use_split(a.shape[1], C, M):
+            da_img, da_img_t = ops.image_pair(dg, ops.PAIR_GELU_ERF_BWD, a)    # da = dg * gelu'(a), as its two operand images only
+            put(w0, linear_dw(None, hn, dy_image_t=da_img_t, shapes=(a.shape, hn.shape)))
+            d_ln = linear_dx(self._images, None, w0, dy_image=da_img, shape=a.shape)
+        else:
+            da = ops.gelu_bwd(dg, a, exact=True)
+            put(w0, linear_dw(da, hn))
+            d_ln = linear_dx(self._images, da, w0)
+        dxb, dw, _ = ops.layernorm_bwd(d_ln, xb, self.ln_chan.weight, dxc)
         put(self.ln_chan.weight, dw)
         mt = self.mix_time
         dto = drop_rows(dxb, s_to)
-        put(mt.proj.weight, linear_dw(dto, sv_t[5]))
-        dxn = mt._attend2d_bwd(sv_t, linear_dx(mt._images, dto, mt.proj.weight), put)
+        im, im_t = grad_images(dto, C)
+        put(mt.proj.weight, linear_dw(dto, sv_t[5], dy_image_t=im_t))
+        dxn = mt._attend2d_bwd(sv_t, linear_dx(mt._images, dto, mt.proj.weight, dy_image=im), put)
         if sv_m is not None:
             mm = self.mix_memory
             dmo = drop_rows(dxb, s_mo)
-            put(mm.proj.weight, linear_dw(dmo, sv_m[5]))
-            mm._attend2d_bwd(sv_m, linear_dx(mm._images, dmo, mm.proj.weight), put, dx_out=dxn, dmem_out=dmem_out)
+            im, im_t = grad_images(dmo, C)
+            put(mm.proj.weight, linear_dw(dmo, sv_m[5], dy_image_t=im_t))
+            mm._attend2d_bwd(sv_m, linear_dx(mm._images, dmo, mm.proj.weight, dy_image=im), put, dx_out=dxn, dmem_out=dmem_out)
         dx0, dw, _ = ops.layernorm_bwd(dxn, x0, self.ln_time.weight, dxb)      # both attentions read the same ln_time(x)
         put(self.ln_time.weight, dw)
         return dx0
