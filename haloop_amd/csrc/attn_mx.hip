@@ -96,29 +96,6 @@ __device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int k0) {
 // operand of O^T = V^T P^T -- no trip through LDS.  The contraction slot (lq, e) of a 32-deep P.V step stands for key
 // 16*(2kk + e/4) + 4*lq + e%4; the transpose read fetches V's rows in the same order.
 
-// all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48).  v_permlane16_swap exchanges the odd
-// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
-// lower half of the second; fed the same value twice they leave (x_r, x_r^1) resp. (x_lo, x_hi) in every lane.
-// Issued as inline asm: through __builtin_amdgcn_permlane*_swap this compiler (ROCm 7.2) folds the second result into
-// the first (the ISA showed max(s0, s0)).  The s_nop covers the VALU-write -> permlane-swap read hazard the compiler
-// would otherwise schedule around.
-__device__ __forceinline__ void swap_rows16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap_rows32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ float rows4_max(float x) {
-    float a = x, b = x;
-    swap_rows16(a, b);
-    a = b = fmaxf(a, b);
-    swap_rows32(a, b);
-    return fmaxf(a, b);
-}
-__device__ __forceinline__ float rows4_sum(float x) {
-    float a = x, b = x;
-    swap_rows16(a, b);
-    a = b = a + b;
-    swap_rows32(a, b);
-    return a + b;
-}
-
 // A fragment of V^T (or any row-major image read across its rows): rows rowA .. rowA+3 and rowB .. rowB+3 of column
 // col0 + (lane & 15), through the hardware transpose read.  ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p
 // addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i receives column i of the 4 rows.  Needs EXEC all

@@ -4,7 +4,7 @@
 #include "halo_common.h"
 #include "halo_internal.h"
 
-#define HALO_LN_BWD_CHUNKS 128   // row chunks of the LayerNorm weight/bias gradient partial sums
+#define HALO_LN_BWD_CHUNKS 512   // row chunks (workgroups) of the LayerNorm weight/bias gradient partial sums
 
 namespace {
 
@@ -118,6 +118,105 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float *__re
         dxr[c] = rr ? rr[c] + d : d;
     }
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// The same backward in ONE pass over dy and x for C % 4 == 0, C <= 256 * MAXV: a wave holds its row in registers (float4 per lane),
+// so x and dy are read once, the four row statistics are DPP / permlane reductions, and the weight / bias gradient partial sums
+// of the rows a workgroup walks (rows b*4 + wave, stepping by 4 * gridDim) stay in registers until the end: pw[b, :], pb[b, :]
+// (fixed order -> reproducible), summed over b by the column-sum kernel.  Replaces the dx kernel + the column pass that
+// re-read dy and x.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                  const float *__restrict__ w, const float *__restrict__ dres,
+                                                                  float *__restrict__ dx, float *__restrict__ pw, float *__restrict__ pb,
+                                                                  int rows, int C, float eps) {
+    extern __shared__ float red[];                       // [2][C]: cross-wave sums of the partials
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int C4 = C >> 2;
+    f32x4 wv[MAXV], aw[MAXV], ab[MAXV];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int q = v * 64 + lane;
+        wv[v] = q < C4 ? *reinterpret_cast<const f32x4 *>(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        aw[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_c = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float *xr = x + (long)row * C, *dyr = dy + (long)row * C;
+        f32x4 xv[MAXV], dv[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const int q = v * 64 + lane;
+            const bool in = q < C4;
+            xv[v] = in ? *reinterpret_cast<const f32x4 *>(xr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[v] = in ? *reinterpret_cast<const f32x4 *>(dyr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
+        }
+        const float mean = wave_sum_dpp(s) * inv_c;
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            if (v * 64 + lane < C4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[v][e] -= mean; var += xv[v][e] * xv[v][e]; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum_dpp(var) * inv_c + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[v][e] *= rstd;                        // xhat (0 in the padding lanes)
+                const float g = dv[v][e] * wv[v][e];
+                sg += g;
+                sgx += g * xv[v][e];
+                aw[v][e] += dv[v][e] * xv[v][e];
+                ab[v][e] += dv[v][e];
+            }
+        const float mg = wave_sum_dpp(sg) * inv_c, mgx = wave_sum_dpp(sgx) * inv_c;
+        float *dxr = dx + (long)row * C;
+        const float *rr = dres ? dres + (long)row * C : nullptr;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const int q = v * 64 + lane;
+            if (q >= C4) continue;
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = rstd * (dv[v][e] * wv[v][e] - mg - xv[v][e] * mgx);
+            if (rr) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4 *>(rr + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] += r4[e];
+            }
+            *reinterpret_cast<f32x4 *>(dxr + 4 * q) = d;
+        }
+    }
+    // the four waves' partials, added in wave order
+    for (int k = 0; k < 4; ++k) {
+        if (wave == k) {
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                const int q = v * 64 + lane;
+                if (q >= C4) continue;
+                f32x4 *rw = reinterpret_cast<f32x4 *>(red + 4 * q), *rb = reinterpret_cast<f32x4 *>(red + C + 4 * q);
+                if (k == 0) { *rw = aw[v]; *rb = ab[v]; }
+                else {
+                    f32x4 a4 = *rw, b4 = *rb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a4[e] += aw[v][e]; b4[e] += ab[v][e]; }
+                    *rw = a4; *rb = b4;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        pw[(long)blockIdx.x * C + c] = red[c];
+        pb[(long)blockIdx.x * C + c] = red[C + c];
+    }
 }
 
 // partial_w[chunk, c] = sum over the chunk's rows of dy * xhat, partial_b[chunk, c] = sum dy (fixed order -> reproducible)
@@ -246,6 +345,17 @@ int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, con
     HALO_CHECK_ARG(dy && x && weight && dx && dweight && workspace && rows > 0 && C > 0);
     hipStream_t st = (hipStream_t)stream;
     float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
+    const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0;
+    if (C % 4 == 0 && C <= 2048 && aligned) {
+        const int wgs = min(HALO_LN_BWD_CHUNKS, (rows + 3) / 4);
+        const size_t lds = (size_t)2 * C * sizeof(float);
+        if (C <= 1024)
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<4>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps);
+        else
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<8>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps);
+        if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
+        return halo_colsum2(pw, wgs, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, wgs, C, C, dbias, nullptr, st) : HALO_OK);
+    }
     hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, weight, dres, dx, stats, rows, C, eps);
     const int chunks = rows < HALO_LN_BWD_CHUNKS ? rows : HALO_LN_BWD_CHUNKS, rpc = (rows + chunks - 1) / chunks;
     const int used = (rows + rpc - 1) / rpc;

@@ -133,6 +133,32 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48).  v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
+// lower half of the second; fed the same value twice they leave (x_r, x_r^1) resp. (x_lo, x_hi) in every lane.
+// Issued as inline asm: through __builtin_amdgcn_permlane*_swap this compiler (ROCm 7.2) folds the second result into
+// the first (the ISA showed max(s0, s0)).  The s_nop covers the VALU-write -> permlane-swap read hazard the compiler
+// would otherwise schedule around.
+__device__ __forceinline__ void swap_rows16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows4_max(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    a = b = fmaxf(a, b);
+    swap_rows32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    a = b = a + b;
+    swap_rows32(a, b);
+    return a + b;
+}
+// whole-wave sums / maxima without a trip through the LDS crossbar: 16 lanes on DPP, then the four rows by permlane swaps
+__device__ __forceinline__ float wave_sum_dpp(float v) { return rows4_sum(row16_sum(v)); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return rows4_max(row16_max(v)); }
+
 // GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result,
 // bit 3 exact (erf) GELU (nn.GELU() / F.gelu: ha/transformer.py:456, ha/conv.py:46)
 __device__ __forceinline__ float gemm_activation(float v, int flags) {

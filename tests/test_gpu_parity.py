@@ -977,3 +977,27 @@ def test_cross_entropy_bwd_images_match_the_in_place_gradient(mode):
             assert torch.equal(ops.gemm_split(tr, xf_img, V, C, rows), ops.gemm_split(ops.split_image(d, transposed=True), xf_img, V, C, rows))
     finally:
         _lib.set_math_mode(prev)
+
+
+@pytest.mark.parametrize('rows,C,with_res', [(301, 200, True), (5000, 768, True), (37, 1536, False), (130, 201, True), (9, 64, False),
+                                             (2100, 1024, False)])
+def test_layernorm_backward_paths(hal, rows, C, with_res):
+    """The one-pass fused kernel (C % 4 == 0, <= 1024 and <= 2048 register tiles, rows walked in strides by <= 512 workgroups)
+    and the two-pass fallback (C % 4 != 0) against torch autograd."""
+    import torch.nn.functional as Fn
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(rows + C)
+    x = (2 * torch.randn(rows, C, generator=g) + 0.5).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy = torch.randn(rows, C, generator=g)
+    dres = torch.randn(rows, C, generator=g) if with_res else None
+    Fn.layer_norm(x, (C,), w, b, 1e-5).backward(dy)
+    dx, dw, db = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), dres.to(DEV) if with_res else None, has_bias=True)
+    want_dx = x.grad + dres if with_res else x.grad
+    np.testing.assert_allclose(dx.cpu().numpy(), want_dx.numpy(), atol=1e-5, rtol=1e-5)
+    scale = float(rows) ** 0.5                                   # the column sums grow like sqrt(rows)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), atol=2e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), atol=2e-5 * scale, rtol=1e-5)
+    dx2, dw2, db2 = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), dres.to(DEV) if with_res else None, has_bias=True)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)      # fixed summation order
