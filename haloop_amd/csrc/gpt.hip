@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
             dv[v] = in ? *reinterpret_cast<const f32x4 *>(dyr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
         }
-        const float mean = wave_sum_dpp(s) * inv_c;
+        const float mean = wave_sum(s) * inv_c;
         float var = 0.f;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
                 for (int e = 0; e < 4; ++e) { xv[v][e] -= mean; var += xv[v][e] * xv[v][e]; }
             }
         }
-        const float rstd = rsqrtf(wave_sum_dpp(var) * inv_c + eps);
+        const float rstd = rsqrtf(wave_sum(var) * inv_c + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
                 aw[v][e] += dv[v][e] * xv[v][e];
                 ab[v][e] += dv[v][e];
             }
-        const float mg = wave_sum_dpp(sg) * inv_c, mgx = wave_sum_dpp(sgx) * inv_c;
+        const float mg = wave_sum(sg) * inv_c, mgx = wave_sum(sgx) * inv_c;
         float *dxr = dx + (long)row * C;
         const float *rr = dres ? dres + (long)row * C : nullptr;
 #pragma unroll

@@ -99,16 +99,6 @@ __device__ __forceinline__ float log_add_exp(float a, float b) {
     return m + log1pf(expf(-fabsf(a - b)));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 // d gelu(x) / dx: kind 0 tanh-GELU (ha/attention.py:12-17), kind 1 exact (erf) GELU
 __device__ __forceinline__ float gelu_grad(float x, int kind) {
@@ -156,8 +146,8 @@ __device__ __forceinline__ float rows4_sum(float x) {
     return a + b;
 }
 // whole-wave sums / maxima without a trip through the LDS crossbar: 16 lanes on DPP, then the four rows by permlane swaps
-__device__ __forceinline__ float wave_sum_dpp(float v) { return rows4_sum(row16_sum(v)); }
-__device__ __forceinline__ float wave_max_dpp(float v) { return rows4_max(row16_max(v)); }
+__device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
 
 // GEMM epilogue flags (include/halo.h): bit 0 relu, bit 1 tanh-GELU (ha/attention.py:12-17), bit 2 C += result,
 // bit 3 exact (erf) GELU (nn.GELU() / F.gelu: ha/transformer.py:456, ha/conv.py:46)
