@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 4
+HALO_ABI_VERSION = 5
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -40,6 +40,8 @@ SIGNATURES = {
     'halo_split_image_bytes': (_sz, [_i, _i]),
     'halo_split_image': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'halo_layernorm_image': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_gemm_split_ce_workspace_bytes': (_sz, [_i, _i]),
+    'halo_gemm_split_ce': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp]),
     'halo_image_pair': (_i, [_vp, _vp, _i, _i, _l, _l, _i, _vp, _vp, _vp]),
     'halo_cross_entropy_bwd_images': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp, _vp, _vp]),
     'halo_gemm_split': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),

@@ -30,8 +30,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import (DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
-                      use_split)
+from ._linear import (SMALL_M, DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx,
+                      ln_linear, use_split)
 from .rnn import DropoutStream
 
 
@@ -209,7 +209,12 @@ class GPT(nn.Module):
             raise NotImplementedError('training-mode dropout is built into the autograd path only: enable grad, or call .eval()')
         x, _ = self._trunk(input_ids, past)
         targets = target_ids.reshape(-1)
-        # lm_head + cross-entropy in row chunks so the [rows, V] logits stay bounded (206 MB per 1024 rows at V=50304)
+        C = self.config.n_embd
+        if use_split(B * T, V, C) and B * T > SMALL_M:
+            # lm_head + cross-entropy in the GEMM's epilogue: the [rows, V] logits are never written
+            loss, _, _ = ops.gemm_split_ce(ops.split_image(x), self._images.split((self.lm_head.weight,)), B * T, V, C, targets, ignore_index=0)
+            return self._reduce(loss, targets, reduction)
+        # otherwise in row chunks so the logits stay bounded (206 MB per 1024 rows at V=50304)
         loss = torch.empty(B * T, device=x.device, dtype=torch.float32)
         chunk = max(64, min(B * T, (1 << 28) // (4 * V)))
         for r0 in range(0, B * T, chunk):
@@ -261,8 +266,12 @@ class GPT(nn.Module):
             blocks.append((x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp))
         xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
-        logits = self._linear(xf, self.lm_head)                              # kept: the backward rewrites it into dlogits
-        loss, row_lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
+        if use_split(B * T, cfg.vocab_size, C) and B * T > SMALL_M:          # statistics in the GEMM epilogue; the logits are kept for the backward
+            loss, row_lse, logits = ops.gemm_split_ce(ops.split_image(xf), self._images.split((self.lm_head.weight,)), B * T, cfg.vocab_size, C,
+                                                      targets, ignore_index=0, want_logits=True, want_lse=True)
+        else:
+            logits = self._linear(xf, self.lm_head)
+            loss, row_lse = ops.cross_entropy_fwd_lse(logits, targets, ignore_index=0)
         return loss, (input_ids, targets, blocks, x, xf, logits, row_lse, s_emb, emb_saved)
 
     @torch.no_grad()

@@ -208,6 +208,11 @@ struct TiledGemmArgs {
     int use_drop;
     int ntiles, ksplit, ktper;   // split-K over k-tiles; raw sums of slice s go to slab[s][M][N]
     float *slab;
+    // fused cross-entropy epilogue (lm_head): per row and 64-column strip the (max, sum exp) of the logits go to
+    // ce_part[row][strip][2], the target's logit to ce_tlogit[row]; C may then be NULL (the logits are never written)
+    const int64_t *ce_target;
+    float *ce_part, *ce_tlogit;
+    int ce_strips;               // strips per row = 2 * tiles_n
 };
 
 template <int PASSES>
@@ -335,6 +340,39 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 
     // epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     const int m0 = tile_m * TR, n0 = tile_n * TR;
+    if (p.ce_part) {        // wave-uniform: softmax statistics of this wave's 64 x 64 block, row by row (a row = 32 lanes x 2)
+        const int c0 = n0 + wn * 64 + lr, c1 = c0 + 32;
+        const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
+        float b0 = 0.f, b1 = 0.f;
+        if (p.bias1) { if (ok0) b0 = p.bias1[c0]; if (ok1) b1 = p.bias1[c1]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v0 = ok0 ? acc[i][0][r] + b0 : -INFINITY, v1 = ok1 ? acc[i][1][r] + b1 : -INFINITY;
+                float mx = row16_max(fmaxf(v0, v1)), other = mx;
+                swap_rows16(mx, other);                      // the two 16-lane rows of each 32-lane half
+                mx = fmaxf(mx, other);
+                const float msafe = mx == -INFINITY ? 0.f : mx;
+                float sm = row16_sum(__expf(v0 - msafe) + __expf(v1 - msafe)), so = sm;
+                swap_rows16(sm, so);
+                sm += so;
+                if (row >= p.M) continue;
+                if (lr == 0) {
+                    float *pp = p.ce_part + ((long)row * p.ce_strips + tile_n * 2 + wn) * 2;
+                    pp[0] = mx; pp[1] = sm;
+                }
+                const long tgt = p.ce_target[row];
+                if (ok0 && c0 == tgt) p.ce_tlogit[row] = v0;
+                if (ok1 && c1 == tgt) p.ce_tlogit[row] = v1;
+                if (p.C) {
+                    if (ok0) p.C[(long)row * p.ldc + c0] = v0;
+                    if (ok1) p.C[(long)row * p.ldc + c1] = v1;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -431,6 +469,31 @@ int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, 
     return halo_launch_status();
 }
 
+// loss[row] = logsumexp(logits[row, :]) - logits[row, target[row]] from the strip statistics of the fused epilogue (0 and lse 0 on
+// ignored rows, like cross_entropy_kernel); one wave per row
+__global__ __launch_bounds__(256) void ce_merge_kernel(const float *__restrict__ part, const float *__restrict__ tlogit,
+                                                       const int64_t *__restrict__ target, float *__restrict__ loss,
+                                                       float *__restrict__ lse_out, int rows, int strips, long ignore_index) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    if (target[row] == ignore_index) {
+        if (lane == 0) { loss[row] = 0.f; if (lse_out) lse_out[row] = 0.f; }
+        return;
+    }
+    const float *pr = part + (long)row * strips * 2;
+    float m = -INFINITY;
+    for (int t = lane; t < strips; t += 64) m = fmaxf(m, pr[2 * t]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int t = lane; t < strips; t += 64) s += pr[2 * t + 1] * __expf(pr[2 * t] - m);      // exp(-inf) = 0 for all-padding strips
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float l = m + logf(s);
+        loss[row] = l - tlogit[row];
+        if (lse_out) lse_out[row] = l;
+    }
+}
+
 static int launch_image_pair(PairArgs &p, int op, hipStream_t st) {
     p.with_lo = halo_math_mode() != HALO_MATH_BF16;
     p.KT_rm = (p.C + TK - 1) / TK;
@@ -450,8 +513,22 @@ static int launch_image_pair(PairArgs &p, int op, hipStream_t st) {
     return halo_launch_status();
 }
 
+struct CeEpilogue {
+    const int64_t *target;
+    float *part, *tlogit;
+};
+static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
+                                  const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
+                                  hipStream_t st);
+
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
+    return gemm_bf16x3_tiled_impl(Aimg, Bimg, M, N, K, C, ldc, bias1, bias2, relu, drop, nullptr, st);
+}
+
+static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
+                                  const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
+                                  hipStream_t st) {
     static int nstage = 0, nstage1 = 0;
     if (!nstage) {
         // ring depth: 2 slots = 64 KiB (two workgroups per CU), 4 slots = 128 KiB (one); opt in to the LDS size once
@@ -478,7 +555,9 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
     p.use_drop = drop && drop->threshold != 0u;
     if (drop) p.drop = *drop; else p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
     p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
-    p.ksplit = halo_pick_ksplit(p.ntiles, p.KT, (long)M * N);
+    p.ksplit = ce ? 1 : halo_pick_ksplit(p.ntiles, p.KT, (long)M * N);      // the fused statistics need whole dot products
+    p.ce_target = ce ? ce->target : nullptr; p.ce_part = ce ? ce->part : nullptr; p.ce_tlogit = ce ? ce->tlogit : nullptr;
+    p.ce_strips = 2 * p.tiles_n;
     p.ktper = (p.KT + p.ksplit - 1) / p.ksplit;
     p.ksplit = (p.KT + p.ktper - 1) / p.ktper;
     void *scratch; size_t bytes;
@@ -534,6 +613,27 @@ int halo_cross_entropy_bwd_images(const float *logits, const int64_t *targets, c
     p.img_rm = (char *)image_rows; p.img_tr = (char *)image_cols;
     p.target = targets; p.lse = lse; p.grad = grad; p.grad_stride = grad_stride; p.ignore_index = ignore_index;
     return launch_image_pair(p, PAIR_CE_BWD, (hipStream_t)stream);
+}
+
+size_t halo_gemm_split_ce_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return ((size_t)M * 2 * ((N + TR - 1) / TR) * 2 + (size_t)M) * sizeof(float);
+}
+
+int halo_gemm_split_ce(const void *a_image, const void *b_image, int M, int N, int K, float *logits, int ldc, const float *bias,
+                       const int64_t *targets, long ignore_index, void *workspace, float *loss, float *lse, halo_stream_t stream) {
+    HALO_CHECK_ARG(a_image && b_image && targets && workspace && loss && M > 0 && N > 0 && K > 0);
+    HALO_CHECK_ARG(!logits || ldc >= N);
+    HALO_CHECK_ARG(halo_math_mode() != HALO_MATH_F32);
+    hipStream_t st = (hipStream_t)stream;
+    const int strips = 2 * ((N + TR - 1) / TR);
+    CeEpilogue ce;
+    ce.target = targets; ce.part = (float *)workspace; ce.tlogit = ce.part + (size_t)M * strips * 2;
+    int rc = gemm_bf16x3_tiled_impl(a_image, b_image, M, N, K, logits, ldc, bias, nullptr, 0, nullptr, &ce, st);
+    if (rc != HALO_OK) return rc;
+    hipLaunchKernelGGL(ce_merge_kernel, dim3((M + 3) / 4), dim3(256), 0, st, ce.part, ce.tlogit, targets, loss, lse, M, strips,
+                       ignore_index);
+    return halo_launch_status();
 }
 
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C, float eps,

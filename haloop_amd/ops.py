@@ -111,6 +111,20 @@ def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=Fal
     return out
 
 
+def gemm_split_ce(a_img, b_img, M, N, K, targets, ignore_index=0, bias=None, want_logits=False, want_lse=False):
+    """Per-row cross-entropy of logits = A B^T (+ bias) straight from the split GEMM's epilogue: -> (loss [M], lse [M] or None,
+    logits [M, N] or None).  Without want_logits nothing of size M x N is written."""
+    tg = _i64c(targets.reshape(-1), 'targets')
+    dev = a_img.device
+    ws = torch.empty(lib().halo_gemm_split_ce_workspace_bytes(M, N), device=dev, dtype=torch.uint8)
+    loss = torch.empty(M, device=dev, dtype=torch.float32)
+    lse = torch.empty(M, device=dev, dtype=torch.float32) if want_lse else None
+    logits = torch.empty(M, N, device=dev, dtype=torch.float32) if want_logits else None
+    check(lib().halo_gemm_split_ce(ptr(a_img), ptr(b_img), M, N, K, ptr(logits), N, ptr(bias), ptr(tg), ignore_index, ptr(ws), ptr(loss),
+                                   ptr(lse), _stream()), 'halo_gemm_split_ce')
+    return loss, lse, logits
+
+
 def dropout_fwd(x, drop, stream_id):
     _f32c(x, 'x')
     y = torch.empty_like(x)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 4
+#define HALO_ABI_VERSION 5
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -144,6 +144,16 @@ int halo_cross_entropy_bwd_images(const float *logits, const int64_t *targets, c
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc,
                     const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                     uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+
+/* lm_head + cross-entropy without materialising the logits (ha/attention.py:228-231): the split GEMM
+ * logits[M,N] = A B^T (+ bias[N]) whose epilogue reduces each 64-column strip of a row to (max, sum exp) and picks out the
+ * target's logit; a second small kernel merges the strips into loss[m] = logsumexp(logits[m,:]) - logits[m, targets[m]]
+ * (0 where targets[m] == ignore_index) and, when lse != NULL, the row log-sum-exp for the backward.  logits may be NULL
+ * (scoring: nothing of size M x N is written) or a [M, ldc] buffer that also receives them (training keeps them for
+ * halo_cross_entropy_bwd_images).  workspace: halo_gemm_split_ce_workspace_bytes(M, N).  Split modes only (HALO_EINVAL in f32). */
+size_t halo_gemm_split_ce_workspace_bytes(int M, int N);
+int halo_gemm_split_ce(const void *a_image, const void *b_image, int M, int N, int K, float *logits, int ldc, const float *bias,
+                       const int64_t *targets, long ignore_index, void *workspace, float *loss, float *lse, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conv1d stride-s subsample + relu + dropout.   replaces: ha/rnn.py:22-24

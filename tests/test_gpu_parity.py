@@ -1001,3 +1001,34 @@ def test_layernorm_backward_paths(hal, rows, C, with_res):
     np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), atol=2e-5 * scale, rtol=1e-5)
     dx2, dw2, db2 = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), dres.to(DEV) if with_res else None, has_bias=True)
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)      # fixed summation order
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('M,V,K', [(200, 333, 64), (130, 1000, 96), (70, 64, 128), (257, 50304, 64)])
+def test_fused_lm_head_cross_entropy_matches_the_two_step_path(mode, M, V, K):
+    """halo_gemm_split_ce (statistics in the GEMM epilogue, strips merged afterwards) against the split GEMM followed by the
+    cross-entropy kernel: same logits bit for bit when kept, loss / lse to fp32 rounding; ignored rows give 0."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(M + V)
+        x = torch.randn(M, K, generator=g).cuda(); w = (0.3 * torch.randn(V, K, generator=g)).cuda()
+        bias = (0.1 * torch.randn(V, generator=g)).cuda()
+        tg = torch.randint(0, V, (M,), generator=g).cuda()
+        tg[::5] = 0
+        tg[1] = V - 1                                                        # the last column of the last (ragged) strip
+        xi, wi = ops.split_image(x), ops.split_image(w)
+        for b in (None, bias):
+            ref_logits = ops.gemm_split(xi, wi, M, V, K, bias1=b)
+            ref_loss, ref_lse = ops.cross_entropy_fwd_lse(ref_logits, tg, ignore_index=0)
+            loss, lse, logits = ops.gemm_split_ce(xi, wi, M, V, K, tg, ignore_index=0, bias=b, want_logits=True, want_lse=True)
+            assert torch.equal(logits, ref_logits)
+            np.testing.assert_allclose(loss.cpu().numpy(), ref_loss.cpu().numpy(), atol=3e-6, rtol=1e-6)
+            np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.cpu().numpy(), atol=3e-6, rtol=1e-6)
+            assert float(loss[::5].abs().max()) == 0.0
+            loss2, none_lse, none_logits = ops.gemm_split_ce(xi, wi, M, V, K, tg, ignore_index=0, bias=b)
+            assert none_lse is None and none_logits is None and torch.equal(loss2, loss)
+    finally:
+        _lib.set_math_mode(prev)
