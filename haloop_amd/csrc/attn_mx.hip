@@ -108,116 +108,139 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, 
     return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 }
 
-template <int HD, int PASSES>
+// QB: 16-query blocks per wave (a workgroup covers 64 * QB queries).  With QB = 2 every K fragment and every V^T fragment read
+// from LDS feeds two MFMAs, and a staged tile (and its two barriers) serves twice the queries.
+template <int HD, int PASSES, int QB>
 __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
     using I = Img<HD>;
+    constexpr int WQ = 16 * QB, TQ = 64 * QB;                  // queries per wave / per workgroup
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
-    // causal: the long (late) query tiles are dispatched first so the short ones fill the tail
-    const int qt = a.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
-    const int q0 = qt * 64 + wave * 16;
-    const int qrow = q0 + lr;                                  // this lane's query
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;
+    // causal: a workgroup takes query tile n-1-x (long) and then tile x (short), n + 1 key tiles in all whichever x, so the grid
+    // (ceil(n/2) wide) drains evenly
+    const int n_tiles_x = (a.Tq + TQ - 1) / TQ, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qt = a.causal ? (pass == 0 ? n_tiles_x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || qt == n_tiles_x - 1 - (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
+        const int q0 = qt * TQ + wave * WQ;
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;
 
-    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS];                       // B[k = 32ks + 8lq + e][col = query lr], pre-scaled
-    {
-        const float *qp = qb + (long)min(qrow, Tq - 1) * a.q_rs;
-#pragma unroll
-        for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
-    }
-    f32x4 o[HD / 16];                                          // O^T[dim = 16m + 4lq + r][query lr]
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow = -INFINITY, lsum = 0.f;                        // lsum: this lane's share (its 16 keys per tile) of the normaliser
+        int qrow[QB];                                              // this lane's query in each block
+        bf16x8 qh[QB][I::KSTEPS], ql[QB][I::KSTEPS];               // B[k = 32ks + 8lq + e][col = query lr], pre-scaled
+        f32x4 o[QB][HD / 16];                                      // O^T[dim = 16m + 4lq + r][query lr]
+        float mrow[QB], lsum[QB];                                  // lsum: this lane's share (its 16 keys per tile) of the normaliser
+    #pragma unroll
+        for (int g = 0; g < QB; ++g) {
+            qrow[g] = q0 + 16 * g + lr;
+            const float *qp = qb + (long)min(qrow[g], Tq - 1) * a.q_rs;
+    #pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale, qh[g][ks], ql[g][ks]);
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m) o[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mrow[g] = -INFINITY; lsum[g] = 0.f;
+        }
 
-    int n_ktiles = (klim + 63) / 64;
-    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
-    f32x4 kreg[I::UNITS], vreg[I::UNITS];
-    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-        __syncthreads();
-        stage_tile<HD, PASSES>(Kimg, kreg);
-        stage_tile<HD, PASSES>(Vimg, vreg);
-        __syncthreads();
-        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-        f32x4 sacc[4];                                         // S^T[key = 64kt + 16n + 4lq + r][query lr]
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
-                const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
-                sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
+        int n_ktiles = (klim + 63) / 64;
+        if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * TQ + TQ - 1, Tq - 1) + coff) / 64 + 1));
+        f32x4 kreg[I::UNITS], vreg[I::UNITS];
+        if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+        for (int kt = 0; kt < n_ktiles; ++kt) {
+            __syncthreads();
+            stage_tile<HD, PASSES>(Kimg, kreg);
+            stage_tile<HD, PASSES>(Vimg, vreg);
+            __syncthreads();
+            if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+            f32x4 sacc[QB][4];                                     // S^T[key = 64kt + 16n + 4lq + r][query lr]
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+    #pragma unroll
+                for (int g = 0; g < QB; ++g) sacc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                    const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+    #pragma unroll
+                    for (int g = 0; g < QB; ++g) sacc[g][n] = mma<PASSES>(sacc[g][n], kh, kl, qh[g][ks], ql[g][ks]);
+                }
+            }
+            bf16x8 ph[QB][2], pl[QB][2];                           // probabilities as the B operand of the two 32-slot P.V steps
+    #pragma unroll
+            for (int g = 0; g < QB; ++g) {
+                // masks only where the tile can need them (wave-uniform): the key-length edge and the causal diagonal
+                if (kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + 16 * g + coff)) {
+                    const int kmax = a.causal ? min(klim - 1, qrow[g] + coff) : klim - 1;    // last visible key of this query
+    #pragma unroll
+                    for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kt * 64 + 16 * n + 4 * lq + r > kmax) sacc[g][n][r] = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(sacc[g][0][0], sacc[g][0][1]), fmaxf(sacc[g][0][2], sacc[g][0][3]));
+    #pragma unroll
+                for (int n = 1; n < 4; ++n) mx = fmaxf(mx, fmaxf(fmaxf(sacc[g][n][0], sacc[g][n][1]), fmaxf(sacc[g][n][2], sacc[g][n][3])));
+                mx = rows4_max(mx);
+                const float mnew = fmaxf(mrow[g], mx);
+                const float msafe = mnew == -INFINITY ? 0.f : mnew;
+                const float alpha = __expf(mrow[g] - msafe);       // exp(-inf) = 0 on the first tile
+                mrow[g] = mnew;
+                float ps = 0.f;
+    #pragma unroll
+                for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sacc[g][n][r] = __expf(sacc[g][n][r] - msafe);
+                        ps += sacc[g][n][r];
+                    }
+                lsum[g] = lsum[g] * alpha + ps;                    // the normaliser keeps the undropped sum
+                if (a.use_drop) {
+                    const uint64_t base = attn_drop_tile_base(b, a.heads, h, Tq, min(qrow[g], Tq - 1), (Tk + 63) / 64, kt);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 dm = dropout_mult4(a.drop, base + 4 * (4 * lq + r));
+    #pragma unroll
+                        for (int n = 0; n < 4; ++n) sacc[g][n][r] *= dm[n];
+                    }
+                }
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) o[g][m][r] *= alpha;
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const float pf[8] = {sacc[g][2 * kk][0], sacc[g][2 * kk][1], sacc[g][2 * kk][2], sacc[g][2 * kk][3],
+                                         sacc[g][2 * kk + 1][0], sacc[g][2 * kk + 1][1], sacc[g][2 * kk + 1][2], sacc[g][2 * kk + 1][3]};
+                    split8(pf, ph[g][kk], pl[g][kk]);
+                }
+            }
+            // O^T += V^T P^T : two 32-slot steps; V^T fragments come from the row-major image through the transpose read
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m) {
+                    const bf16x8 vh = tr_frag2<HD>(Vimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 vl = PASSES == 3 ? tr_frag2<HD>(Vimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : vh;
+    #pragma unroll
+                    for (int g = 0; g < QB; ++g) o[g][m] = mma<PASSES>(o[g][m], vh, vl, ph[g][kk], pl[g][kk]);
+                }
+        }
+    #pragma unroll
+        for (int g = 0; g < QB; ++g) {
+            const float lrow = rows4_sum(lsum[g]);
+            if (qrow[g] < Tq) {
+                const float inv = 1.0f / lrow;
+                float *yp = a.y + (long)b * a.y_bs + (long)qrow[g] * a.y_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m)
+                    *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[g][m][0] * inv, o[g][m][1] * inv, o[g][m][2] * inv, o[g][m][3] * inv};
+                if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mrow[g] + logf(lrow);
             }
         }
-        // masks only where the tile can need them (wave-uniform): the key-length edge and the causal diagonal
-        if (kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff)) {
-            const int kmax = a.causal ? min(klim - 1, qrow + coff) : klim - 1;    // last visible key of this query
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 64 + 16 * n + 4 * lq + r > kmax) sacc[n][r] = -INFINITY;
-        }
-        float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
-#pragma unroll
-        for (int n = 1; n < 4; ++n) mx = fmaxf(mx, fmaxf(fmaxf(sacc[n][0], sacc[n][1]), fmaxf(sacc[n][2], sacc[n][3])));
-        mx = rows4_max(mx);
-        const float mnew = fmaxf(mrow, mx);
-        const float msafe = mnew == -INFINITY ? 0.f : mnew;
-        const float alpha = __expf(mrow - msafe);              // exp(-inf) = 0 on the first tile
-        mrow = mnew;
-        float ps = 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sacc[n][r] = __expf(sacc[n][r] - msafe);
-                ps += sacc[n][r];
-            }
-        lsum = lsum * alpha + ps;                              // the normaliser keeps the undropped sum
-        if (a.use_drop) {
-            const uint64_t base = attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 dm = dropout_mult4(a.drop, base + 4 * (4 * lq + r));
-#pragma unroll
-                for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[m][r] *= alpha;
-        // O^T += V^T P^T : two 32-slot steps; V^T fragments come from the row-major image through the transpose read
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const float pf[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
-                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
-            bf16x8 ph, pl;
-            split8(pf, ph, pl);
-#pragma unroll
-            for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 vh = tr_frag2<HD>(Vimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                const bf16x8 vl = PASSES == 3 ? tr_frag2<HD>(Vimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : vh;
-                o[m] = mma<PASSES>(o[m], vh, vl, ph, pl);
-            }
-        }
-    }
-    const float lrow = rows4_sum(lsum);
-    if (qrow < Tq) {
-        const float inv = 1.0f / lrow;
-        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD + 4 * lq;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[m][0] * inv, o[m][1] * inv, o[m][2] * inv, o[m][3] * inv};
-        if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow] = mrow + logf(lrow);
     }
 }
 
@@ -229,87 +252,92 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a)
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
-    const int qt = a.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x, h = blockIdx.y, b = blockIdx.z;   // causal: long tiles first
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
-    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
-    const int q0 = qt * 64 + wave * 16;
-    const int qrow = q0 + lr, qsafe = min(qrow, Tq - 1);       // this lane's query
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;
-    bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];      // B[k = dims][col = query lr]
-#pragma unroll
-    for (int ks = 0; ks < I::KSTEPS; ++ks) {
-        load_split8(qb + (long)qsafe * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
-        load_split8(dyb + (long)qsafe * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
-    }
-    const long stat = ((long)b * a.heads + h) * Tq + qsafe;
-    const float lse = a.lse[stat], delta = a.delta[stat];
-    f32x4 dq[HD / 16];                                         // dQ^T[dim = 16m + 4lq + r][query lr]
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int n_ktiles = (klim + 63) / 64;
-    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
-    f32x4 kreg[I::UNITS], vreg[I::UNITS];
-    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-        __syncthreads();
-        stage_tile<HD, PASSES>(Kimg, kreg);
-        stage_tile<HD, PASSES>(Vimg, vreg);
-        __syncthreads();
-        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-        f32x4 sacc[4], pacc[4];                                // S^T, dP^T [key = 64kt + 16n + 4lq + r][query lr]
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
-                const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
-                const bf16x8 vh = row_frag<HD>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
-                const bf16x8 vl = PASSES == 3 ? row_frag<HD>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
-                sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
-                pacc[n] = mma<PASSES>(pacc[n], vh, vl, doh[ks], dol[ks]);
-            }
+    // causal: tile n-1-x (long) then tile x (short): n + 1 key tiles per workgroup, whichever x (see the dK/dV sweep)
+    const int n_tiles_x = (a.Tq + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qt = a.causal ? (pass == 0 ? n_tiles_x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || qt == n_tiles_x - 1 - (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+        const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+        const int q0 = qt * 64 + wave * 16;
+        const int qrow = q0 + lr, qsafe = min(qrow, Tq - 1);       // this lane's query
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;
+        bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];      // B[k = dims][col = query lr]
+    #pragma unroll
+        for (int ks = 0; ks < I::KSTEPS; ++ks) {
+            load_split8(qb + (long)qsafe * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
+            load_split8(dyb + (long)qsafe * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
         }
-        // dS^T = P^T (dP^T . dropout - delta), in place in sacc
-        const bool edge = kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff);      // wave-uniform
-        const int kmax = a.causal ? min(klim - 1, qrow + coff) : klim - 1;                     // last visible key of this query
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (a.use_drop)
-                dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe, (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
-#pragma unroll
+        const long stat = ((long)b * a.heads + h) * Tq + qsafe;
+        const float lse = a.lse[stat], delta = a.delta[stat];
+        f32x4 dq[HD / 16];                                         // dQ^T[dim = 16m + 4lq + r][query lr]
+    #pragma unroll
+        for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int n_ktiles = (klim + 63) / 64;
+        if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+        f32x4 kreg[I::UNITS], vreg[I::UNITS];
+        if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+        for (int kt = 0; kt < n_ktiles; ++kt) {
+            __syncthreads();
+            stage_tile<HD, PASSES>(Kimg, kreg);
+            stage_tile<HD, PASSES>(Vimg, vreg);
+            __syncthreads();
+            if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+            f32x4 sacc[4], pacc[4];                                // S^T, dP^T [key = 64kt + 16n + 4lq + r][query lr]
+    #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float p = __expf(sacc[n][r] - lse);
-                if (edge && kt * 64 + 16 * n + 4 * lq + r > kmax) p = 0.f;
-                sacc[n][r] = p * (pacc[n][r] * dm[n] - delta);
+                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                    const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                    const bf16x8 vh = row_frag<HD>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 vl = PASSES == 3 ? row_frag<HD>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
+                    sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
+                    pacc[n] = mma<PASSES>(pacc[n], vh, vl, doh[ks], dol[ks]);
+                }
+            }
+            // dS^T = P^T (dP^T . dropout - delta), in place in sacc
+            const bool edge = kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff);      // wave-uniform
+            const int kmax = a.causal ? min(klim - 1, qrow + coff) : klim - 1;                     // last visible key of this query
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (a.use_drop)
+                    dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe, (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
+    #pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    float p = __expf(sacc[n][r] - lse);
+                    if (edge && kt * 64 + 16 * n + 4 * lq + r > kmax) p = 0.f;
+                    sacc[n][r] = p * (pacc[n][r] * dm[n] - delta);
+                }
+            }
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
+                                     sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
+                bf16x8 dh, dl;
+                split8(df, dh, dl);
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m) {
+                    const bf16x8 kh = tr_frag2<HD>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 kl = PASSES == 3 ? tr_frag2<HD>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
+                    dq[m] = mma<PASSES>(dq[m], kh, kl, dh, dl);
+                }
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
-                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
-            bf16x8 dh, dl;
-            split8(df, dh, dl);
-#pragma unroll
-            for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 kh = tr_frag2<HD>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                const bf16x8 kl = PASSES == 3 ? tr_frag2<HD>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
-                dq[m] = mma<PASSES>(dq[m], kh, kl, dh, dl);
-            }
+        if (qrow < Tq) {
+            float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+                *reinterpret_cast<f32x4 *>(dp + 16 * m) = f32x4{dq[m][0] * a.scale, dq[m][1] * a.scale, dq[m][2] * a.scale, dq[m][3] * a.scale};
         }
-    }
-    if (qrow < Tq) {
-        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD + 4 * lq;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m)
-            *reinterpret_cast<f32x4 *>(dp + 16 * m) = f32x4{dq[m][0] * a.scale, dq[m][1] * a.scale, dq[m][2] * a.scale, dq[m][3] * a.scale};
     }
 }
 
@@ -322,119 +350,135 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
     __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // dO tile
     __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;       // causal: key tile 0 sees every query tile, so the long ones already go first
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
-    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
-    const int k0 = kt * 64 + wave * 16;
-    const int key = k0 + lr;                                    // this lane's key
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;
-    bf16x8 kh[I::KSTEPS], kl[I::KSTEPS], vh[I::KSTEPS], vl[I::KSTEPS];      // B[k = dims][col = key lr]
-    {
-        const int krow = min(key, Tk - 1);
-#pragma unroll
-        for (int ks = 0; ks < I::KSTEPS; ++ks) {
-            load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale, kh[ks], kl[ks]);
-            load_split8(vb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, 1.0f, vh[ks], vl[ks]);
-        }
-    }
-    f32x4 dk[HD / 16], dv[HD / 16];                            // dK^T, dV^T [dim = 16m + 4lq + r][key lr]
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int n_qtiles = (Tq + 63) / 64;
-    const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
-    const long stat0 = ((long)b * a.heads + h) * Tq;
-    f32x4 qreg[I::UNITS], oreg[I::UNITS];
-    if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
-    for (int qt = qt0; qt < n_qtiles; ++qt) {
-        __syncthreads();
-        stage_tile<HD, PASSES>(Qimg, qreg);
-        stage_tile<HD, PASSES>(Oimg, oreg);
-        if (threadIdx.x < 64) {
-            const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
-            lse_s[threadIdx.x] = a.lse[stat0 + qrow];
-            del_s[threadIdx.x] = a.delta[stat0 + qrow];
-        }
-        __syncthreads();
-        if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
-        f32x4 sacc[4], pacc[4];                                // S, dP [query = 64qt + 16n + 4lq + r][key lr]
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    // Causal work per key tile falls from n (tile 0 sees every query tile) to 1: a workgroup takes tile x and then tile n-1-x, so every
+    // workgroup walks n + 1 query tiles and the grid (ceil(n/2) wide) drains evenly instead of leaving the chip to a few long tails.
+    const int n_tiles_x = (a.Tk + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kt = a.causal ? (pass == 0 ? (int)blockIdx.x : n_tiles_x - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || kt == (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+        const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+        const int k0 = kt * 64 + wave * 16;
+        const int key = k0 + lr;                                    // this lane's key
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;
+        bf16x8 kh[I::KSTEPS], kl[I::KSTEPS], vh[I::KSTEPS], vl[I::KSTEPS];      // B[k = dims][col = key lr]
+        {
+            const int krow = min(key, Tk - 1);
+    #pragma unroll
             for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                const bf16x8 qfh = row_frag<HD>(Qimg, 16 * n + lr, 32 * ks + 8 * lq);
-                const bf16x8 qfl = PASSES == 3 ? row_frag<HD>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
-                const bf16x8 ofh = row_frag<HD>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
-                const bf16x8 ofl = PASSES == 3 ? row_frag<HD>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
-                sacc[n] = mma<PASSES>(sacc[n], qfh, qfl, kh[ks], kl[ks]);
-                pacc[n] = mma<PASSES>(pacc[n], ofh, ofl, vh[ks], vl[ks]);
+                load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale, kh[ks], kl[ks]);
+                load_split8(vb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, 1.0f, vh[ks], vl[ks]);
             }
         }
-        // P (dropped) stays in pacc's place, dS in sacc's: both in place
-        const bool edge = k0 + 15 >= klim || qt * 64 + 63 >= Tq || (a.causal && k0 + 15 > qt * 64 + coff);   // wave-uniform
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[16 * n + 4 * lq]);
-            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&del_s[16 * n + 4 * lq]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = qt * 64 + 16 * n + 4 * lq + r;
-                float p = __expf(sacc[n][r] - l4[r]);
-                if (edge && (key >= klim || qrow >= Tq || (a.causal && key > qrow + coff))) p = 0.f;
-                float dm = 1.0f;
-                if (a.use_drop)
-                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + wave);
-                sacc[n][r] = p * (dm * pacc[n][r] - d4[r]);
-                pacc[n][r] = p * dm;
+        f32x4 dk[HD / 16], dv[HD / 16];                            // dK^T, dV^T [dim = 16m + 4lq + r][key lr]
+    #pragma unroll
+        for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int n_qtiles = (Tq + 63) / 64;
+        const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
+        const long stat0 = ((long)b * a.heads + h) * Tq;
+        f32x4 qreg[I::UNITS], oreg[I::UNITS];
+        if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
+        for (int qt = qt0; qt < n_qtiles; ++qt) {
+            __syncthreads();
+            stage_tile<HD, PASSES>(Qimg, qreg);
+            stage_tile<HD, PASSES>(Oimg, oreg);
+            if (threadIdx.x < 64) {
+                const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
+                lse_s[threadIdx.x] = a.lse[stat0 + qrow];
+                del_s[threadIdx.x] = a.delta[stat0 + qrow];
+            }
+            __syncthreads();
+            if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
+            f32x4 sacc[4], pacc[4];                                // S, dP [query = 64qt + 16n + 4lq + r][key lr]
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                    const bf16x8 qfh = row_frag<HD>(Qimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 qfl = PASSES == 3 ? row_frag<HD>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
+                    const bf16x8 ofh = row_frag<HD>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 ofl = PASSES == 3 ? row_frag<HD>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
+                    sacc[n] = mma<PASSES>(sacc[n], qfh, qfl, kh[ks], kl[ks]);
+                    pacc[n] = mma<PASSES>(pacc[n], ofh, ofl, vh[ks], vl[ks]);
+                }
+            }
+            // P (dropped) stays in pacc's place, dS in sacc's: both in place
+            const bool edge = k0 + 15 >= klim || qt * 64 + 63 >= Tq || (a.causal && k0 + 15 > qt * 64 + coff);   // wave-uniform
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[16 * n + 4 * lq]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&del_s[16 * n + 4 * lq]);
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = qt * 64 + 16 * n + 4 * lq + r;
+                    float p = __expf(sacc[n][r] - l4[r]);
+                    if (edge && (key >= klim || qrow >= Tq || (a.causal && key > qrow + coff))) p = 0.f;
+                    float dm = 1.0f;
+                    if (a.use_drop)
+                        dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + wave);
+                    sacc[n][r] = p * (dm * pacc[n][r] - d4[r]);
+                    pacc[n][r] = p * dm;
+                }
+            }
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float pf[8] = {pacc[2 * kk][0], pacc[2 * kk][1], pacc[2 * kk][2], pacc[2 * kk][3],
+                                     pacc[2 * kk + 1][0], pacc[2 * kk + 1][1], pacc[2 * kk + 1][2], pacc[2 * kk + 1][3]};
+                const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
+                                     sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
+                bf16x8 ph, pl, dh, dl;
+                split8(pf, ph, pl);
+                split8(df, dh, dl);
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m) {
+                    const bf16x8 oth = tr_frag2<HD>(Oimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 otl = PASSES == 3 ? tr_frag2<HD>(Oimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : oth;
+                    const bf16x8 qth = tr_frag2<HD>(Qimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 qtl = PASSES == 3 ? tr_frag2<HD>(Qimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : qth;
+                    dv[m] = mma<PASSES>(dv[m], oth, otl, ph, pl);
+                    dk[m] = mma<PASSES>(dk[m], qth, qtl, dh, dl);
+                }
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const float pf[8] = {pacc[2 * kk][0], pacc[2 * kk][1], pacc[2 * kk][2], pacc[2 * kk][3],
-                                 pacc[2 * kk + 1][0], pacc[2 * kk + 1][1], pacc[2 * kk + 1][2], pacc[2 * kk + 1][3]};
-            const float df[8] = {sacc[2 * kk][0], sacc[2 * kk][1], sacc[2 * kk][2], sacc[2 * kk][3],
-                                 sacc[2 * kk + 1][0], sacc[2 * kk + 1][1], sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]};
-            bf16x8 ph, pl, dh, dl;
-            split8(pf, ph, pl);
-            split8(df, dh, dl);
-#pragma unroll
+        if (key < Tk) {
+            float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
+            float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
             for (int m = 0; m < HD / 16; ++m) {
-                const bf16x8 oth = tr_frag2<HD>(Oimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                const bf16x8 otl = PASSES == 3 ? tr_frag2<HD>(Oimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : oth;
-                const bf16x8 qth = tr_frag2<HD>(Qimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                const bf16x8 qtl = PASSES == 3 ? tr_frag2<HD>(Qimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : qth;
-                dv[m] = mma<PASSES>(dv[m], oth, otl, ph, pl);
-                dk[m] = mma<PASSES>(dk[m], qth, qtl, dh, dl);
+                *reinterpret_cast<f32x4 *>(kp + 16 * m) = f32x4{dk[m][0] * a.scale, dk[m][1] * a.scale, dk[m][2] * a.scale, dk[m][3] * a.scale};
+                *reinterpret_cast<f32x4 *>(vp + 16 * m) = dv[m];
             }
-        }
-    }
-    if (key < Tk) {
-        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
-        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) {
-            *reinterpret_cast<f32x4 *>(kp + 16 * m) = f32x4{dk[m][0] * a.scale, dk[m][1] * a.scale, dk[m][2] * a.scale, dk[m][3] * a.scale};
-            *reinterpret_cast<f32x4 *>(vp + 16 * m) = dv[m];
         }
     }
 }
 
 template <int HD, int PASSES>
 int launch_fwd(const AttnArgs &a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES>), dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    // 128-query workgroups (two 16-query blocks per wave) for the single-pass kernel once they still fill the chip: measured at
+    // B=8, T=1024, 12 heads (causal, tiles paired): 61.5 vs 77.6 us; the three-pass kernel is faster on 64 (89.7 vs 116.2 us: its
+    // 214 registers leave two waves per SIMD).  HALO_ATTN_QB=1|2 forces either.
+    static int qb2 = -1;
+    if (qb2 < 0) { const char *e = getenv("HALO_ATTN_QB"); qb2 = e ? atoi(e) : 0; }
+    const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
+    const bool two = qb2 == 2 || (qb2 == 0 && PASSES == 1 && a.Tq >= 256 && wg128 >= 512);
+    const int n2 = (a.Tq + 127) / 128, n1 = (a.Tq + 63) / 64;
+    if (two) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2>), dim3(a.causal ? (n2 + 1) / 2 : n2, a.heads, N), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 1>), dim3(a.causal ? (n1 + 1) / 2 : n1, a.heads, N), dim3(256), 0, st, a);
     return halo_launch_status();
 }
 
 template <int HD, int PASSES>
 int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES>), dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES>), dim3((a.Tk + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    const int nq = (a.Tq + 63) / 64, nk = (a.Tk + 63) / 64;
+    hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES>), dim3(a.causal ? (nq + 1) / 2 : nq, a.heads, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES>), dim3(a.causal ? (nk + 1) / 2 : nk, a.heads, N), dim3(256), 0, st, a);
     return halo_launch_status();
 }
 
