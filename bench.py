@@ -214,7 +214,7 @@ def main():
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
                        'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math},
-            'final_loss': round(loss, 5),
+            'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
             'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel (H=1024, B=64), 42 launches per step; the backward twin runs within 10%',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
@@ -242,7 +242,7 @@ def main():
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             out['bf16_mode'] = {'value': round(B_PER_GPU * n2 / dt2, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt2 / n2, 4),
-                                'dtype': 'bf16', 'final_loss': round(tr2.loss.item(), 5),
+                                'dtype': 'bf16', 'final_loss': round(tr2.loss.item(), 5), 'steps_trained': args.warmup + n2,
                                 'note': 'same step, operands of the dense products rounded to bf16 (--math bf16)'}
             _lib.set_math_mode(args.math)
         if world == 1 and not args.no_cpu_baseline:
