@@ -9,6 +9,22 @@ from . import _lib, ops
 SMALL_M = int(__import__('os').environ.get('HALO_SMALL_M', '64'))
 
 
+_PAIRS = [False]
+
+
+class training_images:
+    """Inside this context a weight's forward image is built together with its transposed image (one read, one launch): the
+    training forward wraps itself in it because the backward will ask for the transposed one."""
+
+    def __enter__(self):
+        self.prev = _PAIRS[0]
+        _PAIRS[0] = True
+
+    def __exit__(self, *exc):
+        _PAIRS[0] = self.prev
+        return False
+
+
 class WeightImages:
     """Per-module cache of GEMM-ready weight operands, rebuilt only when a weight changes."""
 
@@ -31,15 +47,25 @@ class WeightImages:
         return self._lookup('dense', weights,
                             lambda: torch.cat([w.detach().reshape(w.shape[0], -1) for w in weights], dim=0).contiguous())
 
+    def _pair(self, weights):
+        """(image of W, image of W^T) from one read of the (concatenated) weight: a Linear's forward reads the first, the input
+        gradient of its backward the second, and both go stale together when the optimizer steps."""
+        # bf16 mode writes only the hi part of an image: keep the images of different modes apart
+        return self._lookup('pair:' + _lib.get_math_mode(), weights, lambda: ops.image_pair(self.dense(weights).contiguous()))
+
     def split(self, weights):
         """The split/tiled image of the (concatenated) weight."""
-        # bf16 mode writes only the hi part of an image: keep the images of different modes apart
+        if _PAIRS[0] or self._has('pair:' + _lib.get_math_mode(), weights):
+            return self._pair(weights)[0]
         return self._lookup('split:' + _lib.get_math_mode(), weights, lambda: ops.split_image(self.dense(weights).contiguous()))
 
     def split_t(self, weights):
         """The image of W^T (logical [in, sum out]) of the (concatenated) weight: the B operand of dx = dy W."""
-        return self._lookup('split_t:' + _lib.get_math_mode(), weights,
-                            lambda: ops.split_image(self.dense(weights).contiguous(), transposed=True))
+        return self._pair(weights)[1]
+
+    def _has(self, kind, weights):
+        hit = self._cache.get((kind,) + tuple(id(w) for w in weights))
+        return hit is not None and hit[0] == tuple((w._version, w.data_ptr()) for w in weights)
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None,

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import (SMALL_M, DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx,
+from ._linear import (SMALL_M, DropSites, training_images, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx,
                       ln_linear, use_split)
 from .rnn import DropoutStream
 
@@ -118,7 +118,8 @@ class _GPTLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, input_ids, target_ids, *params):
-        per_tok, saved = model._forward_train(input_ids, target_ids)
+        with training_images():
+            per_tok, saved = model._forward_train(input_ids, target_ids)
         ctx.model, ctx.saved, ctx.params = model, saved, params
         return per_tok
 

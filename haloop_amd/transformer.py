@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import (NO_SITES, DropSites, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
+from ._linear import (NO_SITES, DropSites, WeightImages, training_images, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
                       normed_image, use_split)
 from .attention import LayerNorm
 from .conv import ConvEncoder
@@ -93,7 +93,8 @@ class _GradSink:
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
-        out, saved = model._forward_train(x)
+        with training_images():
+            out, saved = model._forward_train(x)
         ctx.model, ctx.saved, ctx.params = model, saved, params
         return out
 
@@ -108,7 +109,8 @@ class _EncoderFn(torch.autograd.Function):
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, features, prompt, tg, mlen, *params):
-        loss, saved = model._forward_train(features, prompt, tg, mlen)
+        with training_images():
+            loss, saved = model._forward_train(features, prompt, tg, mlen)
         ctx.model, ctx.saved, ctx.params = model, saved, params
         return loss
 
