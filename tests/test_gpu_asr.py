@@ -396,3 +396,34 @@ def test_asr_shape_robustness_against_oracle(hal, math_mode, hd, heads, el, dl, 
     with torch.no_grad():                                      # greedy decode runs at these sizes and stops within the step budget
         outs, olen, _, lps, _ = dec.decode(feats.detach(), flen, tl.to(DEV))
     assert olen.shape == (N,) and int(olen.max()) <= int(tl.max()) + 1 and torch.isfinite(lps).all()
+
+
+@pytest.mark.parametrize('T,causal,ragged', [(512, True, False), (520, True, False), (520, False, True), (640, True, True)])
+def test_attention_two_query_blocks_per_wave_against_exact_kernel(hal, T, causal, ragged):
+    """Shapes large enough that the single-pass forward runs 128-query workgroups (two 16-query blocks per wave, causal tiles
+    paired long + short): against the exact-f32 kernels of the same library at the bf16 tolerance, forward and backward."""
+    from haloop_amd import _lib
+    ops = hal['ops']
+    N, heads, hd = 4, 32, 64
+    C = heads * hd
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(N * T, 3 * C, generator=g).to(DEV)
+    dy = torch.randn(N * T, C, generator=g).to(DEV)
+    lens = torch.tensor([T - (37 * n) % T for n in range(N)], dtype=torch.int32).to(DEV) if ragged else None
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    prev = _lib.get_math_mode()
+    out = {}
+    try:
+        for mode in ('f32', 'bf16'):
+            _lib.set_math_mode(mode)
+            y, lse, _ = ops.attention_fwd(q, k, v, N, heads, hd, T, T, causal=causal, key_lengths=lens, want_lse=True)
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(q, k, v, y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], N, heads, hd, T, T, causal=causal,
+                              key_lengths=lens)
+            out[mode] = (y.cpu().numpy(), lse.cpu().numpy(), dqkv.cpu().numpy())
+    finally:
+        _lib.set_math_mode(prev)
+    np.testing.assert_allclose(out['bf16'][0], out['f32'][0], atol=3e-2, rtol=1e-2)
+    np.testing.assert_allclose(out['bf16'][1], out['f32'][1], atol=5e-2, rtol=1e-3)
+    scale = float(np.abs(out['f32'][2]).max())
+    np.testing.assert_allclose(out['bf16'][2], out['f32'][2], atol=2e-2 * scale, rtol=0)
