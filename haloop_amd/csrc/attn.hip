@@ -27,159 +27,164 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Vs[64 * VS_STRIDE];
     __shared__ float Ps[4][16 * PS_STRIDE];
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
-    const int q0 = qt * 64 + wave * 16;                   // this wave's first query row
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;                             // causal: key <= row + coff
+    // causal: query tile n-1-x (long) and then tile x (short): n + 1 key tiles per workgroup whichever x
+    const int n_tiles_x = (a.Tq + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qt = a.causal ? (pass == 0 ? n_tiles_x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || qt == n_tiles_x - 1 - (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * a.kv_hs;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * a.kv_hs;
+        const int q0 = qt * 64 + wave * 16;                   // this wave's first query row
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;                             // causal: key <= row + coff
 
-    // Q fragments, pre-scaled: A[row = lr][k = 4s + lq]
-    float qa[HD / 4];
-    {
-        const int qrow = min(q0 + lr, Tq - 1);
-        const float *qp = qb + (long)qrow * a.q_rs;
-#pragma unroll
-        for (int s = 0; s < HD / 4; ++s) qa[s] = qp[4 * s + lq] * a.scale;
-    }
-    f32x4 o[HD / 16];
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4], erow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; erow[r] = 0.f; }
-
-    int n_ktiles = (klim + 63) / 64;
-    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
-    // K/V tiles are fetched one tile ahead into registers (issue early, write to LDS late), so the global
-    // latency of tile kt+1 hides under the MFMAs of tile kt
-    constexpr int UNITS = 64 * (HD / 4) / 256;            // float4 units of K (and of V) per thread and tile
-    f32x4 kreg[UNITS], vreg[UNITS];
-    auto fetch = [&](int kt, bool with_v) {
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = threadIdx.x + 256 * i;
-            const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
-            const int krow = min(kt * 64 + key, Tk - 1);
-            kreg[i] = *reinterpret_cast<const f32x4 *>(kb + (long)krow * a.kv_rs + d4);
-            if (with_v) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long)krow * a.kv_rs + d4);
+        // Q fragments, pre-scaled: A[row = lr][k = 4s + lq]
+        float qa[HD / 4];
+        {
+            const int qrow = min(q0 + lr, Tq - 1);
+            const float *qp = qb + (long)qrow * a.q_rs;
+    #pragma unroll
+            for (int s = 0; s < HD / 4; ++s) qa[s] = qp[4 * s + lq] * a.scale;
         }
-    };
-    constexpr int N_PASS = ENT ? 2 : 1;
-#pragma unroll
-    for (int pass = 0; pass < N_PASS; ++pass) {
-        if (n_ktiles > 0) fetch(0, pass == 0);
-        for (int kt = 0; kt < n_ktiles; ++kt) {
-            __syncthreads();                              // previous tile fully consumed
-#pragma unroll
+        f32x4 o[HD / 16];
+    #pragma unroll
+        for (int m = 0; m < HD / 16; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrow[4], lrow[4], erow[4];
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; erow[r] = 0.f; }
+
+        int n_ktiles = (klim + 63) / 64;
+        if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+        // K/V tiles are fetched one tile ahead into registers (issue early, write to LDS late), so the global
+        // latency of tile kt+1 hides under the MFMAs of tile kt
+        constexpr int UNITS = 64 * (HD / 4) / 256;            // float4 units of K (and of V) per thread and tile
+        f32x4 kreg[UNITS], vreg[UNITS];
+        auto fetch = [&](int kt, bool with_v) {
+    #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
                 const int u = threadIdx.x + 256 * i;
                 const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4]) = f32x2{kreg[i][0], kreg[i][1]};
-                *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4 + 2]) = f32x2{kreg[i][2], kreg[i][3]};
-                if (pass == 0) *reinterpret_cast<f32x4 *>(&Vs[key * VS_STRIDE + d4]) = vreg[i];
+                const int krow = min(kt * 64 + key, Tk - 1);
+                kreg[i] = *reinterpret_cast<const f32x4 *>(kb + (long)krow * a.kv_rs + d4);
+                if (with_v) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long)krow * a.kv_rs + d4);
             }
-            __syncthreads();
-            if (kt + 1 < n_ktiles) fetch(kt + 1, pass == 0);
-            // S = Q K^T : 4 key sub-tiles of 16
-            f32x4 sacc[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < HD / 4; ++s)
-                    sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * KS_STRIDE + 4 * s + lq], sacc[n], 0, 0, 0);
-            }
-            if (pass == 1) {
-                // entropy sweep: att = exp(s - m) / l with the final m, l; element (row = 4*lq + r, key = kt*64 + 16n + lr)
-#pragma unroll
+        };
+        constexpr int N_PASS = ENT ? 2 : 1;
+    #pragma unroll
+        for (int pass = 0; pass < N_PASS; ++pass) {
+            if (n_ktiles > 0) fetch(0, pass == 0);
+            for (int kt = 0; kt < n_ktiles; ++kt) {
+                __syncthreads();                              // previous tile fully consumed
+    #pragma unroll
+                for (int i = 0; i < UNITS; ++i) {
+                    const int u = threadIdx.x + 256 * i;
+                    const int key = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4]) = f32x2{kreg[i][0], kreg[i][1]};
+                    *reinterpret_cast<f32x2 *>(&Ks[key * KS_STRIDE + d4 + 2]) = f32x2{kreg[i][2], kreg[i][3]};
+                    if (pass == 0) *reinterpret_cast<f32x4 *>(&Vs[key * VS_STRIDE + d4]) = vreg[i];
+                }
+                __syncthreads();
+                if (kt + 1 < n_ktiles) fetch(kt + 1, pass == 0);
+                // S = Q K^T : 4 key sub-tiles of 16
+                f32x4 sacc[4];
+    #pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int s = 0; s < HD / 4; ++s)
+                        sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * KS_STRIDE + 4 * s + lq], sacc[n], 0, 0, 0);
+                }
+                if (pass == 1) {
+                    // entropy sweep: att = exp(s - m) / l with the final m, l; element (row = 4*lq + r, key = kt*64 + 16n + lr)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qrow = q0 + 4 * lq + r;
+                        const float inv = 1.0f / lrow[r];
+    #pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const int key = kt * 64 + 16 * n + lr;
+                            const bool hidden = key >= klim || (a.causal && key > qrow + coff);
+                            const float att = hidden ? 0.f : expf(sacc[n][r] - mrow[r]) * inv;
+                            erow[r] -= att * logf(att + 1e-8f);
+                        }
+                    }
+                    continue;
+                }
+                // mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
+                float alpha[4];
+    #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qrow = q0 + 4 * lq + r;
-                    const float inv = 1.0f / lrow[r];
-#pragma unroll
+                    float mx = -INFINITY;
+    #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         const int key = kt * 64 + 16 * n + lr;
-                        const bool hidden = key >= klim || (a.causal && key > qrow + coff);
-                        const float att = hidden ? 0.f : expf(sacc[n][r] - mrow[r]) * inv;
-                        erow[r] -= att * logf(att + 1e-8f);
+                        if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
+                        mx = fmaxf(mx, sacc[n][r]);
+                    }
+                    mx = row16_max(mx);
+                    const float mnew = fmaxf(mrow[r], mx);
+                    const float msafe = mnew == -INFINITY ? 0.f : mnew;
+                    alpha[r] = __expf(mrow[r] - msafe);       // exp(-inf) = 0 on the first tile (hardware exp2: ~1e-7 rel.)
+                    float ps = 0.f;
+    #pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float pv = __expf(sacc[n][r] - msafe);
+                        sacc[n][r] = pv;
+                        ps += pv;
+                    }
+                    ps = row16_sum(ps);
+                    lrow[r] = lrow[r] * alpha[r] + ps;
+                    mrow[r] = mnew;
+                    if (a.use_drop) {                          // the normaliser keeps the undropped sum (dropout acts on softmax's output)
+                        const f32x4 dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr);
+    #pragma unroll
+                        for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
                     }
                 }
-                continue;
-            }
-            // mask + online softmax; element (row = 4*lq + r, key = kt*64 + 16n + lr)
-            float alpha[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = q0 + 4 * lq + r;
-                float mx = -INFINITY;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int key = kt * 64 + 16 * n + lr;
-                    if (key >= klim || (a.causal && key > qrow + coff)) sacc[n][r] = -INFINITY;
-                    mx = fmaxf(mx, sacc[n][r]);
-                }
-                mx = row16_max(mx);
-                const float mnew = fmaxf(mrow[r], mx);
-                const float msafe = mnew == -INFINITY ? 0.f : mnew;
-                alpha[r] = __expf(mrow[r] - msafe);       // exp(-inf) = 0 on the first tile (hardware exp2: ~1e-7 rel.)
-                float ps = 0.f;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const float pv = __expf(sacc[n][r] - msafe);
-                    sacc[n][r] = pv;
-                    ps += pv;
-                }
-                ps = row16_sum(ps);
-                lrow[r] = lrow[r] * alpha[r] + ps;
-                mrow[r] = mnew;
-                if (a.use_drop) {                          // the normaliser keeps the undropped sum (dropout acts on softmax's output)
-                    const f32x4 dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) sacc[n][r] *= dm[n];
-                }
-            }
-            // P from the D layout to the A layout through this wave's LDS patch
-            float *pw = Ps[wave];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pw[(4 * lq + r) * PS_STRIDE + 16 * n + lr] = sacc[n][r];
-#pragma unroll
-            for (int m = 0; m < HD / 16; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[m][r] *= alpha[r];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // O += P V : 16 key steps of 4
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float pa = pw[lr * PS_STRIDE + 4 * s + lq];
-#pragma unroll
+                // P from the D layout to the A layout through this wave's LDS patch
+                float *pw = Ps[wave];
+    #pragma unroll
+                for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) pw[(4 * lq + r) * PS_STRIDE + 16 * n + lr] = sacc[n][r];
+    #pragma unroll
                 for (int m = 0; m < HD / 16; ++m)
-                    o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vs[(4 * s + lq) * VS_STRIDE + 16 * m + lr], o[m], 0, 0, 0);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) o[m][r] *= alpha[r];
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // O += P V : 16 key steps of 4
+    #pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float pa = pw[lr * PS_STRIDE + 4 * s + lq];
+    #pragma unroll
+                    for (int m = 0; m < HD / 16; ++m)
+                        o[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vs[(4 * s + lq) * VS_STRIDE + 16 * m + lr], o[m], 0, 0, 0);
+                }
             }
         }
-    }
-    // y[b, row, h*HD + dim] = O / l
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * lq + r;
-        if (qrow >= Tq) continue;
-        const float inv = 1.0f / lrow[r];
-        float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) yp[16 * m + lr] = o[m][r] * inv;
-        const long stat = ((long)b * a.heads + h) * Tq + qrow;
-        if (a.lse && lr == 0) a.lse[stat] = mrow[r] + logf(lrow[r]);
-        if (ENT) {
-            float e = erow[r];
-            e = row16_sum(e);
-            if (lr == 0) a.ent[stat] = e;
+        // y[b, row, h*HD + dim] = O / l
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = q0 + 4 * lq + r;
+            if (qrow >= Tq) continue;
+            const float inv = 1.0f / lrow[r];
+            float *yp = a.y + (long)b * a.y_bs + (long)qrow * a.y_rs + (long)h * HD;
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m) yp[16 * m + lr] = o[m][r] * inv;
+            const long stat = ((long)b * a.heads + h) * Tq + qrow;
+            if (a.lse && lr == 0) a.lse[stat] = mrow[r] + logf(lrow[r]);
+            if (ENT) {
+                float e = erow[r];
+                e = row16_sum(e);
+                if (lr == 0) a.ent[stat] = e;
+            }
         }
     }
 }
@@ -445,86 +450,91 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * ST];
     __shared__ __attribute__((aligned(16))) float Vs[64 * ST];
     __shared__ float Ps[4][16 * PS];
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
-    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
-    const int q0 = qt * 64 + wave * 16;
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;
-    float qa[HD / 4], doa[HD / 4];
-    {
-        const int qrow = min(q0 + lr, Tq - 1);
-#pragma unroll
-        for (int s = 0; s < HD / 4; ++s) {
-            qa[s] = qb[(long)qrow * a.q_rs + 4 * s + lq] * a.scale;
-            doa[s] = dyb[(long)qrow * a.dy_rs + 4 * s + lq];
-        }
-    }
-    float lse_r[4], del_r[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long stat = ((long)b * a.heads + h) * Tq + min(q0 + 4 * lq + r, Tq - 1);
-        lse_r[r] = a.lse[stat];
-        del_r[r] = a.delta[stat];
-    }
-    f32x4 dq[HD / 16];
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int n_ktiles = (klim + 63) / 64;
-    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
-    f32x4 kreg[UNITS], vreg[UNITS];
-    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-        __syncthreads();
-        stage_tile<HD>(Ks, kreg);
-        stage_tile<HD>(Vs, vreg);
-        __syncthreads();
-        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-        f32x4 sacc[4], pacc[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    // causal: query tile n-1-x (long) and then tile x (short): n + 1 key tiles per workgroup whichever x
+    const int n_tiles_x = (a.Tq + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qt = a.causal ? (pass == 0 ? n_tiles_x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || qt == n_tiles_x - 1 - (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+        const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+        const int q0 = qt * 64 + wave * 16;
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;
+        float qa[HD / 4], doa[HD / 4];
+        {
+            const int qrow = min(q0 + lr, Tq - 1);
+    #pragma unroll
             for (int s = 0; s < HD / 4; ++s) {
-                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
-                pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[s], Vs[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+                qa[s] = qb[(long)qrow * a.q_rs + 4 * s + lq] * a.scale;
+                doa[s] = dyb[(long)qrow * a.dy_rs + 4 * s + lq];
             }
         }
-        float *pw = Ps[wave];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
-                const bool hidden = key >= klim || (a.causal && key > qrow + coff);
-                const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
-                float dp = pacc[n][r];
-                if (a.use_drop)
-                    dp *= dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + n);
-                pw[(4 * lq + r) * PS + 16 * n + lr] = p * (dp - del_r[r]);
-            }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float da = pw[lr * PS + 4 * s + lq];
-#pragma unroll
-            for (int m = 0; m < HD / 16; ++m)
-                dq[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Ks[(4 * s + lq) * ST + 16 * m + lr], dq[m], 0, 0, 0);
+        float lse_r[4], del_r[4];
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long stat = ((long)b * a.heads + h) * Tq + min(q0 + 4 * lq + r, Tq - 1);
+            lse_r[r] = a.lse[stat];
+            del_r[r] = a.delta[stat];
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * lq + r;
-        if (qrow >= Tq) continue;
-        float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) dp[16 * m + lr] = dq[m][r] * a.scale;
+        f32x4 dq[HD / 16];
+    #pragma unroll
+        for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int n_ktiles = (klim + 63) / 64;
+        if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * 64 + 63, Tq - 1) + coff) / 64 + 1));
+        f32x4 kreg[UNITS], vreg[UNITS];
+        if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+        for (int kt = 0; kt < n_ktiles; ++kt) {
+            __syncthreads();
+            stage_tile<HD>(Ks, kreg);
+            stage_tile<HD>(Vs, vreg);
+            __syncthreads();
+            if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+            f32x4 sacc[4], pacc[4];
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int s = 0; s < HD / 4; ++s) {
+                    sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], Ks[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
+                    pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[s], Vs[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+                }
+            }
+            float *pw = Ps[wave];
+    #pragma unroll
+            for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = q0 + 4 * lq + r, key = kt * 64 + 16 * n + lr;
+                    const bool hidden = key >= klim || (a.causal && key > qrow + coff);
+                    const float p = hidden ? 0.f : __expf(sacc[n][r] - lse_r[r]);
+                    float dp = pacc[n][r];
+                    if (a.use_drop)
+                        dp *= dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + n);
+                    pw[(4 * lq + r) * PS + 16 * n + lr] = p * (dp - del_r[r]);
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    #pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float da = pw[lr * PS + 4 * s + lq];
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m)
+                    dq[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Ks[(4 * s + lq) * ST + 16 * m + lr], dq[m], 0, 0, 0);
+            }
+        }
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = q0 + 4 * lq + r;
+            if (qrow >= Tq) continue;
+            float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD;
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m) dp[16 * m + lr] = dq[m][r] * a.scale;
+        }
     }
 }
 
@@ -535,95 +545,101 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float Os[64 * ST];      // dO tile
     __shared__ float Ps[4][2][16 * PS];
     __shared__ float lse_s[64], del_s[64];
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int Tq = a.Tq, Tk = a.Tk;
-    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
-    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
-    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
-    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
-    const int k0 = kt * 64 + wave * 16;
-    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
-    const int coff = Tk - Tq;
-    float ka[HD / 4], va[HD / 4];
-    {
-        const int krow = min(k0 + lr, Tk - 1);
-#pragma unroll
-        for (int s = 0; s < HD / 4; ++s) {
-            ka[s] = kb[(long)krow * a.kv_rs + 4 * s + lq] * a.scale;
-            va[s] = vb[(long)krow * a.kv_rs + 4 * s + lq];
-        }
-    }
-    f32x4 dk[HD / 16], dv[HD / 16];
-#pragma unroll
-    for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int n_qtiles = (Tq + 63) / 64;
-    const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
-    const long stat0 = ((long)b * a.heads + h) * Tq;
-    f32x4 qreg[UNITS], oreg[UNITS];
-    if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
-    for (int qt = qt0; qt < n_qtiles; ++qt) {
-        __syncthreads();
-        stage_tile<HD>(Qs, qreg);
-        stage_tile<HD>(Os, oreg);
-        if (threadIdx.x < 64) {
-            const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
-            lse_s[threadIdx.x] = a.lse[stat0 + qrow];
-            del_s[threadIdx.x] = a.delta[stat0 + qrow];
-        }
-        __syncthreads();
-        if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
-        f32x4 sacc[4], pacc[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    // causal: key tile x (long: it sees every later query tile) and then tile n-1-x (short), so every workgroup walks n + 1 query
+    // tiles and the grid (ceil(n/2) wide) drains evenly (same pairing as csrc/attn_mx.hip)
+    const int n_tiles_x = (a.Tk + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kt = a.causal ? (pass == 0 ? (int)blockIdx.x : n_tiles_x - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+        if (pass == 1 && (!a.causal || kt == (int)blockIdx.x)) break;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+        const int Tq = a.Tq, Tk = a.Tk;
+        const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+        const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+        const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+        const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+        const int k0 = kt * 64 + wave * 16;
+        const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+        const int coff = Tk - Tq;
+        float ka[HD / 4], va[HD / 4];
+        {
+            const int krow = min(k0 + lr, Tk - 1);
+    #pragma unroll
             for (int s = 0; s < HD / 4; ++s) {
-                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], Qs[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
-                pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], Os[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+                ka[s] = kb[(long)krow * a.kv_rs + 4 * s + lq] * a.scale;
+                va[s] = vb[(long)krow * a.kv_rs + 4 * s + lq];
             }
         }
-        float *pw = Ps[wave][0], *dw = Ps[wave][1];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int qi = 16 * n + lr, qrow = qt * 64 + qi;
-            const float l = lse_s[qi], dl = del_s[qi];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 4 * lq + r;
-                const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
-                const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
-                float dm = 1.0f;
-                if (a.use_drop)
-                    dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) +
-                                                  4 * (4 * lq + r) + wave);
-                pw[(4 * lq + r) * PS + qi] = p * dm;
-                dw[(4 * lq + r) * PS + qi] = p * (dm * pacc[n][r] - dl);
+        f32x4 dk[HD / 16], dv[HD / 16];
+    #pragma unroll
+        for (int m = 0; m < HD / 16; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int n_qtiles = (Tq + 63) / 64;
+        const int qt0 = (a.causal && kt * 64 < klim) ? min(n_qtiles, max(0, kt * 64 - coff) / 64) : (kt * 64 < klim ? 0 : n_qtiles);
+        const long stat0 = ((long)b * a.heads + h) * Tq;
+        f32x4 qreg[UNITS], oreg[UNITS];
+        if (qt0 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, qt0 * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, qt0 * 64, Tq); }
+        for (int qt = qt0; qt < n_qtiles; ++qt) {
+            __syncthreads();
+            stage_tile<HD>(Qs, qreg);
+            stage_tile<HD>(Os, oreg);
+            if (threadIdx.x < 64) {
+                const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
+                lse_s[threadIdx.x] = a.lse[stat0 + qrow];
+                del_s[threadIdx.x] = a.delta[stat0 + qrow];
+            }
+            __syncthreads();
+            if (qt + 1 < n_qtiles) { fetch_tile<HD>(qreg, qb, a.q_rs, (qt + 1) * 64, Tq); fetch_tile<HD>(oreg, dyb, a.dy_rs, (qt + 1) * 64, Tq); }
+            f32x4 sacc[4], pacc[4];
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int s = 0; s < HD / 4; ++s) {
+                    sacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], Qs[(16 * n + lr) * ST + 4 * s + lq], sacc[n], 0, 0, 0);
+                    pacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s], Os[(16 * n + lr) * ST + 4 * s + lq], pacc[n], 0, 0, 0);
+                }
+            }
+            float *pw = Ps[wave][0], *dw = Ps[wave][1];
+    #pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int qi = 16 * n + lr, qrow = qt * 64 + qi;
+                const float l = lse_s[qi], dl = del_s[qi];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + 4 * lq + r;
+                    const bool hidden = key >= klim || qrow >= Tq || (a.causal && key > qrow + coff);
+                    const float p = hidden ? 0.f : __expf(sacc[n][r] - l);
+                    float dm = 1.0f;
+                    if (a.use_drop)
+                        dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) +
+                                                      4 * (4 * lq + r) + wave);
+                    pw[(4 * lq + r) * PS + qi] = p * dm;
+                    dw[(4 * lq + r) * PS + qi] = p * (dm * pacc[n][r] - dl);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    #pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float pa = pw[lr * PS + 4 * s + lq], da = dw[lr * PS + 4 * s + lq];
+    #pragma unroll
+                for (int m = 0; m < HD / 16; ++m) {
+                    dv[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Os[(4 * s + lq) * ST + 16 * m + lr], dv[m], 0, 0, 0);
+                    dk[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Qs[(4 * s + lq) * ST + 16 * m + lr], dk[m], 0, 0, 0);
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float pa = pw[lr * PS + 4 * s + lq], da = dw[lr * PS + 4 * s + lq];
-#pragma unroll
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = k0 + 4 * lq + r;
+            if (key >= Tk) continue;
+            float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+            float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
+    #pragma unroll
             for (int m = 0; m < HD / 16; ++m) {
-                dv[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Os[(4 * s + lq) * ST + 16 * m + lr], dv[m], 0, 0, 0);
-                dk[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, Qs[(4 * s + lq) * ST + 16 * m + lr], dk[m], 0, 0, 0);
+                kp[16 * m + lr] = dk[m][r] * a.scale;
+                vp[16 * m + lr] = dv[m][r];
             }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 4 * lq + r;
-        if (key >= Tk) continue;
-        float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
-        float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD;
-#pragma unroll
-        for (int m = 0; m < HD / 16; ++m) {
-            kp[16 * m + lr] = dk[m][r] * a.scale;
-            vp[16 * m + lr] = dv[m][r];
         }
     }
 }
@@ -631,14 +647,16 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
 template <int HD>
 int launch_attention_bwd(const AttnBwdArgs &a, const float *y, long y_rs, float *delta, int N, hipStream_t st) {
     hipLaunchKernelGGL(attention_delta_kernel<HD>, dim3(N * a.Tq), dim3(256), 0, st, a.dy, a.dy_rs, y, y_rs, delta, a.Tq, a.heads);
-    hipLaunchKernelGGL(attention_bwd_dq_kernel<HD>, dim3((a.Tq + 63) / 64, a.heads, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel<HD>, dim3((a.Tk + 63) / 64, a.heads, N), dim3(256), 0, st, a);
+    const int nq = (a.Tq + 63) / 64, nk = (a.Tk + 63) / 64;
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<HD>, dim3(a.causal ? (nq + 1) / 2 : nq, a.heads, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<HD>, dim3(a.causal ? (nk + 1) / 2 : nk, a.heads, N), dim3(256), 0, st, a);
     return halo_launch_status();
 }
 
 template <int HD>
 int launch_attention(const AttnArgs &a, int N, bool ent, hipStream_t st) {
-    dim3 grid((a.Tq + 63) / 64, a.heads, N);
+    const int nq = (a.Tq + 63) / 64;
+    dim3 grid(a.causal ? (nq + 1) / 2 : nq, a.heads, N);
     if (ent) hipLaunchKernelGGL((attention_fwd_kernel<HD, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attention_fwd_kernel<HD, false>), grid, dim3(256), 0, st, a);
     return halo_launch_status();
