@@ -299,10 +299,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * SLOT, wave, lane);
         stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * SLOT + OPER, wave, lane);
     }
+    if (NSTAGE == 1) {      // single slot: filled here, refilled each iteration once every wave holds its fragments in registers
+        stage_block<PASSES>(Ablk, lds, wave, lane);
+        stage_block<PASSES>(Bblk, lds + OPER, wave, lane);
+    }
     for (int t = 0; t < nkt; ++t) {
         // tile t is complete once all but the newest (NSTAGE-2) stages have landed
-        wait_vm_and_barrier<(NSTAGE - 2) * LOADS>();
-        {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
+        wait_vm_and_barrier<(NSTAGE >= 2 ? NSTAGE - 2 : 0) * LOADS>();
+        if (NSTAGE >= 2) {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
             const int tn = min(t + NSTAGE - 1, nkt - 1);
             char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * SLOT;
             stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
@@ -323,6 +327,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                     fbl[ks][i] = *reinterpret_cast<const bf16x8 *>(bl + boff[i][ks]);
                 }
             }
+        if (NSTAGE == 1) {
+            // every wave has its fragments: the slot is free, the next tile streams in under this tile's MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int tn = min(t + 1, nkt - 1);
+            stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, lds, wave, lane);
+            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, lds + OPER, wave, lane);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -529,9 +540,9 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
 static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                                   const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
                                   hipStream_t st) {
-    static int nstage = 0, nstage1 = 0;
-    if (!nstage) {
-        // ring depth: 2 slots = 64 KiB (two workgroups per CU), 4 slots = 128 KiB (one); opt in to the LDS size once
+    static int nstage = -1, nstage1 = 0;     // nstage: -1 not read yet, 0 chosen per call by tile count, else forced by HALO_GEMM_STAGES
+    if (nstage < 0) {
+        // three-pass ring depth: 1 slot = 32 KiB (three workgroups per CU), 2 = 64 KiB (two), 4 = 128 KiB (one); opt in to the LDS size once
         const char *e = getenv("HALO_GEMM_STAGES");
         const int want = e ? atoi(e) : 2;
         if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -543,10 +554,12 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
-        nstage = want == 4 ? 4 : 2;
-        // single pass: 4 half-size slots = 64 KiB (two workgroups per CU) or 8 = 128 KiB (one)
+        nstage = e ? (want == 4 ? 4 : (want == 1 ? 1 : 2)) : 0;      // 0: by tile count (below)
+        // single pass, half-size slots: 3 = 48 KiB, THREE workgroups per CU (default: [8192 x 3072 x 768] 90 -> 69 us and the lm_head
+        // product 1365 -> 1020 us against 4 slots on the same box); 4 = 64 KiB (two per CU), 8 = 128 KiB (one), 2 = 32 KiB
         const char *e1 = getenv("HALO_GEMM_STAGES_BF16");
-        nstage1 = e1 && atoi(e1) == 8 ? 8 : 4;
+        nstage1 = e1 ? atoi(e1) : 3;
+        if (nstage1 != 8 && nstage1 != 4 && nstage1 != 2) nstage1 = 3;
     }
     TiledGemmArgs p;
     p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.bias1 = bias1; p.bias2 = bias2;
@@ -565,8 +578,15 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     p.slab = (float *)scratch;
     const dim3 grid((unsigned)(p.ntiles * p.ksplit));
     const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
-    if (one_pass && nstage1 == 8) hipLaunchKernelGGL((gemm_bf16x3_kernel<8, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    if (one_pass && nstage1 == 3) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (one_pass && nstage1 == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), STAGE_BYTES, st, p);
+    else if (one_pass && nstage1 == 8) hipLaunchKernelGGL((gemm_bf16x3_kernel<8, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
     else if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    // three passes: ONE 32 KiB slot (refilled under the MFMAs once every wave holds its fragments) lets three workgroups share a CU
+    // and wins where there are that many (>= 768 tiles: [8192 x 3072 x 768] 153 -> 136 us, lm_head 2172 -> 1928 us); with fewer the
+    // two-slot ring at two per CU is faster ([4096 x 1024 x 1344], the LSTM weight gradient: 54 vs 63 us)
+    else if (nstage == 1 || (nstage == 0 && (long)p.ntiles * p.ksplit >= 768))
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, dim3(256), STAGE_BYTES, st, p);
     else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
