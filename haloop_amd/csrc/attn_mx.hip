@@ -1,5 +1,5 @@
 // Softmax attention forward / backward on the bf16 matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16), same
-// tiling, masks and outputs as the exact-f32 kernels of attn.hip.  Operands are fp32 in HBM; on their way into
+// masks, outputs and 64-key tiles as the exact-f32 kernels of attn.hip.  Operands are fp32 in HBM; on their way into
 // LDS / registers they are split x = hi + lo (two bf16) and every product is accumulated in fp32 as
 //     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi        (PASSES = 3, ~2^-16 relative error per product)
 // or just a_hi*b_hi (PASSES = 1, plain bf16 operands).  Three 16-cycle bf16 MFMAs replace eight 32-cycle f32
