@@ -111,7 +111,7 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, 
 // QB: 16-query blocks per wave (a workgroup covers 64 * QB queries).  With QB = 2 every K fragment and every V^T fragment read
 // from LDS feeds two MFMAs, and a staged tile (and its two barriers) serves twice the queries.
 template <int HD, int PASSES, int QB>
-__global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(AttnArgs a) {
     using I = Img<HD>;
     constexpr int WQ = 16 * QB, TQ = 64 * QB;                  // queries per wave / per workgroup
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void attention_fwd_mx_kernel(AttnArgs a) {
 // Same transposed formulation as the forward: S^T = K Q^T and dP^T = V dO^T leave a lane with 16 keys of ONE query, so
 // lse / delta are lane scalars and dS^T is already the B operand of dQ^T = K^T dS^T (K^T through the transpose read).
 template <int HD, int PASSES>
-__global__ __launch_bounds__(256) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
