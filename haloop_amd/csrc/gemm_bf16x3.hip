@@ -246,7 +246,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 // PASSES == 3: split-bf16 (hi*hi + hi*lo + lo*hi);  PASSES == 1: plain bf16 operands (hi parts only: HALO_MATH_BF16)
-template <int NSTAGE, int PASSES>
+// CE: the cross-entropy epilogue is compiled into its own instantiations, so the plain products keep the register count and
+// the epilogue code they had without it
+template <int NSTAGE, int PASSES, bool CE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
     constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
     // ring slot: [A block | B block]; with one pass only the hi parts are staged, so a slot is half the size and the
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 
     // epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     const int m0 = tile_m * TR, n0 = tile_n * TR;
-    if (p.ce_part) {        // wave-uniform: softmax statistics of this wave's 64 x 64 block, row by row (a row = 32 lanes x 2)
+    if (CE) {               // softmax statistics of this wave's 64 x 64 block, row by row (a row = 32 lanes x 2)
         const int c0 = n0 + wn * 64 + lr, c1 = c0 + 32;
         const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
         float b0 = 0.f, b1 = 0.f;
@@ -552,7 +554,9 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                4 * STAGE_BYTES) != hipSuccess)
+                                4 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
         nstage = e ? (want == 4 ? 4 : (want == 1 ? 1 : 2)) : 0;      // 0: by tile count (below)
         // single pass, half-size slots: 3 = 48 KiB, THREE workgroups per CU (default: [8192 x 3072 x 768] 90 -> 69 us and the lm_head
@@ -578,6 +582,12 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     p.slab = (float *)scratch;
     const dim3 grid((unsigned)(p.ntiles * p.ksplit));
     const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
+    if (ce) {                       // the epilogue instantiations (kept apart: compiled into the common kernel the extra registers and
+                                    // epilogue code cost every product 6-17 % and the LSTM-CTC step 2.6 %, same-box A/B)
+        if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, true>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+        else if ((long)p.ntiles * p.ksplit >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, true>), grid, dim3(256), STAGE_BYTES, st, p);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, true>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    } else
     if (one_pass && nstage1 == 3) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (one_pass && nstage1 == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), STAGE_BYTES, st, p);
     else if (one_pass && nstage1 == 8) hipLaunchKernelGGL((gemm_bf16x3_kernel<8, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
