@@ -248,7 +248,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // PASSES == 3: split-bf16 (hi*hi + hi*lo + lo*hi);  PASSES == 1: plain bf16 operands (hi parts only: HALO_MATH_BF16)
 // CE: the cross-entropy epilogue is compiled into its own instantiations, so the plain products keep the register count and
 // the epilogue code they had without it
-template <int NSTAGE, int PASSES, bool CE = false>
+// EPI: 0 the full epilogue; 1 bias + residual add only (no activation, no dropout, no split-K); 2 a split-K slice (raw sums to its slab).
+// The plain products run on 1 / 2: the code they do not need costs them 3-6 % when it is compiled in.
+template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
     constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
     // ring slot: [A block | B block]; with one pass only the hi parts are staged, so a slot is half the size and the
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + lr;
             if (col >= p.N) continue;
-            if (p.ksplit > 1) {
+            if (EPI == 2 || (EPI == 0 && p.ksplit > 1)) {
                 float *slab = p.slab + (long)kslice * p.M * p.N;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -409,9 +411,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bias;
-                v = gemm_activation(v, p.relu);
+                if (EPI == 0) v = gemm_activation(v, p.relu);
                 const long e = (long)row * p.ldc + col;
-                if (p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
+                if (EPI == 0 && p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
                 if (p.relu & 4) v += p.C[e];
                 p.C[e] = v;
             }
@@ -556,6 +558,10 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * STAGE_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
         nstage = e ? (want == 4 ? 4 : (want == 1 ? 1 : 2)) : 0;      // 0: by tile count (below)
@@ -582,22 +588,30 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     p.slab = (float *)scratch;
     const dim3 grid((unsigned)(p.ntiles * p.ksplit));
     const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
+    // epilogue specialisations (same-box A/B: the LSTM-CTC step 1.274 -> 1.247 ms, products 1-7 % faster)
+    const bool slice = p.ksplit > 1;                                                     // raw sums: the reduce kernel applies the epilogue
+    const bool lean = p.ksplit == 1 && !p.use_drop && (relu & ~HALO_GEMM_ACCUM) == 0;
     if (ce) {                       // the epilogue instantiations (kept apart: compiled into the common kernel the extra registers and
                                     // epilogue code cost every product 6-17 % and the LSTM-CTC step 2.6 %, same-box A/B)
         if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, true>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
         else if ((long)p.ntiles * p.ksplit >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, true>), grid, dim3(256), STAGE_BYTES, st, p);
         else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, true>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     } else
-    if (one_pass && nstage1 == 3) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    if (one_pass && nstage1 == 3 && lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (one_pass && nstage1 == 3 && slice) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 2>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (one_pass && nstage1 == 3) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (one_pass && nstage1 == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), STAGE_BYTES, st, p);
     else if (one_pass && nstage1 == 8) hipLaunchKernelGGL((gemm_bf16x3_kernel<8, 1>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
     else if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     // three passes: ONE 32 KiB slot (refilled under the MFMAs once every wave holds its fragments) lets three workgroups share a CU
     // and wins where there are that many (>= 768 tiles: [8192 x 3072 x 768] 153 -> 136 us, lm_head 2172 -> 1928 us); with fewer the
     // two-slot ring at two per CU is faster ([4096 x 1024 x 1344], the LSTM weight gradient: 54 vs 63 us)
-    else if (nstage == 1 || (nstage == 0 && (long)p.ntiles * p.ksplit >= 768))
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, dim3(256), STAGE_BYTES, st, p);
-    else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    else if (nstage == 1 || (nstage == 0 && (long)p.ntiles * p.ksplit >= 768)) {
+        if (lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 1>), grid, dim3(256), STAGE_BYTES, st, p);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, dim3(256), STAGE_BYTES, st, p);
+    } else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
+    else if (lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    else if (slice) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 2>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
     if (rc != HALO_OK || p.ksplit == 1) return rc;
