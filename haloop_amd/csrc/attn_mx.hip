@@ -110,7 +110,8 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, 
 
 // QB: 16-query blocks per wave (a workgroup covers 64 * QB queries).  With QB = 2 every K fragment and every V^T fragment read
 // from LDS feeds two MFMAs, and a staged tile (and its two barriers) serves twice the queries.
-template <int HD, int PASSES, int QB>
+// DROP: the Philox dropout of the probabilities is compiled in only for the launches that use it
+template <int HD, int PASSES, int QB, bool DROP>
 __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(AttnArgs a) {
     using I = Img<HD>;
     constexpr int WQ = 16 * QB, TQ = 64 * QB;                  // queries per wave / per workgroup
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
                         ps += sacc[g][n][r];
                     }
                 lsum[g] = lsum[g] * alpha + ps;                    // the normaliser keeps the undropped sum
-                if (a.use_drop) {
+                if (DROP && a.use_drop) {
                     const uint64_t base = attn_drop_tile_base(b, a.heads, h, Tq, min(qrow[g], Tq - 1), (Tk + 63) / 64, kt);
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
 // ---- backward, dQ sweep: one workgroup = 64 query rows, walks the key tiles ----------------------------------
 // Same transposed formulation as the forward: S^T = K Q^T and dP^T = V dO^T leave a lane with 16 keys of ONE query, so
 // lse / delta are lane scalars and dS^T is already the B operand of dQ^T = K^T dS^T (K^T through the transpose read).
-template <int HD, int PASSES>
+template <int HD, int PASSES, bool DROP>
 __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
     #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (a.use_drop)
+                if (DROP && a.use_drop)
                     dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe, (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
     #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
 // ---- backward, dK/dV sweep: one workgroup = 64 keys, walks the query tiles -----------------------------------
 // Here the lane-fixed index is the KEY: S = Q K^T and dP = dO V^T (this wave's 16 keys as the B operand, from registers)
 // leave a lane with 16 queries of one key, and P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
-template <int HD, int PASSES>
+template <int HD, int PASSES, bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD>;
     __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
                     float p = __expf(sacc[n][r] - l4[r]);
                     if (edge && (key >= klim || qrow >= Tq || (a.causal && key > qrow + coff))) p = 0.f;
                     float dm = 1.0f;
-                    if (a.use_drop)
+                    if (DROP && a.use_drop)
                         dm = dropout_mult(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, min(qrow, Tq - 1), (Tk + 63) / 64, kt) + 4 * lr + wave);
                     sacc[n][r] = p * (dm * pacc[n][r] - d4[r]);
                     pacc[n][r] = p * dm;
@@ -469,16 +470,25 @@ int launch_fwd(const AttnArgs &a, int N, hipStream_t st) {
     const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
     const bool two = qb2 == 2 || (qb2 == 0 && PASSES == 1 && a.Tq >= 256 && wg128 >= 512);
     const int n2 = (a.Tq + 127) / 128, n1 = (a.Tq + 63) / 64;
-    if (two) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2>), dim3(a.causal ? (n2 + 1) / 2 : n2, a.heads, N), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 1>), dim3(a.causal ? (n1 + 1) / 2 : n1, a.heads, N), dim3(256), 0, st, a);
+    const dim3 g2(a.causal ? (n2 + 1) / 2 : n2, a.heads, N), g1(a.causal ? (n1 + 1) / 2 : n1, a.heads, N);
+    if (two && a.use_drop) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2, true>), g2, dim3(256), 0, st, a);
+    else if (two) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2, false>), g2, dim3(256), 0, st, a);
+    else if (a.use_drop) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 1, true>), g1, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 1, false>), g1, dim3(256), 0, st, a);
     return halo_launch_status();
 }
 
 template <int HD, int PASSES>
 int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
     const int nq = (a.Tq + 63) / 64, nk = (a.Tk + 63) / 64;
-    hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES>), dim3(a.causal ? (nq + 1) / 2 : nq, a.heads, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES>), dim3(a.causal ? (nk + 1) / 2 : nk, a.heads, N), dim3(256), 0, st, a);
+    const dim3 gq(a.causal ? (nq + 1) / 2 : nq, a.heads, N), gk(a.causal ? (nk + 1) / 2 : nk, a.heads, N);
+    if (a.use_drop) {
+        hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, true>), gq, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, true>), gk, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, false>), gq, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, false>), gk, dim3(256), 0, st, a);
+    }
     return halo_launch_status();
 }
 
