@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 5
+HALO_ABI_VERSION = 6
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -97,6 +97,10 @@ SIGNATURES = {
     'halo_scale_add': (_i, [_vp, _vp, _f, _f, _sz, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
+    'halo_adamw_multi_tensor_bytes': (_sz, []),
+    'halo_adamw_multi_chunk': (_u32, []),
+    'halo_adamw_multi_max_tensors': (_i, []),
+    'halo_adamw_multi': (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp]),
     'halo_adamw_ranges': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp, _vp]),
     'halo_adamw': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _vp]),
 }

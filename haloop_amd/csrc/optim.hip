@@ -41,6 +41,18 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict_
     }
 }
 
+// One AdamW element update (torch.optim.AdamW, _single_tensor).  Every kernel below calls this, with contraction pinned, so that the
+// per-tensor, ranged and multi-tensor launches (and their vector bodies and scalar tails) produce the same bits.
+__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, float decay_mul, float beta1_w, float beta2,
+                                            float beta2_w, float step_size, float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+    p = p * decay_mul;
+    m = __builtin_fmaf(g - m, beta1_w, m);
+    v = __builtin_fmaf(beta2_w * g, g, v * beta2);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
 struct AdamArgs {
     float *p;
     const float *g;
@@ -69,11 +81,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ge = a.grad_scale ? g[e] * gs : g[e];
-            float pe = p[e] * a.decay_mul;
-            const float me = m[e] + (ge - m[e]) * a.beta1_w;
-            const float ve = v[e] * a.beta2 + a.beta2_w * ge * ge;
-            const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
-            pe -= a.step_size * (me / denom);
+            float pe = p[e], me = m[e], ve = v[e];
+            adam_update(pe, me, ve, ge, a.decay_mul, a.beta1_w, a.beta2, a.beta2_w, a.step_size, a.bc2_sqrt, a.eps);
             p[e] = pe; m[e] = me; v[e] = ve;
         }
         p4[i] = p; m4[i] = m; v4[i] = v;
@@ -81,11 +90,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     if (blockIdx.x == 0) {
         for (size_t i = n4 * 4 + threadIdx.x; i < a.n; i += 256) {
             const float ge = a.grad_scale ? a.g[i] * gs : a.g[i];
-            float pe = a.p[i] * a.decay_mul;
-            const float me = a.m[i] + (ge - a.m[i]) * a.beta1_w;
-            const float ve = a.v[i] * a.beta2 + a.beta2_w * ge * ge;
-            const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
-            pe -= a.step_size * (me / denom);
+            float pe = a.p[i], me = a.m[i], ve = a.v[i];
+            adam_update(pe, me, ve, ge, a.decay_mul, a.beta1_w, a.beta2, a.beta2_w, a.step_size, a.bc2_sqrt, a.eps);
             a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
         }
     }
@@ -122,17 +128,70 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(const AdamRangesArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float ge = a.grad_scale[r] ? g[e] * gs : g[e];
-                float pe = p[e] * decay_mul;
-                const float me = m[e] + (ge - m[e]) * a.beta1_w;
-                const float ve = v[e] * a.beta2 + a.beta2_w * ge * ge;
-                const float denom = sqrtf(ve) / a.bc2_sqrt + a.eps;
-                pe -= a.step_size * (me / denom);
+                float pe = p[e], me = m[e], ve = v[e];
+                adam_update(pe, me, ve, ge, decay_mul, a.beta1_w, a.beta2, a.beta2_w, a.step_size, a.bc2_sqrt, a.eps);
                 p[e] = pe; m[e] = me; v[e] = ve;
             }
             p4[i] = p; m4[i] = m; v4[i] = v;
         }
     }
     if (a.counter && blockIdx.x == 0 && threadIdx.x == 0) *a.counter += 1u;
+}
+
+// One launch over MANY tensors (torch.optim.AdamW(fused / foreach) on a model's parameter list): the device table names each
+// tensor's p / g / m / v and its decay; a workgroup takes one 16384-element chunk (chunk table: tensor index, chunk index).
+// Same per-element arithmetic as adamw_kernel, so the results are bit-identical to per-tensor launches.
+struct AdamTensor {      // static per parameter: lives in a device table built once
+    float *p;
+    float *m;
+    float *v;
+    unsigned long long n;
+    float decay_mul;     // 1 - lr*wd of this tensor
+    int pad;
+};
+constexpr unsigned ADAM_CHUNK = 16384;
+constexpr int ADAM_MULTI_MAX = 256;
+// the gradient tensors are new allocations every backward: their addresses travel in the kernel arguments (copied at launch,
+// so the host may run ahead and prepare the next step's list while this one is still queued)
+struct AdamGrads { const float *g[ADAM_MULTI_MAX]; };
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor *__restrict__ tensors, const uint2 *__restrict__ chunks,
+                                                          const AdamGrads grads, float beta1_w, float beta2, float beta2_w,
+                                                          float step_size, float bc2_sqrt, float eps,
+                                                          const float *__restrict__ grad_scale) {
+    const float gs = grad_scale ? *grad_scale : 1.0f;
+    if (gs != gs) return;   // NaN scale: skip this update entirely
+    const uint2 c = chunks[blockIdx.x];
+    const AdamTensor t = tensors[c.x];
+    const float *tg = grads.g[c.x];
+    const size_t begin = (size_t)c.y * ADAM_CHUNK, end = min(begin + (size_t)ADAM_CHUNK, (size_t)t.n);
+    auto update = [&](float &pe, float &me, float &ve, float g) {
+        adam_update(pe, me, ve, grad_scale ? g * gs : g, t.decay_mul, beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps);
+    };
+    const bool vec = (((uintptr_t)t.p | (uintptr_t)tg | (uintptr_t)t.m | (uintptr_t)t.v) % 16) == 0;
+    size_t done = begin;
+    if (vec) {
+        const size_t e4 = end / 4;
+        f32x4 *p4 = reinterpret_cast<f32x4 *>(t.p), *m4 = reinterpret_cast<f32x4 *>(t.m), *v4 = reinterpret_cast<f32x4 *>(t.v);
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(tg);
+        for (size_t i = begin / 4 + threadIdx.x; i < e4; i += 256) {
+            f32x4 p = p4[i], m = m4[i], v = v4[i];
+            const f32x4 g = g4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = p[e], me = m[e], ve = v[e];
+                update(pe, me, ve, g[e]);
+                p[e] = pe; m[e] = me; v[e] = ve;
+            }
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+        done = e4 * 4;
+    }
+    for (size_t i = done + threadIdx.x; i < end; i += 256) {
+        float pe = t.p[i], me = t.m[i], ve = t.v[i];
+        update(pe, me, ve, tg[i]);
+        t.p[i] = pe; t.m[i] = me; t.v[i] = ve;
+    }
 }
 
 }  // namespace
@@ -200,6 +259,25 @@ int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr,
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return halo_launch_status();
+}
+
+size_t halo_adamw_multi_tensor_bytes(void) { return sizeof(AdamTensor); }
+unsigned halo_adamw_multi_chunk(void) { return ADAM_CHUNK; }
+
+int halo_adamw_multi_max_tensors(void) { return ADAM_MULTI_MAX; }
+
+int halo_adamw_multi(const void *tensor_table, const void *chunk_table, int n_chunks, const float *const *grads, int n_tensors, float lr,
+                     float beta1, float beta2, float eps, int step, const float *grad_scale, halo_stream_t stream) {
+    HALO_CHECK_ARG(tensor_table && chunk_table && n_chunks > 0 && step >= 1 && grads && n_tensors > 0 && n_tensors <= ADAM_MULTI_MAX);
+    AdamGrads gr;
+    for (int i = 0; i < ADAM_MULTI_MAX; ++i) gr.g[i] = i < n_tensors ? grads[i] : nullptr;
+    for (int i = 0; i < n_tensors; ++i) HALO_CHECK_ARG(grads[i] != nullptr);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamTensor *)tensor_table,
+                       (const uint2 *)chunk_table, gr, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
+                       (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale);
     return halo_launch_status();
 }
 

@@ -380,6 +380,53 @@ def adamw_ranges(p, g, m, v, ranges, lr, beta1, beta2, eps, step, counter=None):
     torch.autograd.graph.increment_version(p)
 
 
+class AdamWMulti:
+    """torch.optim.AdamW arithmetic over a whole parameter list in ONE launch per 256 tensors (the reference's fused AdamW,
+    ha/attention_loop.py:141-147).  ``params``: the nn.Parameters (contiguous fp32 on the HIP device); ``weight_decays``: one value
+    per parameter.  The optimizer state lives here; ``step()`` reads each parameter's current ``.grad``."""
+
+    def __init__(self, params, weight_decays, lr, betas=(0.9, 0.999), eps=1e-8):
+        import numpy as np
+        self.params = list(params)
+        self.wds = [float(w) for w in weight_decays]
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise ValueError('AdamWMulti: parameters must be contiguous float32 tensors on the HIP device')
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+        dev = self.params[0].device
+        chunk, group = lib().halo_adamw_multi_chunk(), lib().halo_adamw_multi_max_tensors()
+        assert lib().halo_adamw_multi_tensor_bytes() == 40
+        rec = np.dtype([('p', '<u8'), ('m', '<u8'), ('v', '<u8'), ('n', '<u8'), ('decay', '<f4'), ('pad', '<i4')])
+        self.groups = []                                        # (first parameter, count, device tensor table, device chunk table, chunks)
+        for first in range(0, len(self.params), group):
+            idx = range(first, min(first + group, len(self.params)))
+            table = np.zeros(len(idx), dtype=rec)
+            for k, i in enumerate(idx):
+                p = self.params[i]
+                table[k] = (p.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), 1.0 - self.lr * self.wds[i], 0)
+            pairs = [(k, c) for k, i in enumerate(idx) for c in range((self.params[i].numel() + chunk - 1) // chunk)]
+            self.groups.append((first, len(idx), torch.from_numpy(table.view(np.uint8)).to(dev),
+                                torch.tensor(pairs, dtype=torch.int32).view(-1).to(dev), len(pairs)))
+
+    def step(self, grad_scale=None):
+        self.t += 1
+        for first, count, table, chunks, n_chunks in self.groups:
+            ptrs = (C.c_void_p * count)()
+            for k in range(count):
+                p = self.params[first + k]
+                g = p.grad
+                if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.shape != p.shape:
+                    raise ValueError('AdamWMulti.step: every parameter needs a contiguous float32 .grad of its shape on its device')
+                ptrs[k] = g.data_ptr()
+            check(lib().halo_adamw_multi(ptr(table), ptr(chunks), n_chunks, ptrs, count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.t, ptr(grad_scale), _stream()), 'halo_adamw_multi')
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)          # cached operand images of the weights are rebuilt
+
+
 def scale_add_(y, x, alpha, beta):
     """y <- alpha*y + beta*x in place (flat fp32 buffers)."""
     check(lib().halo_scale_add(ptr(y), ptr(x), float(alpha), float(beta), y.numel(), _stream()), 'halo_scale_add')

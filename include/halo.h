@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 5
+#define HALO_ABI_VERSION 6
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -449,6 +449,20 @@ int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr,
 int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
                       const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2,
                       float eps, int step, uint32_t *counter, halo_stream_t stream);
+
+/* halo_adamw over MANY tensors in one launch (what torch.optim.AdamW(fused=True) does for a parameter list, ha/attention_loop.py:
+ * 141-147).  tensor_table (device, built once): n_tensors records of halo_adamw_multi_tensor_bytes() bytes each:
+ *   { float *p; float *m; float *v; uint64 n; float decay_mul (= 1 - lr*weight_decay); int32 pad }
+ * chunk_table (device, built once): n_chunks pairs { uint32 tensor, uint32 chunk } -- every tensor cut into
+ * ceil(n / halo_adamw_multi_chunk()) chunks, one workgroup each.  grads: HOST array of the n_tensors gradient pointers of this
+ * step (autograd allocates new ones every backward); they are copied into the kernel arguments, so the caller may reuse the
+ * array at once.  n_tensors <= halo_adamw_multi_max_tensors() per call.  The decay factor already contains lr: rebuild the
+ * table when lr changes.  Bit-identical to one halo_adamw call per tensor. */
+size_t halo_adamw_multi_tensor_bytes(void);
+unsigned halo_adamw_multi_chunk(void);
+int halo_adamw_multi_max_tensors(void);
+int halo_adamw_multi(const void *tensor_table, const void *chunk_table, int n_chunks, const float *const *grads, int n_tensors,
+                     float lr, float beta1, float beta2, float eps, int step, const float *grad_scale, halo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1032,3 +1032,27 @@ def test_fused_lm_head_cross_entropy_matches_the_two_step_path(mode, M, V, K):
             assert none_lse is None and none_logits is None and torch.equal(loss2, loss)
     finally:
         _lib.set_math_mode(prev)
+
+
+def test_adamw_multi_is_bit_identical_to_per_tensor_launches():
+    """One launch over a parameter list (chunk table, ragged sizes, a tensor smaller than a chunk, one not a multiple of 4) against
+    halo_adamw per tensor: identical bits after three steps, with a gradient scale."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 3072), (50304, 16), (768,), (3,), (16384 * 2 + 5,), (130, 7)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    wds = [0.1 if len(s) >= 2 else 0.0 for s in shapes]
+    ref_p = [p.detach().clone() for p in params]
+    ref_m = [torch.zeros_like(p) for p in ref_p]; ref_v = [torch.zeros_like(p) for p in ref_p]
+    opt = ops.AdamWMulti(params, wds, lr=3e-3, betas=(0.9, 0.95), eps=1e-8)
+    scale = torch.tensor([0.5], device='cuda')
+    for step in range(1, 4):
+        grads = [torch.randn(*s, generator=g).cuda() for s in shapes]
+        for p, gr in zip(params, grads):
+            p.grad = gr
+        opt.step(grad_scale=scale)
+        for rp, rm, rv, gr, wd in zip(ref_p, ref_m, ref_v, grads, wds):
+            ops.adamw(rp.view(-1), gr.view(-1), rm.view(-1), rv.view(-1), 3e-3, 0.9, 0.95, 1e-8, wd, step, grad_scale=scale)
+    for p, rp, m, rm, v, rv in zip(params, ref_p, opt.m, ref_m, opt.v, ref_v):
+        assert torch.equal(p.detach(), rp) and torch.equal(m, rm) and torch.equal(v, rv)
