@@ -425,6 +425,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 // F.layer_norm fused with the operand-image pass of the GEMM that consumes it: one wave per row normalises the row (fp32,
 // biased variance) and writes it straight into the tiled hi|lo image (and, optionally, as fp32 rows for the backward), so the
 // normalised activations are not written and re-read once more just to be split.  C % 32 == 0 (whole k-tiles).
+// MAXG > 0: the row (C <= 512 * MAXG) is held in registers -- one pass over x instead of three.  MAXG == 0: any C, three passes.
+template <int MAXG>
 __global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                               const float *__restrict__ b, float *__restrict__ y, char *__restrict__ img,
                                                               int rows, int C, float eps, int with_lo) {
@@ -432,6 +434,68 @@ __global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__res
     if (row >= rows) return;
     const float *xr = x + (long)row * C;
     const int groups = C / 8, KT = C / TK;
+    const int rt = row / TR, rin = row % TR;
+    auto emit = [&](int g, const f32x4 &a, const f32x4 &c, float mean, float rstd) {
+        float wv[8], bv[8];
+        if (MAXG > 0) {                                           // weight / bias 16-byte aligned (checked by the launcher)
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + 8 * g), w1 = *reinterpret_cast<const f32x4 *>(w + 8 * g + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wv[e] = w0[e]; wv[4 + e] = w1[e]; }
+            if (b) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b + 8 * g), b1 = *reinterpret_cast<const f32x4 *>(b + 8 * g + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { wv[e] = w[8 * g + e]; bv[e] = b ? b[8 * g + e] : 0.f; }
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (a[e] - mean) * rstd * wv[e];
+            o[4 + e] = (c[e] - mean) * rstd * wv[4 + e];
+        }
+        if (b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += bv[e];
+        }
+        if (y) {
+            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+        bf16x8 hi, lo;
+        split8(o, hi, lo);
+        char *blk = img + ((long)rt * KT + (8 * g) / TK) * BLOCK_BYTES;
+        const int off = swz_byte(rin, ((8 * g) % TK) / 8);
+        *reinterpret_cast<bf16x8 *>(blk + off) = hi;
+        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+    };
+    if (MAXG > 0) {
+        f32x4 ra[MAXG > 0 ? MAXG : 1], rc[MAXG > 0 ? MAXG : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k) {
+            const int g = lane + 64 * k;
+            const bool in = g < groups;
+            ra[k] = in ? *reinterpret_cast<const f32x4 *>(xr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rc[k] = in ? *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (ra[k][0] + ra[k][1]) + (ra[k][2] + ra[k][3]) + (rc[k][0] + rc[k][1]) + (rc[k][2] + rc[k][3]);
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k)
+            if (lane + 64 * k < groups) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d0 = ra[k][e] - mean, d1 = rc[k][e] - mean; v += d0 * d0 + d1 * d1; }
+            }
+        const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k)
+            if (lane + 64 * k < groups) emit(lane + 64 * k, ra[k], rc[k], mean, rstd);
+        return;
+    }
     float s = 0.f;
     for (int g = lane; g < groups; g += 64) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 8 * g), c = *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4);
@@ -445,26 +509,9 @@ __global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__res
         for (int e = 0; e < 4; ++e) { const float d0 = a[e] - mean, d1 = c[e] - mean; v += d0 * d0 + d1 * d1; }
     }
     const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
-    const int rt = row / TR, rin = row % TR;
     for (int g = lane; g < groups; g += 64) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 8 * g), c = *reinterpret_cast<const f32x4 *>(xr + 8 * g + 4);
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[e] = (a[e] - mean) * rstd * w[8 * g + e];
-            o[4 + e] = (c[e] - mean) * rstd * w[8 * g + 4 + e];
-            if (b) { o[e] += b[8 * g + e]; o[4 + e] += b[8 * g + 4 + e]; }
-        }
-        if (y) {
-            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g) = f32x4{o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x4 *>(y + (long)row * C + 8 * g + 4) = f32x4{o[4], o[5], o[6], o[7]};
-        }
-        bf16x8 hi, lo;
-        split8(o, hi, lo);
-        char *blk = img + ((long)rt * KT + (8 * g) / TK) * BLOCK_BYTES;
-        const int off = swz_byte(rin, ((8 * g) % TK) / 8);
-        *reinterpret_cast<bf16x8 *>(blk + off) = hi;
-        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;
+        emit(g, a, c, mean, rstd);
     }
 }
 
@@ -684,8 +731,12 @@ int halo_layernorm_image(const float *x, const float *weight, const float *bias,
                          halo_stream_t stream) {
     HALO_CHECK_ARG(x && weight && image && rows > 0 && C > 0 && C % TK == 0);
     HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)image | (uintptr_t)y) % 16 == 0);
-    hipLaunchKernelGGL(layernorm_image_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image,
-                       rows, C, eps, halo_math_mode() != HALO_MATH_BF16);
+    const int with_lo = halo_math_mode() != HALO_MATH_BF16;
+    const bool vec = (((uintptr_t)weight | (uintptr_t)bias) % 16) == 0;       // the row-in-registers variants load w / b as float4
+    const dim3 grid((rows + 3) / 4);
+    if (vec && C <= 1024) hipLaunchKernelGGL(layernorm_image_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
+    else if (vec && C <= 2048) hipLaunchKernelGGL(layernorm_image_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
+    else hipLaunchKernelGGL(layernorm_image_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
     return halo_launch_status();
 }
 
