@@ -45,9 +45,8 @@ def lstm_step_algorithmic_bytes(B):
 
 
 def build_model(device, seed=42):
-    from haloop_amd import rnn, recognizer
-    from oracle import cpu_ref            # only for the shared deterministic init + synthetic batch
-    enc_p, rec_p = cpu_ref.make_params(F, C_SUB, H, L, V, seed)
+    from haloop_amd import rnn, recognizer, synth
+    enc_p, rec_p = synth.make_params(F, C_SUB, H, L, V, seed)
     enc = rnn.Encoder(F, C_SUB, H, num_layers=L)
     rec = recognizer.TemporalClassifier(H, V)
     enc.load_state_dict(enc_p)
@@ -165,15 +164,14 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=device)
 
-    from haloop_amd import _lib
+    from haloop_amd import _lib, synth
     from haloop_amd.train import LstmCtcTrainer
-    from oracle import cpu_ref
     _lib.lib()                                              # loud failure if the HIP library is absent
     _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
     trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph)
-    x, il, tg, tl = (t.to(device) for t in cpu_ref.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
+    x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
     for _ in range(args.warmup):
         trainer.step(x, il, tg, tl)

@@ -301,3 +301,19 @@ def test_symbol_tape_restatement_on_the_reference_demo():
     assert tape[2][:, 2].tolist() == [43, 44, 45, 46, 47]
     x, y = tape_ref.get_batch(np.arange(100, 200, dtype=np.uint16), [0, 90], 8)
     assert x[1].tolist() == list(range(190, 198)) and y[1].tolist() == list(range(191, 198)) + [0]
+
+
+def test_product_side_synthetic_generators_match_the_oracle_side():
+    """haloop_amd/synth.py (what bench.py's measured legs use) and the oracle's generators (what the parity tests use) must draw
+    the same tensors from the same seeds."""
+    from haloop_amd import synth
+    from oracle import cpu_ref, gpt_ref
+    for (a, b) in zip(synth.make_params(12, 16, 32, 2, 9, 5), cpu_ref.make_params(12, 16, 32, 2, 9, 5)):
+        assert list(a) == list(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for a, b in zip(synth.synthetic_batch(4, 41, 12, 9, 4, 7), cpu_ref.synthetic_batch(4, 41, 12, 9, 4, 7)):
+        assert torch.equal(a, b)
+    for pad in (True, False):
+        for a, b in zip(synth.synthetic_tokens(3, 24, 61, 9, pad_tail=pad), gpt_ref.synthetic_tokens(3, 24, 61, 9, pad_tail=pad)):
+            assert torch.equal(a, b)

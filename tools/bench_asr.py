@@ -2,7 +2,8 @@
 """BASELINE config 5 shape: encoder-decoder attention ASR (`transformer:32`: 12+12 layers, 8x64 heads; ha/init.py:234-239)
 on 80-frame x 80-mel utterances: encoder forward, CTC-head beam decode (beam 16, ha.beam semantics), attention greedy
 decode (fp16 KV caches).  Prints utterances/s per stage and the WER of the HIP hypotheses against the CPU oracle's
-(own edit distance) on a small sample, with the oracle timed on the host cores."""
+(own edit distance) on a small sample, with the oracle timed on the host cores.  The oracle (oracle/transformer_ref.py) is used
+here as the checker, as the CPU baseline and for its seeded parameter / batch generators; none of the timed HIP stages calls it."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

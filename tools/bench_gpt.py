@@ -14,8 +14,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from haloop_amd import _lib, attention, ops
-from oracle import gpt_ref
+from haloop_amd import _lib, attention, ops, synth
 
 MFMA_BF16_PEAK = 2500.0     # TFLOP/s dense bf16, MI355X_MICROARCH.md
 _lib.lib(); _lib.lend_scratch(256 << 20)
@@ -26,7 +25,7 @@ torch.manual_seed(0)
 model = attention.GPT(cfg).cuda().eval()
 with torch.no_grad():                                     # the reference's init zeroes wpe; give it content
     model.transformer.wpe.weight.normal_(0, 0.02)
-inputs, targets = gpt_ref.synthetic_tokens(B, T, cfg.vocab_size, 3, pad_tail=False)
+inputs, targets = synth.synthetic_tokens(B, T, cfg.vocab_size, 3, pad_tail=False)
 inputs_d, targets_d = inputs.cuda(), targets.cuda()
 
 
@@ -98,6 +97,7 @@ res = {
 }
 
 if '--no-cpu-baseline' not in sys.argv:
+    from oracle import gpt_ref                            # the checker and the CPU baseline: nothing above touches oracle/
     # nats/token parity and the CPU baseline on ONE sequence (the oracle = stock torch CPU ops = what the reference runs on CPU)
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     cpu_p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
