@@ -67,10 +67,26 @@ def _event_ms(fn, reps=3):
     return best
 
 
-def time_dominant_kernel(device, math, iters=200):
+def _graph_event_ms(fn, reps=3):
+    """fn's launches replayed from a HIP graph (the way the training step issues them), timed with HIP events on the replay stream."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    return _event_ms(graph.replay, reps)
+
+
+def time_dominant_kernel(device, math, iters=200, use_graph=True):
     """Average duration of one fused LSTM forward step launch (H=1024, B=64): HIP events on the launch
-    stream around a 1-layer, T=`iters` halo_lstm_fwd call, minus the same call's non-step work (its
-    input-projection GEMM and operand preparation, timed on their own with the same entry points)."""
+    stream around a 1-layer, T=`iters` halo_lstm_fwd call -- replayed from a HIP graph, as the training step runs its step
+    chain -- minus the same call's non-step work (its input-projection GEMM and operand preparation, timed on their own with
+    the same entry points)."""
     from haloop_amd import ops
     g = torch.Generator().manual_seed(0)
     x = torch.randn(iters, B_PER_GPU, H, generator=g).to(device) * 0.1
@@ -78,7 +94,7 @@ def time_dominant_kernel(device, math, iters=200):
     b = [torch.zeros(4 * H, device=device)]
     ops.lstm_fwd(x, w, w, b, b)
     torch.cuda.synchronize()
-    full_ms = _event_ms(lambda: ops.lstm_fwd(x, w, w, b, b))
+    full_ms = (_graph_event_ms if use_graph else _event_ms)(lambda: ops.lstm_fwd(x, w, w, b, b))
     xs = x.view(-1, H)
     out = torch.empty(xs.shape[0], 4 * H, device=device)
     if math != 'f32':
@@ -196,7 +212,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B_PER_GPU * args.steps / elapsed
-        step_ms = time_dominant_kernel(device, args.math)
+        step_ms = time_dominant_kernel(device, args.math, use_graph=not args.no_graph)
         kbytes = lstm_step_algorithmic_bytes(B_PER_GPU)
         achieved = kbytes / (step_ms * 1e-3) / 1e9
         traffic = None
