@@ -22,6 +22,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
 template <int HD>
 struct Img {
     static constexpr int ROWB = HD * 2 + 16;           // row stride in bytes (multiple of 16)
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
             qrow[g] = q0 + 16 * g + lr;
             const float *qp = qb + (long)min(qrow[g], Tq - 1) * a.q_rs;
     #pragma unroll
-            for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale, qh[g][ks], ql[g][ks]);
+            for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale * LOG2E, qh[g][ks], ql[g][ks]);   // scores in log2 units: exp is one v_exp_f32
     #pragma unroll
             for (int m = 0; m < HD / 16; ++m) o[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
             mrow[g] = -INFINITY; lsum[g] = 0.f;
@@ -188,14 +190,14 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
                 mx = rows4_max(mx);
                 const float mnew = fmaxf(mrow[g], mx);
                 const float msafe = mnew == -INFINITY ? 0.f : mnew;
-                const float alpha = __expf(mrow[g] - msafe);       // exp(-inf) = 0 on the first tile
+                const float alpha = __builtin_amdgcn_exp2f(mrow[g] - msafe);   // 2^(-inf) = 0 on the first tile
                 mrow[g] = mnew;
                 float ps = 0.f;
     #pragma unroll
                 for (int n = 0; n < 4; ++n)
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        sacc[g][n][r] = __expf(sacc[g][n][r] - msafe);
+                        sacc[g][n][r] = __builtin_amdgcn_exp2f(sacc[g][n][r] - msafe);
                         ps += sacc[g][n][r];
                     }
                 lsum[g] = lsum[g] * alpha + ps;                    // the normaliser keeps the undropped sum
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m)
                     *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[g][m][0] * inv, o[g][m][1] * inv, o[g][m][2] * inv, o[g][m][3] * inv};
-                if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mrow[g] + logf(lrow);
+                if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mrow[g] * LN2 + logf(lrow);
             }
         }
     }
