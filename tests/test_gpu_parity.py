@@ -1056,3 +1056,31 @@ def test_adamw_multi_is_bit_identical_to_per_tensor_launches():
             ops.adamw(rp.view(-1), gr.view(-1), rm.view(-1), rv.view(-1), 3e-3, 0.9, 0.95, 1e-8, wd, step, grad_scale=scale)
     for p, rp, m, rm, v, rv in zip(params, ref_p, opt.m, ref_m, opt.v, ref_v):
         assert torch.equal(p.detach(), rp) and torch.equal(m, rm) and torch.equal(v, rv)
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(4100, 3200, 96), (4096, 3072, 32), (3000, 4500, 200)])
+def test_split_gemm_many_tiles_ring_variants(mode, M, N, K):
+    """Products with >= 768 output tiles take the single-slot three-pass ring (three workgroups per CU) and the lean epilogue
+    instantiations: plain, bias + residual-add, and GELU (full epilogue) variants against an fp64 product, ragged edges included."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        a = torch.randn(M, K, generator=g).cuda(); b = torch.randn(N, K, generator=g).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).cuda()
+        ai, bi = ops.split_image(a), ops.split_image(b)
+        ref = a.double() @ b.double().t()
+        tol = (3e-5 if mode == 'bf16x3' else 2e-2) * float(ref.abs().max())
+        out = ops.gemm_split(ai, bi, M, N, K)
+        assert float((out.double() - ref).abs().max()) <= tol
+        out = ops.gemm_split(ai, bi, M, N, K, out=res.clone(), bias1=bias, accumulate=True)
+        assert float((out.double() - (ref + bias.double() + res.double())).abs().max()) <= tol
+        out = ops.gemm_split(ai, bi, M, N, K, bias1=bias, gelu=True)
+        want = torch.nn.functional.gelu((ref + bias.double()).float(), approximate='tanh').double()
+        assert float((out.double() - want).abs().max()) <= tol
+    finally:
+        _lib.set_math_mode(prev)
