@@ -1084,3 +1084,26 @@ def test_split_gemm_many_tiles_ring_variants(mode, M, N, K):
         assert float((out.double() - want).abs().max()) <= tol
     finally:
         _lib.set_math_mode(prev)
+
+
+def test_adamw_multi_more_tensors_than_one_launch_carries():
+    """300 small parameters: AdamWMulti splits them into launches of at most 256 tensors; still bit-identical to halo_adamw."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    shapes = [(5 + i % 7, 3 + i % 5) if i % 3 else (17 + i,) for i in range(300)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    wds = [0.05 if len(s) >= 2 else 0.0 for s in shapes]
+    ref_p = [p.detach().clone() for p in params]
+    ref_m = [torch.zeros_like(p) for p in ref_p]; ref_v = [torch.zeros_like(p) for p in ref_p]
+    opt = ops.AdamWMulti(params, wds, lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    assert len(opt.groups) == 2
+    for step in range(1, 3):
+        grads = [torch.randn(*s, generator=g).cuda() for s in shapes]
+        for p, gr in zip(params, grads):
+            p.grad = gr
+        opt.step()
+        for rp, rm, rv, gr, wd in zip(ref_p, ref_m, ref_v, grads, wds):
+            ops.adamw(rp.view(-1), gr.view(-1), rm.view(-1), rv.view(-1), 1e-2, 0.9, 0.99, 1e-8, wd, step)
+    for p, rp in zip(params, ref_p):
+        assert torch.equal(p.detach(), rp)
