@@ -583,6 +583,14 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
                                   const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
                                   hipStream_t st);
 
+// both operand images of src [R][C] from one read: image_rm = halo_prep_tiles(src, R, C, ld, 0), image_tr = halo_prep_tiles(src, C, R, ld, 1)
+int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void *image_tr, hipStream_t st) {
+    PairArgs p = {};
+    p.src = src; p.ld = ld; p.R = R; p.C = C;
+    p.img_rm = (char *)image_rm; p.img_tr = (char *)image_tr;
+    return launch_image_pair(p, PAIR_COPY, st);
+}
+
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
     return gemm_bf16x3_tiled_impl(Aimg, Bimg, M, N, K, C, ldc, bias1, bias2, relu, drop, nullptr, st);

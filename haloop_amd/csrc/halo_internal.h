@@ -12,6 +12,7 @@ int halo_colsum2(const float *x, int rows, int cols, int ld, float *out, float *
 size_t halo_tiled_image_bytes(int R, int K);
 // image <- split/tiled copy of logical X[R][K]; src_transposed: memory is [K][R] (leading dim ld)
 int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, void *image, hipStream_t st);
+int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void *image_tr, hipStream_t st);   // both images, one read
 // C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);

@@ -1186,7 +1186,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         // (1) critical path, main stream: the gradient w.r.t. this layer's input feeds layer l-1's steps
         if (need_din) {
             if (tiled) {
-                HALO_TRY(halo_prep_tiles(lb.gates, T * B, 4 * H, 4 * H, 0, img_g, st));           // dG [TB][4H]
+                // dG [TB][4H] for this product and dG^T [4H][TB] for the two weight-gradient products below, from one read
+                HALO_TRY(halo_prep_pair(lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT, st));
                 HALO_TRY(halo_prep_tiles(w_ih[l], in_dim, 4 * H, in_dim, 1, img_wT, st));         // W_ih^T [in][4H]
                 HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
                                                 &ddrop, st));
@@ -1205,7 +1206,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         halo_set_scratch_slot(1);
         int rc = HALO_OK;
         if (tiled) {
-            rc = halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, side);                       // dG^T [4H][TB]
+            if (!need_din) rc = halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, side);        // dG^T [4H][TB] (else: built with dG above)
             if (!rc) rc = halo_prep_tiles(lb.h, H, T * B, H, 1, img_hT, side);                          // h_prev^T [H][TB]
             if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
             if (!rc) rc = halo_prep_tiles(in, in_dim, T * B, in_dim, 1, img_inT, side);                 // in^T [in][TB]
