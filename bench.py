@@ -3,33 +3,72 @@
 
 Workload: 2-layer H=1024 LSTM-CTC ("LC-2x1024"), 64 utterances of 80 frames x
 80 mels per GPU, char vocab 32, dropout 0.2 on, full step = forward + CTC loss + backward +
-encoder-only clip + AdamW (ha/loop.py:176-196).  Synthetic inputs resident in HBM; fp32 arithmetic
-on the exact-f32 MFMA.
+encoder-only clip + AdamW (ha/loop.py:176-196).  Synthetic inputs resident in HBM.  Arithmetic of the
+headline number: `bf16x3` -- every dense operand split x = hi + lo (two bf16), three bf16 MFMAs per
+product, fp32 accumulate, fp32 state / gates / CTC / optimizer; it meets the fp32 parity tolerances of
+tests/test_gpu_parity.py.  The exact-f32-MFMA step (`f32_mode`) and the single-pass bf16 step
+(`bf16_mode`) are reported beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+With --gpus N > 1 and no torch.distributed environment, this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything here has
+touched the GPU) and forwards its JSON line and exit code; under torchrun it is one of the N ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- the dominant kernel (the fused LSTM step) against the HBM roof, duration measured
-                  here with HIP events on the launch stream;
+  roofline     -- the dominant kernel (the recurrent chain of one LSTM layer's backward: one persistent
+                  launch, or T' step launches on the fallback path) against the HBM roof; bytes follow
+                  SURVEY.md 8d (parameters once per pass + per-step activations), duration measured
+                  here with HIP events recorded by the library on the launch stream;
   cpu_baseline -- the CPU restatement of the reference path (oracle/, kind "port") timed on this
-                  box's host cores on a bounded sample of the same workload.
+                  box's host cores on a bounded sample of the same workload (B=64, and B=4 = config 1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 B_PER_GPU, T, F, C_SUB, H, L, V, S = 64, 80, 80, 128, 1024, 2, 32, 10
 T_SUB = (T + 6 - 5) // 4 + 1   # 21
+MATH_DTYPE = {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)', 'bf16': 'bf16'}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the inference / bf16_mode / f32_mode legs')
+    ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16x3',
+                    help="arithmetic of the dense products: 'f32' and 'bf16x3' meet the fp32 parity tolerances; 'bf16' rounds the "
+                         "operands to bf16")
+    ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
+                    help='wire format of the data-parallel gradient all-reduce (N > 1)')
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: run the N ranks as a child job.  Nothing in this process has initialised HIP (torch is not
+    even imported yet), so no GPU state is inherited and no exec of a GPU-holding process happens."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def algorithmic_step_bytes(B):
@@ -38,10 +77,14 @@ def algorithmic_step_bytes(B):
     return 10 * 4 * P + 2_120_000 * B
 
 
-def lstm_step_algorithmic_bytes(B):
-    """Bytes one fused LSTM step launch must move (fp32): W_hh [4H,H] read; h_{t-1}, c_{t-1} read;
-    gate pre-activations [B,4H] read and activated gates written; h_t, c_t written."""
-    return 4 * (4 * H * H + 2 * B * H + 2 * B * 4 * H + 2 * B * H)
+def chain_algorithmic_bytes(B, direction):
+    """Bytes ONE layer's recurrent chain must move over its T' steps, SURVEY.md 8d accounting: the recurrent weight matrix
+    once per pass, plus per step and utterance the fp32 activations that enter or leave the chain.
+    forward : W_hh [4H,H]; per step: gate pre-activations in [4H], activated gates out [4H], c_t out [H], h_t out [H]
+    backward: W_hh^T;      per step: activated gates in [4H], c_t in [H] (c_{t-1} is the same array), dh from above in [H],
+                           gate gradients out [4H]"""
+    per_step = (4 * H + 4 * H + H + H) if direction == 'fwd' else (4 * H + H + H + 4 * H)
+    return 4 * (4 * H * H) + 4 * T_SUB * B * per_step
 
 
 def build_model(device, seed=42):
@@ -54,60 +97,42 @@ def build_model(device, seed=42):
     return enc.to(device).train(), rec.to(device).train(), (enc_p, rec_p)
 
 
-def _event_ms(fn, reps=3):
-    best = None
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1)
-        best = t if best is None else min(best, t)
-    return best
-
-
-def _graph_event_ms(fn, reps=3):
-    """fn's launches replayed from a HIP graph (the way the training step issues them), timed with HIP events on the replay stream."""
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        fn()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        fn()
-    graph.replay()
-    torch.cuda.synchronize()
-    return _event_ms(graph.replay, reps)
-
-
-def time_dominant_kernel(device, math, iters=200, use_graph=True):
-    """Average duration of one fused LSTM forward step launch (H=1024, B=64): HIP events on the launch
-    stream around a 1-layer, T=`iters` halo_lstm_fwd call -- replayed from a HIP graph, as the training step runs its step
-    chain -- minus the same call's non-step work (its input-projection GEMM and operand preparation, timed on their own with
-    the same entry points)."""
-    from haloop_amd import ops
+def time_chain(device, direction, reps=20):
+    """Average duration of the dominant kernel: the recurrent chain of one H=1024, B=64, T'=21 layer.  The library records
+    two HIP events on its launch stream right around the chain (halo_lstm_chain_events), so the batched GEMMs and operand
+    preparation of the same call are outside the bracket.  Returns (microseconds per chain, launches per chain, kernel name)."""
+    import torch
+    from haloop_amd import _lib, ops
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(iters, B_PER_GPU, H, generator=g).to(device) * 0.1
+    x = (torch.randn(T_SUB, B_PER_GPU, H, generator=g) * 0.1).to(device)
     w = [(torch.rand(4 * H, H, generator=g) - 0.5).mul(0.06).to(device)]
     b = [torch.zeros(4 * H, device=device)]
-    ops.lstm_fwd(x, w, w, b, b)
+    dy = (torch.randn(B_PER_GPU, T_SUB, H, generator=g) * 0.01).to(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
     torch.cuda.synchronize()
-    full_ms = (_graph_event_ms if use_graph else _event_ms)(lambda: ops.lstm_fwd(x, w, w, b, b))
-    xs = x.view(-1, H)
-    out = torch.empty(xs.shape[0], 4 * H, device=device)
-    if math != 'f32':
-        ai, bi = ops.split_image(xs), ops.split_image(w[0])
-        other_ms = (_event_ms(lambda: ops.split_image(xs)) + _event_ms(lambda: ops.split_image(w[0])) +
-                    _event_ms(lambda: ops.gemm_split(ai, bi, xs.shape[0], 4 * H, H, out=out, bias1=b[0], bias2=b[0])))
-    else:
-        other_ms = _event_ms(lambda: ops.gemm(xs, w[0], True, True, xs.shape[0], 4 * H, H, out=out, bias1=b[0], bias2=b[0]))
-    return max(full_ms - other_ms, 1e-6) / iters
+    grads = {k: [torch.zeros_like(w[0])] for k in ('dw_ih', 'dw_hh')}
+    grads.update({k: [torch.zeros_like(b[0])] for k in ('db_ih', 'db_hh')})
+    total, n = 0.0, 0
+    for i in range(reps + 3):
+        if direction == 'fwd':
+            _lib.lstm_chain_events(e0, e1)
+        y, _, _, reserve = ops.lstm_fwd(x, w, w, b, b, y_strides=None, y_relu=False)
+        if direction == 'bwd':
+            _lib.lstm_chain_events(e0, e1)
+            ops.lstm_bwd(x, w, w, dy, (H, T_SUB * H), False, reserve, grads=grads)
+        _lib.lstm_chain_events(None, None)
+        torch.cuda.synchronize()
+        if i >= 3:
+            total += e0.elapsed_time(e1)
+            n += 1
+    info = _lib.lstm_chain_info(direction)
+    return 1e3 * total / n, info['launches'], info['kernel']
 
 
 def time_inference(enc, rec, x, steps):
     """Second half of the metric: forward-only + greedy decode, eval mode."""
+    import torch
     from haloop_amd.infer import LstmCtcRecognizer
     was_training = enc.training
     reco = LstmCtcRecognizer(enc, rec)
@@ -117,12 +142,33 @@ def time_inference(enc, rec, x, steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        reco.recognize(x)
+        reco.recognize(x, clone=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     enc.train(was_training); rec.train(was_training)
     return {'metric': 'utterances/sec, forward + greedy CTC decode (eval)', 'value': round(steps * x.shape[0] / dt, 1),
             'unit': 'utterances/s', 'ms_per_batch': round(1e3 * dt / steps, 4), 'batch': x.shape[0]}
+
+
+def time_other_mode(mode, device, batch, warmup, steps, use_graph):
+    """The same training step in another arithmetic mode (own model + trainer, same seeds and batch)."""
+    import torch
+    from haloop_amd import _lib
+    from haloop_amd.train import LstmCtcTrainer
+    _lib.set_math_mode(mode)
+    enc, rec, _ = build_model(device)
+    tr = LstmCtcTrainer(enc, rec, seed=1337, use_graph=use_graph, alias_loss=True)
+    for _ in range(warmup):
+        tr.step(*batch)
+    b2 = tr.static_inputs() or batch
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(*b2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    return {'value': round(B_PER_GPU * steps / dt, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt / steps, 4),
+            'dtype': MATH_DTYPE[mode], 'final_loss': round(tr.loss.item(), 5), 'steps_trained': warmup + steps}
 
 
 def host_cores():
@@ -137,12 +183,12 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('HALO_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(params, budget_s=20.0):
+def _cpu_leg(params, B, budget_s, max_steps):
+    import torch
     from oracle import cpu_ref
     enc_p, rec_p = params
-    torch.set_num_threads(host_cores())
     tr = cpu_ref.Trainer(enc_p, rec_p)
-    x, il, tg, tl = cpu_ref.synthetic_batch(B_PER_GPU, T, F, V, S, 42)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F, V, S, 42)
     for _ in range(2):
         tr.step(x, il, tg, tl, p_torch=0.2)
     n, t0 = 0, time.perf_counter()
@@ -150,30 +196,50 @@ def cpu_baseline(params, budget_s=20.0):
         tr.step(x, il, tg, tl, p_torch=0.2)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 200:
+        if dt >= budget_s or n >= max_steps:
             break
-    return {'value': round(n * B_PER_GPU / dt, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': f'{n} training steps of the same B={B_PER_GPU} workload '
-                                      f'(stock torch CPU ops: conv1d, nn.LSTM kernel, ctc_loss, clip, AdamW), {dt:.1f} s'}
+    return n, dt
+
+
+def cpu_baseline(params):
+    """The oracle's Trainer (stock torch CPU ops = what the reference runs on CPU, ha/loop.py:176-196) on this box's host cores:
+    the bench workload (B=64) and BASELINE config 1 (B=4)."""
+    import torch
+    torch.set_num_threads(host_cores())
+    n64, dt64 = _cpu_leg(params, B_PER_GPU, 16.0, 200)
+    n4, dt4 = _cpu_leg(params, 4, 8.0, 400)
+    return {'value': round(n64 * B_PER_GPU / dt64, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n64} training steps of the same B={B_PER_GPU} workload (stock torch CPU ops: conv1d, nn.LSTM kernel, '
+                      f'ctc_loss, clip, AdamW), {dt64:.1f} s',
+            'config1_b4': {'value': round(n4 * 4 / dt4, 2), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt4 / n4, 2),
+                           'sample': f'{n4} training steps at B=4 (BASELINE.json configs[0]), {dt4:.1f} s'}}
+
+
+def read_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py writes the
+    file from the FETCH_SIZE / WRITE_SIZE CSVs with the guide's gfx950 corrections); null unless it is for THIS kernel."""
+    tpath = os.path.join(ROOT, 'profiles', 'lstm_chain_traffic.json')
+    if not os.path.exists(tpath):
+        return None
+    for rec in json.load(open(tpath)).get('kernels', []):
+        if rec.get('kernel') and (rec['kernel'] in kernel_name or kernel_name in rec['kernel']):
+            return rec.get('hbm_bytes_per_launch')
+    return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16x3',
-                    help="arithmetic of the dense products: 'f32' and 'bf16x3' meet the fp32 parity tolerances; 'bf16' rounds the "
-                         "batched-GEMM operands to bf16 (the recurrent step keeps the split form)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     if world > 1:
@@ -186,7 +252,7 @@ def main():
     _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
-    trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph)
+    trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True)
     x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
     for _ in range(args.warmup):
@@ -203,61 +269,62 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_ranks_seen = 1
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                                # every rank that really took part adds one
+        n_ranks_seen = int(ones.item())
     loss = trainer.loss.item()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B_PER_GPU * args.steps / elapsed
-        step_ms = time_dominant_kernel(device, args.math, use_graph=not args.no_graph)
-        kbytes = lstm_step_algorithmic_bytes(B_PER_GPU)
-        achieved = kbytes / (step_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'lstm_step_traffic.json')
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        step_bytes = algorithmic_step_bytes(B_PER_GPU)
         out = {
             'metric': 'utterances/sec, LSTM-CTC training step (fwd + CTC loss + bwd + clip + AdamW)',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.math == 'bf16' else 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': MATH_DTYPE[args.math], 'data': 'synthetic',
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math},
+                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math,
+                       'grad_allreduce_dtype': args.grad_dtype if world > 1 else None},
+            'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
-            'roofline': {'bound': 'hbm', 'kernel': 'lstm_step_fwd_kernel (H=1024, B=64), 42 launches per step; the backward twin runs within 10%',
-                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': kbytes, 'avg_launch_us': round(step_ms * 1e3, 3)},
-            'step_roofline': {'algorithmic_bytes_per_step': algorithmic_step_bytes(B_PER_GPU),
-                              'achieved_GBs': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9, 1),
-                              'frac_of_hbm_peak': round(algorithmic_step_bytes(B_PER_GPU) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
+                              'achieved_GBs': round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              'frac_of_hbm_peak': round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              'note': 'whole training step against SURVEY.md 8d bytes(B) = 10*4*P + 2.12e6*B'},
         }
         if world == 1:
+            # dominant kernel: the backward recurrent chain (2 per step); the forward twin beside it
+            us_b, launches_b, name_b = time_chain(device, 'bwd')
+            us_f, launches_f, name_f = time_chain(device, 'fwd')
+            kb, kf = chain_algorithmic_bytes(B_PER_GPU, 'bwd'), chain_algorithmic_bytes(B_PER_GPU, 'fwd')
+            ach = kb / launches_b / (us_b / launches_b * 1e-6) / 1e9
+            out['roofline'] = {
+                'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': L,
+                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                'traffic': read_traffic(name_b),
+                'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
+                'accounting': 'SURVEY.md 8d: W_hh^T once per pass + per step the fp32 activations entering/leaving the chain '
+                              '(gates in, c in, dh in, gate gradients out), divided over the launches of the chain',
+                'share_of_step': round(L * us_b * 1e-3 / ms_per_step, 3),
+                'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
+                                 'algorithmic_bytes_per_launch': kf // launches_f,
+                                 'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
+                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': read_traffic(name_f),
+                                 'share_of_step': round(L * us_f * 1e-3 / ms_per_step, 3)}}
+        if world == 1 and not args.no_extras:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
-        if world == 1 and args.math != 'bf16':
-            # the same step with every dense operand rounded to bf16 (the reference's autocast arithmetic on GPUs,
-            # ha/loop.py:125); parity at the bf16-MFMA tolerance of SURVEY.md 8d (loss rel <= 2e-2, tests/test_gpu_parity.py)
-            _lib.set_math_mode('bf16')
-            enc2, rec2, _ = build_model(device)
-            tr2 = LstmCtcTrainer(enc2, rec2, seed=1337, use_graph=not args.no_graph)
-            for _ in range(args.warmup):
-                tr2.step(x, il, tg, tl)
-            x2, il2, tg2, tl2 = tr2.static_inputs() or (x, il, tg, tl)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
             n2 = max(20, args.steps // 2)
-            for _ in range(n2):
-                tr2.step(x2, il2, tg2, tl2)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            out['bf16_mode'] = {'value': round(B_PER_GPU * n2 / dt2, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt2 / n2, 4),
-                                'dtype': 'bf16', 'final_loss': round(tr2.loss.item(), 5), 'steps_trained': args.warmup + n2,
-                                'note': 'same step, operands of the dense products rounded to bf16 (--math bf16)'}
+            for mode in ('bf16', 'f32'):
+                if mode != args.math:
+                    out[mode + '_mode'] = time_other_mode(mode, device, (x, il, tg, tl), args.warmup, n2, not args.no_graph)
             _lib.set_math_mode(args.math)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(params)

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 6
+HALO_ABI_VERSION = 7
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -52,6 +52,11 @@ SIGNATURES = {
     'halo_lstm_bwd_workspace_bytes': (_sz, [_i] * 5),
     'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
     'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
+    'halo_set_lstm_persistent': (_i, [_i]),
+    'halo_lstm_persistent_eligible': (_i, [_i, _i]),
+    'halo_lstm_status_offset': (_sz, [_i] * 6),
+    'halo_lstm_chain_events': (_i, [_vp, _vp]),
+    'halo_lstm_chain_info': (_i, [_i, C.POINTER(_i), C.c_char_p, _i]),
     'halo_log_softmax_fwd': (_i, [_vp, _vp, _i, _i, _vp]),
     'halo_log_softmax_bwd': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'halo_colsum': (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -95,6 +100,11 @@ SIGNATURES = {
     'halo_tape_batch': (_i, [_vp, _i, _l, _i, _i, _l, _i, _l, _vp, _vp]),
     'halo_lm_batch_u16': (_i, [_vp, _l, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'halo_scale_add': (_i, [_vp, _vp, _f, _f, _sz, _vp]),
+    'halo_cast_f32_bf16': (_i, [_vp, _vp, _sz, _vp]),
+    'halo_cast_bf16_f32': (_i, [_vp, _vp, _f, _sz, _vp]),
+    'halo_scale_add_guarded': (_i, [_vp, _vp, _f, _f, _sz, _vp, _vp]),
+    'halo_clip_coef_step': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp]),
+    'halo_adamw_ranges_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw_multi_tensor_bytes': (_sz, []),
@@ -148,6 +158,26 @@ def set_math_mode(mode):
 def set_lstm_fusion(on):
     """Layer-diagonal fused schedule for multi-layer LSTMs (off by default; see include/halo.h)."""
     check(lib().halo_set_lstm_fusion(int(bool(on))), 'halo_set_lstm_fusion')
+
+
+def set_lstm_persistent(on):
+    """Weight-resident persistent LSTM recurrence (one launch per layer and direction) on / off (include/halo.h)."""
+    check(lib().halo_set_lstm_persistent(int(bool(on))), 'halo_set_lstm_persistent')
+
+
+def lstm_chain_events(ev_begin, ev_end):
+    """Measurement hook (include/halo.h): torch.cuda.Events (already recorded once, so their handles exist) that the library
+    records around every LSTM recurrent chain; (None, None) clears."""
+    h0 = None if ev_begin is None else ev_begin.cuda_event
+    h1 = None if ev_end is None else ev_end.cuda_event
+    check(lib().halo_lstm_chain_events(h0, h1), 'halo_lstm_chain_events')
+
+
+def lstm_chain_info(direction):
+    n = _i(0)
+    buf = C.create_string_buffer(128)
+    check(lib().halo_lstm_chain_info(1 if direction == 'bwd' else 0, C.byref(n), buf, 128), 'halo_lstm_chain_info')
+    return {'launches': n.value, 'kernel': buf.value.decode()}
 
 
 _mode = None       # the library's arithmetic mode, mirrored here: it only changes through set_math_mode, and the Linear helpers

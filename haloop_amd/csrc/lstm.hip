@@ -21,8 +21,10 @@
 // epilogue next to the row-major copy that the batched GEMMs consume.
 // Row-major buffers are time-major: h/c [T+1,B,H], gates [T,B,4H].
 #include <stdlib.h>
+#include <string.h>
 #include "halo_common.h"
 #include "halo_internal.h"
+#include "lstm_persist.h"
 
 namespace {
 
@@ -835,6 +837,18 @@ inline unsigned pack_grid(size_t units) {
     return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
+// ---- measurement hook (halo_lstm_chain_events): two events recorded on the launch stream right around a layer's recurrent
+// chain, so a caller can time the chain without the batched GEMMs / operand preparation of the same call ----
+hipEvent_t g_chain_ev0 = nullptr, g_chain_ev1 = nullptr;
+struct ChainInfo { int launches; const char *kernel; };
+ChainInfo g_chain_info[2] = {{0, ""}, {0, ""}};      // [0] forward, [1] backward: what the last chain ran as
+inline void chain_begin(hipStream_t st) { if (g_chain_ev0) (void)hipEventRecord(g_chain_ev0, st); }
+inline void chain_end(hipStream_t st, int dir, int launches, const char *kernel) {
+    if (g_chain_ev1) (void)hipEventRecord(g_chain_ev1, st);
+    g_chain_info[dir].launches = launches;
+    g_chain_info[dir].kernel = kernel;
+}
+
 #define HALO_TRY(expr)            \
     do {                          \
         int rc_ = (expr);         \
@@ -1002,28 +1016,67 @@ int lstm_bwd_fused_chain(const float *const *w_ih, const float *const *w_hh, con
     return HALO_OK;
 }
 
+// reserve = [ ... as laid out above ... | epoch words of the persistent recurrence (PERSIST_FLAG_BYTES, 256-byte aligned) ]
+inline size_t reserve_flags_offset(int T, int B, int in0, int H, int L) {
+    const int kin = in0 > H ? in0 : H;
+    const size_t n = ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float) +
+                     halo_tiled_image_bytes(T * B, kin) + halo_tiled_image_bytes(4 * H, kin) +
+                     (L >= 2 ? fused_fwd_extra_floats(T, B, H, L) * sizeof(float) : 0);
+    return (n + 255) & ~(size_t)255;
+}
+// workspace of the backward = [ W_hh^T | dc carry | din | packed gate-gradient images | tiled images | fused extra | epoch words ]
+inline int bwd_dg_images(int T) { return T > 2 ? T : 2; }     // the persistent recurrence writes one image per time step
+inline size_t bwd_flags_offset(int T, int B, int in0, int H, int L) {
+    const int kin = in0 > H ? in0 : H;
+    const size_t n = ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + (size_t)bwd_dg_images(T) * bt16(B) * 4 * H) * sizeof(float) +
+                     halo_tiled_image_bytes(4 * H, T * B) + halo_tiled_image_bytes(T * B, 4 * H) +
+                     2 * halo_tiled_image_bytes(kin, T * B) + halo_tiled_image_bytes(kin, 4 * H) +
+                     (L >= 2 ? (size_t)L * fused_bwd_layer_floats(B, H) * sizeof(float) : 0);
+    return (n + 255) & ~(size_t)255;
+}
+
 }  // namespace
 
 extern "C" {
 
+int halo_lstm_chain_events(void *ev_begin, void *ev_end) {
+    g_chain_ev0 = (hipEvent_t)ev_begin;
+    g_chain_ev1 = (hipEvent_t)ev_end;
+    return HALO_OK;
+}
+
+int halo_lstm_chain_info(int backward, int *launches, char *kernel, int kernel_len) {
+    const ChainInfo &ci = g_chain_info[backward ? 1 : 0];
+    if (launches) *launches = ci.launches;
+    if (kernel && kernel_len > 0) {
+        strncpy(kernel, ci.kernel, (size_t)kernel_len - 1);
+        kernel[kernel_len - 1] = 0;
+    }
+    return HALO_OK;
+}
 
 size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
-    const int kin = in0 > H ? in0 : H;
-    return ((size_t)4 * H * H + (size_t)L * layer_floats(T, B, H)) * sizeof(float) +
-           halo_tiled_image_bytes(T * B, kin) + halo_tiled_image_bytes(4 * H, kin) +
-           (L >= 2 ? fused_fwd_extra_floats(T, B, H, L) * sizeof(float) : 0);
+    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES;
+}
+
+int halo_set_lstm_persistent(int on) {
+    halo_lstm_persist_enable(on);
+    return HALO_OK;
+}
+
+int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B, H) && use_x3(H) ? 1 : 0; }
+
+size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L) {
+    if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
+    return backward ? bwd_flags_offset(T, B, in0, H, L) : reserve_flags_offset(T, B, in0, H, L);
 }
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
-        // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H]
-    // + two packed gate-gradient images [BT16, 4H] + tiled images for the batched gradient GEMMs
-    const int kin = in0 > H ? in0 : H;
-    return ((size_t)H * 4 * H + (size_t)B * H + (size_t)T * B * H + 2 * bt16(B) * 4 * H) * sizeof(float) +
-           halo_tiled_image_bytes(4 * H, T * B) + halo_tiled_image_bytes(T * B, 4 * H) +
-           2 * halo_tiled_image_bytes(kin, T * B) + halo_tiled_image_bytes(kin, 4 * H) +
-           (L >= 2 ? (size_t)L * fused_bwd_layer_floats(B, H) * sizeof(float) : 0);
+    // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H] + packed gate-gradient images
+    // [BT16, 4H] (one per time step) + tiled images for the batched gradient GEMMs + epoch words
+    return bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES;
 }
 
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
@@ -1074,6 +1127,26 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
         // one launch: packed h_{-1}, row-major h_{-1} and c_{-1} (zeros when no initial state is given)
         HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st, lb.h, c0 ? c0 + (size_t)l * BH : nullptr, lb.c));
         const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
+        if (x3 && halo_lstm_persist_ok(B, H)) {
+            // ONE launch for all T steps: W_hh stays in registers, h_t is handed between workgroups (lstm_persist.hip)
+            PersistFwd a;
+            a.wp = (const char *)wp;
+            a.hp = (char *)lb.hp;
+            a.gates = lb.gates; a.h = lb.h; a.c = lb.c;
+            a.T = T; a.B = B; a.H = H;
+            a.drop = dc;
+            if (last && y) { a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y_relu ? Y_RELU : Y_PLAIN; }
+            else if (drop_out) { a.y = lb.ydrop; a.y_stride_t = (long)BH; a.y_stride_b = H; a.y_mode = Y_DROPOUT; }
+            else { a.y = nullptr; a.y_stride_t = 0; a.y_stride_b = 0; a.y_mode = Y_NONE; }
+            a.flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
+            chain_begin(st);
+            HALO_TRY(halo_lstm_persist_fwd(a, st));
+            chain_end(st, 0, 1, "lstm_persist_fwd_kernel");
+            if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
+            if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
+            continue;
+        }
+        chain_begin(st);
         for (int t = 0; t < T; ++t) {
             StepFwdArgs a;
             a.hp_prev = lb.hp + (size_t)t * PH;
@@ -1099,6 +1172,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             }
             HALO_TRY(launch_step_fwd(a, x3, st));
         }
+        chain_end(st, 0, T, "lstm_step_fwd_kernel");
         if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
         if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
     }
@@ -1118,17 +1192,16 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H;
     const bool x3 = use_x3(H);
-    hipStream_t side;
-    hipEvent_t fork_ev, join_ev;
-    HALO_TRY(halo_side_stream(&side, &fork_ev, &join_ev));
-    static const bool use_side = getenv("HALO_SIDE_STREAM") && atoi(getenv("HALO_SIDE_STREAM")) != 0;
-    if (!use_side) side = st;
+    // The weight-gradient GEMMs run on the call's own stream.  (Forking them onto a side stream beside the next layer's step chain
+    // was measured slower -- the chain is fetch-bound and any co-runner stretches it, DESIGN.md section 3 -- and shared the
+    // operand-image workspace across layers without a per-layer join; the option is gone.)
+    hipStream_t side = st;
     float *wpT = workspace;
     float *dcarry = wpT + (size_t)H * 4 * H;
     float *din = dcarry + BH;          // [T,B,H] gradient w.r.t. the current layer's input
-    float *dgp = din + (size_t)T * BH; // two packed gate-gradient images, ping-pong
+    float *dgp = din + (size_t)T * BH; // packed gate-gradient images: ping-pong for the step launches, one per step otherwise
     const int kin = in0 > H ? in0 : H;
-    char *img_gT = (char *)(dgp + 2 * PG);
+    char *img_gT = (char *)(dgp + (size_t)bwd_dg_images(T) * PG);
     char *img_g = img_gT + halo_tiled_image_bytes(4 * H, T * B);
     char *img_hT = img_g + halo_tiled_image_bytes(T * B, 4 * H);
     char *img_inT = img_hT + halo_tiled_image_bytes(kin, T * B);
@@ -1145,7 +1218,24 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
         if (!fused) HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
-        for (int t = T - 1; t >= 0 && !fused; --t) {
+        const bool persist = !fused && x3 && halo_lstm_persist_ok(B, H);
+        if (persist) {
+            PersistBwd a;
+            a.wpT = (const char *)wpT;
+            a.dgp = (char *)dgp;
+            a.gates = lb.gates; a.c = lb.c; a.dc = dcarry;
+            if (last) { a.dy = dy; a.dy_stride_t = y_stride_t; a.dy_stride_b = y_stride_b; a.dy_relu = y_relu; }
+            else { a.dy = din; a.dy_stride_t = (long)BH; a.dy_stride_b = H; a.dy_relu = 0; }
+            a.dhinit = dhn ? dhn + (size_t)l * BH : nullptr;
+            a.dcinit = dcn ? dcn + (size_t)l * BH : nullptr;
+            a.flags = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L));
+            a.T = T; a.B = B; a.H = H;
+            chain_begin(st);
+            HALO_TRY(halo_lstm_persist_bwd(a, st));
+            chain_end(st, 1, 1, "lstm_persist_bwd_kernel");
+        }
+        if (!fused && !persist) chain_begin(st);
+        for (int t = T - 1; t >= 0 && !fused && !persist; --t) {
             StepBwdArgs a;
             a.dgp_next = (t == T - 1) ? nullptr : dgp + (size_t)((t + 1) & 1) * PG;
             a.dgp_out = dgp + (size_t)(t & 1) * PG;
@@ -1169,6 +1259,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.B = B; a.H = H;
             HALO_TRY(launch_step_bwd(a, x3, st));
         }
+        if (!fused && !persist) chain_end(st, 1, T, "lstm_step_bwd_kernel");
         // parameter gradients over all frames at once
         const float *in;
         int in_dim;
@@ -1197,13 +1288,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                                        HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0), offset, offset_dev, stream));
             }
         }
-        // (2) off the critical path, side stream: this layer's parameter gradients run beside the next
-        //     layer's (latency-bound) step chain.  Fork after the steps, join at the end of the call.
-        if (side != st) {
-            HALO_CHECK_ARG(hipEventRecord(fork_ev, st) == hipSuccess);
-            HALO_CHECK_ARG(hipStreamWaitEvent(side, fork_ev, 0) == hipSuccess);
-        }
-        halo_set_scratch_slot(1);
+        // (2) this layer's parameter gradients
         int rc = HALO_OK;
         if (tiled) {
             if (!need_din) rc = halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, side);        // dG^T [4H][TB] (else: built with dG above)
@@ -1221,12 +1306,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                                         nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
         }
         if (!rc) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
-        halo_set_scratch_slot(0);
         if (rc) return rc;
-    }
-    if (side != st) {
-        HALO_CHECK_ARG(hipEventRecord(join_ev, side) == hipSuccess);
-        HALO_CHECK_ARG(hipStreamWaitEvent(st, join_ev, 0) == hipSuccess);
     }
     return HALO_OK;
 }

@@ -1,0 +1,41 @@
+// Host-side interface of the weight-resident persistent LSTM recurrence (lstm_persist.hip); not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "halo_common.h"
+
+constexpr int PERSIST_FLAG_HEADER = 16;                  // words: [0] abort / timeout word, rest reserved
+constexpr int PERSIST_MAX_BLOCKS = 256;                  // one epoch word per workgroup
+constexpr size_t PERSIST_FLAG_BYTES = (size_t)(PERSIST_FLAG_HEADER + PERSIST_MAX_BLOCKS) * sizeof(unsigned);   // multiple of 16
+
+struct PersistFwd {
+    const char *wp;      // packed W_hh: tile (jt*4 + gate), H/32 k-blocks of 2 KiB (hi | lo), lstm.hip Packed<true>
+    char *hp;            // packed h images [T+1][ceil(B/16)][H/32] blocks; image 0 = initial state, image t+1 written by step t
+    float *gates;        // [T][B][4H] in: x W_ih^T + b_ih + b_hh ; out: activated i,f,g,o
+    float *h;            // [T+1][B][H] row-major, row 0 = initial state (read by the weight-gradient GEMM)
+    float *c;            // [T+1][B][H]
+    float *y;            // optional second output of h_t (next layer's input / features), may be NULL with y_mode 0
+    long y_stride_t, y_stride_b;
+    int y_mode;          // 0 none, 1 plain, 2 relu, 3 dropout
+    DropoutCfg drop;
+    unsigned *flags;     // PERSIST_FLAG_BYTES, zeroed by the launcher
+    int T, B, H;
+};
+
+struct PersistBwd {
+    const char *wpT;     // packed W_hh^T: tile jt, 4H/32 k-blocks
+    char *dgp;           // packed gate-gradient images [T][ceil(B/16)][4H/32] blocks; image t written by the step of time t
+    float *gates;        // [T][B][4H] in: activated gates ; out: gradients w.r.t. the pre-activations
+    const float *c;      // [T+1][B][H]
+    float *dc;           // [B][H] final cell-gradient carry (may be NULL)
+    const float *dy;     // gradient arriving from above, dy[t*stride_t + b*stride_b + j], may be NULL
+    long dy_stride_t, dy_stride_b;
+    int dy_relu;
+    const float *dhinit, *dcinit;   // [B][H] added at t = T-1, may be NULL
+    unsigned *flags;
+    int T, B, H;
+};
+
+bool halo_lstm_persist_ok(int B, int H);        // shape, arithmetic mode, CU count, switch
+void halo_lstm_persist_enable(int on);
+int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st);
+int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st);

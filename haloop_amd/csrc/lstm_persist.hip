@@ -1,0 +1,480 @@
+// Weight-resident persistent LSTM recurrence for gfx950 ("step-fused persistent LSTM"; replaces the
+// T dependent step launches of one nn.LSTM layer, ha/rnn.py:25, by ONE launch per layer and direction).
+//
+// Decomposition.  Workgroup (jt, bt) owns hidden units [16 jt, 16 jt + 16) of batch rows [16 bt, 16 bt + 16): the same
+// 16 x 16 x 4-gate tile as the step kernels of lstm.hip, so (H/16) x ceil(B/16) workgroups (256 at H=1024, B=64: one per
+// CU).  What is new is that the workgroup lives for all T steps and keeps its slice of the recurrent matrix IN REGISTERS:
+// 64 gate rows x H (forward) or 16 columns x 4H (backward) as split bf16 hi|lo MFMA fragments = 256 KiB at H=1024, i.e.
+// 128 VGPRs in each of 8 waves (wave w holds the k-blocks of K-eighth w).  W_hh is therefore read from HBM once per
+// pass instead of once per time step (SURVEY.md 8d counts parameters once per pass), and a step moves only activations.
+//
+// The recurrence couples workgroups: step t needs ALL hidden units of h_{t-1} (forward) / all 4H gate gradients of step
+// t+1 (backward) -- but only of the workgroup's own 16 batch rows.  So the exchange is not chip-wide: the (H/16) workgroups
+// of one batch tile form a group (64 workgroups at H=1024), and block ids are mapped so that a group sits on as few XCDs
+// as the dispatcher's round-robin allows (speed only).  Hand-off protocol (cdna_hip_programming.md Guideline 16, recipe
+// R1, and MI355X_MICROARCH.md "Valid forms", first table row): the producer writes its piece of the packed operand image
+// of step t with 16-byte WRITE-THROUGH (sc1) stores, every storing wave drains them (s_waitcnt vmcnt(0)), then ONE lane
+// stores the workgroup's epoch word (agent-scope relaxed atomic store = sc1); a consumer polls its group's epoch words
+// with one 64-lane sc1 load (lane l reads producer l's word), joins a workgroup barrier, and then every wave reads its
+// fragments with sc1 buffer loads straight into registers (they bypass the CU's L1, so no acquire fence is needed).
+// Images of different steps are different buffers and epochs only grow, so nothing is ever overwritten while it may
+// still be read.  Every spin is bounded by the 100 MHz real-time counter: on a timeout the workgroup raises the abort
+// word and leaves, its peers time out the same way, the grid drains (the host reads the word: halo_lstm_persist_status).
+// All workgroups must be co-resident: the host launches at most one workgroup per CU (the LDS request forces 1/CU).
+#include <stdlib.h>
+#include "halo_common.h"
+#include "halo_internal.h"
+#include "lstm_persist.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NWAVE = 8;
+constexpr unsigned long long SPIN_TIMEOUT_TICKS = 20000000ull;   // 0.2 s of the 100 MHz s_memrealtime counter
+
+enum YMode { Y_NONE = 0, Y_PLAIN = 1, Y_RELU = 2, Y_DROPOUT = 3 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+// 16-byte write-through / L1-bypassing accesses (aux 16 = sc1)
+__device__ __forceinline__ bf16x8 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, bf16x8 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
+
+// block id -> (hidden tile, batch tile).  Blocks b and b + 8 share an XCD under the dispatcher's round-robin: when the number
+// of batch tiles divides 8, group g takes the XCD labels [g * 8/NBT, (g + 1) * 8/NBT).  Any placement is CORRECT; this one
+// keeps a group's 64 KB .. 256 KB per-step exchange inside one or two L2s.
+__device__ __forceinline__ void map_block(int bid, int nblocks, int NJ, int NBT, int &jt, int &bt) {
+    if (NBT <= 8 && 8 % NBT == 0 && nblocks % 8 == 0) {
+        const int per = 8 / NBT, x = bid & 7;
+        bt = x / per;
+        jt = (bid >> 3) * per + (x % per);
+    } else {
+        jt = bid / NBT;
+        bt = bid % NBT;
+    }
+}
+
+// wait until every producer of this batch group has published epoch >= need; one wave calls it, result is wave-uniform
+__device__ __forceinline__ bool poll_group(const unsigned *grp_flags, int NJ, unsigned need, int lane) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = lane < NJ ? __hip_atomic_load(grp_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        if (__all(v >= need)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) return false;
+    }
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void split8(const float *x, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+
+// ================================================================================================================
+// forward
+// ================================================================================================================
+// KBW: k-blocks (32 deep) per wave = H / 256.  ONE: single-pass bf16 (only the hi halves are held and multiplied).
+template <int KBW, bool ONE>
+__global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistFwd p) {
+    __shared__ float red[NWAVE][4][256];     // partial gate sums of the 8 K-slices
+    __shared__ __attribute__((aligned(16))) float hbuf[16][16];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, T = p.T;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb = H / 32;
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
+    const int j0 = jt * 16;
+
+    // this wave's slice of W_hh: gates 0..3, k-blocks [wave*KBW, wave*KBW + KBW)
+    bf16x8 wh[4][KBW], wl[4][KBW];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            const char *src = p.wp + (((long)jt * 4 + g) * nkb + wave * KBW + i) * 2048 + lane * 16;
+            wh[g][i] = *reinterpret_cast<const bf16x8 *>(src);
+            if (!ONE) wl[g][i] = *reinterpret_cast<const bf16x8 *>(src + 1024);
+        }
+
+    const int ci = tid >> 4, cj = tid & 15;             // cell threads: tid < 256 -> (batch row, hidden unit) of the tile
+    const int b = bt * 16 + ci;
+    const bool cell = tid < 256 && b < B;
+    const long BH = (long)B * H;
+    const long e0 = (long)b * H + j0 + cj;
+    float cst = cell ? p.c[e0] : 0.f;                   // c_{t-1}, carried in a register for the whole sequence
+    float gin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gin[g] = p.gates[(long)b * 4 * H + (long)g * H + j0 + cj];
+    }
+    const __amdgpu_buffer_rsrc_t hp_rsrc = make_rsrc(p.hp);
+    unsigned *grp_flags = p.flags + PERSIST_FLAG_HEADER + bt * NJ;
+    if (tid == 0) s_abort = 0;
+
+    for (int t = 0; t < T; ++t) {
+        // ---- image t (= h_{t-1}) complete? ----
+        if (t > 0 && wave == 5) {
+            if (!poll_group(grp_flags, NJ, (unsigned)t, lane) && lane == 0) {
+                s_abort = 1;
+                __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        lds_barrier();                                                             // (A)
+        if (s_abort) return;
+        // ---- this wave's fragments of the group's h_{t-1} tile, L1-bypassing ----
+        const int img = (int)((((long)t * NBT + bt) * nkb + wave * KBW) * 2048) + lane * 16;
+        bf16x8 ah[KBW], al[KBW];
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            ah[i] = load_sc1(hp_rsrc, img + i * 2048);
+            if (!ONE) al[i] = load_sc1(hp_rsrc, img + i * 2048 + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // every fragment load is in flight before the first MFMA waits
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!ONE) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], wh[g][i], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wl[g][i], acc[g], 0, 0, 0);
+                }
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wh[g][i], acc[g], 0, 0, 0);
+            }
+        }
+        {   // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + reg (batch row)
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave][g][(4 * q + e) * 16 + r] = acc[g][e];
+        }
+        lds_barrier();                                                             // (B)
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
+        if (tid < 256) {
+            if (cell) {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NWAVE; ++k) s += red[k][g][tid];
+                    pre[g] = s + gin[g];
+                }
+                ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+                cst = fg * cst + ig * gg;
+                h = og * tanhf(cst);
+            }
+            hbuf[ci][cj] = h;                            // rows >= B: zeros
+        }
+        lds_barrier();                                                             // (C)
+        if (wave == 4) {
+            // packed image of h_t: this tile is k-groups (2 (jt & 1)) and (2 (jt & 1) + 1) of k-block jt / 2, hi part | lo part
+            const int part = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = hbuf[row][kg * 8 + e];
+            bf16x8 hi, lo;
+            split8(x, hi, lo);
+            const int dst = (int)((((long)(t + 1) * NBT + bt) * nkb + (jt >> 1)) * 2048) + part * 1024 +
+                            (((jt & 1) * 2 + kg) * 16 + row) * 16;
+            store_sc1(hp_rsrc, dst, part ? lo : hi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
+            if (lane == 0) __hip_atomic_store(grp_flags + jt, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cell) {
+            float *gp = p.gates + ((long)t * B + b) * 4 * H + j0 + cj;
+            gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
+            p.c[(long)(t + 1) * BH + e0] = cst;
+            p.h[(long)(t + 1) * BH + e0] = h;
+            if (p.y_mode != Y_NONE) {
+                float v = h;
+                if (p.y_mode == Y_RELU) v = fmaxf(h, 0.f);
+                else if (p.y_mode == Y_DROPOUT) v = h * dropout_mult(p.drop, (uint64_t)t * BH + (uint64_t)e0);
+                p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = v;
+            }
+            if (t + 1 < T) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gin[g] = p.gates[((long)(t + 1) * B + b) * 4 * H + (long)g * H + j0 + cj];
+            }
+        }
+    }
+}
+
+// ================================================================================================================
+// backward
+// ================================================================================================================
+// KC: chunks of 4 k-blocks per wave = (4H / 32 / 8) / 4 = H / 256.
+template <int KC, bool ONE>
+__global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistBwd p) {
+    __shared__ float red[NWAVE][256];
+    __shared__ __attribute__((aligned(16))) float dgbuf[4][16][16];
+    __shared__ int s_abort;
+    __shared__ unsigned s_published;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, T = p.T, K = 4 * H;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb4 = K / 32;
+    constexpr int KBW = 4 * KC;                           // k-blocks per wave
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
+    const int j0 = jt * 16;
+
+    // this wave's slice of W_hh^T: columns j0..j0+15, k-blocks [wave*KBW, wave*KBW + KBW) of the 4H-deep contraction
+    bf16x8 wh[KBW], wl[KBW];
+#pragma unroll
+    for (int i = 0; i < KBW; ++i) {
+        const char *src = p.wpT + ((long)jt * nkb4 + wave * KBW + i) * 2048 + lane * 16;
+        wh[i] = *reinterpret_cast<const bf16x8 *>(src);
+        if (!ONE) wl[i] = *reinterpret_cast<const bf16x8 *>(src + 1024);
+    }
+
+    const int ci = tid >> 4, cj = tid & 15;
+    const int b = bt * 16 + ci;
+    const bool cell = tid < 256 && b < B;
+    const long BH = (long)B * H;
+    const long e0 = (long)b * H + j0 + cj;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cprev = 0.f, dyv = 0.f, dcarry = 0.f, dh0 = 0.f;
+    if (cell) {
+        const int t = T - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = p.gates[((long)t * B + b) * K + (long)g * H + j0 + cj];
+        cc = p.c[(long)(t + 1) * BH + e0];
+        cprev = p.c[(long)t * BH + e0];
+        if (p.dy) dyv = p.dy[(long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+        if (p.dcinit) dcarry = p.dcinit[e0];
+        if (p.dhinit) dh0 = p.dhinit[e0];
+    }
+    const __amdgpu_buffer_rsrc_t dg_rsrc = make_rsrc(p.dgp);
+    unsigned *grp_flags = p.flags + PERSIST_FLAG_HEADER + bt * NJ;
+    if (tid == 0) { s_abort = 0; s_published = 0; }
+
+    for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            // ---- image t+1 (gate gradients of the step done before) complete? ----
+            if (wave == 7) {
+                if (!poll_group(grp_flags, NJ, (unsigned)s, lane) && lane == 0) {
+                    s_abort = 1;
+                    __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            lds_barrier();                                                         // (A)
+            if (s_abort) return;
+            const int img = (int)((((long)(t + 1) * NBT + bt) * nkb4 + wave * KBW) * 2048) + lane * 16;
+            bf16x8 ah[2][4], al[2][4];
+            auto load4 = [&](int buf, int c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[buf][i] = load_sc1(dg_rsrc, img + (c * 4 + i) * 2048);
+                    if (!ONE) al[buf][i] = load_sc1(dg_rsrc, img + (c * 4 + i) * 2048 + 1024);
+                }
+            };
+            auto mma4 = [&](int buf, int c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!ONE) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[buf][i], wh[c * 4 + i], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], wl[c * 4 + i], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], wh[c * 4 + i], acc, 0, 0, 0);
+                }
+            };
+            load4(0, 0);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) load4((c + 1) & 1, c + 1);
+                __builtin_amdgcn_sched_barrier(0);       // the next chunk's loads are issued before this chunk's MFMAs wait
+                mma4(c & 1, c);
+            }
+        } else {
+            lds_barrier();
+        }
+        {
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
+        }
+        lds_barrier();                                                             // (B)
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 256) {
+            if (cell) {
+                float dh = s == 0 ? dh0 : 0.f;
+                if (s > 0) {
+#pragma unroll
+                    for (int k = 0; k < NWAVE; ++k) dh += red[k][tid];
+                }
+                const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+                const float tc = tanhf(cc);
+                if (p.dy) {
+                    float d = dyv;
+                    if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
+                    dh += d;
+                }
+                const float dcc = dcarry + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc;
+                const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
+                dcarry = dcc * fg;
+                dg[0] = d_i * ig * (1.f - ig);
+                dg[1] = d_f * fg * (1.f - fg);
+                dg[2] = d_g * (1.f - gg * gg);
+                dg[3] = d_o * og * (1.f - og);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgbuf[g][ci][cj] = dg[g];
+        }
+        lds_barrier();                                                             // (C)
+        if (tid >= 256) {
+            // packed image of dG_t: gate g's columns j0..j0+15 are k-groups (2 (jt & 1)), (2 (jt & 1) + 1) of k-block g H/32 + jt/2
+            const int u = tid - 256;
+            const int g = u >> 6, part = (u >> 5) & 1, kg = (u >> 4) & 1, row = u & 15;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = dgbuf[g][row][kg * 8 + e];
+            bf16x8 hi, lo;
+            split8(x, hi, lo);
+            const int dst = (int)((((long)t * NBT + bt) * nkb4 + g * (H / 32) + (jt >> 1)) * 2048) + part * 1024 +
+                            (((jt & 1) * 2 + kg) * 16 + row) * 16;
+            store_sc1(dg_rsrc, dst, part ? lo : hi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the last of the four storing waves to get here signals for the workgroup (counter in LDS: Guideline 16)
+            if (lane == 0) {
+                const unsigned old = atomicAdd(&s_published, 1u);
+                if (old == 4u * (unsigned)s + 3u)
+                    __hip_atomic_store(grp_flags + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (cell) {
+            float *gp = p.gates + ((long)t * B + b) * K + j0 + cj;
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
+            if (t > 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv[g] = p.gates[((long)(t - 1) * B + b) * K + (long)g * H + j0 + cj];
+                cc = cprev;
+                cprev = p.c[(long)(t - 1) * BH + e0];
+                if (p.dy) dyv = p.dy[(long)(t - 1) * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+            }
+        }
+    }
+    if (cell && p.dc) p.dc[e0] = dcarry;
+}
+
+int g_cu_count = 0;
+int g_persist_enabled = 1;
+
+inline int cu_count() {
+    if (!g_cu_count) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
+        else g_cu_count = -1;
+    }
+    return g_cu_count;
+}
+
+constexpr size_t FORCE_ONE_PER_CU_LDS = 64 * 1024;    // dynamic LDS request on top of the static arrays: one workgroup per CU
+
+template <typename K, typename A>
+int launch_persist(K kernel, const A &a, int blocks, hipStream_t st) {
+    static_assert(sizeof(A) <= 4096, "kernel arguments");
+    if (hipMemsetAsync(a.flags, 0, PERSIST_FLAG_BYTES, st) != hipSuccess) return HALO_ELAUNCH;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), FORCE_ONE_PER_CU_LDS, st, a);
+    return halo_launch_status();
+}
+
+template <typename K>
+int allow_lds(K kernel) {
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FORCE_ONE_PER_CU_LDS) == hipSuccess
+               ? HALO_OK : HALO_ELAUNCH;
+}
+
+}  // namespace
+
+void halo_lstm_persist_enable(int on) { g_persist_enabled = on ? 1 : 0; }
+
+bool halo_lstm_persist_ok(int B, int H) {
+    static const bool env_off = getenv("HALO_LSTM_PERSIST") && atoi(getenv("HALO_LSTM_PERSIST")) == 0;
+    if (env_off || !g_persist_enabled) return false;
+    if (halo_math_mode() == HALO_MATH_F32) return false;
+    if (H % 256 != 0 || H > 1024 || B <= 0) return false;
+    const int blocks = (H / 16) * ((B + 15) / 16);
+    return blocks <= cu_count();
+}
+
+int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st) {
+    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
+    const bool one = halo_math_mode() == HALO_MATH_BF16;
+    static bool attr = false;
+    if (!attr) {
+        int rc = allow_lds(lstm_persist_fwd_kernel<1, false>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<2, false>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<3, false>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<4, false>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<1, true>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<2, true>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<3, true>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<4, true>);
+        if (rc) return rc;
+        attr = true;
+    }
+    switch ((a.H / 256) * 2 + (one ? 1 : 0)) {
+        case 2: return launch_persist(lstm_persist_fwd_kernel<1, false>, a, blocks, st);
+        case 3: return launch_persist(lstm_persist_fwd_kernel<1, true>, a, blocks, st);
+        case 4: return launch_persist(lstm_persist_fwd_kernel<2, false>, a, blocks, st);
+        case 5: return launch_persist(lstm_persist_fwd_kernel<2, true>, a, blocks, st);
+        case 6: return launch_persist(lstm_persist_fwd_kernel<3, false>, a, blocks, st);
+        case 7: return launch_persist(lstm_persist_fwd_kernel<3, true>, a, blocks, st);
+        case 8: return launch_persist(lstm_persist_fwd_kernel<4, false>, a, blocks, st);
+        case 9: return launch_persist(lstm_persist_fwd_kernel<4, true>, a, blocks, st);
+        default: return HALO_ENOTSUP;
+    }
+}
+
+int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st) {
+    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
+    const bool one = halo_math_mode() == HALO_MATH_BF16;
+    static bool attr = false;
+    if (!attr) {
+        int rc = allow_lds(lstm_persist_bwd_kernel<1, false>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<2, false>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<3, false>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<4, false>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<1, true>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<2, true>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<3, true>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<4, true>);
+        if (rc) return rc;
+        attr = true;
+    }
+    switch ((a.H / 256) * 2 + (one ? 1 : 0)) {
+        case 2: return launch_persist(lstm_persist_bwd_kernel<1, false>, a, blocks, st);
+        case 3: return launch_persist(lstm_persist_bwd_kernel<1, true>, a, blocks, st);
+        case 4: return launch_persist(lstm_persist_bwd_kernel<2, false>, a, blocks, st);
+        case 5: return launch_persist(lstm_persist_bwd_kernel<2, true>, a, blocks, st);
+        case 6: return launch_persist(lstm_persist_bwd_kernel<3, false>, a, blocks, st);
+        case 7: return launch_persist(lstm_persist_bwd_kernel<3, true>, a, blocks, st);
+        case 8: return launch_persist(lstm_persist_bwd_kernel<4, false>, a, blocks, st);
+        case 9: return launch_persist(lstm_persist_bwd_kernel<4, true>, a, blocks, st);
+        default: return HALO_ENOTSUP;
+    }
+}

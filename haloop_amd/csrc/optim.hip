@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
 }
 
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ partials, int count, float max_norm,
-                                                        float *coef, float *norm_out) {
+                                                        float *coef, float *norm_out, uint32_t *applied_steps) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict_
         coef[0] = finite ? (c > 1.0f ? 1.0f : c) : NAN;
         coef[1] = finite ? 1.0f : NAN;
         if (norm_out) *norm_out = norm;
+        if (applied_steps && finite) *applied_steps += 1u;      // the Adam step count advances only with an applied update
     }
 }
 
@@ -113,11 +114,20 @@ struct AdamRangesArgs {
     int n_ranges;
     float beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps;
     uint32_t *counter;
+    const uint32_t *step_dev;     // optional: 1-based update count on the device (halo_clip_coef_step); overrides step_size / bc2_sqrt
+    float lr, beta1;
 };
 
 __global__ __launch_bounds__(256) void adamw_ranges_kernel(const AdamRangesArgs a) {
     f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);
+    float step_size = a.step_size, bc2_sqrt = a.bc2_sqrt;
+    if (a.step_dev) {
+        // the same scalar preparation as the host path (double, like torch's python-side bias corrections), from the device counter
+        const double t = (double)max(*a.step_dev, 1u);
+        step_size = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+    }
     for (int r = 0; r < a.n_ranges; ++r) {
         const float gs = a.grad_scale[r] ? *a.grad_scale[r] : 1.0f;
         if (gs != gs) continue;                                   // NaN scale: this range's update is skipped
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(const AdamRangesArgs 
             for (int e = 0; e < 4; ++e) {
                 const float ge = a.grad_scale[r] ? g[e] * gs : g[e];
                 float pe = p[e], me = m[e], ve = v[e];
-                adam_update(pe, me, ve, ge, decay_mul, a.beta1_w, a.beta2, a.beta2_w, a.step_size, a.bc2_sqrt, a.eps);
+                adam_update(pe, me, ve, ge, decay_mul, a.beta1_w, a.beta2, a.beta2_w, step_size, bc2_sqrt, a.eps);
                 p[e] = pe; m[e] = me; v[e] = ve;
             }
             p4[i] = p; m4[i] = m; v4[i] = v;
@@ -146,7 +156,7 @@ struct AdamTensor {      // static per parameter: lives in a device table built 
     float *m;
     float *v;
     unsigned long long n;
-    float decay_mul;     // 1 - lr*wd of this tensor
+    float weight_decay;  // of this tensor; the decay factor 1 - lr*wd is formed in the kernel from the CURRENT lr
     int pad;
 };
 constexpr unsigned ADAM_CHUNK = 16384;
@@ -156,17 +166,18 @@ constexpr int ADAM_MULTI_MAX = 256;
 struct AdamGrads { const float *g[ADAM_MULTI_MAX]; };
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor *__restrict__ tensors, const uint2 *__restrict__ chunks,
-                                                          const AdamGrads grads, float beta1_w, float beta2, float beta2_w,
+                                                          const AdamGrads grads, float lr, float beta1_w, float beta2, float beta2_w,
                                                           float step_size, float bc2_sqrt, float eps,
                                                           const float *__restrict__ grad_scale) {
     const float gs = grad_scale ? *grad_scale : 1.0f;
     if (gs != gs) return;   // NaN scale: skip this update entirely
     const uint2 c = chunks[blockIdx.x];
     const AdamTensor t = tensors[c.x];
+    const float decay_mul = (float)(1.0 - (double)lr * (double)t.weight_decay);      // as halo_adamw forms it on the host
     const float *tg = grads.g[c.x];
     const size_t begin = (size_t)c.y * ADAM_CHUNK, end = min(begin + (size_t)ADAM_CHUNK, (size_t)t.n);
     auto update = [&](float &pe, float &me, float &ve, float g) {
-        adam_update(pe, me, ve, grad_scale ? g * gs : g, t.decay_mul, beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps);
+        adam_update(pe, me, ve, grad_scale ? g * gs : g, decay_mul, beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps);
     };
     const bool vec = (((uintptr_t)t.p | (uintptr_t)tg | (uintptr_t)t.m | (uintptr_t)t.v) % 16) == 0;
     size_t done = begin;
@@ -197,29 +208,84 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor *__re
 }  // namespace
 
 namespace {
-// y = alpha * y + beta * x : gradient accumulation over micro-batches (ha/loop.py:176-181: loss / accumulate, backward, ...)
+// y = alpha * y + beta * x : gradient accumulation over micro-batches (ha/loop.py:176-181: loss / accumulate, backward, ...).
+// alpha == 0 never reads y (0 * NaN would keep a poisoned sum alive: the first micro-step of a cycle must be a plain scaled copy);
+// guard != NULL with a non-finite *guard drops x's contribution: the reference skips a micro-batch whose loss is NaN/Inf
+// (ha/loop.py:167-174) and the cycle recovers.
 __global__ __launch_bounds__(256) void scale_add_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha, float beta, size_t n4,
-                                                        size_t n) {
+                                                        size_t n, const float *__restrict__ guard) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool take_x = !guard || isfinite(*guard);
+    const bool take_y = alpha != 0.f;
     if (i < n4) {
-        f32x4 a = reinterpret_cast<f32x4 *>(y)[i];
-        const f32x4 b = reinterpret_cast<const f32x4 *>(x)[i];
-        a = alpha * a + beta * b;
-        reinterpret_cast<f32x4 *>(y)[i] = a;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (take_y) a = alpha * reinterpret_cast<f32x4 *>(y)[i];
+        if (take_x) b = beta * reinterpret_cast<const f32x4 *>(x)[i];
+        reinterpret_cast<f32x4 *>(y)[i] = a + b;
     } else if (i == n4) {
-        for (size_t e = 4 * n4; e < n; ++e) y[e] = alpha * y[e] + beta * x[e];
+        for (size_t e = 4 * n4; e < n; ++e) y[e] = (take_y ? alpha * y[e] : 0.f) + (take_x ? beta * x[e] : 0.f);
     }
+}
+}  // namespace
+
+namespace {
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// gradient wire format of the data-parallel all-reduce (haloop_amd/dp.py, wire_dtype='bf16'): fp32 -> bf16 before, bf16 -> fp32 * scale after
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float *__restrict__ x, __bf16 *__restrict__ y, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        reinterpret_cast<bf16x4 *>(y)[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (size_t e = 4 * n4 + threadIdx.x; e < n; e += 256) y[e] = (__bf16)x[e];
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const __bf16 *__restrict__ x, float *__restrict__ y, float scale, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const bf16x4 v = reinterpret_cast<const bf16x4 *>(x)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (float)v[e] * scale;
+        reinterpret_cast<f32x4 *>(y)[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (size_t e = 4 * n4 + threadIdx.x; e < n; e += 256) y[e] = (float)x[e] * scale;
+}
+inline unsigned cast_grid(size_t n4) {
+    size_t g = (n4 + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 }  // namespace
 
 extern "C" {
 
-int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, halo_stream_t stream) {
+int halo_cast_f32_bf16(const float *x, void *y, size_t n, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && y && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0));
+    if (n == 0) return HALO_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cast_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (__bf16 *)y, n / 4, n);
+    return halo_launch_status();
+}
+
+int halo_cast_bf16_f32(const void *x, float *y, float scale, size_t n, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && y && ((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 16 == 0));
+    if (n == 0) return HALO_OK;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cast_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, y, scale, n / 4, n);
+    return halo_launch_status();
+}
+
+int halo_scale_add_guarded(float *y, const float *x, float alpha, float beta, size_t n, const float *guard, halo_stream_t stream) {
     HALO_CHECK_ARG(y && x && ((uintptr_t)y % 16 == 0) && ((uintptr_t)x % 16 == 0));
     if (n == 0) return HALO_OK;
     const size_t n4 = n / 4;
-    hipLaunchKernelGGL(scale_add_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n4, n);
+    hipLaunchKernelGGL(scale_add_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, beta, n4, n,
+                       guard);
     return halo_launch_status();
+}
+
+int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, halo_stream_t stream) {
+    return halo_scale_add_guarded(y, x, alpha, beta, n, nullptr, stream);
 }
 
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream) {
@@ -228,12 +294,17 @@ int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream) 
     return halo_launch_status();
 }
 
-int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
-                   halo_stream_t stream) {
+int halo_clip_coef_step(const float *partials, int count, float max_norm, float *coef, float *norm_out, uint32_t *applied_steps,
+                        halo_stream_t stream) {
     HALO_CHECK_ARG(partials && coef && count > 0);
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, count, max_norm, coef,
-                       norm_out);
+                       norm_out, applied_steps);
     return halo_launch_status();
+}
+
+int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
+                   halo_stream_t stream) {
+    return halo_clip_coef_step(partials, count, max_norm, coef, norm_out, nullptr, stream);
 }
 
 int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
@@ -276,19 +347,21 @@ int halo_adamw_multi(const void *tensor_table, const void *chunk_table, int n_ch
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamTensor *)tensor_table,
-                       (const uint2 *)chunk_table, gr, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
+                       (const uint2 *)chunk_table, gr, lr, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
                        (float)((double)lr / bc1), (float)sqrt(bc2), eps, grad_scale);
     return halo_launch_status();
 }
 
-int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+static int adamw_ranges_impl(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
                       const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps, int step,
-                      uint32_t *counter, halo_stream_t stream) {
+                      const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream) {
     HALO_CHECK_ARG(p && g && m && v && begin && end && weight_decay && grad_scale && n_ranges > 0 && n_ranges <= ADAM_MAX_RANGES &&
-                   step >= 1);
+                   (step >= 1 || step_dev));
     HALO_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0));
     AdamRangesArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n_ranges = n_ranges; a.counter = counter;
+    a.step_dev = step_dev; a.lr = lr; a.beta1 = beta1;
+    if (step < 1) step = 1;
     size_t biggest = 0;
     for (int r = 0; r < n_ranges; ++r) {
         HALO_CHECK_ARG(begin[r] % 4 == 0 && end[r] % 4 == 0 && begin[r] <= end[r]);
@@ -310,6 +383,21 @@ int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return halo_launch_status();
+}
+
+int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+                      const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps, int step,
+                      uint32_t *counter, halo_stream_t stream) {
+    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, step, nullptr, counter,
+                             stream);
+}
+
+int halo_adamw_ranges_dev(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+                          const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps,
+                          const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream) {
+    HALO_CHECK_ARG(step_dev);
+    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, 0, step_dev, counter,
+                             stream);
 }
 
 }  // extern "C"

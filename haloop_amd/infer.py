@@ -34,8 +34,10 @@ class LstmCtcRecognizer:
         return self._static
 
     @torch.no_grad()
-    def recognize(self, x):
-        """x [B,T,F] on the HIP device -> (alignments [B,T'], scores [B,T'], hyp [B,T'] padded, hyp_len [B])."""
+    def recognize(self, x, clone=True):
+        """x [B,T,F] on the HIP device -> (alignments [B,T'], scores [B,T'], hyp [B,T'] padded, hyp_len [B]).
+        The results are copies the caller owns.  clone=False returns the graph's own output buffers instead, which the NEXT
+        call overwrites (for loops that consume each result before asking for the next one)."""
         if not self.use_graph:
             return self._run(x.contiguous())
         if self._graph is None or self._static.shape != x.shape:
@@ -51,4 +53,4 @@ class LstmCtcRecognizer:
         if x.data_ptr() != self._static.data_ptr():
             self._static.copy_(x)
         self._graph.replay()
-        return self._out
+        return tuple(o.clone() for o in self._out) if clone else self._out

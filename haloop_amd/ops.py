@@ -356,8 +356,10 @@ def sumsq_partials(flat, partials=None):
     return partials
 
 
-def clip_coef(partials, count, max_norm, coef, norm):
-    check(lib().halo_clip_coef(ptr(partials), count, float(max_norm), ptr(coef), ptr(norm), _stream()), 'halo_clip_coef')
+def clip_coef(partials, count, max_norm, coef, norm, applied_steps=None):
+    """applied_steps: optional device int32 counter advanced when the norm is finite (the Adam step count of applied updates)."""
+    check(lib().halo_clip_coef_step(ptr(partials), count, float(max_norm), ptr(coef), ptr(norm), ptr(applied_steps), _stream()),
+          'halo_clip_coef_step')
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
@@ -369,14 +371,19 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None
 
 
 def adamw_ranges(p, g, m, v, ranges, lr, beta1, beta2, eps, step, counter=None):
-    """One-launch AdamW over ``ranges`` = [(begin, end, weight_decay, grad_scale tensor or None), ...] of flat buffers."""
+    """One-launch AdamW over ``ranges`` = [(begin, end, weight_decay, grad_scale tensor or None), ...] of flat buffers.
+    ``step``: the 1-based update count as a python int, or a device int32 tensor holding it (no host scalar: graph-capturable)."""
     n = len(ranges)
     begin = (C.c_size_t * n)(*[r[0] for r in ranges])
     end = (C.c_size_t * n)(*[r[1] for r in ranges])
     wd = (C.c_float * n)(*[float(r[2]) for r in ranges])
     gs = (C.c_void_p * n)(*[ptr(r[3]) for r in ranges])
-    check(lib().halo_adamw_ranges(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, step, ptr(counter),
-                                  _stream()), 'halo_adamw_ranges')
+    if torch.is_tensor(step):
+        check(lib().halo_adamw_ranges_dev(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, ptr(step),
+                                          ptr(counter), _stream()), 'halo_adamw_ranges_dev')
+    else:
+        check(lib().halo_adamw_ranges(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, step, ptr(counter),
+                                      _stream()), 'halo_adamw_ranges')
     torch.autograd.graph.increment_version(p)
 
 
@@ -389,7 +396,8 @@ class AdamWMulti:
         import numpy as np
         self.params = list(params)
         self.wds = [float(w) for w in weight_decays]
-        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.param_groups = [{'lr': float(lr), 'params': self.params}]
+        self.betas, self.eps = betas, float(eps)
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
                 raise ValueError('AdamWMulti: parameters must be contiguous float32 tensors on the HIP device')
@@ -406,10 +414,18 @@ class AdamWMulti:
             table = np.zeros(len(idx), dtype=rec)
             for k, i in enumerate(idx):
                 p = self.params[i]
-                table[k] = (p.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), 1.0 - self.lr * self.wds[i], 0)
+                table[k] = (p.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), self.wds[i], 0)
             pairs = [(k, c) for k, i in enumerate(idx) for c in range((self.params[i].numel() + chunk - 1) // chunk)]
             self.groups.append((first, len(idx), torch.from_numpy(table.view(np.uint8)).to(dev),
                                 torch.tensor(pairs, dtype=torch.int32).view(-1).to(dev), len(pairs)))
+
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]['lr'] = float(value)
 
     def step(self, grad_scale=None):
         self.t += 1
@@ -427,10 +443,22 @@ class AdamWMulti:
             torch.autograd.graph.increment_version(p)          # cached operand images of the weights are rebuilt
 
 
-def scale_add_(y, x, alpha, beta):
-    """y <- alpha*y + beta*x in place (flat fp32 buffers)."""
-    check(lib().halo_scale_add(ptr(y), ptr(x), float(alpha), float(beta), y.numel(), _stream()), 'halo_scale_add')
+def scale_add_(y, x, alpha, beta, guard=None):
+    """y <- alpha*y + beta*x in place (flat fp32 buffers); alpha == 0 never reads y.  guard: optional device scalar; when it is not
+    finite, x contributes nothing (a micro-batch with a NaN/Inf loss is dropped, ha/loop.py:167-174)."""
+    check(lib().halo_scale_add_guarded(ptr(y), ptr(x), float(alpha), float(beta), y.numel(), ptr(guard), _stream()),
+          'halo_scale_add_guarded')
     return y
+
+
+def cast_f32_to_bf16_(dst_bf16, src_f32):
+    check(lib().halo_cast_f32_bf16(ptr(src_f32), ptr(dst_bf16), src_f32.numel(), _stream()), 'halo_cast_f32_bf16')
+    return dst_bf16
+
+
+def cast_bf16_to_f32_(dst_f32, src_bf16, scale=1.0):
+    check(lib().halo_cast_bf16_f32(ptr(src_bf16), ptr(dst_f32), float(scale), dst_f32.numel(), _stream()), 'halo_cast_bf16_f32')
+    return dst_f32
 
 
 def counter_inc(counter):

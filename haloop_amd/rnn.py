@@ -40,11 +40,27 @@ def lstm_param_list(lstm):
     return out
 
 
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
 class DropoutStream:
-    """Host-side bookkeeping of the Philox stream: one (seed, offset) per training forward."""
+    """Host-side bookkeeping of the Philox stream: one (seed, offset) per training forward.
+
+    Without an explicit seed, every instance gets its own key derived from torch's initial seed and the order of construction
+    (splitmix64), so that two modules whose dropout sites carry the same stream ids (an encoder and a decoder, two GPTs in one
+    process) draw independent masks, as torch's global generator would give them; runs with the same torch seed and the same
+    construction order repeat.  Tests and the oracle pin ``.seed`` explicitly."""
+    _instances = 0
 
     def __init__(self, seed=None):
-        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        if seed is None:
+            seed = _splitmix64((torch.initial_seed() & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(DropoutStream._instances))
+            DropoutStream._instances += 1
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
         self.counter = None      # optional device uint32 advanced inside captured graphs
 

@@ -86,9 +86,17 @@ class FlatParams:
 
 class LstmCtcTrainer:
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
-                 clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1):
+                 clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
+                 alias_loss=False):
         """accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
-        forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call."""
+        forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call.
+        A micro-batch whose loss is NaN/Inf contributes nothing (the reference skips it, loop.py:167-174; here it still counts
+        towards the cycle, because nothing synchronises with the host); an update whose gradient norm is not finite is
+        skipped on the device and does not advance the Adam step count (loop.py:185-189).
+        grad_dtype: wire format of the data-parallel all-reduce ('f32' = DistributedDataParallel's; 'bf16' halves the bytes).
+        alias_loss: step() returns ``self.loss`` itself -- ONE device scalar that every later step overwrites -- instead of a
+        copy the caller owns (for loops that read each loss before the next step, or never)."""
+        self.alias_loss = bool(alias_loss)
         self.encoder, self.recognizer = encoder, recognizer
         self.accumulate = int(accumulate)
         self._micro = 0
@@ -103,14 +111,15 @@ class LstmCtcTrainer:
         self.coef = torch.ones(2, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.loss = torch.zeros((), device=dev, dtype=torch.float32)
-        self.step_count = 0
+        self.step_count = 0                                                # step() calls that reached the optimizer
+        self.adam_step = torch.zeros(1, device=dev, dtype=torch.int32)    # APPLIED updates: advanced on the device (clip_coef)
         self.use_graph = use_graph
         self.pg = process_group
         self.world = dp.world_size(process_group)
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
         # two buckets in readiness order: [top layer + recognizer] then [the rest]
-        self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range)
-        self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range)
+        self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range, wire_dtype=grad_dtype)
+        self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range, wire_dtype=grad_dtype)
         self._graphs = None
         self._static = None
         self._accum = torch.zeros_like(self.flat.grads) if self.accumulate > 1 else None
@@ -171,8 +180,16 @@ class LstmCtcTrainer:
         y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L) = st
         gv = self.flat.grad_views
         if top > 0:
-            ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
-                         workspace=ws, dx=dy_sub)
+            # with data parallelism this part runs beside the first bucket's all-reduce, whose kernels hold CUs: the
+            # persistent recurrence needs every workgroup resident at once, so the lower layers use the launch chain there
+            if self.world > 1:
+                _lib.set_lstm_persistent(False)
+            try:
+                ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
+                             workspace=ws, dx=dy_sub)
+            finally:
+                if self.world > 1:
+                    _lib.set_lstm_persistent(True)
         ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
                           dbias=gv['encoder.subsample.bias'])
 
@@ -180,21 +197,39 @@ class LstmCtcTrainer:
         self.avg_early.average()
         self.avg_late.average()
 
-    def _optimizer(self, step):
+    def _warm_optimizer_kernels(self):
+        """The optimizer's three kernels launched once on scratch data (nothing of the model is touched), so that their code
+        objects are loaded before a stream capture records them."""
+        dev = self.device
+        d = [torch.zeros(8, device=dev, dtype=torch.float32) for _ in range(4)]
+        parts = torch.zeros(_lib.HALO_SUMSQ_PARTS, device=dev, dtype=torch.float32)
+        coef, norm = torch.ones(2, device=dev, dtype=torch.float32), torch.zeros(1, device=dev, dtype=torch.float32)
+        cnt = torch.ones(1, device=dev, dtype=torch.int32)
+        ops.sumsq_partials(d[1], parts)
+        ops.clip_coef(parts, _lib.HALO_SUMSQ_PARTS, self.clip, coef, norm, applied_steps=cnt)
+        ops.adamw_ranges(d[0], d[1], d[2], d[3], [(0, 8, 0.0, coef[0:1])], self.lr, self.betas[0], self.betas[1], self.eps, cnt)
+
+    def _optimizer(self):
+        """clip + AdamW; the update count lives on the device, so these three launches have no host scalar and are captured
+        in the step graph."""
         f = self.flat
         e0, e1 = f.encoder_range
         ops.sumsq_partials(f.grads[e0:e1], self.partials)
-        ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm)
+        ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm, applied_steps=self.adam_step)
         # all (decay, clip) ranges and the dropout step counter in one launch
         ranges = [(a, b, self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
                   for a, b, decays, clipped in f.ranges if b > a]
-        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self.lr, self.betas[0], self.betas[1], self.eps, step,
-                         counter=self.counter)
+        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self.lr, self.betas[0], self.betas[1], self.eps,
+                         self.adam_step, counter=self.counter)
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):
-        """One optimizer step (one micro-step of it when accumulate > 1).  Returns the (device) loss tensor of this batch;
-        nothing here synchronises."""
+        """One optimizer step (one micro-step of it when accumulate > 1).  Returns the (device) loss of this batch: a copy the
+        caller owns, or ``self.loss`` itself under ``alias_loss``; nothing here synchronises."""
+        loss = self._step(x, input_lengths, targets, target_lengths)
+        return loss if self.alias_loss else loss.clone()
+
+    def _step(self, x, input_lengths, targets, target_lengths):
         if self.accumulate > 1:
             return self._accumulating_step(x, input_lengths, targets, target_lengths)
         self.step_count += 1
@@ -205,7 +240,7 @@ class LstmCtcTrainer:
             w2 = self.avg_late.start()
             self.avg_early.finish(w1)
             self.avg_late.finish(w2)
-            self._optimizer(self.step_count)
+            self._optimizer()
             return self.loss
         return self._graph_step(x, input_lengths, targets, target_lengths)
 
@@ -218,7 +253,8 @@ class LstmCtcTrainer:
             self._forward_backward(x, il, tg, tl)
         self._micro += 1
         first, last = self._micro == 1, self._micro == self.accumulate
-        ops.scale_add_(self._accum, self.flat.grads, 0.0 if first else 1.0, 1.0 / self.accumulate)
+        # alpha = 0 on the first micro-step is a plain scaled copy (never reads the old sum); a non-finite loss drops the batch
+        ops.scale_add_(self._accum, self.flat.grads, 0.0 if first else 1.0, 1.0 / self.accumulate, guard=self.loss)
         if not last:
             ops.counter_inc(self.counter)                        # the next micro-batch draws fresh dropout masks
             return self.loss
@@ -226,7 +262,7 @@ class LstmCtcTrainer:
         self.flat.grads.copy_(self._accum)
         self._all_reduce()                                   # only on the last micro-step (attention_loop.py:203)
         self.step_count += 1
-        self._optimizer(self.step_count)
+        self._optimizer()
         return self.loss
 
     def _replay_forward_backward(self, x, il, tg, tl):
@@ -249,10 +285,9 @@ class LstmCtcTrainer:
         self._graphs[0].replay()
 
     def _graph_step(self, x, il, tg, tl):
-        # AdamW's bias corrections depend on the step number (a host scalar in the kernel arguments), so
-        # forward/backward are captured and the 7-launch optimizer runs eagerly.  With data parallelism
+        # One graph for the whole step (the Adam update count is a device counter).  With data parallelism
         # backward is captured as TWO graphs so that the first gradient bucket's all-reduce (eager, on
-        # RCCL's stream) runs beside the second graph.
+        # RCCL's stream) runs beside the second graph, and the optimizer is a third.
         if self._graphs is None or self._static[0].shape != x.shape or self._static[2].shape != tg.shape:
             # private buffers: refilling them for the next batch must never write into a tensor the caller still owns
             self._static = tuple(t.contiguous().clone() for t in (x, il.to(torch.int64), tg.to(torch.int64), tl.to(torch.int64)))
@@ -261,20 +296,24 @@ class LstmCtcTrainer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # warm-up outside capture (lazy module loads)
                 self._forward_backward(sx, sil, stg, stl)
+                self._warm_optimizer_kernels()
             torch.cuda.current_stream().wait_stream(side)
             if self.world == 1:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._forward_backward(sx, sil, stg, stl)
+                    self._optimizer()
                 self._graphs = (g,)
             else:
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     state = self._forward_backward_top(sx, sil, stg, stl)
                 with torch.cuda.graph(g2, pool=g1.pool()):
                     self._backward_rest(state)
-                self._graphs = (g1, g2)
-                self._keep = state                       # buffers shared by the two graphs stay alive
+                with torch.cuda.graph(g3, pool=g1.pool()):
+                    self._optimizer()
+                self._graphs = (g1, g2, g3)
+                self._keep = state                       # buffers shared by the graphs stay alive
         sx, sil, stg, stl = self._static
         for dst, src in ((sx, x), (sil, il), (stg, tg), (stl, tl)):
             if src.data_ptr() != dst.data_ptr():       # a new batch: refill the captured input buffers
@@ -288,7 +327,7 @@ class LstmCtcTrainer:
             w2 = self.avg_late.start()
             self.avg_early.finish(w1)
             self.avg_late.finish(w2)
-        self._optimizer(self.step_count)
+            self._graphs[2].replay()
         return self.loss
 
     def static_inputs(self):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 6
+#define HALO_ABI_VERSION 7
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -203,6 +203,26 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                   float *const *db_ih, float *const *db_hh, int T, int B, int in0, int H, int L,
                   int layer_begin, int layer_end, float p_drop, uint64_t seed, uint32_t offset,
                   const uint32_t *offset_dev, halo_stream_t stream);
+
+/* Weight-resident persistent recurrence (csrc/lstm_persist.hip): when the shape is eligible (split-bf16 arithmetic modes,
+ * H in {256, 512, 768, 1024}, (H/16) * ceil(B/16) <= number of CUs) a layer's T dependent step launches become ONE launch
+ * whose workgroups keep their W_hh slice in registers and hand h_t (forward) / the gate gradients (backward) to each other
+ * through write-through stores and per-workgroup epoch words.  On by default; halo_set_lstm_persistent(0) selects the
+ * per-step launch chain (also HALO_LSTM_PERSIST=0 in the environment).  The kernel needs every workgroup resident at once, so
+ * nothing else should occupy the GPU's CUs for long while it runs; all its waits are bounded (0.2 s): on a timeout the u32 at
+ * byte offset halo_lstm_status_offset() of the reserve (backward != 0: of the backward workspace) is set to 1 and the results
+ * of that call are invalid.  It reads 0 after a good call. */
+int halo_set_lstm_persistent(int on);
+int halo_lstm_persistent_eligible(int B, int H);
+size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
+
+/* Measurement hook (bench.py): while set, every layer's recurrent chain inside halo_lstm_fwd / halo_lstm_bwd is bracketed by
+ * hipEventRecord(ev_begin) / hipEventRecord(ev_end) on the call's stream (hipEvent_t handles; NULL, NULL clears).  The
+ * batched GEMMs and operand preparation of the same call stay outside the bracket.  Not for use under stream capture.
+ * halo_lstm_chain_info: how the last forward (backward != 0: backward) chain ran: number of kernel launches
+ * (1 = the persistent weight-resident kernel, T = one launch per time step) and the kernel's name. */
+int halo_lstm_chain_events(void *ev_begin, void *ev_end);
+int halo_lstm_chain_info(int backward, int *launches, char *kernel, int kernel_len);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise log-softmax.   replaces: features.log_softmax(dim=-1) ha/recognizer.py:46
@@ -438,9 +458,21 @@ int halo_lm_batch_u16(const uint16_t *data, long n_tokens, const int64_t *offset
 #define HALO_SUMSQ_PARTS 1024
 /* y = alpha*y + beta*x on flat buffers: accumulates micro-batch gradients (loss / accumulate; ha/loop.py:176-181) */
 int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, halo_stream_t stream);
+/* the same with a device guard: when *guard (e.g. this micro-batch's loss) is not finite, x contributes nothing -- the reference
+ * skips a micro-batch whose loss is NaN/Inf (ha/loop.py:167-174).  alpha == 0 never reads y (a poisoned sum cannot survive). */
+int halo_scale_add_guarded(float *y, const float *x, float alpha, float beta, size_t n, const float *guard,
+                           halo_stream_t stream);
+/* wire format of the data-parallel gradient all-reduce (optional bf16 buckets, haloop_amd/dp.py): y_bf16[i] = bf16(x[i]);
+ * y[i] = float(x_bf16[i]) * scale (scale = 1 / world after an all-reduce SUM) */
+int halo_cast_f32_bf16(const float *x, void *y_bf16, size_t n, halo_stream_t stream);
+int halo_cast_bf16_f32(const void *x_bf16, float *y, float scale, size_t n, halo_stream_t stream);
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
 int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                    halo_stream_t stream);
+/* halo_clip_coef that also advances a device-side update counter (uint32) when the norm is finite: torch's AdamW step count
+ * advances only with an applied update (the reference skips optimizer.step() on a non-finite norm, ha/loop.py:185-189). */
+int halo_clip_coef_step(const float *partials, int count, float max_norm, float *coef, float *norm_out,
+                        uint32_t *applied_steps, halo_stream_t stream);
 int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, const float *grad_scale, halo_stream_t stream);
 /* halo_adamw over n_ranges (<= 8) contiguous element ranges [begin[r], end[r]) of the same flat buffers in ONE launch (host
@@ -450,14 +482,21 @@ int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges
                       const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2,
                       float eps, int step, uint32_t *counter, halo_stream_t stream);
 
+/* halo_adamw_ranges with the 1-based update count read from the device (the counter halo_clip_coef_step advances), so that a
+ * whole training step -- optimizer included -- has no host-side scalar and replays from one hipGraph. */
+int halo_adamw_ranges_dev(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
+                          const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2,
+                          float eps, const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream);
+
 /* halo_adamw over MANY tensors in one launch (what torch.optim.AdamW(fused=True) does for a parameter list, ha/attention_loop.py:
  * 141-147).  tensor_table (device, built once): n_tensors records of halo_adamw_multi_tensor_bytes() bytes each:
- *   { float *p; float *m; float *v; uint64 n; float decay_mul (= 1 - lr*weight_decay); int32 pad }
+ *   { float *p; float *m; float *v; uint64 n; float weight_decay; int32 pad }
  * chunk_table (device, built once): n_chunks pairs { uint32 tensor, uint32 chunk } -- every tensor cut into
  * ceil(n / halo_adamw_multi_chunk()) chunks, one workgroup each.  grads: HOST array of the n_tensors gradient pointers of this
  * step (autograd allocates new ones every backward); they are copied into the kernel arguments, so the caller may reuse the
- * array at once.  n_tensors <= halo_adamw_multi_max_tensors() per call.  The decay factor already contains lr: rebuild the
- * table when lr changes.  Bit-identical to one halo_adamw call per tensor. */
+ * array at once.  n_tensors <= halo_adamw_multi_max_tensors() per call.  lr may change from call to call (LR schedules,
+ * ha/optim.py:68-72): the decay factor 1 - lr*weight_decay is formed in the kernel.  Bit-identical to one halo_adamw call per
+ * tensor. */
 size_t halo_adamw_multi_tensor_bytes(void);
 unsigned halo_adamw_multi_chunk(void);
 int halo_adamw_multi_max_tensors(void);

@@ -108,6 +108,64 @@ def save_lc2x1024():
     print('g1_lc2x1024 loss', float(r['loss']))
 
 
+def save_lc2x1024_b64():
+    """BASELINE config 2's grid: the same 2-layer H=1024 model at B=64 (256 step workgroups: 64 hidden tiles x 4 batch tiles),
+    ragged input lengths (T' from 16 to 21).  Slices, sums and norms only: the full tensors would be 50 MB."""
+    cfg = dict(F_=80, C=128, H=1024, L=2, V=32, B=64, T=80, S=10, seed=42)
+    enc_p, rec_p = cpu_ref.make_params(cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'], cfg['seed'])
+    x, il, tg, tl = cpu_ref.synthetic_batch(cfg['B'], cfg['T'], cfg['F_'], cfg['V'], cfg['S'], cfg['seed'])
+    il = torch.tensor([cfg['T'] - 3 * (i % 8) for i in range(cfg['B'])], dtype=torch.int64)
+    enc, rec = build_reference_model(enc_p, rec_p, cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'])
+    enc.eval(); rec.eval()
+    feats, flen, _ = enc(x, il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg, flen, tl)
+    loss.backward()
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+        hyps, hlen, ali, scores, _ = rec.decode(feats, flen, tl)
+    d = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+    d.update(il=il.numpy(), flen=flen.numpy(), loss=loss.detach().numpy(), ali=ali.numpy(), hlen=hlen.numpy())
+    d['feats_slice'] = feats.detach()[:, :, ::61].numpy()
+    d['feats_sum'] = feats.detach().double().sum().numpy()
+    d['dfeats_slice'] = feats.grad[:, :, ::61].numpy()
+    d['lp_slice'] = lp[::3].numpy()
+    grads = {('encoder.' + k): p.grad for k, p in enc.named_parameters()}
+    grads.update({('recognizer.' + k): p.grad for k, p in rec.named_parameters()})
+    for k, v in grads.items():
+        d['gradnorm.' + k] = v.double().norm().numpy()
+        d['gradslice.' + k] = v.reshape(-1)[::9973].numpy()
+    maxlen = max(1, max(len(h) for h in hyps))
+    d['hyps'] = np.array([[int(v) for v in h] + [-1] * (maxlen - len(h)) for h in hyps], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'g1_lc2x1024_b64.npz'), **d)
+    print('g1_lc2x1024_b64 loss', float(loss))
+
+    # three optimizer steps of the same model the way ha/loop.py:176-196 runs them (eval-mode dropout), on three seeded batches
+    enc, rec = build_reference_model(enc_p, rec_p, cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'])
+    enc.eval(); rec.eval()
+    model = nn.ModuleDict({'encoder': enc, 'recognizer': rec})
+    args = types.SimpleNamespace(lr=3e-4, weight_decay=0.01, beta1=0.9, beta2=0.99)
+    opt = ha.optim.configure_optimizers(model, args, device_type='cpu', decay_lm_head=False)
+    losses, gnorms = [], []
+    t = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+    t['cfg_lr'] = np.array(args.lr)
+    for step in range(3):
+        x, il, tg, tl = cpu_ref.synthetic_batch(cfg['B'], cfg['T'], cfg['F_'], cfg['V'], cfg['S'], 200 + step)
+        feats, flen, _ = enc(x, il)
+        loss, _ = rec(feats, tg, flen, tl)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 0.1, error_if_nonfinite=False)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        losses.append(float(loss)); gnorms.append(float(gn))
+    t['losses'] = np.array(losses); t['gnorms'] = np.array(gnorms)
+    for prefix, mod in (('encoder.', enc), ('recognizer.', rec)):
+        for k, v in mod.state_dict().items():
+            t['finalslice.' + prefix + k] = v.reshape(-1)[::4999].numpy()
+            t['finalsum.' + prefix + k] = v.double().sum().numpy()
+    np.savez_compressed(os.path.join(OUT, 'g1_train3_b64.npz'), **t)
+    print('g1_train3_b64 losses', losses, 'gnorms', gnorms)
+
+
 def save_train_steps():
     """Three optimizer steps the way ha/loop.py:176-196 runs them (eval-mode dropout)."""
     cfg = dict(F_=12, C=16, H=32, L=2, V=9, B=3, T=41, S=4, seed=11)
@@ -380,6 +438,11 @@ def save_asr():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                       # e.g. `make_golden.py save_lc2x1024_b64`: regenerate the named fixtures only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    save_lc2x1024_b64()
     save_asr()
     save_gpt()
     save_tiny()

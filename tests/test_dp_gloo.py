@@ -41,11 +41,14 @@ def _worker(rank, world, port, out):
         loss, _, _ = cpu_ref.lstm_ctc_loss(pe, pr, x[sl], il[sl], tg[sl], tl[sl])
         loss.backward()
         grads = torch.cat([(pe[k] if w == 'e' else pr[k]).grad.reshape(-1) for w, k in names])
+        g16 = grads.clone()
         avg = dp.GradientAverager(grads, bucket_bytes=4096, boundaries=[1000, 5000])
         assert len(avg.buckets) > 3
         avg.average()
+        avg16 = dp.GradientAverager(g16, bucket_bytes=4096, boundaries=[1000, 5000], wire_dtype='bf16')     # bf16 on the wire
+        avg16.average()
         if rank == 0:
-            out.put((flat.numpy(), grads.numpy(), float(loss)))
+            out.put((flat.numpy(), grads.numpy(), float(loss), g16.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -59,7 +62,7 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    flat, grads, _ = out.get()
+    flat, grads, _, g16 = out.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -74,6 +77,9 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     loss.backward()
     want = torch.cat([v.grad.reshape(-1) for v in list(pe.values()) + list(pr.values())]).numpy()
     np.testing.assert_allclose(grads, want, rtol=1e-4, atol=1e-7)         # mean of shard means == global mean
+    # the bf16 wire format: each rank's contribution rounded to 8 significant bits, summed in bf16, averaged in fp32
+    np.testing.assert_allclose(g16, want, rtol=2e-2, atol=1e-2 * np.abs(want).max())
+    assert np.abs(g16 - want).max() > 0                                   # it really went through bf16
 
 
 def test_shard_slice_and_buckets():

@@ -1,0 +1,182 @@
+"""BASELINE config 2 on the GPU (LC-2x1024 at B=64: the benchmarked grid, 64 hidden tiles x 4 batch tiles = 256 workgroups) and the
+weight-resident persistent recurrence (csrc/lstm_persist.hip) against the reference-generated fixtures, the CPU oracle and the
+per-step launch chain it replaces.  Tolerances are the fp32-grade ones of tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def hal():
+    from haloop_amd import _lib, ops, rnn, recognizer
+    _lib.lib()
+    _lib.lend_scratch()
+    return dict(ops=ops, rnn=rnn, recognizer=recognizer, lib=_lib)
+
+
+@pytest.fixture
+def math_mode(request, hal):
+    prev = hal['lib'].get_math_mode()
+    hal['lib'].set_math_mode(request.param)
+    yield request.param
+    hal['lib'].set_math_mode(prev)
+
+
+@pytest.fixture
+def persistent(request, hal):
+    hal['lib'].set_lstm_persistent(request.param)
+    yield request.param
+    hal['lib'].set_lstm_persistent(True)
+
+
+PERSIST = pytest.mark.parametrize('persistent', [True, False], indirect=True)
+
+
+def _status(hal, buf, backward, T, B, in0, H, L):
+    off = hal['lib'].lib().halo_lstm_status_offset(int(backward), T, B, in0, H, L)
+    return int(buf.view(torch.int32)[off // 4].item())
+
+
+@PERSIST
+@pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+def test_lc2x1024_b64_matches_reference(hal, math_mode, persistent):
+    """Config 2's real grid against the reference's own numbers (fixture g1_lc2x1024_b64, ragged lengths)."""
+    from oracle import cpu_ref
+    g = load_golden('g1_lc2x1024_b64')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc_p, rec_p = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    enc = hal['rnn'].Encoder(c['F_'], c['C'], c['H'], num_layers=c['L'])
+    rec = hal['recognizer'].TemporalClassifier(c['H'], c['V'])
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    il = torch.from_numpy(g['il']).to(DEV)
+    feats, flen, _ = enc(x.to(DEV), il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg.to(DEV), flen, tl.to(DEV))
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=1e-5)
+    np.testing.assert_allclose(feats[:, :, ::61].detach().cpu().numpy(), g['feats_slice'], atol=1e-4)
+    np.testing.assert_allclose(feats.detach().double().sum().item(), float(g['feats_sum']), rtol=1e-5)
+    assert np.array_equal(flen.cpu().numpy(), g['flen'])
+    loss.backward()
+    np.testing.assert_allclose(feats.grad[:, :, ::61].cpu().numpy(), g['dfeats_slice'], atol=1e-6)
+    for k, p in list(enc.named_parameters()) + list(rec.named_parameters()):
+        key = ('recognizer.' if k.startswith('classifier') else 'encoder.') + k
+        np.testing.assert_allclose(p.grad.double().norm().item(), float(g['gradnorm.' + key]), rtol=1e-4, err_msg=key)
+        np.testing.assert_allclose(p.grad.reshape(-1)[::9973].cpu().numpy(), g['gradslice.' + key], rtol=1e-3, atol=1e-6, err_msg=key)
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+    np.testing.assert_allclose(lp[::3].cpu().numpy(), g['lp_slice'], atol=1e-4)
+    ali, scores, hyp, hlen = hal['ops'].ctc_greedy(lp.contiguous())
+    # greedy alignments of a random-init model: frames whose two best log-probs are closer than the feature tolerance may flip
+    lp_ref_top2 = np.sort(g['lp_slice'], axis=-1)[..., -2:]
+    decisive = (lp_ref_top2[..., 1] - lp_ref_top2[..., 0]) > 2e-4
+    assert np.array_equal(ali.cpu().numpy()[::3][decisive], g['ali'][::3][decisive])
+    if persistent and math_mode != 'f32':
+        assert hal['lib'].lib().halo_lstm_persistent_eligible(c['B'], c['H']) == 1
+
+
+@pytest.mark.parametrize('math_mode', ['f32', 'bf16x3'], indirect=True)
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_three_train_steps_b64_match_reference(hal, math_mode, use_graph):
+    """Three optimizer steps at config 2's shape against the reference's own run (fixture g1_train3_b64)."""
+    from oracle import cpu_ref
+    from haloop_amd.train import LstmCtcTrainer
+    g = load_golden('g1_train3_b64')
+    c = {k[4:]: v for k, v in g.items() if k.startswith('cfg_')}
+    F_, C, H, L, V = (int(c[k]) for k in ('F_', 'C', 'H', 'L', 'V'))
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, int(c['seed']))
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    tr = LstmCtcTrainer(enc, rec, lr=float(c['lr']), use_graph=use_graph)
+    for step in range(3):
+        x, il, tg, tl = cpu_ref.synthetic_batch(int(c['B']), int(c['T']), F_, V, int(c['S']), 200 + step)
+        loss = tr.step(x.to(DEV), il.to(DEV), tg.to(DEV), tl.to(DEV))
+        np.testing.assert_allclose(loss.item(), g['losses'][step], rtol=2e-5)
+        np.testing.assert_allclose(tr.grad_norm.item(), g['gnorms'][step], rtol=1e-4)
+    sd = {**{'encoder.' + k: v for k, v in enc.state_dict().items()}, **{'recognizer.' + k: v for k, v in rec.state_dict().items()}}
+    atol = 5e-6 if math_mode == 'f32' else 2e-5          # same bound as test_train_steps_match_reference
+    for k, v in sd.items():
+        np.testing.assert_allclose(v.reshape(-1)[::4999].cpu().numpy(), g['finalslice.' + k], atol=atol, err_msg=k)
+
+
+def _lstm_case(hal, T, B, in0, H, L, p_drop, seed, with_state):
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, B, in0, generator=g).to(DEV)
+    k = 1.0 / H ** 0.5
+    w_ih = [((torch.rand(4 * H, in0 if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_ih = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_hh = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    h0 = (torch.randn(L, B, H, generator=g) * 0.3).to(DEV) if with_state else None
+    c0 = (torch.randn(L, B, H, generator=g) * 0.3).to(DEV) if with_state else None
+    dy = torch.randn(T, B, H, generator=g).to(DEV)
+    dhn = (torch.randn(L, B, H, generator=g) * 0.1).to(DEV) if with_state else None
+    dcn = (torch.randn(L, B, H, generator=g) * 0.1).to(DEV) if with_state else None
+    drop = ops.Dropout(p_drop, 1234, 3) if p_drop > 0 else ops.NO_DROPOUT
+    y, hn, cn, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, h0=h0, c0=c0, want_state=True, drop=drop)
+    st_f = _status(hal, reserve, False, T, B, in0, H, L)
+    ws = ops.lstm_bwd_workspace(x, w_hh)
+    dx, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, dhn=dhn, dcn=dcn, want_dx=True, drop=drop, workspace=ws)
+    st_b = _status(hal, ws, True, T, B, in0, H, L)
+    out = {'y': y, 'hn': hn, 'cn': cn, 'dx': dx}
+    for name, lst in grads.items():
+        for l, t in enumerate(lst):
+            out[f'{name}{l}'] = t
+    return {k: v.cpu() for k, v in out.items()}, (st_f, st_b)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,L,p_drop,with_state', [
+    (7, 5, 40, 256, 2, 0.0, True),          # 16 workgroups, one batch tile, carried state
+    (5, 33, 64, 512, 1, 0.0, False),        # 96 workgroups, 3 batch tiles (falls back to the plain block map)
+    (6, 16, 128, 768, 2, 0.25, False),      # 48 workgroups, inter-layer dropout
+    (21, 64, 128, 1024, 2, 0.2, False),     # the benchmark's grid: 256 workgroups
+    (3, 1, 32, 1024, 1, 0.0, True),         # a single utterance
+])
+def test_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
+    """The one-launch recurrence and the T-launch chain compute the same function; only the order of the K-slice sums differs."""
+    assert hal['lib'].lib().halo_lstm_persistent_eligible(B, H) == 1
+    hal['lib'].set_lstm_persistent(True)
+    a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    hal['lib'].set_lstm_persistent(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    finally:
+        hal['lib'].set_lstm_persistent(True)
+    assert st_a == (0, 0) and st_b == (0, 0)                       # no bounded wait timed out
+    tol = dict(rtol=2e-4, atol=2e-5) if math_mode == 'bf16x3' else dict(rtol=3e-2, atol=3e-3)
+    for k in a:
+        scale = float(b[k].abs().max()) + 1e-12
+        np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, err_msg=k, **tol)
+
+
+def test_persistent_recurrence_sees_fresh_data_on_every_launch(hal):
+    """Hand-off buffers are re-used across launches (torch's allocator returns the same reserve): results must follow the inputs
+    of THIS launch, never lines cached from the previous one.  Runs the forward on alternating inputs and compares each result
+    with the step-chain result for the same input."""
+    hal['lib'].set_math_mode('bf16x3')
+    T, B, in0, H, L = 21, 64, 128, 1024, 1
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(9)
+    k = 1.0 / H ** 0.5
+    w_ih = [((torch.rand(4 * H, in0, generator=g) * 2 - 1) * k).to(DEV)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV)]
+    b = [torch.zeros(4 * H, device=DEV)]
+    xs = [torch.randn(T, B, in0, generator=g).to(DEV) * s for s in (1.0, -0.5, 2.0)]
+    hal['lib'].set_lstm_persistent(False)
+    try:
+        refs = [ops.lstm_fwd(x, w_ih, w_hh, b, b)[0].cpu() for x in xs]
+    finally:
+        hal['lib'].set_lstm_persistent(True)
+    for rep in range(4):
+        for x, ref in zip(xs, refs):
+            y = ops.lstm_fwd(x, w_ih, w_hh, b, b)[0]
+            np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)

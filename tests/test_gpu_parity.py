@@ -894,6 +894,77 @@ def test_gradient_accumulation_equals_one_large_batch(hal, use_graph):
     np.testing.assert_allclose(acc.flat.params.cpu().numpy(), whole.flat.params.cpu().numpy(), atol=5e-6)
 
 
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_accumulation_recovers_after_a_nonfinite_micro_batch(hal, use_graph):
+    """An infeasible utterance (il < tl: F.ctc_loss = inf, NaN gradients) in one micro-batch must not poison the running sum: the
+    reference skips that batch and carries on (ha/loop.py:167-174).  Here its contribution is dropped on the device, the cycle's
+    update uses the clean micro-batch alone, and the NEXT cycle is an ordinary one.  A cycle whose every micro-batch is bad
+    leaves parameters and the Adam step count untouched."""
+    from haloop_amd.train import LstmCtcTrainer
+    from oracle import cpu_ref
+    F_, C, H, L, V, B, T, S = 12, 16, 32, 2, 9, 4, 41, 4
+    x, il, tg, tl = (t.to(DEV) for t in cpu_ref.synthetic_batch(B, T, F_, V, S, 7))
+    bad_il = il.clone(); bad_il[0] = 9                      # T' = 3 frames for up to 4 labels
+    bad_tg = tg.clone(); bad_tg[0] = 1                      # 4 equal labels need 7 frames
+    bad_tl = tl.clone(); bad_tl[0] = 4
+
+    def build():
+        enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 100)
+        enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+        enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+        return enc.to(DEV).eval(), rec.to(DEV).eval()
+
+    enc, rec = build()
+    tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, accumulate=2)
+    p0 = tr.flat.params.clone()
+    # cycle 1: bad micro-batch first (the case that used to leave NaN in the sum for good), then a clean one
+    l1 = tr.step(x[:2], bad_il[:2], bad_tg[:2], bad_tl[:2])
+    assert not np.isfinite(l1.item())
+    tr.step(x[2:], il[2:], tg[2:], tl[2:])
+    assert np.isfinite(tr.grad_norm.item()) and int(tr.adam_step.item()) == 1
+    p1 = tr.flat.params.clone()
+    assert torch.isfinite(p1).all() and not torch.equal(p1, p0)
+    # the same update from a trainer that only ever saw the clean micro-batch at half weight
+    enc2, rec2 = build()
+    ref = LstmCtcTrainer(enc2, rec2, lr=3e-3, use_graph=False, accumulate=1)
+    ref._forward_backward(x[2:], il[2:], tg[2:], tl[2:])
+    ref.flat.grads.mul_(0.5)
+    ref._optimizer()
+    np.testing.assert_allclose(p1.cpu().numpy(), ref.flat.params.cpu().numpy(), atol=2e-6)
+    # cycle 2: clean, must update again
+    tr.step(x[:2], il[:2], tg[:2], tl[:2]); tr.step(x[2:], il[2:], tg[2:], tl[2:])
+    assert int(tr.adam_step.item()) == 2 and not torch.equal(tr.flat.params, p1) and torch.isfinite(tr.flat.params).all()
+    # cycle 3: both micro-batches bad -> gradient sum is zero, finite: an (empty) update; parameters move only by decay/momentum.
+    # a non-finite NORM (single-batch trainer) leaves everything untouched, including the Adam step count
+    enc3, rec3 = build()
+    one = LstmCtcTrainer(enc3, rec3, lr=3e-3, use_graph=use_graph)
+    q0 = one.flat.params.clone()
+    one.step(x[:2], bad_il[:2], bad_tg[:2], bad_tl[:2])
+    assert torch.equal(one.flat.params, q0) and int(one.adam_step.item()) == 0
+    one.step(x[2:], il[2:], tg[2:], tl[2:])
+    assert int(one.adam_step.item()) == 1 and not torch.equal(one.flat.params, q0)
+
+
+def test_adamw_multi_follows_a_changing_learning_rate(hal):
+    """ha/optim.py:68-72 sets the learning rate on every step; weight decay must use the CURRENT lr (torch.optim.AdamW does)."""
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.randn(300, 7, generator=g), torch.randn(1000, generator=g)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    topt = torch.optim.AdamW([{'params': [ref[0]], 'weight_decay': 0.1}, {'params': [ref[1]], 'weight_decay': 0.0}], lr=1e-2, betas=(0.9, 0.99))
+    mine = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    opt = hal['ops'].AdamWMulti(mine, [0.1, 0.0], lr=1e-2, betas=(0.9, 0.99))
+    for step, lr in enumerate([1e-2, 3e-1, 5e-2]):
+        gs = [torch.randn(p.shape, generator=g) for p in ps]
+        for grp in topt.param_groups:
+            grp['lr'] = lr
+        opt.param_groups[0]['lr'] = lr
+        for p, q, gr in zip(ref, mine, gs):
+            p.grad = gr.clone(); q.grad = gr.clone().to(DEV)
+        topt.step(); opt.step()
+    for p, q in zip(ref, mine):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
 @BOTH_MODES
 @pytest.mark.parametrize('vocab,block,n_layer,n_head,n_embd,bias,B,T', [(131, 80, 2, 3, 96, True, 3, 77), (53, 200, 1, 2, 128, False, 1, 193)])
 def test_gpt_shape_robustness_against_oracle(hal, math_mode, vocab, block, n_layer, n_head, n_embd, bias, B, T):

@@ -52,6 +52,41 @@ def test_lc2x1024_matches_reference():
     assert np.array_equal(flen.numpy(), g['flen'])
 
 
+def test_lc2x1024_b64_matches_reference():
+    """BASELINE config 2's shape (B=64, ragged lengths): oracle == reference on loss, feature slices and gradient norms/slices."""
+    g = load_golden('g1_lc2x1024_b64')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    il = torch.from_numpy(g['il'])
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec.items()}
+    loss, feats, flen = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-6)
+    np.testing.assert_allclose(feats.detach()[:, :, ::61].numpy(), g['feats_slice'], atol=1e-6)
+    assert np.array_equal(flen.numpy(), g['flen'])
+    for prefix, d in (('encoder.', pe), ('recognizer.', pr)):
+        for k, v in d.items():
+            np.testing.assert_allclose(v.grad.double().norm().item(), float(g['gradnorm.' + prefix + k]), rtol=1e-5, err_msg=k)
+            np.testing.assert_allclose(v.grad.reshape(-1)[::9973].numpy(), g['gradslice.' + prefix + k], rtol=1e-4, atol=1e-8, err_msg=k)
+
+
+def test_train_steps_b64_match_reference():
+    g = load_golden('g1_train3_b64')
+    c = {k[4:]: v for k, v in g.items() if k.startswith('cfg_')}
+    enc, rec = cpu_ref.make_params(int(c['F_']), int(c['C']), int(c['H']), int(c['L']), int(c['V']), int(c['seed']))
+    tr = cpu_ref.Trainer(enc, rec, lr=float(c['lr']))
+    for step in range(3):
+        x, il, tg, tl = cpu_ref.synthetic_batch(int(c['B']), int(c['T']), int(c['F_']), int(c['V']), int(c['S']), 200 + step)
+        loss, gn = tr.step(x, il, tg, tl)
+        np.testing.assert_allclose(float(loss), g['losses'][step], rtol=1e-5)
+        np.testing.assert_allclose(float(gn), g['gnorms'][step], rtol=1e-4)
+    for prefix, d in (('encoder.', tr.enc), ('recognizer.', tr.rec)):
+        for k, v in d.items():
+            np.testing.assert_allclose(v.detach().reshape(-1)[::4999].numpy(), g['finalslice.' + prefix + k], atol=2e-6, err_msg=k)
+
+
 def test_train_steps_match_reference():
     g = load_golden('g1_train3')
     c = {k[4:]: v for k, v in g.items() if k.startswith('cfg_')}
