@@ -113,7 +113,7 @@ def time_chain(device, direction, reps=20):
     torch.cuda.synchronize()
     grads = {k: [torch.zeros_like(w[0])] for k in ('dw_ih', 'dw_hh')}
     grads.update({k: [torch.zeros_like(b[0])] for k in ('db_ih', 'db_hh')})
-    total, n = 0.0, 0
+    ts = []
     for i in range(reps + 3):
         if direction == 'fwd':
             _lib.lstm_chain_events(e0, e1)
@@ -124,10 +124,10 @@ def time_chain(device, direction, reps=20):
         _lib.lstm_chain_events(None, None)
         torch.cuda.synchronize()
         if i >= 3:
-            total += e0.elapsed_time(e1)
-            n += 1
+            ts.append(e0.elapsed_time(e1))
     info = _lib.lstm_chain_info(direction)
-    return 1e3 * total / n, info['launches'], info['kernel']
+    ts.sort()
+    return 1e3 * ts[len(ts) // 2], info['launches'], info['kernel']          # median: one preempted sample must not move it
 
 
 def time_inference(enc, rec, x, steps):

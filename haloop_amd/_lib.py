@@ -55,6 +55,7 @@ SIGNATURES = {
     'halo_set_lstm_persistent': (_i, [_i]),
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),
+    'halo_lstm_persist_stamps': (_i, [_vp]),
     'halo_lstm_chain_events': (_i, [_vp, _vp]),
     'halo_lstm_chain_info': (_i, [_i, C.POINTER(_i), C.c_char_p, _i]),
     'halo_log_softmax_fwd': (_i, [_vp, _vp, _i, _i, _vp]),

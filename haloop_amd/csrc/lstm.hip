@@ -1139,6 +1139,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             else if (drop_out) { a.y = lb.ydrop; a.y_stride_t = (long)BH; a.y_stride_b = H; a.y_mode = Y_DROPOUT; }
             else { a.y = nullptr; a.y_stride_t = 0; a.y_stride_b = 0; a.y_mode = Y_NONE; }
             a.flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
+            a.stamps = halo_lstm_persist_stamp_buffer();
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_fwd(a, st));
             chain_end(st, 0, 1, "lstm_persist_fwd_kernel");
@@ -1229,6 +1230,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.dhinit = dhn ? dhn + (size_t)l * BH : nullptr;
             a.dcinit = dcn ? dcn + (size_t)l * BH : nullptr;
             a.flags = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L));
+            a.stamps = nullptr;
             a.T = T; a.B = B; a.H = H;
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_bwd(a, st));

@@ -61,15 +61,44 @@ __device__ __forceinline__ void map_block(int bid, int nblocks, int NJ, int NBT,
     }
 }
 
-// wait until every producer of this batch group has published epoch >= need; one wave calls it, result is wave-uniform
-__device__ __forceinline__ bool poll_group(const unsigned *grp_flags, int NJ, unsigned need, int lane) {
+// wait until producers [first, first + count) of this batch group have published epoch >= need (count <= 64); the calling wave
+// polls with one load per pass, lane l reading producer first + l; the result is wave-uniform
+__device__ __forceinline__ bool poll_group(const unsigned *grp_flags, int first, int count, unsigned need, int lane, int nap) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        const unsigned v = lane < NJ ? __hip_atomic_load(grp_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        const unsigned v = lane < count ? __hip_atomic_load(grp_flags + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0xffffffffu;
         if (__all(v >= need)) return true;
-        __builtin_amdgcn_s_sleep(1);
+        if (nap == 1) __builtin_amdgcn_s_sleep(1);
+        else if (nap == 2) __builtin_amdgcn_s_sleep(4);
+        else if (nap == 3) __builtin_amdgcn_s_sleep(16);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) return false;
     }
+}
+
+__device__ __forceinline__ int xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 0xf);
+}
+// one wave instruction publishes the epoch to every replica (lane r -> replica r)
+__device__ __forceinline__ void publish_epoch(unsigned *flags, int slot, unsigned epoch, int lane) {
+    if (lane < PERSIST_REPLICAS)
+        __hip_atomic_store(flags + lane * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// diagnostic time stamps (100 MHz counter), one slot per (block, step, point); compiled in, dormant while p.stamps == NULL
+__device__ __forceinline__ void stamp(unsigned long long *stamps, int T, int step, int point, int lane) {
+    if (stamps && lane == 0) stamps[((long)blockIdx.x * T + step) * 16 + point] = __builtin_amdgcn_s_memrealtime();
+}
+
+// Gate non-linearities on the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): the cell update sits on the serial
+// path of every step.  |error| <= ~2e-7 absolute for both (tanh as 1 - 2 / (1 + e^{2x}), the forms the parity tests bound).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -125,19 +154,38 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
         for (int g = 0; g < 4; ++g) gin[g] = p.gates[(long)b * 4 * H + (long)g * H + j0 + cj];
     }
     const __amdgpu_buffer_rsrc_t hp_rsrc = make_rsrc(p.hp);
-    unsigned *grp_flags = p.flags + PERSIST_FLAG_HEADER + bt * NJ;
+    // The copy of the epoch words this workgroup polls, by XCD.  Measured (tools/persist_stamps.py): a copy in the poller's half of
+    // the package's memory shows a new epoch ~0.8 us sooner than one in the other half, pages p and p + 2 lie in different halves,
+    // and which half a page is in depends on the physical pages behind the buffer.  With an ODD shift the two XCDs of a batch group
+    // (XCC 2g, 2g + 1 under round-robin dispatch) poll pages of different halves, so every group runs at the same, middle speed
+    // (4.5 us per step at H=1024, B=64) instead of two groups at 4.0 and two at 5.0 -- and the slowest group sets the chain time.
+    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
     if (tid == 0) s_abort = 0;
-
+    if (p.stamps && tid == 0) p.stamps[((long)blockIdx.x * T + 0) * 16 + 14] = my_replica;
+    if (p.stamps && tid == 0) p.stamps[((long)blockIdx.x * T + 0) * 16 + 15] = xcc_id();
     for (int t = 0; t < T; ++t) {
-        // ---- image t (= h_{t-1}) complete? ----
-        if (t > 0 && wave == 5) {
-            if (!poll_group(grp_flags, NJ, (unsigned)t, lane) && lane == 0) {
-                s_abort = 1;
-                __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (wave == 0) stamp(p.stamps, T, t, 0, lane);
+        if (wave == 5) stamp(p.stamps, T, t, 8, lane);
+        // ---- the pieces of image t (= h_{t-1}) this wave contracts: k-blocks [wave*KBW, +KBW) = hidden tiles [2*wave*KBW, +2*KBW).
+        //      Every wave polls for itself (its own loads follow its own matched poll); a timeout is agreed on at barrier (B). ----
+        // poll_mode 2: every wave polls for itself; 0 / 1: ONE otherwise idle wave polls the whole group (with / without a nap between
+        // polls) and releases the others at a barrier -- fewer pollers load the fabric less (MI355X_MICROARCH.md, polling-cost)
+        bool ok = true;
+        if (t > 0) {
+            if (p.poll_mode == 2) ok = poll_group(grp_flags, 2 * wave * KBW, 2 * KBW, (unsigned)t, lane, 0);
+            else if (wave == 5) ok = poll_group(grp_flags, 0, NJ, (unsigned)t, lane, p.nap);
         }
-        lds_barrier();                                                             // (A)
-        if (s_abort) return;
+        if (!ok && lane == 0) {
+            s_abort = 1;
+            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave == 5) stamp(p.stamps, T, t, 9, lane);
+        if (p.poll_mode != 2) {
+            lds_barrier();                                                         // (A)
+            if (s_abort) return;
+        }
+        if (wave == 0) stamp(p.stamps, T, t, 1, lane);
         // ---- this wave's fragments of the group's h_{t-1} tile, L1-bypassing ----
         const int img = (int)((((long)t * NBT + bt) * nkb + wave * KBW) * 2048) + lane * 16;
         bf16x8 ah[KBW], al[KBW];
@@ -168,7 +216,11 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
 #pragma unroll
                 for (int e = 0; e < 4; ++e) red[wave][g][(4 * q + e) * 16 + r] = acc[g][e];
         }
+        if (wave == 0) stamp(p.stamps, T, t, 2, lane);
+        if (wave == 7) stamp(p.stamps, T, t, 10, lane);
         lds_barrier();                                                             // (B)
+        if (s_abort) return;
+        if (wave == 0) stamp(p.stamps, T, t, 3, lane);
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
         if (tid < 256) {
             if (cell) {
@@ -180,13 +232,15 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
                     for (int k = 0; k < NWAVE; ++k) s += red[k][g][tid];
                     pre[g] = s + gin[g];
                 }
-                ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+                ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
                 cst = fg * cst + ig * gg;
-                h = og * tanhf(cst);
+                h = og * fast_tanh(cst);
             }
             hbuf[ci][cj] = h;                            // rows >= B: zeros
         }
+        if (wave == 0) stamp(p.stamps, T, t, 4, lane);
         lds_barrier();                                                             // (C)
+        if (wave == 4) stamp(p.stamps, T, t, 5, lane);
         if (wave == 4) {
             // packed image of h_t: this tile is k-groups (2 (jt & 1)) and (2 (jt & 1) + 1) of k-block jt / 2, hi part | lo part
             const int part = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
@@ -199,7 +253,9 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
                             (((jt & 1) * 2 + kg) * 16 + row) * 16;
             store_sc1(hp_rsrc, dst, part ? lo : hi);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
-            if (lane == 0) __hip_atomic_store(grp_flags + jt, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stamp(p.stamps, T, t, 6, lane);
+            publish_epoch(p.flags, bt * NJ + jt, (unsigned)(t + 1), lane);
+            stamp(p.stamps, T, t, 7, lane);
         }
         if (cell) {
             float *gp = p.gates + ((long)t * B + b) * 4 * H + j0 + cj;
@@ -265,22 +321,30 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
         if (p.dhinit) dh0 = p.dhinit[e0];
     }
     const __amdgpu_buffer_rsrc_t dg_rsrc = make_rsrc(p.dgp);
-    unsigned *grp_flags = p.flags + PERSIST_FLAG_HEADER + bt * NJ;
+    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;       // see the forward kernel
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
     if (tid == 0) { s_abort = 0; s_published = 0; }
 
     for (int s = 0; s < T; ++s) {
         const int t = T - 1 - s;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            // ---- image t+1 (gate gradients of the step done before) complete? ----
-            if (wave == 7) {
-                if (!poll_group(grp_flags, NJ, (unsigned)s, lane) && lane == 0) {
-                    s_abort = 1;
-                    __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            // ---- the pieces of image t+1 (gate gradients of the step done before) this wave contracts: k-blocks
+            //      [wave*KBW, +KBW) of the 4H-deep contraction = gate wave/2, hidden tiles [(wave & 1) * NJ/2, +NJ/2) ----
+            const int per_gate = H / 32;                       // k-blocks per gate
+            const int kb0 = wave * KBW;
+            const int jt_first = (kb0 % per_gate) * 2;
+            bool ok = true;
+            if (p.poll_mode == 2) ok = poll_group(grp_flags, jt_first, 2 * KBW > NJ ? NJ : 2 * KBW, (unsigned)s, lane, 0);
+            else if (wave == 7) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+            if (!ok && lane == 0) {
+                s_abort = 1;
+                __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lds_barrier();                                                         // (A)
-            if (s_abort) return;
+            if (p.poll_mode != 2) {
+                lds_barrier();                                                     // (A)
+                if (s_abort) return;
+            }
             const int img = (int)((((long)(t + 1) * NBT + bt) * nkb4 + wave * KBW) * 2048) + lane * 16;
             bf16x8 ah[2][4], al[2][4];
             auto load4 = [&](int buf, int c) {
@@ -307,8 +371,6 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
                 __builtin_amdgcn_sched_barrier(0);       // the next chunk's loads are issued before this chunk's MFMAs wait
                 mma4(c & 1, c);
             }
-        } else {
-            lds_barrier();
         }
         {
             const int r = lane & 15, q = lane >> 4;
@@ -316,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
             for (int e = 0; e < 4; ++e) red[wave][(4 * q + e) * 16 + r] = acc[e];
         }
         lds_barrier();                                                             // (B)
+        if (s_abort) return;
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (tid < 256) {
             if (cell) {
@@ -325,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
                     for (int k = 0; k < NWAVE; ++k) dh += red[k][tid];
                 }
                 const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-                const float tc = tanhf(cc);
+                const float tc = fast_tanh(cc);
                 if (p.dy) {
                     float d = dyv;
                     if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
@@ -358,11 +421,10 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
             store_sc1(dg_rsrc, dst, part ? lo : hi);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the last of the four storing waves to get here signals for the workgroup (counter in LDS: Guideline 16)
-            if (lane == 0) {
-                const unsigned old = atomicAdd(&s_published, 1u);
-                if (old == 4u * (unsigned)s + 3u)
-                    __hip_atomic_store(grp_flags + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(&s_published, 1u);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
         }
         if (cell) {
             float *gp = p.gates + ((long)t * B + b) * K + j0 + cj;
@@ -379,7 +441,12 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
     if (cell && p.dc) p.dc[e0] = dcarry;
 }
 
+unsigned long long *g_stamps = nullptr;
 int g_cu_count = 0;
+inline int poll_mode() {
+    static const int m = getenv("HALO_PERSIST_POLL") ? atoi(getenv("HALO_PERSIST_POLL")) : 0;
+    return m;
+}
 int g_persist_enabled = 1;
 
 inline int cu_count() {
@@ -395,8 +462,13 @@ inline int cu_count() {
 constexpr size_t FORCE_ONE_PER_CU_LDS = 64 * 1024;    // dynamic LDS request on top of the static arrays: one workgroup per CU
 
 template <typename K, typename A>
-int launch_persist(K kernel, const A &a, int blocks, hipStream_t st) {
+int launch_persist(K kernel, const A &a0, int blocks, hipStream_t st) {
     static_assert(sizeof(A) <= 4096, "kernel arguments");
+    A a = a0;
+    a.poll_mode = poll_mode();
+    static const int shift = getenv("HALO_PERSIST_REPLICA_SHIFT") ? atoi(getenv("HALO_PERSIST_REPLICA_SHIFT")) : 3;
+    static const int nap = getenv("HALO_PERSIST_NAP") ? atoi(getenv("HALO_PERSIST_NAP")) : 2;
+    a.replica_shift = shift; a.nap = nap;
     if (hipMemsetAsync(a.flags, 0, PERSIST_FLAG_BYTES, st) != hipSuccess) return HALO_ELAUNCH;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), FORCE_ONE_PER_CU_LDS, st, a);
     return halo_launch_status();
@@ -411,6 +483,11 @@ int allow_lds(K kernel) {
 }  // namespace
 
 void halo_lstm_persist_enable(int on) { g_persist_enabled = on ? 1 : 0; }
+unsigned long long *halo_lstm_persist_stamp_buffer() { return g_stamps; }
+extern "C" int halo_lstm_persist_stamps(void *buf) {
+    g_stamps = (unsigned long long *)buf;
+    return HALO_OK;
+}
 
 bool halo_lstm_persist_ok(int B, int H) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST") && atoi(getenv("HALO_LSTM_PERSIST")) == 0;

@@ -216,6 +216,10 @@ int halo_set_lstm_persistent(int on);
 int halo_lstm_persistent_eligible(int B, int H);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 
+/* Diagnostic: device buffer of uint64 [blocks][T][16] that the persistent forward fills with 100 MHz time stamps of its phases
+ * (tools/persist_stamps.py reads them); NULL (default) turns the stamps off. */
+int halo_lstm_persist_stamps(void *device_buffer);
+
 /* Measurement hook (bench.py): while set, every layer's recurrent chain inside halo_lstm_fwd / halo_lstm_bwd is bracketed by
  * hipEventRecord(ev_begin) / hipEventRecord(ev_end) on the call's stream (hipEvent_t handles; NULL, NULL clears).  The
  * batched GEMMs and operand preparation of the same call stay outside the bracket.  Not for use under stream capture.
