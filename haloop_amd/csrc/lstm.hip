@@ -438,57 +438,79 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArg
 // rows: tile = bt,         row r -> x[bt*16 + r][k] (0 beyond B)     (k over W)
 // MODE 2 also initialises the layer's row-major state rows: h_rm <- src (or 0), c_rm <- csrc (or 0)
 template <bool X3, int MODE>   // MODE 0: wp, 1: wpT, 2: rows
-__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src, void *__restrict__ dst, int H, int B,
-                                                   int Kdim, long units, float *__restrict__ h_rm,
-                                                   const float *__restrict__ csrc, float *__restrict__ c_rm) {
+__device__ __forceinline__ void pack_unit(long u, const float *__restrict__ src, void *__restrict__ dst, int H, int B, int Kdim,
+                                          float *__restrict__ h_rm, const float *__restrict__ csrc, float *__restrict__ c_rm) {
     using PK = Packed<X3>;
     constexpr int EPL = X3 ? 8 : 4;            // elements per lane and block
     const int nkb = Kdim / PK::KB;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-        const int lane = (int)(u & 63);
-        long blk = u >> 6;
-        const int kb = (int)(blk % nkb);
-        const int tile = (int)(blk / nkb);
-        const int r = lane & 15, k0 = kb * PK::KB + (lane >> 4) * EPL;
-        float x[EPL];
+    const int lane = (int)(u & 63);
+    long blk = u >> 6;
+    const int kb = (int)(blk % nkb);
+    const int tile = (int)(blk / nkb);
+    const int r = lane & 15, k0 = kb * PK::KB + (lane >> 4) * EPL;
+    float x[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            float v = 0.f;
-            if (MODE == 0) {
-                const int g = tile & 3, jt = tile >> 2;
-                v = src[((long)g * H + jt * 16 + r) * H + k0 + e];
-            } else if (MODE == 1) {
-                v = src[(long)(k0 + e) * H + tile * 16 + r];
-            } else {
-                const int bb = tile * 16 + r;
-                if (src && bb < B) v = src[(long)bb * Kdim + k0 + e];
-                if (bb < B) {
-                    if (h_rm) h_rm[(long)bb * Kdim + k0 + e] = v;
-                    if (c_rm) c_rm[(long)bb * Kdim + k0 + e] = csrc ? csrc[(long)bb * Kdim + k0 + e] : 0.f;
-                }
-            }
-            x[e] = v;
-        }
-        char *base = (char *)dst + blk * PK::BLOCK_BYTES;
-        if (X3) {
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const __bf16 hh = (__bf16)x[e];
-                hi[e] = hh;
-                lo[e] = (__bf16)(x[e] - (float)hh);
-            }
-            *reinterpret_cast<bf16x8 *>(base + lane * 16) = hi;
-            *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
+    for (int e = 0; e < EPL; ++e) {
+        float v = 0.f;
+        if (MODE == 0) {
+            const int g = tile & 3, jt = tile >> 2;
+            v = src[((long)g * H + jt * 16 + r) * H + k0 + e];
+        } else if (MODE == 1) {
+            v = src[(long)(k0 + e) * H + tile * 16 + r];
         } else {
-            f32x4 v4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = x[e];
-            *reinterpret_cast<f32x4 *>(base + lane * 16) = v4;
+            const int bb = tile * 16 + r;
+            if (src && bb < B) v = src[(long)bb * Kdim + k0 + e];
+            if (bb < B) {
+                if (h_rm) h_rm[(long)bb * Kdim + k0 + e] = v;
+                if (c_rm) c_rm[(long)bb * Kdim + k0 + e] = csrc ? csrc[(long)bb * Kdim + k0 + e] : 0.f;
+            }
         }
+        x[e] = v;
+    }
+    char *base = (char *)dst + blk * PK::BLOCK_BYTES;
+    if (X3) {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 hh = (__bf16)x[e];
+            hi[e] = hh;
+            lo[e] = (__bf16)(x[e] - (float)hh);
+        }
+        *reinterpret_cast<bf16x8 *>(base + lane * 16) = hi;
+        *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
+    } else {
+        f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = x[e];
+        *reinterpret_cast<f32x4 *>(base + lane * 16) = v4;
     }
 }
 
+template <bool X3, int MODE>
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src, void *__restrict__ dst, int H, int B,
+                                                   int Kdim, long units, float *__restrict__ h_rm,
+                                                   const float *__restrict__ csrc, float *__restrict__ c_rm) {
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < units; u += (long)gridDim.x * 256)
+        pack_unit<X3, MODE>(u, src, dst, H, B, Kdim, h_rm, csrc, c_rm);
+}
+
+// Everything a persistent recurrence needs ahead of its launch, in ONE launch: the packed image of W_hh (WMODE 0, forward) or
+// W_hh^T (WMODE 1, backward), for the forward also the packed + row-major initial state (pack MODE 2), and the zeroed epoch words.
+struct PrologueArgs {
+    const float *w; void *wdst; long w_units; int wK;
+    const float *h0; void *hp0; float *h_rm; const float *c0; float *c_rm; long s_units;
+    unsigned *zero; long zero_units;      // 16-byte units
+    int H, B;
+};
+template <int WMODE>
+__global__ __launch_bounds__(256) void persist_prologue_kernel(const PrologueArgs a) {
+    const long total = a.w_units + a.s_units + a.zero_units;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        if (u < a.w_units) pack_unit<true, WMODE>(u, a.w, a.wdst, a.H, a.B, a.wK, nullptr, nullptr, nullptr);
+        else if (u < a.w_units + a.s_units) pack_unit<true, 2>(u - a.w_units, a.h0, a.hp0, a.H, a.B, a.H, a.h_rm, a.c0, a.c_rm);
+        else reinterpret_cast<uint4 *>(a.zero)[u - a.w_units - a.s_units] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
 
 // =================================================================================================
 // Layer-diagonal ("wavefront") fusion.  Step t of layer l only needs step t of layer l-1 and step
@@ -1122,12 +1144,26 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[l], in_dim, lb.gates, 4 * H, b_ih[l],
                                    b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
         }
-        HALO_TRY(launch_pack<0>(w_hh[l], wp, H, B, H, (H / 16) * 4, x3, st));
         const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
-        // one launch: packed h_{-1}, row-major h_{-1} and c_{-1} (zeros when no initial state is given)
-        HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st, lb.h, c0 ? c0 + (size_t)l * BH : nullptr, lb.c));
+        const bool persist = x3 && halo_lstm_persist_ok(B, H);
+        unsigned *flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
+        if (persist) {
+            // one launch: packed W_hh, packed + row-major initial state, zeroed epoch words
+            PrologueArgs pa;
+            pa.w = w_hh[l]; pa.wdst = wp; pa.w_units = (long)(H / 16) * 4 * (H / 32) * 64; pa.wK = H;
+            pa.h0 = h0l; pa.hp0 = lb.hp; pa.h_rm = lb.h; pa.c0 = c0 ? c0 + (size_t)l * BH : nullptr; pa.c_rm = lb.c;
+            pa.s_units = (long)((B + 15) / 16) * (H / 32) * 64;
+            pa.zero = flags; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+            pa.H = H; pa.B = B;
+            hipLaunchKernelGGL(persist_prologue_kernel<0>, dim3(pack_grid((size_t)(pa.w_units + pa.s_units + pa.zero_units))), dim3(256), 0, st, pa);
+            HALO_TRY(halo_launch_status());
+        } else {
+            HALO_TRY(launch_pack<0>(w_hh[l], wp, H, B, H, (H / 16) * 4, x3, st));
+            // one launch: packed h_{-1}, row-major h_{-1} and c_{-1} (zeros when no initial state is given)
+            HALO_TRY(launch_pack<2>(h0l, lb.hp, H, B, H, (B + 15) / 16, x3, st, lb.h, c0 ? c0 + (size_t)l * BH : nullptr, lb.c));
+        }
         const DropoutCfg dc = make_dropout(drop_out ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)l, offset, offset_dev);
-        if (x3 && halo_lstm_persist_ok(B, H)) {
+        if (persist) {
             // ONE launch for all T steps: W_hh stays in registers, h_t is handed between workgroups (lstm_persist.hip)
             PersistFwd a;
             a.wp = (const char *)wp;
@@ -1138,7 +1174,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             if (last && y) { a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y_relu ? Y_RELU : Y_PLAIN; }
             else if (drop_out) { a.y = lb.ydrop; a.y_stride_t = (long)BH; a.y_stride_b = H; a.y_mode = Y_DROPOUT; }
             else { a.y = nullptr; a.y_stride_t = 0; a.y_stride_b = 0; a.y_mode = Y_NONE; }
-            a.flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
+            a.flags = flags;
             a.stamps = halo_lstm_persist_stamp_buffer();
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_fwd(a, st));
@@ -1218,8 +1254,18 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
-        if (!fused) HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
         const bool persist = !fused && x3 && halo_lstm_persist_ok(B, H);
+        if (persist) {
+            PrologueArgs pa;                                  // packed W_hh^T and zeroed epoch words in one launch
+            pa.w = w_hh[l]; pa.wdst = wpT; pa.w_units = (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
+            pa.h0 = nullptr; pa.hp0 = nullptr; pa.h_rm = nullptr; pa.c0 = nullptr; pa.c_rm = nullptr; pa.s_units = 0;
+            pa.zero = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L)); pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+            pa.H = H; pa.B = B;
+            hipLaunchKernelGGL(persist_prologue_kernel<1>, dim3(pack_grid((size_t)(pa.w_units + pa.zero_units))), dim3(256), 0, st, pa);
+            HALO_TRY(halo_launch_status());
+        } else if (!fused) {
+            HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
+        }
         if (persist) {
             PersistBwd a;
             a.wpT = (const char *)wpT;

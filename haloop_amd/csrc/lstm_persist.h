@@ -22,7 +22,7 @@ struct PersistFwd {
     long y_stride_t, y_stride_b;
     int y_mode;          // 0 none, 1 plain, 2 relu, 3 dropout
     DropoutCfg drop;
-    unsigned *flags;     // PERSIST_FLAG_BYTES, zeroed by the launcher
+    unsigned *flags;     // PERSIST_FLAG_BYTES, zeroed by the launch ahead of this one (lstm.hip, persist_prologue_kernel)
     unsigned long long *stamps;   // diagnostic: [block][T][16] s_memrealtime stamps (halo_lstm_persist_stamps), normally NULL
     int poll_mode;       // set by the launcher
     int replica_shift;   // copy of the epoch words polled = (XCC id + replica_shift) % PERSIST_REPLICAS

@@ -469,7 +469,7 @@ int launch_persist(K kernel, const A &a0, int blocks, hipStream_t st) {
     static const int shift = getenv("HALO_PERSIST_REPLICA_SHIFT") ? atoi(getenv("HALO_PERSIST_REPLICA_SHIFT")) : 3;
     static const int nap = getenv("HALO_PERSIST_NAP") ? atoi(getenv("HALO_PERSIST_NAP")) : 2;
     a.replica_shift = shift; a.nap = nap;
-    if (hipMemsetAsync(a.flags, 0, PERSIST_FLAG_BYTES, st) != hipSuccess) return HALO_ELAUNCH;
+    // a.flags is zeroed by the caller's prologue launch (lstm.hip, persist_prologue_kernel)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), FORCE_ONE_PER_CU_LDS, st, a);
     return halo_launch_status();
 }
