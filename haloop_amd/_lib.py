@@ -66,6 +66,8 @@ SIGNATURES = {
     'halo_ctc_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'halo_ctc_mean_loss': (_i, [_vp, _vp, _i, _vp, _vp]),
     'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'halo_set_beam_vector_chunk': (_i, [_i]),
+    'halo_logaddexp_aten': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'halo_ctc_beam_workspace_bytes': (_sz, [_i] * 4),
     'halo_ctc_beam': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_topk_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

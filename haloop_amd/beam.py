@@ -2,7 +2,17 @@
 plus a batched entry (``decode_batch``) that runs one workgroup per utterance."""
 import torch
 
-from . import ops
+from . import _lib, ops
+
+# ATen's CPU logaddexp sends whole chunks of 2 * Vectorized<float>::size() candidates through Sleef and the rest through libm;
+# which candidates those are depends on the CPU the reference ran on.  The kernel reproduces either arithmetic bit for bit.
+_CHUNK = {'AVX512': 32, 'AVX2': 16}
+
+
+def set_reference_cpu(capability='AVX512'):
+    """Which reference machine to reproduce: 'AVX512' (default; the fixtures under tests/golden/ were generated on one), 'AVX2',
+    or any other torch.backends.cpu.get_cpu_capability() string (no vector ISA: scalar loop everywhere)."""
+    _lib.check(_lib.lib().halo_set_beam_vector_chunk(_CHUNK.get(capability, 0)), 'halo_set_beam_vector_chunk')
 
 
 def decode_batch(emissions, beam_size=3, log_domain=True):

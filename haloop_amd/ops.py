@@ -337,6 +337,14 @@ def ctc_beam(em, beam, log_domain=True):
     return seqs, lens, scores
 
 
+def logaddexp_aten(a, b):
+    """torch.logaddexp(a, b) with ATen's CPU arithmetic bit for bit (1-D contiguous float32; see halo_set_beam_vector_chunk)."""
+    _f32c(a, 'a'); _f32c(b, 'b')
+    out = torch.empty_like(a)
+    check(lib().halo_logaddexp_aten(ptr(a), ptr(b), ptr(out), a.numel(), _stream()), 'halo_logaddexp_aten')
+    return out
+
+
 def topk(values2d, k):
     """Row-wise top-k in torch.topk's CPU order (ties included). -> (values [rows,k], indices [rows,k] int64)"""
     _f32c(values2d, 'values')

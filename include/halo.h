@@ -287,7 +287,15 @@ int halo_ctc_greedy(const float *lp, int N, int T, int C, int64_t *alignments, f
 /* Beam search with the reference's exact (quirky) semantics, one workgroup per utterance.
  * replaces: ha/beam.py:71-137 (logits) and ha/beam.py:5-68 (probs, log_domain = 0).
  *   em [N,T,V]; seqs [N,beam,T] int64, lens [N,beam] int32, scores [N,beam] f32, ranked best first.
- *   workspace: halo_ctc_beam_workspace_bytes().  Requires beam <= 1+V (reference: topk raises). */
+ *   workspace: halo_ctc_beam_workspace_bytes().  Requires beam <= 1+V (reference: topk raises).
+ *   Scores are formed with torch.logaddexp's CPU arithmetic reproduced bit for bit (ATen's vector loop on Sleef's expf / log1pf
+ *   for whole vector chunks of the candidate array, the scalar loop on glibc's expf / log1pf for the remainder and for the
+ *   per-prefix update), because on flat emissions score-tied hypotheses are separated by its last ulp.
+ *   halo_set_beam_vector_chunk: 2 * Vectorized<float>::size() of the machine whose reference run is to be reproduced:
+ *   32 (AVX-512, default: the fixtures under tests/golden/), 16 (AVX2), 0 (no vector ISA: everything through the scalar loop).
+ *   halo_logaddexp_aten: that function on its own, element i of n taking the vector path iff i < n - n % chunk. */
+int halo_set_beam_vector_chunk(int elements);
+int halo_logaddexp_aten(const float *a, const float *b, float *out, size_t n, halo_stream_t stream);
 size_t halo_ctc_beam_workspace_bytes(int N, int T, int V, int beam);
 int halo_ctc_beam(const float *em, int N, int T, int V, int beam, int log_domain, int64_t *seqs,
                   int32_t *lens, float *scores, void *workspace, halo_stream_t stream);
