@@ -97,6 +97,7 @@ SIGNATURES = {
     'halo_embed_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_add_rows_bcast': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'halo_im2col_cl': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'halo_col2im_cl': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_dwconv1d_cl': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_dwconv1d_cl_bwd_workspace_bytes': (_sz, [_i, _i]),
     'halo_dwconv1d_cl_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -111,6 +111,82 @@ class Block(nn.Module):
         self.mlp = MLP(config)
 
 
+# ---- one pre-LN GPT block (ha/attention.py:147-180), shared by GPT and haloop_amd.attention_audio.AudioEncoder ----------------
+def block_forward(images, blk, x, B, T, cfg):
+    """Inference: the residual stream x [B*T, C] is updated in place."""
+    C, H = cfg.n_embd, cfg.n_head
+    qkv, _ = ln_linear(images, x, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias)
+    y, _, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
+    linear(images, y, blk.attn.c_proj.weight, bias=blk.attn.c_proj.bias, out=x, accumulate=True)           # x += c_proj(y)
+    h, _ = ln_linear(images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True)
+    linear(images, h, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x, accumulate=True)              # x += mlp(h)
+    return x
+
+
+def block_forward_train(images, blk, x0, B, T, cfg, sites):
+    """Training forward: returns (x_out, saved).  Dropout sites in forward order (ha/attention.py:90,127,141): attention
+    probabilities, c_proj output, MLP output; the output dropouts are GEMM epilogues."""
+    C, H = cfg.n_embd, cfg.n_head
+    qkv, h1 = ln_linear(images, x0, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias, want_normed=True)
+    s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
+    y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
+                                  drop=s_att[0], stream_id=s_att[1])
+    # y and gelu(a) each feed one Linear now and its weight gradient later: both operand images come out of one read, and
+    # gelu(a) is never written in fp32
+    y_img, y_img_t = forward_images(y, C)
+    x1 = linear(images, y, blk.attn.c_proj.weight, bias=blk.attn.c_proj.bias, out=x0.clone(), accumulate=True, drop=s_res[0],
+                stream_id=s_res[1], a_image=y_img)
+    a, h2 = ln_linear(images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
+    g_img, g_img_t = forward_images(a, C, ops.PAIR_GELU)
+    g = ops.gelu_fwd(a) if g_img is None else None
+    x = linear(images, g, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x1.clone(), accumulate=True, drop=s_mlp[0],
+               stream_id=s_mlp[1], a_image=g_img, shape=a.shape)
+    return x, (x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp)
+
+
+def block_backward(images, blk, saved, dx, B, T, cfg, put):
+    """dx: gradient w.r.t. the block's output [B*T, C]; returns the gradient w.r.t. its input; parameter gradients go to put(p, g)."""
+    C, H = cfg.n_embd, cfg.n_head
+    M = B * T
+    img = images
+    x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp = saved
+    # x = x1 + drop(c_proj(gelu(c_fc(ln_2(x1)))))
+    dm = drop_rows(dx, s_mlp)
+    dm_img, dm_img_t = grad_images(dm, 4 * C)
+    put(blk.mlp.c_proj.weight, linear_dw(dm, g, dy_image_t=dm_img_t, x_image_t=g_img_t, shapes=(dm.shape, a.shape)))
+    if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dm))
+    dg = linear_dx(img, dm, blk.mlp.c_proj.weight, dy_image=dm_img)
+    if blk.mlp.c_fc.bias is None and use_split(M, C, 4 * C) and use_split(4 * C, C, M):
+        # da = dg * gelu'(a) is only ever a GEMM operand: write its two images, not the fp32 matrix
+        da_img, da_img_t = ops.image_pair(dg, ops.PAIR_GELU_BWD, a)
+        put(blk.mlp.c_fc.weight, linear_dw(None, h2, dy_image_t=da_img_t, shapes=(a.shape, h2.shape)))
+        d_ln2 = linear_dx(img, None, blk.mlp.c_fc.weight, dy_image=da_img, shape=a.shape)
+        del da_img, da_img_t
+    else:
+        da = ops.gelu_bwd(dg, a)
+        put(blk.mlp.c_fc.weight, linear_dw(da, h2))
+        if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
+        d_ln2 = linear_dx(img, da, blk.mlp.c_fc.weight)
+    dx1, dw, db = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
+    put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
+    # x1 = x0 + drop(c_proj(attention(c_attn(ln_1(x0)))))
+    dr = drop_rows(dx1, s_res)
+    dr_img, dr_img_t = grad_images(dr, C)
+    put(blk.attn.c_proj.weight, linear_dw(dr, y, dy_image_t=dr_img_t, x_image_t=y_img_t))
+    if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dr))
+    dy = linear_dx(img, dr, blk.attn.c_proj.weight, dy_image=dr_img)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
+                      B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
+    dq_img, dq_img_t = grad_images(dqkv, C)
+    put(blk.attn.c_attn.weight, linear_dw(dqkv, h1, dy_image_t=dq_img_t))
+    if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
+    dx0, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight, dy_image=dq_img), x0, blk.ln_1.weight, dx1,
+                                    blk.ln_1.bias is not None)
+    put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
+    return dx0
+
+
 class _GPTLoss(torch.autograd.Function):
     """Per-token NLL of GPT.forward_all with its hand-written backward (the autograd graph the reference gets from
     torch for ha/attention.py:205-232).  The parameters ride along as inputs so that loss.backward() fills their
@@ -250,21 +326,8 @@ class GPT(nn.Module):
         x = drop_rows(x, s_emb)
         blocks = []
         for blk in tr.h:
-            x0 = x
-            qkv, h1 = ln_linear(self._images, x0, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias,
-                                want_normed=True)
-            s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
-            y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
-                                          drop=s_att[0], stream_id=s_att[1])
-            # y and gelu(a) each feed one Linear now and its weight gradient later: both operand images come out of one read, and
-            # gelu(a) is never written in fp32
-            y_img, y_img_t = forward_images(y, C)
-            x1 = self._linear(y, blk.attn.c_proj, out=x0.clone(), accumulate=True, site=s_res, a_image=y_img)
-            a, h2 = ln_linear(self._images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
-            g_img, g_img_t = forward_images(a, C, ops.PAIR_GELU)
-            g = ops.gelu_fwd(a) if g_img is None else None
-            x = self._linear(g, blk.mlp.c_proj, out=x1.clone(), accumulate=True, site=s_mlp, a_image=g_img, shape=a.shape)
-            blocks.append((x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp))
+            x, sv = block_forward_train(self._images, blk, x, B, T, cfg, sites)
+            blocks.append(sv)
         xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
         if use_split(B * T, cfg.vocab_size, C) and B * T > SMALL_M:          # statistics in the GEMM epilogue; the logits are kept for the backward
@@ -302,41 +365,8 @@ class GPT(nn.Module):
             dxf = linear_dx(img, dlogits, self.lm_head.weight)
         dx, dw, db = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None)
         put(tr.ln_f.weight, dw); put(tr.ln_f.bias, db)
-        for blk, (x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp) in zip(reversed(tr.h), reversed(blocks)):
-            # x = x1 + drop(c_proj(gelu(c_fc(ln_2(x1)))))
-            dm = drop_rows(dx, s_mlp)
-            dm_img, dm_img_t = grad_images(dm, 4 * C)
-            put(blk.mlp.c_proj.weight, linear_dw(dm, g, dy_image_t=dm_img_t, x_image_t=g_img_t, shapes=(dm.shape, a.shape)))
-            if blk.mlp.c_proj.bias is not None: put(blk.mlp.c_proj.bias, ops.colsum(dm))
-            dg = linear_dx(img, dm, blk.mlp.c_proj.weight, dy_image=dm_img)
-            if blk.mlp.c_fc.bias is None and use_split(M, C, 4 * C) and use_split(4 * C, C, M):
-                # da = dg * gelu'(a) is only ever a GEMM operand: write its two images, not the fp32 matrix
-                da_img, da_img_t = ops.image_pair(dg, ops.PAIR_GELU_BWD, a)
-                put(blk.mlp.c_fc.weight, linear_dw(None, h2, dy_image_t=da_img_t, shapes=(a.shape, h2.shape)))
-                d_ln2 = linear_dx(img, None, blk.mlp.c_fc.weight, dy_image=da_img, shape=a.shape)
-                del da_img, da_img_t
-            else:
-                da = ops.gelu_bwd(dg, a)
-                put(blk.mlp.c_fc.weight, linear_dw(da, h2))
-                if blk.mlp.c_fc.bias is not None: put(blk.mlp.c_fc.bias, ops.colsum(da))
-                d_ln2 = linear_dx(img, da, blk.mlp.c_fc.weight)
-            dx1, dw, db = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None)
-            put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
-            # x1 = x0 + drop(c_proj(attention(c_attn(ln_1(x0)))))
-            dr = drop_rows(dx1, s_res)
-            dr_img, dr_img_t = grad_images(dr, C)
-            put(blk.attn.c_proj.weight, linear_dw(dr, y, dy_image_t=dr_img_t, x_image_t=y_img_t))
-            if blk.attn.c_proj.bias is not None: put(blk.attn.c_proj.bias, ops.colsum(dr))
-            dy = linear_dx(img, dr, blk.attn.c_proj.weight, dy_image=dr_img)
-            dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
-                              B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
-            dq_img, dq_img_t = grad_images(dqkv, C)
-            put(blk.attn.c_attn.weight, linear_dw(dqkv, h1, dy_image_t=dq_img_t))
-            if blk.attn.c_attn.bias is not None: put(blk.attn.c_attn.bias, ops.colsum(dqkv))
-            dx, dw, db = ops.layernorm_bwd(linear_dx(img, dqkv, blk.attn.c_attn.weight, dy_image=dq_img), x0, blk.ln_1.weight, dx1,
-                                           blk.ln_1.bias is not None)
-            put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
+        for blk, sv in zip(reversed(tr.h), reversed(blocks)):
+            dx = block_backward(img, blk, sv, dx, B, T, cfg, put)
         dwpe = torch.zeros_like(tr.wpe.weight)
         dx = drop_rows(dx, s_emb)
         if emb_saved is not None:                                                # StableEmbedding: through the two LayerNorms first

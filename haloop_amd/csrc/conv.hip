@@ -23,6 +23,25 @@ __global__ __launch_bounds__(256) void im2col_cl_kernel(const float *__restrict_
     col[idx] = (t >= 0 && t < T) ? x[((long)n * T + t) * Cin + cin] : 0.f;
 }
 
+// transpose of im2col_cl (the gradient of the unfold): dx[n, t, cin] = sum over (t', k) with t'*stride + k - pad == t of dcol[(n, t'), cin*ks + k]
+__global__ __launch_bounds__(256) void col2im_cl_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int N, int T, int Cin,
+                                                        int To, int ks, int stride, int pad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * T * Cin) return;
+    const int cin = (int)(idx % Cin);
+    const long row = idx / Cin;
+    const int t = (int)(row % T), n = (int)(row / T);
+    const long K = (long)Cin * ks;
+    float acc = 0.f;
+    for (int k = 0; k < ks; ++k) {
+        const int u = t + pad - k;
+        if (u < 0 || u % stride) continue;
+        const int to = u / stride;
+        if (to < To) acc += dcol[((long)n * To + to) * K + (long)cin * ks + k];
+    }
+    dx[idx] = acc;
+}
+
 // y[n, t', c] = bias[c] + sum_k w[c, k] * x[n, t'*stride + k - pad, c]
 __global__ __launch_bounds__(256) void dwconv1d_cl_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ bias, float *__restrict__ y, int N, int T, int C,
@@ -96,6 +115,16 @@ int halo_im2col_cl(const float *x, float *col, int N, int T, int Cin, int ks, in
     HALO_CHECK_ARG(To > 0);
     const long n = (long)N * To * Cin * ks;
     hipLaunchKernelGGL(im2col_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, col, N, T, Cin, To, ks,
+                       stride, pad);
+    return halo_launch_status();
+}
+
+int halo_col2im_cl(const float *dcol, float *dx, int N, int T, int Cin, int ks, int stride, int pad, halo_stream_t stream) {
+    HALO_CHECK_ARG(dcol && dx && N > 0 && T > 0 && Cin > 0 && ks > 0 && stride > 0 && pad >= 0);
+    const int To = (T + 2 * pad - ks) / stride + 1;
+    HALO_CHECK_ARG(To > 0);
+    const long n = (long)N * T * Cin;
+    hipLaunchKernelGGL(col2im_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcol, dx, N, T, Cin, To, ks,
                        stride, pad);
     return halo_launch_status();
 }

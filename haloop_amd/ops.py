@@ -626,6 +626,14 @@ def im2col_cl(x3d, ks, stride, pad):
     return col, To
 
 
+def col2im_cl(dcol, N, T, Cin, ks, stride, pad):
+    """The fold: gradient of im2col_cl. dcol [N*T', Cin*ks] -> dx [N, T, Cin]."""
+    _f32c(dcol, 'dcol')
+    dx = torch.empty(N, T, Cin, device=dcol.device, dtype=torch.float32)
+    check(lib().halo_col2im_cl(ptr(dcol), ptr(dx), N, T, Cin, ks, stride, pad, _stream()), 'halo_col2im_cl')
+    return dx
+
+
 def dwconv1d_cl(x3d, weight, bias, stride, pad):
     _f32c(x3d, 'x')
     N, T, Cn = x3d.shape

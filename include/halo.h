@@ -431,6 +431,10 @@ int halo_add_rows_bcast(float *x, const float *p, int rows, int T, int C, halo_s
  * x [N, T, C] -> [N, T', C] with T' = (T + 2*pad - ks)/stride + 1; no length masking (the reference has none). */
 int halo_im2col_cl(const float *x, float *col, int N, int T, int Cin, int ks, int stride, int pad,
                    halo_stream_t stream);
+/* gradient of the unfold (the fold): dx [N,T,Cin] from dcol [N*T', Cin*ks]; with it a dense Conv1d whose input is an activation
+ * (ha/attention_audio.py:71 conv_subsample) back-propagates as GEMM + halo_col2im_cl */
+int halo_col2im_cl(const float *dcol, float *dx, int N, int T, int Cin, int ks, int stride, int pad,
+                   halo_stream_t stream);
 int halo_dwconv1d_cl(const float *x, const float *weight, const float *bias, float *y, int N, int T, int C, int ks,
                      int stride, int pad, halo_stream_t stream);
 /* gradient of halo_dwconv1d_cl: dx [N,T,C] (NULL to skip), dweight [C,ks], dbias [C] (NULL when bias-free); ks <= 8;

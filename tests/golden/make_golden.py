@@ -24,9 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init, ha.transformer, ha.conv   # the reference
+import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init, ha.transformer, ha.conv, ha.attention_audio   # the reference
 
-from oracle import cpu_ref, gpt_ref, transformer_ref
+from oracle import cpu_ref, gpt_ref, transformer_ref, audio_encoder_ref
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -346,6 +346,43 @@ def gpt_case(name, vocab, block, n_layer, n_head, n_embd, bias, B, T, seed, stor
     print(name, 'mean nats/token', float(mean))
 
 
+def audio_encoder_case(name, d_input, n_embd, n_head, n_layer, block, bias, vocab, B, T, S, seed, full_grads):
+    """ha.attention_audio.AudioEncoder without rotary embeddings (the `audio-encoder` arch, ha/init.py:132-139) + the CTC head it is
+    trained with: features, lengths, loss, and the gradient of every parameter."""
+    cfg = ha.init.AudioEncoderConfig(block_size=block, vocab_size=vocab, n_layer=n_layer, n_head=n_head, n_embd=n_embd, bias=bias,
+                                     d_input=d_input)
+    cfg.rotary_emb_dim = 0
+    enc = ha.attention_audio.AudioEncoder(cfg).eval()
+    params = audio_encoder_ref.make_params(d_input, n_embd, n_layer, block, bias, seed)
+    enc.load_state_dict(params, strict=True)
+    assert not enc.transformer.wpe.weight.requires_grad
+    rec = ha.recognizer.TemporalClassifier(feat_dim=n_embd, vocab_size=vocab).eval()
+    rec_p, x, il, tg, tl = audio_encoder_ref.make_head_and_batch(n_embd, vocab, d_input, B, T, S, seed)
+    rec.load_state_dict(rec_p)
+    feats, flen, stats = enc(x, il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg, flen, tl)
+    loss.backward()
+    d = {'cfg': np.array([d_input, n_embd, n_head, n_layer, block, int(bias), vocab, B, T, S, seed]),
+         'feats': feats.detach().numpy(), 'flen': flen.numpy(), 'loss': loss.detach().numpy(),
+         'dfeats': feats.grad.numpy(), 'wpe_head': enc.transformer.wpe.weight[:8].detach().numpy()}
+    grads = {('grad.' + k): v.grad for k, v in enc.named_parameters() if v.grad is not None}
+    grads.update({('recgrad.' + k): v.grad for k, v in rec.named_parameters()})
+    for k, v in grads.items():
+        if full_grads:
+            d[k] = v.numpy()
+        else:
+            d['norm.' + k] = np.array(float(v.double().norm()))
+            d['slice.' + k] = v.reshape(-1)[::97].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'loss', float(loss), 'flen', flen.tolist())
+
+
+def save_audio_encoder():
+    audio_encoder_case('g7_audio_encoder_tiny', 20, 64, 2, 2, 64, False, 11, 3, 41, 4, 21, True)
+    audio_encoder_case('g7_audio_encoder_bias', 80, 128, 4, 3, 128, True, 32, 4, 80, 10, 22, False)
+
+
 def save_gpt():
     gpt_case('g5_gpt_tiny_nobias', 97, 32, 2, 2, 64, False, 3, 20, 5, True)
     gpt_case('g5_gpt_tiny_bias', 97, 48, 3, 1, 64, True, 2, 40, 6, True)
@@ -443,6 +480,7 @@ if __name__ == '__main__':
             globals()[name]()
         sys.exit(0)
     save_lc2x1024_b64()
+    save_audio_encoder()
     save_asr()
     save_gpt()
     save_tiny()

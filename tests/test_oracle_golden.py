@@ -318,6 +318,35 @@ def test_asr_gradients_match_reference(name):
     assert n == sum(1 for k in g if k.startswith('grad.'))
 
 
+@pytest.mark.parametrize('name', ['g7_audio_encoder_tiny', 'g7_audio_encoder_bias'])
+def test_audio_encoder_matches_reference(name):
+    """ha.attention_audio.AudioEncoder (rotary_emb_dim = 0) + CTC head: oracle == reference on features, lengths, loss, gradients."""
+    from oracle import audio_encoder_ref as ae
+    g = load_golden(name)
+    d_input, n_embd, n_head, n_layer, block, bias, vocab, B, T, S, seed = (int(v) for v in g['cfg'])
+    p = {k: v.clone().requires_grad_(k != 'transformer.wpe.weight') for k, v in ae.make_params(d_input, n_embd, n_layer, block, bool(bias), seed).items()}
+    np.testing.assert_array_equal(p['transformer.wpe.weight'][:8].detach().numpy(), g['wpe_head'])
+    rec_p, x, il, tg, tl = ae.make_head_and_batch(n_embd, vocab, d_input, B, T, S, seed)
+    rec_p = {k: v.clone().requires_grad_(True) for k, v in rec_p.items()}
+    feats, flen, _ = ae.forward(p, n_layer, n_head, x, il)
+    feats.retain_grad()
+    loss, _ = cpu_ref.classifier_loss(rec_p, feats, tg, flen, tl)
+    loss.backward()
+    assert flen.dtype == torch.int32 and np.array_equal(flen.numpy(), g['flen'])
+    np.testing.assert_allclose(feats.detach().numpy(), g['feats'], atol=2e-5)
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-6)
+    np.testing.assert_allclose(feats.grad.numpy(), g['dfeats'], rtol=1e-4, atol=1e-6)
+    for k, v in list(p.items()) + [('rec:' + k, v) for k, v in rec_p.items()]:
+        if v.grad is None:
+            continue
+        key = ('recgrad.' + k[4:]) if k.startswith('rec:') else 'grad.' + k
+        if key in g:
+            np.testing.assert_allclose(v.grad.numpy(), g[key], rtol=1e-3, atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(float(v.grad.double().norm()), float(g['norm.' + key]), rtol=1e-4, err_msg=k)
+            np.testing.assert_allclose(v.grad.reshape(-1)[::97].numpy(), g['slice.' + key], rtol=1e-3, atol=1e-6, err_msg=k)
+
+
 def test_symbol_tape_restatement_on_the_reference_demo():
     """ha/symbol_tape.py:311-313 (`__main__`): the 48-letter tape, batch_size 2, bptt_len 8.  tape_len = 24, three parts, no
     trailing part; column b of part i is data[b*23 + 8i : b*23 + 8i + 8] (worked out by hand from :252-277)."""
