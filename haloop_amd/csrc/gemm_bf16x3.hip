@@ -35,9 +35,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &
 }
 
 // src row-major [R][K] (leading dimension ld): one workgroup writes one (rt, kt) block
-__global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restrict__ src, int R, int K, int ld,
-                                                            char *__restrict__ img, int KT, int with_lo) {
-    const int kt = blockIdx.x, rt = blockIdx.y;
+__device__ __forceinline__ void prep_rowmajor_block(const float *__restrict__ src, int R, int K, int ld, char *__restrict__ img,
+                                                    int KT, int with_lo, int kt, int rt) {
     char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
     const bool vec = (ld % 4 == 0) && ((uintptr_t)src % 16 == 0);
 #pragma unroll
@@ -65,11 +64,14 @@ __global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restr
     }
 }
 
+__global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restrict__ src, int R, int K, int ld,
+                                                            char *__restrict__ img, int KT, int with_lo) {
+    prep_rowmajor_block(src, R, K, ld, img, KT, with_lo, blockIdx.x, blockIdx.y);
+}
+
 // src stored transposed: memory [K][R] (leading dimension ld, R contiguous); logical X[r][k] = src[k*ld + r]
-__global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__restrict__ src, int R, int K, int ld,
-                                                              char *__restrict__ img, int KT, int with_lo) {
-    __shared__ float tile[TK][TR + 1];
-    const int kt = blockIdx.x, rt = blockIdx.y;
+__device__ __forceinline__ void prep_transposed_block(const float *__restrict__ src, int R, int K, int ld, char *__restrict__ img,
+                                                      int KT, int with_lo, int kt, int rt, float (*tile)[TR + 1]) {
     char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
     const bool vec = (ld % 4 == 0) && ((uintptr_t)src % 16 == 0);
     for (int u = threadIdx.x; u < TK * (TR / 4); u += 256) {
@@ -100,6 +102,12 @@ __global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__res
     }
 }
 
+__global__ __launch_bounds__(256) void prep_transposed_kernel(const float *__restrict__ src, int R, int K, int ld,
+                                                              char *__restrict__ img, int KT, int with_lo) {
+    __shared__ float tile[TK][TR + 1];
+    prep_transposed_block(src, R, K, ld, img, KT, with_lo, blockIdx.x, blockIdx.y, tile);
+}
+
 // One read of a [R][C] fp32 source (optionally through an elementwise operator) -> BOTH operand images a Linear's backward wants:
 // the row-major image (rows R, k = C: the A operand of dx = dy W) and the transposed one (rows C, k = R: the A / B operand of
 // dW = dy^T x).  A workgroup owns a 128 x 32 source tile: it is one whole block of the row-major image and a 32-row quarter of
@@ -119,9 +127,7 @@ struct PairArgs {
 };
 
 template <int OP>
-__global__ __launch_bounds__(256) void image_pair_kernel(const PairArgs p) {
-    __shared__ float tile[TR][TK + 1];
-    const int kt = blockIdx.x, rt = blockIdx.y;
+__device__ __forceinline__ void image_pair_block(const PairArgs &p, int kt, int rt, float (*tile)[TK + 1]) {
     const bool vec = (p.ld % 4 == 0) && ((uintptr_t)p.src % 16 == 0) &&
                      (!(OP == PAIR_GELU_TANH_BWD || OP == PAIR_GELU_ERF_BWD) || ((p.ld2 % 4 == 0) && ((uintptr_t)p.src2 % 16 == 0)));
     const bool write_rm = p.img_rm && kt < p.KT_rm;
@@ -192,6 +198,34 @@ __global__ __launch_bounds__(256) void image_pair_kernel(const PairArgs p) {
         *reinterpret_cast<bf16x8 *>(tb + off) = hi;
         if (p.with_lo) *reinterpret_cast<bf16x8 *>(tb + PART_BYTES + off) = lo;
     }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void image_pair_kernel(const PairArgs p) {
+    __shared__ float tile[TR][TK + 1];
+    image_pair_block<OP>(p, blockIdx.x, blockIdx.y, tile);
+}
+
+// Several operand images in ONE launch (the LSTM builds 2-4 per layer and direction, each a ~5 us kernel behind its own ~1.5 us
+// launch boundary): block b belongs to the job whose [first, first + gx*gy) range holds it.
+constexpr int PREP_MAX_JOBS = 6;
+struct PrepJobs {
+    PairArgs job[PREP_MAX_JOBS];      // kind 0: row-major source -> img_rm; 1: transposed source -> img_rm; 2: pair (copy) -> img_rm + img_tr
+    int kind[PREP_MAX_JOBS], first[PREP_MAX_JOBS], gx[PREP_MAX_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void prep_jobs_kernel(const PrepJobs a) {
+    __shared__ float tile[TR * (TK + 1)];           // >= TK * (TR + 1) as well
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < PREP_MAX_JOBS; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.first[i]) j = i;
+    const PairArgs &p = a.job[j];
+    const int local = blockIdx.x - a.first[j];
+    const int kt = local % a.gx[j], rt = local / a.gx[j];
+    if (a.kind[j] == 0) prep_rowmajor_block(p.src, p.R, p.C, (int)p.ld, p.img_rm, p.KT_rm, p.with_lo, kt, rt);
+    else if (a.kind[j] == 1) prep_transposed_block(p.src, p.R, p.C, (int)p.ld, p.img_rm, p.KT_rm, p.with_lo, kt, rt, reinterpret_cast<float (*)[TR + 1]>(tile));
+    else image_pair_block<PAIR_COPY>(p, kt, rt, reinterpret_cast<float (*)[TK + 1]>(tile));
 }
 
 struct TiledGemmArgs {
@@ -528,6 +562,34 @@ int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, 
         hipLaunchKernelGGL(prep_transposed_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT, with_lo);
     else
         hipLaunchKernelGGL(prep_rowmajor_kernel, dim3(KT, RT), dim3(256), 0, st, src, R, K, ld, (char *)image, KT, with_lo);
+    return halo_launch_status();
+}
+
+int halo_prep_jobs(const HaloPrepJob *jobs, int n, hipStream_t st) {
+    if (n <= 0) return HALO_OK;
+    if (n > PREP_MAX_JOBS) return HALO_EINVAL;
+    PrepJobs a = {};
+    a.n = n;
+    const int with_lo = halo_math_mode() != HALO_MATH_BF16;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const HaloPrepJob &q = jobs[i];
+        PairArgs &p = a.job[i];
+        p.src = q.src; p.ld = q.ld; p.R = q.R; p.C = q.K; p.with_lo = with_lo;
+        p.img_rm = (char *)q.image; p.img_tr = (char *)q.image_tr;
+        a.kind[i] = q.kind; a.first[i] = total;
+        const int RT = (q.R + TR - 1) / TR;
+        if (q.kind == 2) {
+            p.KT_rm = (q.K + TK - 1) / TK;
+            p.KT_tr = (q.R + TK - 1) / TK;
+            a.gx[i] = p.img_tr ? 4 * ((q.K + TR - 1) / TR) : p.KT_rm;
+        } else {
+            p.KT_rm = (q.K + TK - 1) / TK;
+            a.gx[i] = p.KT_rm;
+        }
+        total += a.gx[i] * RT;
+    }
+    hipLaunchKernelGGL(prep_jobs_kernel, dim3((unsigned)total), dim3(256), 0, st, a);
     return halo_launch_status();
 }
 

@@ -13,6 +13,15 @@ size_t halo_tiled_image_bytes(int R, int K);
 // image <- split/tiled copy of logical X[R][K]; src_transposed: memory is [K][R] (leading dim ld)
 int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, void *image, hipStream_t st);
 int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void *image_tr, hipStream_t st);   // both images, one read
+// several images in one launch.  kind 0: image <- row-major src [R][K]; 1: image <- src stored [K][R] (logical X[r][k] = src[k*ld + r]);
+// 2: image (rows R, k = K) and image_tr (rows K, k = R) from one read of a row-major src [R][K] (halo_prep_pair)
+struct HaloPrepJob {
+    int kind;
+    const float *src;
+    int R, K, ld;
+    void *image, *image_tr;
+};
+int halo_prep_jobs(const HaloPrepJob *jobs, int n, hipStream_t st);
 // C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);

@@ -1136,8 +1136,8 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
         }
         // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
         if (halo_math_mode() != HALO_MATH_F32 && in_dim >= 64) {
-            HALO_TRY(halo_prep_tiles(in, T * B, in_dim, in_dim, 0, img_in, st));
-            HALO_TRY(halo_prep_tiles(w_ih[l], 4 * H, in_dim, in_dim, 0, img_w, st));
+            const HaloPrepJob jobs[2] = {{0, in, T * B, in_dim, in_dim, img_in, nullptr}, {0, w_ih[l], 4 * H, in_dim, in_dim, img_w, nullptr}};
+            HALO_TRY(halo_prep_jobs(jobs, 2, st));                    // both operand images in one launch
             HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, lb.gates, 4 * H, b_ih[l], b_hh[l], 0,
                                             nullptr, st));
         } else {
@@ -1322,12 +1322,25 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
                                               offset, offset_dev);
         const bool tiled = halo_math_mode() != HALO_MATH_F32 && in_dim >= 64;
-        // (1) critical path, main stream: the gradient w.r.t. this layer's input feeds layer l-1's steps
+        // every operand image of this layer's gradient GEMMs in ONE launch: dG [TB][4H] (input gradient) and dG^T [4H][TB] (both
+        // weight gradients) from one read, W_ih^T, h_prev^T, in^T
+        int rc = HALO_OK;
+        if (tiled) {
+            HaloPrepJob jobs[4];
+            int nj = 0;
+            if (need_din) {
+                jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};
+                jobs[nj++] = {1, w_ih[l], in_dim, 4 * H, in_dim, img_wT, nullptr};                      // W_ih^T [in][4H]
+            } else {
+                jobs[nj++] = {1, lb.gates, 4 * H, T * B, 4 * H, img_gT, nullptr};                       // dG^T [4H][TB]
+            }
+            jobs[nj++] = {1, lb.h, H, T * B, H, img_hT, nullptr};                                       // h_prev^T [H][TB]
+            jobs[nj++] = {1, in, in_dim, T * B, in_dim, img_inT, nullptr};                              // in^T [in][TB]
+            HALO_TRY(halo_prep_jobs(jobs, nj, st));
+        }
+        // (1) the gradient w.r.t. this layer's input feeds layer l-1's recurrence
         if (need_din) {
             if (tiled) {
-                // dG [TB][4H] for this product and dG^T [4H][TB] for the two weight-gradient products below, from one read
-                HALO_TRY(halo_prep_pair(lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT, st));
-                HALO_TRY(halo_prep_tiles(w_ih[l], in_dim, 4 * H, in_dim, 1, img_wT, st));         // W_ih^T [in][4H]
                 HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
                                                 &ddrop, st));
             } else {
@@ -1337,12 +1350,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             }
         }
         // (2) this layer's parameter gradients
-        int rc = HALO_OK;
         if (tiled) {
-            if (!need_din) rc = halo_prep_tiles(lb.gates, 4 * H, T * B, 4 * H, 1, img_gT, side);        // dG^T [4H][TB] (else: built with dG above)
-            if (!rc) rc = halo_prep_tiles(lb.h, H, T * B, H, 1, img_hT, side);                          // h_prev^T [H][TB]
-            if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
-            if (!rc) rc = halo_prep_tiles(in, in_dim, T * B, in_dim, 1, img_inT, side);                 // in^T [in][TB]
+            rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
             if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
                                                  nullptr, side);
         } else {
