@@ -65,6 +65,12 @@ SIGNATURES = {
     'halo_ctc_bwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp]),
     'halo_ctc_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'halo_ctc_mean_loss': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'halo_ctc_head_supported': (_i, [_i, _i, _i, _i]),
+    'halo_ctc_head_workspace_bytes': (_sz, [_i, _i, _i]),
+    'halo_ctc_head_fwd': (_i, [_vp, _vp, _vp, _f, _u64, _u32, _u32, _vp, _vp, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _i, _i, _i, _i, _vp]),
+    'halo_ctc_head_bwd': (_i, [_vp, _vp, _f, _u64, _u32, _u32, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i, _i, _i, _i, _vp]),
     'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_set_beam_vector_chunk': (_i, [_i]),
     'halo_logaddexp_aten': (_i, [_vp, _vp, _vp, _sz, _vp]),

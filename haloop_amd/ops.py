@@ -310,6 +310,43 @@ def ctc_mean_loss(nll, target_lengths, out):
     return out
 
 
+def ctc_head_supported(T, H, V, S):
+    return bool(lib().halo_ctc_head_supported(T, H, V, S))
+
+
+def ctc_head_fwd(feats, weight, bias, drop, stream_id, input_lengths, targets, target_lengths, loss, ticket, ks=5, stride=4, pad=3):
+    """The CTC head's forward in one launch (include/halo.h): feats [B,T,H] -> (lp, alpha, nll, feature_lengths, grad_out); the mean
+    loss goes to ``loss`` (device scalar); ``ticket``: a zero-initialised device int32 the caller keeps."""
+    _f32c(feats, 'features')
+    B, T, H = feats.shape
+    V = weight.shape[0]
+    tg = _i64c(targets, 'targets')
+    il, tl = _i64c(input_lengths, 'input_lengths'), _i64c(target_lengths, 'target_lengths')
+    S = tg.shape[1]
+    dev = feats.device
+    lp = torch.empty(B, T, V, device=dev, dtype=torch.float32)
+    alpha = torch.empty(B, T, 2 * S + 1, device=dev, dtype=torch.float32)
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    flen = torch.empty(B, device=dev, dtype=torch.int64)
+    grad_out = torch.empty(B, device=dev, dtype=torch.float32)
+    check(lib().halo_ctc_head_fwd(ptr(feats), ptr(weight), ptr(bias), drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr,
+                                  ptr(il), ks, stride, pad, ptr(tg), tg.stride(0), S, ptr(tl), ptr(lp), ptr(alpha), ptr(nll), ptr(flen),
+                                  ptr(grad_out), ptr(loss), ptr(ticket), B, T, H, V, _stream()), 'halo_ctc_head_fwd')
+    return lp, alpha, nll, flen, grad_out, (tg, tl)
+
+
+def ctc_head_bwd(feats, weight, drop, stream_id, flen, tg, tl, lp, alpha, nll, grad_out, dweight, dbias):
+    """The CTC head's backward (two launches): returns d features [B,T,H]; the classifier's gradients go to dweight / dbias."""
+    B, T, H = feats.shape
+    V = weight.shape[0]
+    dfeats = torch.empty_like(feats)
+    ws = torch.empty(lib().halo_ctc_head_workspace_bytes(B, H, V), device=feats.device, dtype=torch.uint8)
+    check(lib().halo_ctc_head_bwd(ptr(feats), ptr(weight), drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, ptr(flen), ptr(tg),
+                                  tg.stride(0), tg.shape[1], ptr(tl), ptr(lp), ptr(alpha), ptr(nll), ptr(grad_out), ptr(dfeats),
+                                  ptr(dweight), ptr(dbias), ptr(ws), B, T, H, V, _stream()), 'halo_ctc_head_bwd')
+    return dfeats
+
+
 def ctc_greedy(lp):
     _f32c(lp, 'log-probs')
     N, T, Cn = lp.shape

@@ -87,7 +87,7 @@ class FlatParams:
 class LstmCtcTrainer:
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
-                 alias_loss=False):
+                 alias_loss=False, fused_head=True):
         """accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
         forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call.
         A micro-batch whose loss is NaN/Inf contributes nothing (the reference skips it, loop.py:167-174; here it still counts
@@ -97,6 +97,7 @@ class LstmCtcTrainer:
         alias_loss: step() returns ``self.loss`` itself -- ONE device scalar that every later step overwrites -- instead of a
         copy the caller owns (for loops that read each loss before the next step, or never)."""
         self.alias_loss = bool(alias_loss)
+        self.fused_head = fused_head
         self.encoder, self.recognizer = encoder, recognizer
         self.accumulate = int(accumulate)
         self._micro = 0
@@ -113,6 +114,7 @@ class LstmCtcTrainer:
         self.loss = torch.zeros((), device=dev, dtype=torch.float32)
         self.step_count = 0                                                # step() calls that reached the optimizer
         self.adam_step = torch.zeros(1, device=dev, dtype=torch.int32)    # APPLIED updates: advanced on the device (clip_coef)
+        self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)      # last-workgroup ticket of the fused CTC head
         self.use_graph = use_graph
         self.pg = process_group
         self.world = dp.world_size(process_group)
@@ -150,6 +152,19 @@ class LstmCtcTrainer:
         _, _, _, reserve = ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True, drop=drop)
         p_cls = rec.dropout.p if rec.training else 0.0
         cdrop = Dropout(p_cls, self.seed, 0, self.counter) if p_cls > 0 else NO_DROPOUT
+        grads = {'dw_ih': [gv[f'encoder.lstm.weight_ih_l{k}'] for k in range(L)],
+                 'dw_hh': [gv[f'encoder.lstm.weight_hh_l{k}'] for k in range(L)],
+                 'db_ih': [gv[f'encoder.lstm.bias_ih_l{k}'] for k in range(L)],
+                 'db_hh': [gv[f'encoder.lstm.bias_hh_l{k}'] for k in range(L)]}
+        if self.fused_head and ops.ctc_head_supported(Tp, H, V, tg.shape[1]):
+            # the whole head in three launches: dropout + Linear + log_softmax + lengths + CTC alpha + mean loss; then CTC beta +
+            # log_softmax backward + d features + per-utterance d W / d b; then their fixed-order sum (csrc/head.hip)
+            sid = _lib.HALO_STREAM_CLASSIFIER
+            lp, alpha, nll, flen, grad_out, (tg64, tl64) = ops.ctc_head_fwd(feats, rec.classifier.weight, rec.classifier.bias, cdrop, sid,
+                                                                           il, tg, tl, self.loss, self._ticket)
+            dfeats = ops.ctc_head_bwd(feats, rec.classifier.weight, cdrop, sid, flen, tg64, tl64, lp, alpha, nll, grad_out,
+                                      gv['recognizer.classifier.weight'], gv['recognizer.classifier.bias']).view(B * Tp, H)
+            return self._lstm_backward_top(x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats, (B, T, F, Cc, H, Tp, L))
         fdrop = ops.dropout_fwd(feats, cdrop, _lib.HALO_STREAM_CLASSIFIER) if p_cls > 0 else feats
         f2d = fdrop.view(B * Tp, H)
         logits = ops.gemm(f2d, rec.classifier.weight, True, True, B * Tp, V, H, bias1=rec.classifier.bias)
@@ -164,10 +179,10 @@ class LstmCtcTrainer:
         ops.colsum(dlogits, out=gv['recognizer.classifier.bias'])
         dfeats = ops.gemm(dlogits, rec.classifier.weight, True, False, B * Tp, H, V, drop=cdrop,
                           stream_id=_lib.HALO_STREAM_CLASSIFIER)
-        grads = {'dw_ih': [gv[f'encoder.lstm.weight_ih_l{k}'] for k in range(L)],
-                 'dw_hh': [gv[f'encoder.lstm.weight_hh_l{k}'] for k in range(L)],
-                 'db_ih': [gv[f'encoder.lstm.bias_ih_l{k}'] for k in range(L)],
-                 'db_hh': [gv[f'encoder.lstm.bias_hh_l{k}'] for k in range(L)]}
+        return self._lstm_backward_top(x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats, (B, T, F, Cc, H, Tp, L))
+
+    def _lstm_backward_top(self, x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats, dims):
+        B, T, F, Cc, H, Tp, L = dims
         ws = ops.lstm_bwd_workspace(y_sub, w_hh)
         dy_sub = torch.empty_like(y_sub)
         top = L - 1 if L > 1 else 0

@@ -278,6 +278,32 @@ int halo_ctc_prepare(const int64_t *input_lengths, const int64_t *target_lengths
 int halo_ctc_mean_loss(const float *nll, const int64_t *target_lengths, int n, float *loss,
                        halo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole CTC head of a training step (TemporalClassifier.forward and its backward) in three launches.
+ * replaces: dropout -> nn.Linear -> log_softmax -> F.ctc_loss(mean) ha/recognizer.py:43-46,61-73 plus the feature-length arithmetic of
+ *           ha/rnn.py:13-18, i.e. halo_dropout_fwd + halo_gemm_f32 + halo_log_softmax_fwd + halo_ctc_prepare + halo_ctc_fwd +
+ *           halo_ctc_mean_loss, and in the backward halo_ctc_bwd + halo_log_softmax_bwd + 2 x halo_gemm_f32 + halo_colsum.
+ * Fast path for T <= 32 frames, V <= 32 classes, 2S+1 <= 64 lattice states, H % 64 == 0 (halo_ctc_head_supported; otherwise
+ * HALO_ENOTSUP and the caller uses the separate operators).  One workgroup per utterance, products on the exact-f32 MFMA.
+ *   features [B,T,H] (the encoder's output), weight [V,H], bias [V]; the classifier dropout (p_drop, stream_id) is applied to the
+ *   features as halo_dropout_fwd would (flat index of [B,T,H]) and again, from the same stream, to d features in the backward.
+ *   input_lengths: frames BEFORE the subsample conv (ks, stride, pad); feature_lengths [B] int64 out.
+ *   lp [B,T,V], alpha [B,T,2S+1], nll [B], grad_out [B] (= 1 / (max(tl,1) * B)), loss (scalar: reduction='mean') out;
+ *   ticket: device uint32, 0 before the first call (the kernel leaves it 0).
+ *   backward: dfeatures [B,T,H], dweight [V,H], dbias [V] out; workspace halo_ctc_head_workspace_bytes(). */
+int halo_ctc_head_supported(int T, int H, int V, int S);
+size_t halo_ctc_head_workspace_bytes(int B, int H, int V);
+int halo_ctc_head_fwd(const float *features, const float *weight, const float *bias, float p_drop, uint64_t seed,
+                      uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, const int64_t *input_lengths, int ks,
+                      int stride, int pad, const int64_t *targets, long tg_stride, int S, const int64_t *target_lengths,
+                      float *lp, float *alpha, float *nll, int64_t *feature_lengths, float *grad_out, float *loss,
+                      uint32_t *ticket, int B, int T, int H, int V, halo_stream_t stream);
+int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, uint64_t seed, uint32_t stream_id,
+                      uint32_t offset, const uint32_t *offset_dev, const int64_t *feature_lengths, const int64_t *targets,
+                      long tg_stride, int S, const int64_t *target_lengths, const float *lp, const float *alpha,
+                      const float *nll, const float *grad_out, float *dfeatures, float *dweight, float *dbias,
+                      void *workspace, int B, int T, int H, int V, halo_stream_t stream);
+
 /* Greedy decode.   replaces: logits.max(-1) + unique_consecutive + drop-0 loop, recognizer.py:51-55
  *   lp [N,T,C] contiguous; alignments [N,T] int64, scores [N,T] f32, hyp [N,T] int64 (first
  *   hyp_len[n] entries valid), hyp_len [N] int64.  Input lengths are ignored, as in the reference. */

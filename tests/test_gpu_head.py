@@ -1,0 +1,100 @@
+"""The fused CTC head (csrc/head.hip: three launches) against the separate operators it replaces and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _separate(ops, lib, feats, W, b, drop, il, tg, tl):
+    B, T, H = feats.shape
+    V = W.shape[0]
+    fdrop = ops.dropout_fwd(feats, drop, lib.HALO_STREAM_CLASSIFIER) if drop.p > 0 else feats
+    f2d = fdrop.view(B * T, H)
+    logits = ops.gemm(f2d, W, True, True, B * T, V, H, bias1=b)
+    lp = ops.log_softmax_fwd(logits)
+    flen, grad_out = ops.ctc_prepare(il, tl)
+    nll, alpha, saved = ops.ctc_fwd(lp.view(B, T, V), False, tg, flen, tl)
+    loss = torch.zeros((), device=DEV)
+    ops.ctc_mean_loss(nll, tl, loss)
+    dlp = ops.ctc_bwd(lp.view(B, T, V), False, saved, alpha, nll, grad_out)
+    dlogits = ops.log_softmax_bwd(dlp.view(B * T, V), lp)
+    dW = ops.gemm(dlogits, f2d, False, False, V, H, B * T)
+    db = ops.colsum(dlogits)
+    dfeats = ops.gemm(dlogits, W, True, False, B * T, H, V, drop=drop, stream_id=lib.HALO_STREAM_CLASSIFIER)
+    return dict(lp=lp.view(B, T, V), nll=nll, flen=flen, loss=loss, dW=dW, db=db, dfeats=dfeats.view(B, T, H), alpha=alpha)
+
+
+@pytest.mark.parametrize('B,T_in,H,V,S,p', [(64, 80, 1024, 32, 10, 0.2), (3, 41, 64, 9, 4, 0.0), (5, 120, 256, 32, 12, 0.3), (1, 9, 128, 5, 1, 0.0)])
+def test_fused_head_equals_separate_operators(B, T_in, H, V, S, p):
+    from haloop_amd import _lib, ops
+    _lib.lib(); _lib.lend_scratch()
+    T = (T_in + 6 - 5) // 4 + 1
+    assert ops.ctc_head_supported(T, H, V, S)
+    g = torch.Generator().manual_seed(B * 7 + H)
+    feats = torch.randn(B, T, H, generator=g).relu().to(DEV)
+    W = (torch.randn(V, H, generator=g) / H ** 0.5).to(DEV)
+    b = (torch.randn(V, generator=g) * 0.1).to(DEV)
+    il = torch.tensor([T_in - 3 * (i % 5) for i in range(B)], dtype=torch.int64)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+    if B >= 3:
+        il[1] = 9; tg[1] = 1; tl[1] = min(S, 4)          # infeasible when S >= 4 (equal labels need 2S-1 frames): nll = inf
+    il, tg, tl = il.to(DEV), tg.to(DEV), tl.to(DEV)
+    drop = ops.Dropout(p, 0x1234ABCD5678, 5) if p > 0 else ops.NO_DROPOUT
+    want = _separate(ops, _lib, feats, W, b, drop, il, tg, tl)
+    loss = torch.zeros((), device=DEV)
+    ticket = torch.zeros(1, device=DEV, dtype=torch.int32)
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    for rep in range(2):                                  # twice: the ticket must come back to zero
+        lp, alpha, nll, flen, grad_out, (tg64, tl64) = ops.ctc_head_fwd(feats, W, b, drop, _lib.HALO_STREAM_CLASSIFIER, il, tg, tl, loss, ticket)
+        dfeats = ops.ctc_head_bwd(feats, W, drop, _lib.HALO_STREAM_CLASSIFIER, flen, tg64, tl64, lp, alpha, nll, grad_out, dW, db)
+        assert int(ticket.item()) == 0
+        assert torch.equal(flen.cpu(), want['flen'].cpu())
+        np.testing.assert_allclose(lp.cpu().numpy(), want['lp'].cpu().numpy(), atol=2e-6)
+        fin = torch.isfinite(want['nll']).cpu().numpy()
+        assert np.array_equal(np.isfinite(nll.cpu().numpy()), fin)
+        np.testing.assert_allclose(nll.cpu().numpy()[fin], want['nll'].cpu().numpy()[fin], rtol=2e-6, atol=2e-6)
+        if fin.all():
+            np.testing.assert_allclose(loss.item(), want['loss'].item(), rtol=2e-6)
+            for k, got in (('dW', dW), ('db', db), ('dfeats', dfeats)):
+                ref = want[k].cpu().numpy()
+                np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=1e-6 + 2e-5 * np.abs(ref).max(), err_msg=k)
+        else:
+            assert not np.isfinite(loss.item())
+
+
+def test_fused_head_refuses_unsupported_shapes():
+    from haloop_amd import ops
+    assert not ops.ctc_head_supported(40, 1024, 32, 10)      # more than 32 frames
+    assert not ops.ctc_head_supported(21, 1024, 256, 10)     # more than 32 classes
+    assert not ops.ctc_head_supported(21, 96, 32, 10)        # H % 64 != 0
+    assert not ops.ctc_head_supported(21, 1024, 32, 40)      # 2S+1 > 64
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_trainer_step_with_and_without_fused_head_match_oracle(fused):
+    """One LC-style training step (dropout off) vs the CPU oracle's Trainer, on the fused head and on the separate operators."""
+    from haloop_amd import _lib, rnn, recognizer
+    from haloop_amd.train import LstmCtcTrainer
+    from oracle import cpu_ref
+    _lib.lib(); _lib.set_math_mode('bf16x3')
+    F_, C, H, L, V, B, T, S = 20, 32, 64, 2, 11, 6, 45, 5
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 3)
+    x, il, tg, tl = cpu_ref.synthetic_batch(B, T, F_, V, S, 4)
+    il = torch.clamp(il - torch.arange(B) % 4, min=T // 2)
+    enc = rnn.Encoder(F_, C, H, num_layers=L); rec = recognizer.TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=False, fused_head=fused)
+    ref = cpu_ref.Trainer(enc_p, rec_p, lr=3e-3)
+    for _ in range(2):
+        loss = tr.step(x.to(DEV), il.to(DEV), tg.to(DEV), tl.to(DEV))
+        loss_ref, gn_ref = ref.step(x, il, tg, tl)
+        np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-5)
+        np.testing.assert_allclose(tr.grad_norm.item(), gn_ref.item(), rtol=2e-4)
+    for k, v in enc.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), ref.enc[k].detach().numpy(), atol=3e-5, err_msg=k)
+    for k, v in rec.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), ref.rec[k].detach().numpy(), atol=3e-5, err_msg=k)
