@@ -42,30 +42,46 @@ __device__ __forceinline__ int feature_length(long il, int ks, int stride, int p
     return max(0, min(f, T));
 }
 
+constexpr int KC = 256;                  // K-chunk staged through LDS per pass
+constexpr int LDK = KC + 1;              // row stride in floats: lanes (row r, k) hit bank (r + k) % 32 -> conflict-free fragment reads
+
 __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][32*32] partial tiles
+    extern __shared__ __attribute__((aligned(16))) float dyn[];   // [As: 32 x LDK][Ws: 32 x LDK][red: NW x 1024]
+    float *As = dyn, *Ws = dyn + 32 * LDK, *red = dyn + 64 * LDK;
     __shared__ float tile[32][LDT];                               // logits, then log-probs
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H, V = p.V;
     const int r = lane & 31, kh = lane >> 5;
-    // ---- logits[t][v] = sum_k drop(f[n,t,k]) W[v,k]: this wave's K-slice ----
-    const int ksl = H / NW, k0 = wave * ksl;
+    // ---- logits[t][v] = sum_k drop(f[n,t,k]) W[v,k]: K in chunks of KC; rows are read from global memory as whole float4 runs
+    //      (coalesced), the MFMA fragments (lane = row) come from LDS; wave w contracts k in [w * KC/NW, (w + 1) * KC/NW) of a chunk ----
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const float *frow = p.feats + ((long)n * T + r) * H + k0;
-    const float *wrow = p.w + (long)r * H + k0;
-    const bool arow = r < T, brow = r < V;
-    for (int q = 0; q < ksl / 4; ++q) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (arow) {
-            a = *reinterpret_cast<const f32x4 *>(frow + 4 * q);
-            if (p.drop.threshold) a = a * dropout_mult4(p.drop, (uint64_t)(((long)n * T + r) * H + k0 + 4 * q));
+    for (int c0 = 0; c0 < H; c0 += KC) {
+        const int kc = min(KC, H - c0);                          // H % 64 == 0: a multiple of 64
+        for (int u = tid; u < 32 * (KC / 4); u += 1024) {
+            const int row = u / (KC / 4), k4 = (u % (KC / 4)) * 4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (k4 < kc) {
+                if (row < T) {
+                    const long e = ((long)n * T + row) * H + c0 + k4;
+                    a = *reinterpret_cast<const f32x4 *>(p.feats + e);
+                    if (p.drop.threshold) a = a * dropout_mult4(p.drop, (uint64_t)e);
+                }
+                if (row < V) b = *reinterpret_cast<const f32x4 *>(p.w + (long)row * H + c0 + k4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { As[row * LDK + k4 + e] = a[e]; Ws[row * LDK + k4 + e] = b[e]; }
         }
-        if (brow) b = *reinterpret_cast<const f32x4 *>(wrow + 4 * q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? a[1] : a[0], kh ? b[1] : b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? a[3] : a[2], kh ? b[3] : b[2], acc, 0, 0, 0);
+        __syncthreads();
+        const int kw = wave * (KC / NW);
+#pragma unroll
+        for (int s2 = 0; s2 < KC / NW / 2; ++s2) {
+            const int k = kw + 2 * s2 + kh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[r * LDK + k], Ws[r * LDK + k], acc, 0, 0, 0);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r] = acc[e];
@@ -125,6 +141,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
             if (lane < S_) alpha[(long)t * S_ + lane] = v;
             if (t == tlast) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
         }
+        unsigned old = 0;
         if (lane == 0) {
             const float out = il == 0 ? (tl == 0 ? 0.f : INFINITY) : -log_add_exp_fast2(ra, rb);
             // nll travels to the workgroup that finishes last: write-through store, drained, then the ticket (Guideline 16 R1)
@@ -132,18 +149,28 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
             p.flen[n] = il;
             p.grad_out[n] = 1.0f / (fmaxf((float)p.tl[n], 1.0f) * (float)p.B);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)p.B - 1u) {
-                // reduction='mean' (ha/recognizer.py:71): mean_n(nll[n] / max(tl[n], 1)), summed in index order
-                float s = 0.f;
-                for (int i = 0; i < p.B; ++i)
-                    s += __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / fmaxf((float)p.tl[i], 1.0f);
+            old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == (unsigned)p.B - 1u) {
+            // reduction='mean' (ha/recognizer.py:71): mean_n(nll[n] / max(tl[n], 1)); the whole wave loads (one utterance per lane and
+            // pass), partial sums combine in a fixed order
+            float s = 0.f;
+            for (int i0 = 0; i0 < p.B; i0 += 64) {
+                const int i = i0 + lane;
+                float v = 0.f;
+                if (i < p.B) v = __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / fmaxf((float)p.tl[i], 1.0f);
+                s += wave_sum(v);
+            }
+            if (lane == 0) {
                 *p.loss = s / (float)p.B;
                 __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
             }
         }
     }
 }
+
+constexpr size_t HEAD_FWD_LDS = (size_t)(64 * LDK + NW * 1024) * sizeof(float);
 
 struct HeadBwdArgs {
     const float *feats, *w;
@@ -157,23 +184,29 @@ struct HeadBwdArgs {
     int B, T, H, V, S;
 };
 
-__global__ __launch_bounds__(1024) void ctc_head_bwd_kernel(const HeadBwdArgs p) {
+constexpr int NWB = 8;                   // waves of the backward workgroup (512 threads: 256 VGPRs per lane, no spills)
+__global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) {
     __shared__ float lps[32][LDT];        // log-probs
     __shared__ float dl[32][LDT];         // gradient at the logits (0 outside [T) x [V))
     __shared__ float ab[32][65];          // alpha, then alpha + beta
+    extern __shared__ __attribute__((aligned(16))) float mask_s[];     // [T][H] dropout multipliers of this utterance's features
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H, V = p.V, S_ = 2 * p.S + 1;
+    if (p.drop.threshold) {               // one Philox call covers four consecutive elements
+        for (int u = tid; u < T * H / 4; u += 512)
+            *reinterpret_cast<f32x4 *>(mask_s + 4 * u) = dropout_mult4(p.drop, (uint64_t)((long)n * T * H + 4 * u));
+    }
     const int64_t *tg = p.targets + (long)n * p.tg_stride;
     const int il = max(0, min((int)p.flen[n], T));
     const int tl = max(0, min((int)p.tl[n], p.S));
     const int states = 2 * tl + 1;
-    {
-        const int i = tid >> 5, j = tid & 31;
+    for (int u = tid; u < 1024; u += 512) {
+        const int i = u >> 5, j = u & 31;
         lps[i][j] = (i < T && j < V) ? p.lp[((long)n * T + i) * V + j] : -INFINITY;
         dl[i][j] = 0.f;
     }
-    for (int idx = tid; idx < T * S_; idx += 1024) ab[idx / S_][idx % S_] = p.alpha[(long)n * T * S_ + idx];
+    for (int idx = tid; idx < T * S_; idx += 512) ab[idx / S_][idx % S_] = p.alpha[(long)n * T * S_ + idx];
     __syncthreads();
     const float nll = p.nll[n], go = p.grad_out[n];
     if (wave == 0 && il > 0) {            // beta recursion, one state per lane (as ctc_beta_grad_wave_kernel)
@@ -198,8 +231,8 @@ __global__ __launch_bounds__(1024) void ctc_head_bwd_kernel(const HeadBwdArgs p)
         }
     }
     __syncthreads();
-    {   // gradient at the log-probs in ATen's convention, then log_softmax backward: dlogit = g - exp(lp) * sum_c g
-        const int t = tid >> 5, c = tid & 31;
+    for (int u = tid; u < 1024; u += 512) {   // gradient at the log-probs in ATen's convention, then log_softmax backward: dlogit = g - exp(lp) * sum_c g
+        const int t = u >> 5, c = u & 31;
         float g = 0.f;
         if (t < il && c < V) {
             const float *row = ab[t];
@@ -229,54 +262,70 @@ __global__ __launch_bounds__(1024) void ctc_head_bwd_kernel(const HeadBwdArgs p)
     }
     // ---- the two products, column tiles of 32 over H: wave w takes tiles w, w + NW, ... ----
     const int r = lane & 31, kh = lane >> 5;
-    for (int nt = wave; nt < H / 32; nt += NW) {
+    for (int nt = wave; nt < H / 32; nt += NWB) {
         const int c0 = nt * 32;
-        f32x16 dx, dwp;
+        {   // d features[t][c0 + j] = sum_v dl[t][v] * W[v][c0 + j], times the dropout mask of the element
+            float wv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { dx[e] = 0.f; dwp[e] = 0.f; }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int kk = 2 * s + kh;                      // class index (d features) / frame index (d W)
-            // d features[t][c0 + j] += dl[t][kk] * W[kk][c0 + j]
-            const float wv = kk < V ? p.w[(long)kk * H + c0 + r] : 0.f;
-            dx = __builtin_amdgcn_mfma_f32_32x32x2f32(dl[r][kk], wv, dx, 0, 0, 0);
-            // d W[v][c0 + j] += dl[kk][v] * fdrop[kk][c0 + j]
-            float fv = 0.f;
-            if (kk < T) {
-                const long e = ((long)n * T + kk) * H + c0 + r;
-                fv = p.feats[e];
-                if (p.drop.threshold) fv *= dropout_mult(p.drop, (uint64_t)e);
+            for (int s = 0; s < 16; ++s) wv[s] = (2 * s + kh) < V ? p.w[(long)(2 * s + kh) * H + c0 + r] : 0.f;
+            f32x16 dx;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dx[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(dl[r][2 * s + kh], wv[s], dx, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < T) {
+                    float v = dx[e];
+                    if (p.drop.threshold) v *= mask_s[row * H + c0 + r];
+                    p.dfeats[((long)n * T + row) * H + c0 + r] = v;
+                }
             }
-            dwp = __builtin_amdgcn_mfma_f32_32x32x2f32(dl[kk][r], fv, dwp, 0, 0, 0);
         }
+        {   // d W[v][c0 + j] (this utterance's share) = sum_t dl[t][v] * dropped features[t][c0 + j]
+            float fv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (row < T) {
-                const long idx = ((long)n * T + row) * H + c0 + r;
-                float v = dx[e];
-                if (p.drop.threshold) v *= dropout_mult(p.drop, (uint64_t)idx);
-                p.dfeats[idx] = v;
+            for (int s = 0; s < 16; ++s) {
+                const int kk = 2 * s + kh;
+                float f = kk < T ? p.feats[((long)n * T + kk) * H + c0 + r] : 0.f;
+                if (p.drop.threshold && kk < T) f *= mask_s[kk * H + c0 + r];
+                fv[s] = f;
             }
-            if (row < V) p.dw_part[((long)n * V + row) * H + c0 + r] = dwp[e];
+            f32x16 dwp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dwp[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dwp = __builtin_amdgcn_mfma_f32_32x32x2f32(dl[2 * s + kh][r], fv[s], dwp, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < V) p.dw_part[((long)n * V + row) * H + c0 + r] = dwp[e];
+            }
         }
     }
 }
 
-// dW[v][k] = sum_n dw_part[n][v][k], db[v] = sum_n db_part[n][v], in index order
+// dW[v][k] = sum_n dw_part[n][v][k], db[v] = sum_n db_part[n][v]: a block takes 64 consecutive elements, its four waves a quarter of the
+// utterances each (fixed order inside a quarter, then quarter 0 + 1 + 2 + 3)
 __global__ __launch_bounds__(256) void ctc_head_reduce_kernel(const float *__restrict__ dw_part, const float *__restrict__ db_part,
                                                               float *__restrict__ dw, float *__restrict__ db, int B, long VH, int V) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < VH) {
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += dw_part[(long)n * VH + i];
-        dw[i] = s;
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + e;
+    const int n0 = q * ((B + 3) / 4), n1 = min(B, n0 + (B + 3) / 4);
+    const bool is_db = i >= VH;                       // the blocks behind the weight elements sum the bias partials
+    const long j = is_db ? i - VH : i;
+    const float *src = is_db ? db_part : dw_part;
+    const long stride = is_db ? V : VH;
+    float s = 0.f;
+    if (j < (is_db ? (long)V : VH)) {
+#pragma unroll 8
+        for (int n = n0; n < n1; ++n) s += src[(long)n * stride + j];
     }
-    if (i < V) {
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += db_part[(long)n * V + i];
-        db[i] = s;
-    }
+    part[q][e] = s;
+    __syncthreads();
+    if (q == 0 && j < (is_db ? (long)V : VH)) (is_db ? db : dw)[j] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
 }  // namespace
@@ -301,7 +350,7 @@ int halo_ctc_head_fwd(const float *features, const float *weight, const float *b
     HALO_CHECK_ARG(((uintptr_t)features % 16 == 0) && ((uintptr_t)weight % 16 == 0));
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)ctc_head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NW * 1024 * 4) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)ctc_head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_LDS) != hipSuccess)
             return HALO_ELAUNCH;
         attr = true;
     }
@@ -311,7 +360,7 @@ int halo_ctc_head_fwd(const float *features, const float *weight, const float *b
     a.il = input_lengths; a.targets = targets; a.tl = target_lengths; a.tg_stride = tg_stride;
     a.lp = lp; a.alpha = alpha; a.nll = nll; a.grad_out = grad_out; a.loss = loss; a.flen = feature_lengths; a.ticket = ticket;
     a.B = B; a.T = T; a.H = H; a.V = V; a.S = S; a.ks = ks; a.stride = stride; a.pad = pad;
-    hipLaunchKernelGGL(ctc_head_fwd_kernel, dim3(B), dim3(1024), NW * 1024 * 4, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ctc_head_fwd_kernel, dim3(B), dim3(1024), HEAD_FWD_LDS, (hipStream_t)stream, a);
     return halo_launch_status();
 }
 
@@ -330,12 +379,21 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
     a.lp = lp; a.alpha = alpha; a.nll = nll; a.grad_out = grad_out;
     a.dfeats = dfeatures; a.dw_part = (float *)workspace; a.db_part = a.dw_part + (size_t)B * V * H;
     a.B = B; a.T = T; a.H = H; a.V = V; a.S = S;
-    hipLaunchKernelGGL(ctc_head_bwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, a);
+    const size_t mask_bytes = p_drop > 0.f ? (size_t)T * H * sizeof(float) : 0;       // <= 128 KiB at T = 32, H = 1024
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)ctc_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 4) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    if (mask_bytes > 32 * 1024 * 4) return HALO_ENOTSUP;
+    hipLaunchKernelGGL(ctc_head_bwd_kernel, dim3(B), dim3(512), mask_bytes, (hipStream_t)stream, a);
     int rc = halo_launch_status();
     if (rc != HALO_OK) return rc;
     const long VH = (long)V * H;
-    hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)((VH + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.dw_part, a.db_part,
-                       dweight, dbias, B, VH, V);
+    // VH is a multiple of 64 (H % 64 == 0): weight elements fill whole blocks, one more block for the bias
+    hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)(VH / 64 + (V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a.dw_part,
+                       a.db_part, dweight, dbias, B, VH, V);
     return halo_launch_status();
 }
 
