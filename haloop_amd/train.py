@@ -321,11 +321,15 @@ class LstmCtcTrainer:
                 self._graphs = (g,)
             else:
                 g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                # the collective backend's own threads (RCCL watchdog: event queries) must not invalidate the capture, and nothing
+                # of the broadcast may still be in flight
+                torch.cuda.synchronize()
+                mode = dict(capture_error_mode='thread_local')
+                with torch.cuda.graph(g1, **mode):
                     state = self._forward_backward_top(sx, sil, stg, stl)
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), **mode):
                     self._backward_rest(state)
-                with torch.cuda.graph(g3, pool=g1.pool()):
+                with torch.cuda.graph(g3, pool=g1.pool(), **mode):
                     self._optimizer()
                 self._graphs = (g1, g2, g3)
                 self._keep = state                       # buffers shared by the graphs stay alive
