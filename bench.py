@@ -255,8 +255,20 @@ def main():
     trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True)
     x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
-    for _ in range(args.warmup):
-        trainer.step(x, il, tg, tl)
+    use_graph = not args.no_graph
+    try:
+        for _ in range(args.warmup):
+            trainer.step(x, il, tg, tl)
+        torch.cuda.synchronize()
+    except Exception as e:              # e.g. a collective backend that cannot live beside stream capture: run the step eagerly
+        if not use_graph:
+            raise
+        print(f'[bench rank {rank}] graph mode failed ({type(e).__name__}: {e}); falling back to eager launches', file=sys.stderr, flush=True)
+        use_graph = False
+        enc, rec, params = build_model(device)
+        trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=False, grad_dtype=args.grad_dtype, alias_loss=True)
+        for _ in range(args.warmup):
+            trainer.step(x, il, tg, tl)
     if trainer.static_inputs() is not None:                 # inputs resident in the step graph's own buffers (no per-step copy)
         x, il, tg, tl = trainer.static_inputs()
     if world > 1:
@@ -291,7 +303,7 @@ def main():
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}', 'hip_graph': not args.no_graph, 'math': args.math,
+                       'parallelism': f'dp{world}', 'hip_graph': use_graph, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None},
             'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
