@@ -20,7 +20,8 @@ def timeit(fn, n=50):
 
 mode = os.environ.get('HALO_MATH', 'bf16x3'); _lib.set_math_mode(mode)
 print('math', mode, 'ring', os.environ.get('HALO_GEMM_STAGES', 'auto'), os.environ.get('HALO_GEMM_STAGES_BF16', '3'))
-for M, N, K in [(1344, 4096, 1024), (4096, 1024, 1344), (1344, 1024, 4096), (12800, 4096, 1024), (8192, 3072, 768), (8192, 768, 3072),
+print('wide', os.environ.get('HALO_GEMM_WIDE', 'auto'))
+for M, N, K in [(1280, 4096, 1024), (1280, 1024, 4096), (4096, 2048, 1280), (4096, 1024, 1280), (1344, 4096, 1024), (4096, 1024, 1344), (1344, 1024, 4096), (12800, 4096, 1024), (8192, 3072, 768), (8192, 768, 3072),
                 (8192, 2304, 768), (8192, 768, 768), (3072, 768, 8192), (8300, 50304, 768), (700, 4096, 512)]:
     a = torch.randn(M, K, generator=g).to(dev); b = torch.randn(N, K, generator=g).to(dev)
     ai, bi = ops.split_image(a), ops.split_image(b)
