@@ -649,6 +649,49 @@ def greedy_update(val, idx, negent, tokens, t, plen, etx, alive, out_len, log_pr
                                    ptr(out_len), ptr(log_probs), ptr(sum_ent), tokens.shape[0], _stream()), 'halo_greedy_update')
 
 
+# ---- fused launches of a greedy decode step (csrc/decode.hip) -------------------------------------------------
+def decode_linear_supported(k, layernorm):
+    return bool(lib().halo_decode_linear_supported(k, int(layernorm)))
+
+
+def decode_image(weight):
+    """Decode image (split-bf16 fragments in MFMA operand order) of an nn.Linear weight [n_out, k]."""
+    _f32c(weight, 'weight')
+    n_out, k = weight.shape
+    img = torch.empty(lib().halo_decode_image_bytes(n_out, k), device=weight.device, dtype=torch.uint8)
+    check(lib().halo_decode_image(ptr(weight), n_out, k, k, ptr(img), _stream()), 'halo_decode_image')
+    return img
+
+
+def decode_linear(x, image, n_out, out, ln_weight=None, eps=1e-5, accumulate=False, gelu=False):
+    """out (+)= act(layer_norm?(x) W^T) with W given by its decode image; x [rows, k] and out [rows, >= n_out] fp32 (row strides kept)."""
+    rows, k = x.shape
+    flags = (_lib.HALO_GEMM_ACCUM if accumulate else 0) | (_lib.HALO_GEMM_GELU_ERF if gelu else 0)
+    check(lib().halo_decode_linear(ptr(x), x.stride(0), rows, k, ptr(ln_weight), eps, ptr(image), n_out, ptr(out), out.stride(0), flags,
+                                   _stream()), 'halo_decode_linear')
+    return out
+
+
+def decode_attention_pair(a, mem_k, mem_v, memory_lengths, time_k, time_v, n_keys, table, out):
+    """a [N, 4C] = cross query | self q | k | v -> out [N, 2C] = cross-attention output | self-attention output (one launch)."""
+    N, heads, S, hd = mem_k.shape
+    check(lib().halo_decode_attention_pair(ptr(a), a.stride(0), N, heads, hd, ptr(mem_k), ptr(mem_v), S, ptr(memory_lengths), ptr(time_k),
+                                           ptr(time_v), time_k.shape[2], n_keys, ptr(table.cos) if table else None,
+                                           ptr(table.sin) if table else None, ptr(out), out.stride(0), _stream()),
+          'halo_decode_attention_pair')
+    return out
+
+
+def decode_token(logits, tokens, t, plen, etx, alive, out_len, log_probs, sum_ent, wte=None, y_next=None):
+    """alive: uint8 [2, N], double-buffered -- step t reads plane t & 1 and writes plane (t + 1) & 1."""
+    N, V = logits.shape
+    if alive.shape != (2, N) or not alive.is_contiguous():
+        raise ValueError('decode_token: alive must be a contiguous [2, N] uint8 tensor')
+    check(lib().halo_decode_token(ptr(logits), logits.stride(0), N, V, ptr(tokens), tokens.stride(0), t, plen, etx, ptr(alive),
+                                  ptr(out_len), ptr(log_probs), ptr(sum_ent), ptr(wte), wte.shape[0] if wte is not None else 0,
+                                  wte.shape[1] if wte is not None else 0, ptr(y_next), _stream()), 'halo_decode_token')
+
+
 # ---- channels-last conv front-end (ha/conv.py) -------------------------------------------------------------
 def conv_out_length(T, ks, stride, pad):
     return (T + 2 * pad - ks) // stride + 1

@@ -538,22 +538,87 @@ class Decoder(nn.Module):
             ops.greedy_update(val, idx, negent, tokens, t, plen, ETX, alive, out_len, log_probs, sum_entropies)
         return tokens, out_len, log_probs, sum_entropies
 
+    def _fused_decode_ok(self, C):
+        """The fused decode launches (csrc/decode.hip): split-bf16 arithmetic, so not in exact-f32 mode; HALO_DECODE_FUSED=0 keeps
+        the operator-per-launch path (same results up to the products' rounding)."""
+        return (os.environ.get('HALO_DECODE_FUSED', '1') != '0' and _lib.get_math_mode() != 'f32'
+                and ops.decode_linear_supported(C, True) and ops.decode_linear_supported(2 * C, False)
+                and ops.decode_linear_supported(4 * C, False) and self.h[0].head_dim in (16, 32, 64, 128))
+
+    @torch.no_grad()
+    def _decode_images(self):
+        """Decode images of every product of a step, rebuilt when a parameter changes: per layer the merged projection
+        [mm.q; mt.q; mt.k; mt.v], the merged output projection [mm.proj | mt.proj] (K = 2C: cross | self attention outputs), the two
+        MLP weights; and lm_head."""
+        stamp = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        if getattr(self, '_dec_images', None) is None or self._dec_images[0] != stamp:
+            layers = []
+            for block in self.h:
+                mm, mt = block.mix_memory, block.mix_time
+                layers.append((ops.decode_image(torch.cat([mm.q.weight, mt.q.weight, mt.k.weight, mt.v.weight], 0).float().contiguous()),
+                               ops.decode_image(torch.cat([mm.proj.weight, mt.proj.weight], 1).float().contiguous()),
+                               ops.decode_image(block.mix_chan[0].weight.detach().float().contiguous()),
+                               ops.decode_image(block.mix_chan[2].weight.detach().float().contiguous())))
+            head = ops.decode_image(self.lm_head.weight.detach().float().contiguous())
+            self._dec_images = (stamp, layers, head)
+        return self._dec_images[1], self._dec_images[2]
+
+    @torch.no_grad()
+    def _decode_core_fused(self, mem2d, mlen, tokens_init, plen, N, S, T):
+        """_decode_core on the fused launches: 5 per layer and step, 2 per step for the head (+ the cache warm-up)."""
+        dev = mem2d.device
+        C = mem2d.shape[1]
+        L = len(self.h)
+        heads, head_dim = self.h[0].heads, self.h[0].head_dim
+        V = self.lm_head.weight.shape[0]
+        layers, head_img = self._decode_images()
+        tokens = tokens_init.clone()
+        mem_cache = torch.zeros((L, 2, N, heads, S, head_dim), dtype=torch.float16, device=dev)
+        time_cache = torch.zeros((L, 2, N, heads, T, head_dim), dtype=torch.float16, device=dev)
+        for l, block in enumerate(self.h):                                   # cross-attention caches, warmed once (:324-334)
+            mm = block.mix_memory
+            kv = linear(mm._images, mem2d, (mm.k.weight, mm.v.weight))
+            ops.kv_cache_store(kv, C, mem_cache[l, 0], mem_cache[l, 1], N, S, heads, head_dim, 0)
+        table = ops.RopeTable(T, head_dim, dev)
+        alive = torch.ones(2, N, dtype=torch.uint8, device=dev)             # double-buffered by step parity (halo_decode_token)
+        out_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        log_probs = torch.zeros(N, dtype=torch.float32, device=dev)
+        sum_entropies = torch.zeros(N, dtype=torch.float32, device=dev)
+        a = torch.empty(N, 4 * C, device=dev, dtype=torch.float32)           # cross query | self q | k | v, then the MLP hidden rows
+        att = torch.empty(N, 2 * C, device=dev, dtype=torch.float32)         # cross | self attention outputs
+        hid = torch.empty(N, 4 * C, device=dev, dtype=torch.float32)
+        logits = torch.empty(N, V, device=dev, dtype=torch.float32)
+        wte = self.wte.weight.detach()
+        y = ops.embed_fwd(tokens[:, 0:1], wte, None)                         # [N, C]; later steps: written by decode_token
+        for t in range(T):
+            for l, block in enumerate(self.h):
+                w_qkv, w_proj, w_fc, w_fc2 = layers[l]
+                ops.decode_linear(y, w_qkv, 4 * C, a, ln_weight=block.ln_time.weight)       # both attentions read ln_time(x) (:476-494)
+                ops.decode_attention_pair(a, mem_cache[l, 0], mem_cache[l, 1], mlen, time_cache[l, 0], time_cache[l, 1], t + 1, table, att)
+                ops.decode_linear(att, w_proj, C, y, accumulate=True)                       # x += cross proj + self proj
+                ops.decode_linear(y, w_fc, 4 * C, hid, ln_weight=block.ln_chan.weight, gelu=True)
+                ops.decode_linear(hid, w_fc2, C, y, accumulate=True)
+            ops.decode_linear(y, head_img, V, logits, ln_weight=self.ln_f.weight)
+            ops.decode_token(logits, tokens, t, plen, ETX, alive, out_len, log_probs, sum_entropies, wte, y if t + 1 < T else None)
+        return tokens, out_len, log_probs, sum_entropies
+
     def _decode_graph(self, key, mem2d, mlen, tokens, plen, N, S, T):
         """One HIP graph per (shape, parameter version): ~13 launches x layers x steps become one replay."""
         stamp = tuple((p._version, p.data_ptr()) for p in self.parameters())
         entry = self._graphs.get(key)
         if entry is None or entry['stamp'] != stamp:
+            core = self._decode_core_fused if self._fused_decode_ok(mem2d.shape[1]) else self._decode_core
             static = (mem2d.clone(), mlen.clone(), tokens.clone())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._decode_core(*static, plen, N, S, T)               # warm-up: weight images are built outside the capture
+                core(*static, plen, N, S, T)                            # warm-up: weight images are built outside the capture
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = self._decode_core(*static, plen, N, S, T)
+                outs = core(*static, plen, N, S, T)
             # the graph reads the cached weight images by address: keep them alive as long as the graph
-            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')]
+            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')] + [getattr(self, '_dec_images', None)]
             if len(self._graphs) >= 8:
                 self._graphs.pop(next(iter(self._graphs)))
             entry = dict(stamp=stamp, graph=graph, static=static, outs=outs, held=held)
@@ -583,10 +648,11 @@ class Decoder(nn.Module):
         mlen = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
         mem2d = features.reshape(N * S, C).float().contiguous()
         if os.environ.get('HALO_DECODE_GRAPH', '1') != '0':
-            key = (N, S, T, tokens.shape[1], plen, str(dev), _lib.get_math_mode())
+            key = (N, S, T, tokens.shape[1], plen, str(dev), _lib.get_math_mode(), self._fused_decode_ok(C))
             tokens, out_len, log_probs, sum_entropies = self._decode_graph(key, mem2d, mlen, tokens, plen, N, S, T)
         else:
-            tokens, out_len, log_probs, sum_entropies = self._decode_core(mem2d, mlen, tokens, plen, N, S, T)
+            core = self._decode_core_fused if self._fused_decode_ok(C) else self._decode_core
+            tokens, out_len, log_probs, sum_entropies = core(mem2d, mlen, tokens, plen, N, S, T)
         output_lengths = out_len.to(input_lengths.dtype)
         lens = output_lengths.tolist()
         outputs = torch.nested.nested_tensor([p[1:l] for p, l in zip(tokens, lens)])
@@ -676,7 +742,7 @@ class AudioEncoder(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out, _ = self._forward_core(static)
-            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')]
+            held = [list(m._images._cache.values()) for m in self.modules() if hasattr(m, '_images')] + [getattr(self, '_dec_images', None)]
             if len(self._graphs) >= 8:
                 self._graphs.pop(next(iter(self._graphs)))
             entry = dict(stamp=stamp, graph=graph, static=static, out=out, held=held)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 7
+#define HALO_ABI_VERSION 8
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -412,6 +412,33 @@ int halo_logprob_max(const float *logits, long ld, int rows, int V, float *value
 int halo_greedy_update(const float *values, const int64_t *indices, const float *neg_entropy_bits, int64_t *tokens,
                        long tokens_ld, int t, int plen, int etx, uint8_t *alive, int *output_lengths,
                        float *log_probs, float *sum_entropies, int N, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused launches of one batched greedy decode step (ha/transformer.py:160-195; Block.forward :476-494 with kv caches, T == 1):
+ * 5 launches per decoder layer + 2 per token.  M = N utterances is one or a few 16-row MFMA tiles, so these do not go through the
+ * tiled GEMM: activations are read as fp32 rows, weights from "decode images" (split-bf16 fragments in MFMA operand order).
+ *   halo_decode_image        image of a weight matrix W [n_out][k] (nn.Linear layout); halo_decode_image_bytes() bytes, 16-aligned
+ *   halo_decode_linear       out (+)= act(layer_norm?(x) W^T): x [rows][k] fp32; ln_weight != NULL applies F.layer_norm(x, weight, no
+ *                            bias, eps) first (k in {512, 768, 1024}); flags: HALO_GEMM_ACCUM (residual add into out) and / or
+ *                            HALO_GEMM_GELU_ERF; without LayerNorm k % 512 == 0.  Split-bf16 arithmetic (three MFMAs per product, fp32 accumulate).
+ *   halo_decode_attention_pair  both attentions of a step from the packed projection rows a [N][4C] = cross query | self q | k | v:
+ *                            cross-attention over the fp16 memory caches [N][heads][S][head_dim] (keys < memory_lengths[n]) into
+ *                            y[:, 0:C]; halo_attention_decode_step on the time caches (store at n_keys - 1, rotary) into y[:, C:2C]
+ *   halo_decode_token        halo_logprob_max + halo_greedy_update on logits [N][V], then y_next[n] = wte[tokens[n, t + 1]] (the next
+ *                            step's embedding; y_next may be NULL).  alive is [2][N], double-buffered: step t reads plane t & 1 and
+ *                            writes the other (several workgroups share the step).  N <= 1024. */
+size_t halo_decode_image_bytes(int n_out, int k);
+int halo_decode_image(const float *weight, int n_out, int k, long ld, void *image, halo_stream_t stream);
+int halo_decode_linear_supported(int k, int layernorm);
+int halo_decode_linear(const float *x, long ldx, int rows, int k, const float *ln_weight, float eps, const void *w_image,
+                       int n_out, float *out, long ldo, int flags, halo_stream_t stream);
+int halo_decode_attention_pair(const float *a, long a_row_stride, int N, int heads, int head_dim, const void *mem_k,
+                               const void *mem_v, int S, const int *memory_lengths, void *time_k, void *time_v,
+                               int cache_len, int n_keys, const float *cos_table, const float *sin_table, float *y,
+                               long y_row_stride, halo_stream_t stream);
+int halo_decode_token(const float *logits, long ld, int N, int V, int64_t *tokens, long tokens_ld, int t, int plen, int etx,
+                      uint8_t *alive, int *output_lengths, float *log_probs, float *sum_entropies, const float *wte,
+                      int vocab, int C, float *y_next, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward operators of the GPT / transformer training step (the autograd graph of ha/attention.py:205-232 as
