@@ -97,6 +97,7 @@ SIGNATURES = {
     'halo_decode_linear_supported': (_i, [_i, _i]),
     'halo_decode_linear': (_i, [_vp, _l, _i, _i, _vp, _f, _vp, _i, _vp, _l, _i, _vp]),
     'halo_decode_attention_pair': (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _l, _vp]),
+    'halo_decode_memory_caches': (_i, [_vp, _l, _i, _vp, _i, _i, _i, _i, _vp]),
     'halo_decode_token': (_i, [_vp, _l, _i, _i, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'halo_attention_bwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _l, _l, _vp, _vp, _l, _l,
                                 _i, _i, _i, _i, _i, _i, _vp, _f, _u64, _u32, _u32, _vp, _vp]),

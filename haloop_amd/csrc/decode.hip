@@ -340,6 +340,22 @@ __global__ __launch_bounds__(64) void dec_attention_pair_kernel(const DecAttnArg
     }
 }
 
+// ---- the cross-attention caches of ALL layers from one product (transformer.py:324-334, warmed once per decode): kv rows [N*S] hold,
+//      for layer l, its memory keys at columns [l*2C, l*2C + C) and values at [l*2C + C, (l+1)*2C); caches [L][2][N][heads][S][hd] fp16
+__global__ __launch_bounds__(256) void dec_memory_caches_kernel(const float *__restrict__ kv, long rs, __half *__restrict__ caches, int N,
+                                                                int S, int heads, int hd, int L) {
+    const long C = (long)heads * hd, per_layer = (long)N * S * 2 * C;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_layer * L) return;
+    const int l = (int)(idx / per_layer);
+    const long r = idx % per_layer;
+    const long row = r / (2 * C);                         // n * S + s
+    const int col = (int)(r % (2 * C)), which = col >= C, c = col - which * (int)C;
+    const int n = (int)(row / S), sidx = (int)(row % S), h = c / hd, d = c % hd;
+    const long plane = (long)N * C * S;
+    caches[((long)l * 2 + which) * plane + (((long)n * heads + h) * S + sidx) * hd + d] = __float2half(kv[row * rs + (long)l * 2 * C + col]);
+}
+
 // ---- the greedy head of one step (transformer.py:175-192) and the next step's input: per row log_softmax max / argmax (first index
 //      on ties) / sum p*logp/log 2, the alive-row bookkeeping (every alive row receives the entropy sum over ALL alive rows, sic),
 //      then y[n] = wte[tokens[n, t + 1]].  Workgroup b owns rows [b*TOK_ROWS, +TOK_ROWS): their bookkeeping and embedding; the entropy
@@ -539,6 +555,16 @@ int halo_decode_attention_pair(const float *a, long a_row_stride, int N, int hea
     else if (head_dim == 32) HALO_DEC_ATTN(32);
     else HALO_DEC_ATTN(16);
 #undef HALO_DEC_ATTN
+    return halo_launch_status();
+}
+
+int halo_decode_memory_caches(const float *kv, long row_stride, int layers, void *caches, int N, int S, int heads, int head_dim,
+                              halo_stream_t stream) {
+    HALO_CHECK_ARG(kv && caches && layers > 0 && N > 0 && S > 0 && heads > 0 && head_dim > 0);
+    HALO_CHECK_ARG(row_stride >= 2L * layers * heads * head_dim);
+    const long n = (long)layers * N * S * 2 * heads * head_dim;
+    hipLaunchKernelGGL(dec_memory_caches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kv, row_stride,
+                       (__half *)caches, N, S, heads, head_dim, layers);
     return halo_launch_status();
 }
 

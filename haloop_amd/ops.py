@@ -682,6 +682,12 @@ def decode_attention_pair(a, mem_k, mem_v, memory_lengths, time_k, time_v, n_key
     return out
 
 
+def decode_memory_caches(kv, caches):
+    """caches [L, 2, N, heads, S, head_dim] float16 <- kv rows [N*S, L*2C] (layer l: keys at columns l*2C, values at l*2C + C)."""
+    L, _, N, heads, S, hd = caches.shape
+    check(lib().halo_decode_memory_caches(ptr(kv), kv.stride(0), L, ptr(caches), N, S, heads, hd, _stream()), 'halo_decode_memory_caches')
+
+
 def decode_token(logits, tokens, t, plen, etx, alive, out_len, log_probs, sum_ent, wte=None, y_next=None):
     """alive: uint8 [2, N], double-buffered -- step t reads plane t & 1 and writes plane (t + 1) & 1."""
     N, V = logits.shape

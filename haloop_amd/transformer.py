@@ -573,12 +573,11 @@ class Decoder(nn.Module):
         V = self.lm_head.weight.shape[0]
         layers, head_img = self._decode_images()
         tokens = tokens_init.clone()
-        mem_cache = torch.zeros((L, 2, N, heads, S, head_dim), dtype=torch.float16, device=dev)
+        mem_cache = torch.empty((L, 2, N, heads, S, head_dim), dtype=torch.float16, device=dev)
         time_cache = torch.zeros((L, 2, N, heads, T, head_dim), dtype=torch.float16, device=dev)
-        for l, block in enumerate(self.h):                                   # cross-attention caches, warmed once (:324-334)
-            mm = block.mix_memory
-            kv = linear(mm._images, mem2d, (mm.k.weight, mm.v.weight))
-            ops.kv_cache_store(kv, C, mem_cache[l, 0], mem_cache[l, 1], N, S, heads, head_dim, 0)
+        # cross-attention caches, warmed once (:324-334): the memory keys / values of all layers are ONE product and one store
+        kv_weights = tuple(w for block in self.h for w in (block.mix_memory.k.weight, block.mix_memory.v.weight))
+        ops.decode_memory_caches(linear(self._images, mem2d, kv_weights), mem_cache)
         table = ops.RopeTable(T, head_dim, dev)
         alive = torch.ones(2, N, dtype=torch.uint8, device=dev)             # double-buffered by step parity (halo_decode_token)
         out_len = torch.zeros(N, dtype=torch.int32, device=dev)

@@ -424,9 +424,13 @@ int halo_greedy_update(const float *values, const int64_t *indices, const float 
  *   halo_decode_attention_pair  both attentions of a step from the packed projection rows a [N][4C] = cross query | self q | k | v:
  *                            cross-attention over the fp16 memory caches [N][heads][S][head_dim] (keys < memory_lengths[n]) into
  *                            y[:, 0:C]; halo_attention_decode_step on the time caches (store at n_keys - 1, rotary) into y[:, C:2C]
+ *   halo_decode_memory_caches  the float16 cross-attention caches [layers][2][N][heads][S][head_dim] of every layer (transformer.py:324-334)
+ *                            from ONE product: kv rows [N*S], layer l's keys at columns [l*2C, l*2C + C), values at [l*2C + C, (l+1)*2C)
  *   halo_decode_token        halo_logprob_max + halo_greedy_update on logits [N][V], then y_next[n] = wte[tokens[n, t + 1]] (the next
  *                            step's embedding; y_next may be NULL).  alive is [2][N], double-buffered: step t reads plane t & 1 and
  *                            writes the other (several workgroups share the step).  N <= 1024. */
+int halo_decode_memory_caches(const float *kv, long row_stride, int layers, void *caches, int N, int S, int heads,
+                              int head_dim, halo_stream_t stream);
 size_t halo_decode_image_bytes(int n_out, int k);
 int halo_decode_image(const float *weight, int n_out, int k, long ld, void *image, halo_stream_t stream);
 int halo_decode_linear_supported(int k, int layernorm);

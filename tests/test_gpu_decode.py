@@ -85,6 +85,19 @@ def test_decode_attention_pair_matches_two_launches(hal, N, heads, hd, S, T, t):
     assert torch.equal(time_a, time_b)                                               # the fp16 caches: bitwise
 
 
+def test_decode_memory_caches_equals_per_layer_stores(hal):
+    ops = hal['ops']
+    L, N, S, heads, hd = 3, 5, 7, 4, 32
+    C = heads * hd
+    kv = torch.randn(N * S, L * 2 * C + 8, generator=torch.Generator().manual_seed(2)).to(DEV)
+    ref = torch.zeros(L, 2, N, heads, S, hd, dtype=torch.float16, device=DEV)
+    for l in range(L):
+        ops.kv_cache_store(kv[:, l * 2 * C:], C, ref[l, 0], ref[l, 1], N, S, heads, hd, 0)
+    got = torch.full_like(ref, float('nan'))
+    ops.decode_memory_caches(kv, got)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize('N,V,C,t,plen', [(64, 32, 512, 0, 0), (64, 32, 512, 3, 0), (10, 100, 64, 0, 1), (130, 300, 128, 2, 0), (300, 32, 64, 1, 0)])
 def test_decode_token_equals_three_launches(hal, N, V, C, t, plen):
     ops = hal['ops']
