@@ -92,6 +92,12 @@ SIGNATURES = {
     'halo_attention_decode_step': (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'halo_logprob_max': (_i, [_vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
     'halo_greedy_update': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    'halo_star_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
+    'halo_star_ctc_fwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    'halo_star_ctc_bwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    'halo_transducer_workspace_bytes': (_sz, [_i, _i, _i]),
+    'halo_transducer_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'halo_transducer_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'halo_decode_image_bytes': (_sz, [_i, _i]),
     'halo_decode_image': (_i, [_vp, _i, _i, _l, _vp, _vp]),
     'halo_decode_linear_supported': (_i, [_i, _i]),

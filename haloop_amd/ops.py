@@ -649,6 +649,68 @@ def greedy_update(val, idx, negent, tokens, t, plen, etx, alive, out_len, log_pr
                                    ptr(out_len), ptr(log_probs), ptr(sum_ent), tokens.shape[0], _stream()), 'halo_greedy_update')
 
 
+# ---- star-CTC and transducer lattices (csrc/lattice.hip) -------------------------------------------------------
+def _check_lengths(name, lengths, hi):
+    if lengths.numel() and (int(lengths.min()) < 0 or int(lengths.max()) > hi):
+        raise ValueError(f'{name} out of range [0, {hi}]')
+
+
+def star_ctc_fwd(em, targets, emission_lengths, target_lengths, star_penalty, keep=False):
+    """em [T, N, C] fp32 log-probabilities (unit column stride) -> (losses [N], workspace or None)."""
+    T, N, C = em.shape
+    S = targets.shape[1]
+    if targets.shape[0] != N or S < 1 or C < 2:
+        raise ValueError('star_ctc: targets must be [N, S >= 1] and C >= 2')
+    if targets.numel() and (int(targets.min()) < 0 or int(targets.max()) >= C):
+        raise ValueError('star_ctc: target label out of range')
+    if emission_lengths.numel() and int(emission_lengths.min()) < 1:
+        raise ValueError('star_ctc: emission_lengths must be >= 1')
+    _check_lengths('star_ctc: emission_lengths', emission_lengths, T)
+    _check_lengths('star_ctc: target_lengths', target_lengths, S)
+    losses = torch.empty(N, device=em.device, dtype=torch.float32)
+    ws = torch.empty(lib().halo_star_ctc_workspace_bytes(T, N, S), device=em.device, dtype=torch.uint8) if keep else None
+    check(lib().halo_star_ctc_fwd(ptr(em), em.stride(0), em.stride(1), T, N, C, ptr(targets), S, ptr(emission_lengths), ptr(target_lengths),
+                                  star_penalty, ptr(ws), ptr(losses), _stream()), 'halo_star_ctc_fwd')
+    return losses, ws
+
+
+def star_ctc_bwd(em, targets, emission_lengths, target_lengths, star_penalty, workspace, losses, grad_losses):
+    T, N, C = em.shape
+    if workspace is None:
+        raise ValueError('star_ctc backward: the forward did not keep its lattice')
+    grad = torch.empty_like(em)
+    check(lib().halo_star_ctc_bwd(ptr(em), em.stride(0), em.stride(1), T, N, C, ptr(targets), targets.shape[1], ptr(emission_lengths),
+                                  ptr(target_lengths), star_penalty, ptr(workspace), ptr(losses), ptr(grad_losses), ptr(grad), _stream()),
+          'halo_star_ctc_bwd')
+    return grad
+
+
+def transducer_fwd(joint, targets, joint_lengths, target_lengths, keep=False):
+    """joint [N, T, U+1, K] fp32 contiguous log-probabilities -> (losses [N], workspace or None)."""
+    N, T, U1, K = joint.shape
+    if targets.numel() and (int(targets.min()) < 0 or int(targets.max()) >= K):
+        raise ValueError('transducer: target label out of range')
+    if joint_lengths.numel() and int(joint_lengths.min()) < 1:
+        raise ValueError('transducer: joint_lengths must be >= 1')
+    _check_lengths('transducer: joint_lengths', joint_lengths, T)
+    _check_lengths('transducer: target_lengths', target_lengths, U1 - 1)
+    losses = torch.empty(N, device=joint.device, dtype=torch.float32)
+    ws = torch.empty(lib().halo_transducer_workspace_bytes(N, T, U1), device=joint.device, dtype=torch.uint8) if keep else None
+    check(lib().halo_transducer_fwd(ptr(joint), N, T, U1, K, ptr(targets), ptr(joint_lengths), ptr(target_lengths), ptr(ws), ptr(losses),
+                                    _stream()), 'halo_transducer_fwd')
+    return losses, ws
+
+
+def transducer_bwd(joint, targets, joint_lengths, target_lengths, workspace, losses, grad_losses):
+    N, T, U1, K = joint.shape
+    if workspace is None:
+        raise ValueError('transducer backward: the forward did not keep its lattice')
+    grad = torch.empty_like(joint)
+    check(lib().halo_transducer_bwd(ptr(joint), N, T, U1, K, ptr(targets), ptr(joint_lengths), ptr(target_lengths), ptr(workspace),
+                                    ptr(losses), ptr(grad_losses), ptr(grad), _stream()), 'halo_transducer_bwd')
+    return grad
+
+
 # ---- fused launches of a greedy decode step (csrc/decode.hip) -------------------------------------------------
 def decode_linear_supported(k, layernorm):
     return bool(lib().halo_decode_linear_supported(k, int(layernorm)))

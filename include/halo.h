@@ -310,6 +310,32 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
 int halo_ctc_greedy(const float *lp, int N, int T, int C, int64_t *alignments, float *scores,
                     int64_t *hyp, int64_t *hyp_len, halo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The reference's two further lattices, one workgroup per utterance, forward score and gradient.
+ *   halo_star_ctc_fwd     ha/star.py:65-166 star_ctc_forward_score(emissions [T, N, C] log-probabilities, targets [N, S], lengths,
+ *                         star_penalty): losses [N] = -log of the 4S+3-state star lattice (stars are evaluated from the C symbols in
+ *                         the kernel: the 2C-wide emissions of intersperse_stars :9-49 are never built).  workspace (optional, needed
+ *                         for the backward): halo_star_ctc_workspace_bytes(T, N, S) bytes, keeps the alpha lattice.
+ *   halo_star_ctc_bwd     d sum_n grad_losses[n] * losses[n] / d emissions (what autograd gives the reference), written to
+ *                         grad_log_probs with the strides of log_probs; rows at or past emission_lengths[n] are zero.
+ *   halo_transducer_fwd   ha/transducer.py:175-207 transducer_forward_score(joint [N, T, U+1, K] log-probabilities, targets [N, U],
+ *                         joint_lengths, target_lengths) -> losses [N]; any T (the reference's scan needs T in (2^(k-1/2), 2^k]).
+ *   halo_transducer_bwd   its gradient w.r.t. joint (dense [N, T, U+1, K], zero outside the two symbols of every lattice cell). */
+size_t halo_star_ctc_workspace_bytes(int T, int N, int S);
+int halo_star_ctc_fwd(const float *log_probs, long stride_t, long stride_n, int T, int N, int C, const int64_t *targets, int S,
+                      const int64_t *emission_lengths, const int64_t *target_lengths, float star_penalty, void *workspace,
+                      float *losses, halo_stream_t stream);
+int halo_star_ctc_bwd(const float *log_probs, long stride_t, long stride_n, int T, int N, int C, const int64_t *targets, int S,
+                      const int64_t *emission_lengths, const int64_t *target_lengths, float star_penalty,
+                      const void *workspace, const float *losses, const float *grad_losses, float *grad_log_probs,
+                      halo_stream_t stream);
+size_t halo_transducer_workspace_bytes(int N, int T, int U1);
+int halo_transducer_fwd(const float *joint, int N, int T, int U1, int K, const int64_t *targets, const int *joint_lengths,
+                        const int *target_lengths, void *workspace, float *losses, halo_stream_t stream);
+int halo_transducer_bwd(const float *joint, int N, int T, int U1, int K, const int64_t *targets, const int *joint_lengths,
+                        const int *target_lengths, const void *workspace, const float *losses, const float *grad_losses,
+                        float *grad_joint, halo_stream_t stream);
+
 /* Beam search with the reference's exact (quirky) semantics, one workgroup per utterance.
  * replaces: ha/beam.py:71-137 (logits) and ha/beam.py:5-68 (probs, log_domain = 0).
  *   em [N,T,V]; seqs [N,beam,T] int64, lens [N,beam] int32, scores [N,beam] f32, ranked best first.

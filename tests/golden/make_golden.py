@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import ha.rnn, ha.recognizer, ha.ctc, ha.beam, ha.optim, ha.attention, ha.init, ha.transformer, ha.conv, ha.attention_audio   # the reference
+import ha.star, ha.transducer
 
 from oracle import cpu_ref, gpt_ref, transformer_ref, audio_encoder_ref
 
@@ -474,11 +475,78 @@ def save_asr():
     np.savez_compressed(os.path.join(OUT, 'g6_asr_parts.npz'), **d)
 
 
+def star_case(name, T, N, C, S, seed, penalty, targets=None, il=None, tl=None):
+    """ha.star.star_ctc_forward_score on seeded log-probabilities + its autograd gradient w.r.t. the emissions (sum of losses)."""
+    g = torch.Generator().manual_seed(seed)
+    em = torch.randn(T, N, C, generator=g).log_softmax(-1).requires_grad_(True)
+    if targets is None:
+        targets = torch.randint(1, C, (N, S), generator=g)
+    il = torch.full((N,), T, dtype=torch.int64) if il is None else il
+    tl = torch.full((N,), S, dtype=torch.int64) if tl is None else tl
+    losses = ha.star.star_ctc_forward_score(em, targets, il, tl, star_penalty=penalty)
+    losses.sum().backward()
+    with torch.no_grad():
+        s_em, s_tg = ha.star.intersperse_stars(em, targets)
+    return {name + '.emissions': em.detach().numpy(), name + '.targets': targets.numpy(), name + '.il': il.numpy(), name + '.tl': tl.numpy(),
+            name + '.penalty': np.float32(penalty), name + '.losses': losses.detach().numpy(), name + '.grad': em.grad.numpy(),
+            name + '.star_targets': s_tg.numpy(), name + '.star_emissions_t0': s_em[0].numpy()}
+
+
+def save_star():
+    d = {}
+    d.update(star_case('random', 21, 4, 32, 10, 0, -0.5, il=torch.tensor([21, 17, 20, 12]), tl=torch.tensor([10, 7, 5, 9])))
+    d.update(star_case('repeat', 21, 3, 8, 6, 1, -0.5, targets=torch.tensor([[3, 3, 3, 3, 3, 3], [1, 1, 2, 2, 1, 1], [5, 4, 4, 4, 5, 5]])))
+    d.update(star_case('s1', 9, 2, 6, 1, 2, -2.0))
+    d.update(star_case('nopenalty', 12, 3, 10, 4, 3, 0.0, tl=torch.tensor([4, 2, 3])))
+    d.update(star_case('padded', 15, 3, 9, 5, 4, -0.5, targets=torch.tensor([[2, 5, 0, 0, 0], [1, 1, 7, 0, 0], [8, 3, 3, 2, 1]]),
+                       il=torch.tensor([15, 9, 15]), tl=torch.tensor([2, 3, 5])))
+    # the reference's own __main__ demo (ha/star.py:199-215): seed 2, penalty -100
+    torch.manual_seed(2)
+    logits = torch.stack([torch.randn(10, 7).log_softmax(-1), torch.randn(10, 7).log_softmax(-1)], dim=1)
+    targets = torch.tensor([[1, 2, 3, 3], [1, 2, 3, 4]])
+    il, tl = torch.LongTensor([5, 10]), torch.LongTensor([3, 4])
+    d['demo.emissions'], d['demo.targets'], d['demo.il'], d['demo.tl'] = logits.numpy(), targets.numpy(), il.numpy(), tl.numpy()
+    d['demo.penalty'] = np.float32(-100)
+    d['demo.losses'] = ha.star.star_ctc_forward_score(logits, targets, il, tl, star_penalty=-100).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g8_star.npz'), **d)
+    print('g8_star demo', d['demo.losses'], 'random', d['random.losses'], 'padded', d['padded.losses'])
+
+
+def transducer_case(name, N, T, U, K, seed, jl=None, tl=None):
+    """ha.transducer.transducer_forward_score on a seeded joint + its autograd gradient w.r.t. the joint (sum of losses)."""
+    g = torch.Generator().manual_seed(seed)
+    f, p = torch.randn(N, T, K, generator=g), torch.randn(N, U + 1, K, generator=g)
+    joint = (f[:, :, None, :] + p[:, None, :, :]).log_softmax(dim=-1).requires_grad_(True)
+    targets = torch.randint(0, K, (N, U), generator=g)                  # label 0 (= the blank id) does occur, as in the reference's tests
+    jl = torch.full((N,), T, dtype=torch.int32) if jl is None else jl
+    tl = torch.full((N,), U, dtype=torch.int32) if tl is None else tl
+    losses = ha.transducer.transducer_forward_score(joint, targets, jl, tl)
+    losses.sum().backward()
+    return {name + '.joint': joint.detach().numpy(), name + '.targets': targets.numpy(), name + '.jl': jl.numpy(), name + '.tl': tl.numpy(),
+            name + '.losses': losses.detach().numpy(), name + '.grad': joint.grad.numpy()}
+
+
+def save_transducer():
+    d = {}
+    d.update(transducer_case('batched', 13, 7, 4, 6, 42))                   # the shape of ha/transducer.py:210-231 (test_batched)
+    # T must lie in (2^(k-1/2), 2^k]: the reference pads its scan to 2 ** round(log2(T)) (ha/transducer.py:194) and raises otherwise
+    d.update(transducer_case('ragged', 5, 24, 10, 32, 1, jl=torch.tensor([24, 17, 20, 12, 1], dtype=torch.int32),
+                             tl=torch.tensor([10, 7, 0, 9, 3], dtype=torch.int32)))
+    d.update(transducer_case('long', 2, 64, 33, 8, 2, jl=torch.tensor([64, 50], dtype=torch.int32), tl=torch.tensor([33, 20], dtype=torch.int32)))
+    # single-sequence flood-fill variant (ha/transducer.py:145-172) on sequence 0 of 'batched'
+    j0, t0 = torch.from_numpy(d['batched.joint'][0]), torch.from_numpy(d['batched.targets'][0])
+    d['batched.score4_seq0'] = ha.transducer.transducer_forward_score4(j0, t0).numpy()
+    np.savez_compressed(os.path.join(OUT, 'g9_transducer.npz'), **d)
+    print('g9_transducer batched', d['batched.losses'][:4], 'score4', d['batched.score4_seq0'], 'ragged', d['ragged.losses'])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                       # e.g. `make_golden.py save_lc2x1024_b64`: regenerate the named fixtures only
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
+    save_star()
+    save_transducer()
     save_lc2x1024_b64()
     save_audio_encoder()
     save_asr()

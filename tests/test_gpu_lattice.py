@@ -1,0 +1,103 @@
+"""GPU parity of the star-CTC and transducer lattices (haloop_amd.star / haloop_amd.transducer, csrc/lattice.hip) against the
+reference-generated fixtures (tests/golden/g8_star.npz, g9_transducer.npz: ha.star.star_ctc_forward_score and
+ha.transducer.transducer_forward_score run on CPU, with their autograd gradients) and against the CPU oracle (oracle/star_ref.py) on
+further seeded cases.  fp32 lattices: losses rel <= 1e-5 (abs 1e-4: they are sums of ~T log-probabilities), gradients <= 1e-4 rel /
+5e-6 abs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_oracle_golden import STAR_CASES, TRANSDUCER_CASES, star_case_from_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def hal():
+    from haloop_amd import _lib, star, transducer
+    _lib.lib()
+    return dict(star=star, transducer=transducer, lib=_lib)
+
+
+@pytest.mark.parametrize('name', STAR_CASES + ['demo'])
+def test_star_ctc_matches_reference(hal, name):
+    g = load_golden('g8_star')
+    em, tg, il, tl, pen = star_case_from_golden(g, name)
+    x = em.to(DEV).requires_grad_(True)
+    losses = hal['star'].star_ctc_forward_score(x, tg.to(DEV), il.to(DEV), tl.to(DEV), star_penalty=pen)
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), g[name + '.losses'], rtol=1e-5, atol=1e-4)
+    if name == 'demo':
+        return
+    losses.sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[name + '.grad'], rtol=1e-4, atol=5e-6)
+
+
+def test_star_ctc_weighted_backward_time_strided_and_helpers(hal):
+    """Upstream gradient weights, a [N, T, C] buffer viewed time-major (what recognizer.py:77 passes), no_grad forward, and the small
+    tensor helpers against the oracle's."""
+    from oracle import star_ref
+    star = hal['star']
+    g = torch.Generator().manual_seed(11)
+    T, N, C, S = 30, 6, 40, 9
+    base = torch.randn(N, T, C, generator=g).log_softmax(-1)
+    tg = torch.randint(1, C, (N, S), generator=g)
+    il = torch.randint(20, T + 1, (N,), generator=g)
+    tl = torch.randint(1, S + 1, (N,), generator=g)
+    w = torch.rand(N, generator=g) + 0.5
+    ref_l = star_ref.star_ctc_forward_score(base.permute(1, 0, 2), tg, il, tl, star_penalty=-1.25)
+    ref_g = star_ref.star_ctc_grad(base.permute(1, 0, 2), tg, il, tl, star_penalty=-1.25) * w[None, :, None]
+    x = base.to(DEV).requires_grad_(True)
+    losses = star.star_ctc_forward_score(x.permute(1, 0, 2), tg.to(DEV), il.to(DEV), tl.to(DEV), star_penalty=-1.25)
+    (losses * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), ref_l.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(x.grad.permute(1, 0, 2).cpu().numpy(), ref_g.numpy(), rtol=1e-4, atol=5e-6)
+    with torch.no_grad():
+        l2 = star.star_ctc_forward_score(base.to(DEV).permute(1, 0, 2), tg.to(DEV), il.to(DEV), tl.to(DEV), star_penalty=-1.25)
+    assert torch.equal(l2, losses.detach())
+    s_em, s_tg = star.intersperse_stars(base.permute(1, 0, 2).to(DEV), tg.to(DEV))
+    np.testing.assert_allclose(s_em.cpu().numpy(), star_ref.star_emissions(base.permute(1, 0, 2)).numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(star.intersperse_blanks(s_tg).cpu(), star_ref.star_states(tg, C))
+    with pytest.raises(NotImplementedError):
+        star.star_ctc_forward_score(x.permute(1, 0, 2), tg.to(DEV), il.to(DEV), tl.to(DEV), animate=True)
+    with pytest.raises(hal['lib'].HaloError):
+        star.star_ctc_forward_score(base.permute(1, 0, 2), tg, il, tl)
+    with pytest.raises(ValueError):
+        star.star_ctc_forward_score(x.permute(1, 0, 2), tg.to(DEV), il.to(DEV) + T, tl.to(DEV))
+
+
+@pytest.mark.parametrize('name', TRANSDUCER_CASES)
+def test_transducer_matches_reference(hal, name):
+    g = load_golden('g9_transducer')
+    t = lambda k: torch.from_numpy(g[name + '.' + k])
+    x = t('joint').to(DEV).requires_grad_(True)
+    losses = hal['transducer'].transducer_forward_score(x, t('targets').to(DEV), t('jl').to(DEV), t('tl').to(DEV))
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), g[name + '.losses'], rtol=1e-5, atol=1e-4)
+    losses.sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[name + '.grad'], rtol=1e-4, atol=5e-6)
+    if name == 'batched':
+        with torch.no_grad():
+            l4 = hal['transducer'].transducer_forward_score4(x[0].detach(), t('targets')[0].to(DEV))
+        np.testing.assert_allclose(float(l4), float(g['batched.score4_seq0']), rtol=1e-5)
+
+
+def test_transducer_any_length_against_oracle(hal):
+    """T = 21 (config 2's frame count): the reference's scan raises there; the recurrence it defines is checked against the oracle."""
+    from oracle import star_ref
+    g = torch.Generator().manual_seed(3)
+    N, T, U, K = 4, 21, 6, 12
+    joint = (torch.randn(N, T, 1, K, generator=g) + torch.randn(N, 1, U + 1, K, generator=g)).log_softmax(-1)
+    tg = torch.randint(0, K, (N, U), generator=g)
+    jl, tl = torch.tensor([21, 20, 9, 1], dtype=torch.int32), torch.tensor([6, 3, 0, 2], dtype=torch.int32)
+    w = torch.rand(N, generator=g) + 0.5
+    ref_l = star_ref.transducer_forward_score(joint, tg, jl, tl)
+    ref_g = star_ref.transducer_grad(joint, tg, jl, tl) * w[:, None, None, None]
+    x = joint.to(DEV).requires_grad_(True)
+    losses = hal['transducer'].transducer_forward_score(x, tg.to(DEV), jl.to(DEV), tl.to(DEV))
+    (losses * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), ref_l.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_g.numpy(), rtol=1e-4, atol=5e-6)
+    with pytest.raises(ValueError):
+        hal['transducer'].transducer_forward_score(x, tg[:, :3].to(DEV), jl.to(DEV), tl.to(DEV))

@@ -381,3 +381,47 @@ def test_product_side_synthetic_generators_match_the_oracle_side():
     for pad in (True, False):
         for a, b in zip(synth.synthetic_tokens(3, 24, 61, 9, pad_tail=pad), gpt_ref.synthetic_tokens(3, 24, 61, 9, pad_tail=pad)):
             assert torch.equal(a, b)
+
+
+# ---- star-CTC and transducer lattices (ha/star.py, ha/transducer.py): oracle/star_ref.py against the reference's own outputs ----
+STAR_CASES = ['random', 'repeat', 's1', 'nopenalty', 'padded']
+TRANSDUCER_CASES = ['batched', 'ragged', 'long']
+
+
+def star_case_from_golden(g, name):
+    t = lambda k: torch.from_numpy(g[name + '.' + k])
+    return t('emissions'), t('targets'), t('il'), t('tl'), float(g[name + '.penalty'])
+
+
+@pytest.mark.parametrize('name', STAR_CASES + ['demo'])
+def test_star_ctc_restatement_matches_reference(name):
+    from oracle import star_ref
+    g = load_golden('g8_star')
+    em, tg, il, tl, pen = star_case_from_golden(g, name)
+    losses = star_ref.star_ctc_forward_score(em, tg, il, tl, star_penalty=pen)
+    np.testing.assert_allclose(losses.numpy(), g[name + '.losses'], rtol=2e-6, atol=1e-5)
+    if name == 'demo':
+        return
+    C = em.shape[-1]
+    assert np.array_equal(star_ref.star_states(tg, C)[:, 1::2].numpy(), g[name + '.star_targets'])       # the non-blank states
+    np.testing.assert_allclose(star_ref.star_emissions(em)[0].numpy(), g[name + '.star_emissions_t0'], rtol=1e-6, atol=1e-6)
+    # the analytic alpha-beta gradient against the reference's autograd gradient of sum(losses)
+    grad = star_ref.star_ctc_grad(em, tg, il, tl, star_penalty=pen)
+    np.testing.assert_allclose(grad.numpy(), g[name + '.grad'], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', TRANSDUCER_CASES)
+def test_transducer_restatement_matches_reference(name):
+    from oracle import star_ref
+    g = load_golden('g9_transducer')
+    t = lambda k: torch.from_numpy(g[name + '.' + k])
+    joint, tg, jl, tl = t('joint'), t('targets'), t('jl'), t('tl')
+    if name == 'long':                                      # pure-Python cells: keep the big lattice to its first sequence
+        joint, tg, jl, tl = joint[:1], tg[:1], jl[:1], tl[:1]
+    n = joint.shape[0]
+    losses = star_ref.transducer_forward_score(joint, tg, jl, tl)
+    np.testing.assert_allclose(losses.numpy(), g[name + '.losses'][:n], rtol=1e-5, atol=1e-5)
+    grad = star_ref.transducer_grad(joint, tg, jl, tl)
+    np.testing.assert_allclose(grad.numpy(), g[name + '.grad'][:n], rtol=1e-4, atol=2e-6)
+    if name == 'batched':
+        np.testing.assert_allclose(losses[0].numpy(), g['batched.score4_seq0'], rtol=1e-5)
