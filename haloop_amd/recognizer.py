@@ -3,7 +3,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, functional as HF, ops
+from .ctc import ctc_reduce_mean
 from .rnn import DropoutStream
+from .star import star_ctc_forward_score
 
 
 class TemporalClassifier(nn.Module):
@@ -36,10 +38,14 @@ class TemporalClassifier(nn.Module):
             input_lengths = torch.full((features.shape[0],), features.shape[1], dtype=torch.long)
         if target_lengths is None:
             target_lengths = torch.full((features.shape[0],), len(targets), dtype=torch.long)
-        if star_penalty is not None:
-            # the reference path reads a non-existent self.star_penalty (recognizer.py:80) and fails
-            raise AttributeError("'TemporalClassifier' object has no attribute 'star_penalty'")
         logits = self.log_probs(features)
+        if star_penalty is not None:
+            # recognizer.py:74-82: the star-CTC branch reads self.star_penalty, which the reference's constructor never sets (so it raises
+            # AttributeError unless the caller has assigned the attribute); same here, through the same attribute access
+            dev = logits.device
+            losses = star_ctc_forward_score(logits.permute(1, 0, 2), targets.to(dev), input_lengths.to(dev), target_lengths.to(dev),
+                                            star_penalty=self.star_penalty)
+            return ctc_reduce_mean(losses, target_lengths.to(dev)), {}
         logits1 = logits.permute(1, 0, 2)                     # T, N, C (a view; the kernel takes strides)
         dev = logits.device
         loss = HF.ctc_loss(logits1, targets.to(dev), input_lengths.to(dev), target_lengths.to(dev))

@@ -101,3 +101,31 @@ def test_transducer_any_length_against_oracle(hal):
     np.testing.assert_allclose(x.grad.cpu().numpy(), ref_g.numpy(), rtol=1e-4, atol=5e-6)
     with pytest.raises(ValueError):
         hal['transducer'].transducer_forward_score(x, tg[:, :3].to(DEV), jl.to(DEV), tl.to(DEV))
+
+
+def test_temporal_classifier_star_branch(hal):
+    """recognizer.py:74-82: the star-CTC branch of TemporalClassifier.forward reads self.star_penalty -- AttributeError unless the caller
+    set it (the reference's constructor does not), then ctc_reduce_mean(star_ctc_forward_score(...)); gradients reach the classifier."""
+    from haloop_amd import recognizer
+    from oracle import star_ref
+    g = torch.Generator().manual_seed(21)
+    N, T, H, V, S = 5, 21, 64, 32, 6
+    feats = torch.randn(N, T, H, generator=g)
+    tg = torch.randint(1, V, (N, S), generator=g)
+    il, tl = torch.tensor([21, 18, 21, 9, 15]), torch.tensor([6, 4, 1, 3, 5])
+    rec = recognizer.TemporalClassifier(H, V).to(DEV).eval()
+    with pytest.raises(AttributeError):
+        rec(feats.to(DEV), tg, il, tl, star_penalty=-0.5)
+    rec.star_penalty = -0.75
+    loss, stats = rec(feats.to(DEV), tg, il, tl, star_penalty=-0.5)          # the argument only selects the branch, as in the reference
+    loss.backward()
+    w, b = rec.classifier.weight.detach().cpu().clone().requires_grad_(True), rec.classifier.bias.detach().cpu().clone().requires_grad_(True)
+    em = torch.nn.functional.linear(feats, w, b).log_softmax(-1).permute(1, 0, 2)
+    ref_losses = star_ref.star_ctc_forward_score(em.detach(), tg, il, tl, star_penalty=-0.75)
+    ref = (ref_losses / tl).mean()
+    g_em = star_ref.star_ctc_grad(em.detach(), tg, il, tl, star_penalty=-0.75) / (tl[None, :, None] * N)
+    em.backward(gradient=g_em)
+    assert stats == {}
+    np.testing.assert_allclose(float(loss.detach()), float(ref), rtol=2e-5)
+    np.testing.assert_allclose(rec.classifier.weight.grad.cpu().numpy(), w.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(rec.classifier.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-5)
