@@ -190,12 +190,18 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
     __shared__ float dl[32][LDT];         // gradient at the logits (0 outside [T) x [V))
     __shared__ float ab[32][65];          // alpha, then alpha + beta
     extern __shared__ __attribute__((aligned(16))) float mask_s[];     // [T][H] dropout multipliers of this utterance's features
+    // blockIdx.y: which slice of the H-wide outputs (d features, dW) this workgroup produces.  The lattice part (beta, gradient at the
+    // logits: ~10 us of latency-bound work) is repeated by every slice of an utterance; the two products and the dropout masks -- the
+    // bulk -- are divided, and B utterances fill B * slices CUs instead of B
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H, V = p.V, S_ = 2 * p.S + 1;
+    const int Hs = H / (int)gridDim.y, h0 = (int)blockIdx.y * Hs;       // this slice: columns [h0, h0 + Hs), Hs % 32 == 0
     if (p.drop.threshold) {               // one Philox call covers four consecutive elements
-        for (int u = tid; u < T * H / 4; u += 512)
-            *reinterpret_cast<f32x4 *>(mask_s + 4 * u) = dropout_mult4(p.drop, (uint64_t)((long)n * T * H + 4 * u));
+        for (int u = tid; u < T * Hs / 4; u += 512) {
+            const int row = (4 * u) / Hs, col = (4 * u) % Hs;
+            *reinterpret_cast<f32x4 *>(mask_s + 4 * u) = dropout_mult4(p.drop, (uint64_t)(((long)n * T + row) * H + h0 + col));
+        }
     }
     const int64_t *tg = p.targets + (long)n * p.tg_stride;
     const int il = max(0, min((int)p.flen[n], T));
@@ -255,15 +261,15 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
         if (t < T && c < V) dl[t][c] = g - expf(lps[t][c]) * gs;
     }
     __syncthreads();
-    if (tid < V) {
+    if (tid < V && blockIdx.y == 0) {
         float s = 0.f;
         for (int t = 0; t < T; ++t) s += dl[t][tid];
         p.db_part[(long)n * V + tid] = s;
     }
     // ---- the two products, column tiles of 32 over H: wave w takes tiles w, w + NW, ... ----
     const int r = lane & 31, kh = lane >> 5;
-    for (int nt = wave; nt < H / 32; nt += NWB) {
-        const int c0 = nt * 32;
+    for (int nt = wave; nt < Hs / 32; nt += NWB) {
+        const int c0 = h0 + nt * 32, m0 = nt * 32;                      // column of the tile in the row / in the slice's mask
         {   // d features[t][c0 + j] = sum_v dl[t][v] * W[v][c0 + j], times the dropout mask of the element
             float wv[16];
 #pragma unroll
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
                 if (row < T) {
                     float v = dx[e];
-                    if (p.drop.threshold) v *= mask_s[row * H + c0 + r];
+                    if (p.drop.threshold) v *= mask_s[row * Hs + m0 + r];
                     p.dfeats[((long)n * T + row) * H + c0 + r] = v;
                 }
             }
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
             for (int s = 0; s < 16; ++s) {
                 const int kk = 2 * s + kh;
                 float f = kk < T ? p.feats[((long)n * T + kk) * H + c0 + r] : 0.f;
-                if (p.drop.threshold && kk < T) f *= mask_s[kk * H + c0 + r];
+                if (p.drop.threshold && kk < T) f *= mask_s[kk * Hs + m0 + r];
                 fv[s] = f;
             }
             f32x16 dwp;
@@ -379,7 +385,10 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
     a.lp = lp; a.alpha = alpha; a.nll = nll; a.grad_out = grad_out;
     a.dfeats = dfeatures; a.dw_part = (float *)workspace; a.db_part = a.dw_part + (size_t)B * V * H;
     a.B = B; a.T = T; a.H = H; a.V = V; a.S = S;
-    const size_t mask_bytes = p_drop > 0.f ? (size_t)T * H * sizeof(float) : 0;       // <= 128 KiB at T = 32, H = 1024
+    // slices of H per utterance: as many as keep the grid within the chip's CUs (4 at B = 64), whole 32-column tiles per slice
+    int slices = 1;
+    while (slices < 8 && (H / 32) % (2 * slices) == 0 && (long)B * 2 * slices <= 256) slices *= 2;
+    const size_t mask_bytes = p_drop > 0.f ? (size_t)T * (H / slices) * sizeof(float) : 0;       // <= 128 KiB at T = 32, H = 1024
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void *)ctc_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 4) != hipSuccess)
@@ -387,7 +396,7 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
         attr = true;
     }
     if (mask_bytes > 32 * 1024 * 4) return HALO_ENOTSUP;
-    hipLaunchKernelGGL(ctc_head_bwd_kernel, dim3(B), dim3(512), mask_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ctc_head_bwd_kernel, dim3(B, slices), dim3(512), mask_bytes, (hipStream_t)stream, a);
     int rc = halo_launch_status();
     if (rc != HALO_OK) return rc;
     const long VH = (long)V * H;

@@ -475,6 +475,34 @@ def save_asr():
     np.savez_compressed(os.path.join(OUT, 'g6_asr_parts.npz'), **d)
 
 
+def save_rnn_decoder():
+    """ha.rnn.Decoder (the `hal` LSTM language model, ha/rnn.py:30-77) as the reference runs it: two TBPTT chunks with the carried,
+    detached state (rnnlm.py:191-211 pattern), cross-entropy on the tied output layer, every gradient of the second chunk."""
+    V, E, L, T, N = 50, 64, 2, 9, 3
+    torch.manual_seed(7)
+    dec = ha.rnn.Decoder(V, E, E, L).eval()
+    g = torch.Generator().manual_seed(8)
+    tokens = torch.randint(0, V, (2, T + 1, N), generator=g)
+    d = {'cfg': np.array([V, E, L, T, N]), 'tokens': tokens.numpy()}
+    for k, v in dec.state_dict().items():
+        d['param.' + k] = v.numpy()
+    state = dec.init_hidden(N)
+    for chunk in range(2):
+        dec.zero_grad()
+        logits, state = dec(tokens[chunk, :-1], dec.truncate_hidden(state))
+        loss = F.cross_entropy(logits, tokens[chunk, 1:].reshape(-1))
+        loss.backward()
+        d[f'chunk{chunk}.logits'] = logits.detach().numpy()
+        d[f'chunk{chunk}.h'], d[f'chunk{chunk}.c'] = state[0].detach().numpy(), state[1].detach().numpy()
+        d[f'chunk{chunk}.loss'] = loss.detach().numpy()
+    for k, p_ in dec.named_parameters():
+        d['grad.' + k] = p_.grad.numpy()
+    lbf, _ = dec.forward_batch_first(tokens[0, :-1].t(), dec.init_hidden(N))
+    d['batch_first.logits'] = lbf.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'g10_rnn_decoder.npz'), **d)
+    print('g10_rnn_decoder losses', d['chunk0.loss'], d['chunk1.loss'])
+
+
 def star_case(name, T, N, C, S, seed, penalty, targets=None, il=None, tl=None):
     """ha.star.star_ctc_forward_score on seeded log-probabilities + its autograd gradient w.r.t. the emissions (sum of losses)."""
     g = torch.Generator().manual_seed(seed)
@@ -547,6 +575,7 @@ if __name__ == '__main__':
         sys.exit(0)
     save_star()
     save_transducer()
+    save_rnn_decoder()
     save_lc2x1024_b64()
     save_audio_encoder()
     save_asr()

@@ -419,6 +419,36 @@ def test_decoder_lm_matches_torch_lstm(hal, math_mode, fusion, E):
     np.testing.assert_allclose(lbf.detach().cpu().numpy(), logits_ref.detach().view(T, N, V).transpose(0, 1).numpy(), atol=1e-5)
 
 
+@BOTH_MODES
+def test_decoder_lm_matches_reference_fixture(hal, math_mode):
+    """ha.rnn.Decoder as the reference itself ran it (tests/golden/g10_rnn_decoder.npz: ha/rnn.py:30-77 under the TBPTT pattern of
+    rnnlm.py:191-211): two chunks with the carried, detached state, tied output layer, cross-entropy; logits, states, losses and
+    every gradient of the second chunk."""
+    g = load_golden('g10_rnn_decoder')
+    V, E, L, T, N = (int(v) for v in g['cfg'])
+    dec = hal['rnn'].Decoder(V, E, E, L)
+    dec.load_state_dict({k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}, strict=True)
+    dec = dec.to(DEV).eval()
+    tokens = torch.from_numpy(g['tokens']).to(DEV)
+    state = dec.init_hidden(N)
+    assert state[0].shape == (L, N, E) and state[0].device.type == 'cuda'
+    tol = 1e-5 if math_mode == 'f32' else 3e-5
+    for chunk in range(2):
+        dec.zero_grad()
+        logits, state = dec(tokens[chunk, :-1], dec.truncate_hidden(state))
+        loss = torch.nn.functional.cross_entropy(logits, tokens[chunk, 1:].reshape(-1))
+        loss.backward()
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[f'chunk{chunk}.logits'], atol=tol)
+        np.testing.assert_allclose(state[0].detach().cpu().numpy(), g[f'chunk{chunk}.h'], atol=tol)
+        np.testing.assert_allclose(state[1].detach().cpu().numpy(), g[f'chunk{chunk}.c'], atol=tol)
+        np.testing.assert_allclose(float(loss.detach()), float(g[f'chunk{chunk}.loss']), rtol=1e-5)
+    for k, p in dec.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g['grad.' + k], rtol=1e-3, atol=2e-6, err_msg=k)
+    with torch.no_grad():
+        lbf, _ = dec.forward_batch_first(tokens[0, :-1].t(), dec.init_hidden(N))
+    np.testing.assert_allclose(lbf.cpu().numpy(), g['batch_first.logits'], atol=tol)
+
+
 def test_product_fails_loudly_on_cpu_tensors(hal):
     enc = hal['rnn'].Encoder(12, 16, 32, num_layers=1)
     with pytest.raises(hal['lib'].HaloError):
