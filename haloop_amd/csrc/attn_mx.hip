@@ -24,9 +24,13 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-template <int HD>
+template <int HD, int PASSES = 3>
 struct Img {
-    static constexpr int ROWB = HD * 2 + 16;           // row stride in bytes (multiple of 16)
+    // row stride in bytes (multiple of 16).  HD = 64: 160 -- with the hardware's lane groups (MI355X_MICROARCH.md, LDS) the 16 lanes of a
+    // ds_read_b128 group land on 16 different 16-byte slots (row * 10 + chunk mod 16) and the 32 lanes of a ds_read_b64_tr_b16 group
+    // on 64 different banks (row * 40 mod 64 in steps of 8); 144 left 40 % of the LDS cycles as bank conflicts
+    // (single-pass kernels only: the three-pass dK/dV sweep holds four hi|lo image pairs and loses a workgroup per CU to the wider rows)
+    static constexpr int ROWB = (HD == 64 && PASSES == 1) ? 160 : HD * 2 + 16;
     static constexpr int BYTES = 64 * ROWB;            // one image (hi or lo) of a 64-row tile
     static constexpr int UNITS = 64 * (HD / 4) / 256;  // float4 units per thread and tile
     static constexpr int KSTEPS = HD / 32;             // 32-deep MFMA steps across the head dimension
@@ -67,11 +71,19 @@ __device__ __forceinline__ void fetch_tile(f32x4 *reg, const float *base, long r
     }
 }
 
+// the same units from precomputed element offsets (row * rs + d4 of this thread's units inside a 64-row tile) for tiles that lie
+// wholly inside the operand: one 64-bit add per 16-byte load instead of a clamp, a multiply and an add chain
+template <int HD>
+__device__ __forceinline__ void fetch_tile_inner(f32x4 *reg, const float *tile_base, const int *uoff) {
+#pragma unroll
+    for (int i = 0; i < Img<HD>::UNITS; ++i) reg[i] = *reinterpret_cast<const f32x4 *>(tile_base + uoff[i]);
+}
+
 // registers (fetch_tile layout) -> hi | lo row-major bf16 images
 template <int HD, int PASSES>
 __device__ __forceinline__ void stage_tile(char *img, const f32x4 *reg) {
 #pragma unroll
-    for (int i = 0; i < Img<HD>::UNITS; ++i) {
+    for (int i = 0; i < Img<HD, PASSES>::UNITS; ++i) {
         const int u = threadIdx.x + 256 * i;
         const int row = u / (HD / 4), d4 = (u % (HD / 4)) * 4;
         bf16x4 h, l;
@@ -80,15 +92,15 @@ __device__ __forceinline__ void stage_tile(char *img, const f32x4 *reg) {
             h[e] = (__bf16)reg[i][e];
             l[e] = (__bf16)(reg[i][e] - (float)h[e]);
         }
-        *reinterpret_cast<bf16x4 *>(img + row * Img<HD>::ROWB + d4 * 2) = h;
-        if (PASSES == 3) *reinterpret_cast<bf16x4 *>(img + Img<HD>::BYTES + row * Img<HD>::ROWB + d4 * 2) = l;
+        *reinterpret_cast<bf16x4 *>(img + row * Img<HD, PASSES>::ROWB + d4 * 2) = h;
+        if (PASSES == 3) *reinterpret_cast<bf16x4 *>(img + Img<HD, PASSES>::BYTES + row * Img<HD, PASSES>::ROWB + d4 * 2) = l;
     }
 }
 
 // B (or A) fragment whose k runs along the row: 8 consecutive elements of `row` starting at element k0
-template <int HD>
+template <int HD, int PASSES>
 __device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int k0) {
-    return *reinterpret_cast<const bf16x8 *>(img + row * Img<HD>::ROWB + k0 * 2);
+    return *reinterpret_cast<const bf16x8 *>(img + row * Img<HD, PASSES>::ROWB + k0 * 2);
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------
@@ -102,11 +114,11 @@ __device__ __forceinline__ bf16x8 row_frag(const char *img, int row, int k0) {
 // col0 + (lane & 15), through the hardware transpose read.  ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p
 // addresses row q, columns 4p..4p+3 of a 4 x 16 block and lane i receives column i of the 4 rows.  Needs EXEC all
 // ones: call it from wave-uniform code only.
-template <int HD>
+template <int HD, int PASSES>
 __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, int col0, int lr) {
-    const int off = (lr >> 2) * Img<HD>::ROWB + (col0 + 4 * (lr & 3)) * 2;
-    const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowA * Img<HD>::ROWB + off));
-    const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowB * Img<HD>::ROWB + off));
+    const int off = (lr >> 2) * Img<HD, PASSES>::ROWB + (col0 + 4 * (lr & 3)) * 2;
+    const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowA * Img<HD, PASSES>::ROWB + off));
+    const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + rowB * Img<HD, PASSES>::ROWB + off));
     return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 }
 
@@ -115,16 +127,19 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, 
 // DROP: the Philox dropout of the probabilities is compiled in only for the launches that use it
 template <int HD, int PASSES, int QB, bool DROP>
 __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(AttnArgs a) {
-    using I = Img<HD>;
+    using I = Img<HD, PASSES>;
     constexpr int WQ = 16 * QB, TQ = 64 * QB;                  // queries per wave / per workgroup
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
-    // causal: a workgroup takes query tile n-1-x (long) and then tile x (short), n + 1 key tiles in all whichever x, so the grid
-    // (ceil(n/2) wide) drains evenly
-    const int n_tiles_x = (a.Tq + TQ - 1) / TQ, h = blockIdx.y, b = blockIdx.z;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int qt = a.causal ? (pass == 0 ? n_tiles_x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
-        if (pass == 1 && (!a.causal || qt == n_tiles_x - 1 - (int)blockIdx.x)) break;
+    // One query tile per workgroup, dispatched LONGEST FIRST when causal: grid (heads * N, n_tiles), blockIdx.y = rank,
+    // tile = n_tiles - 1 - rank.  Tile x walks x + 1 key tiles (two per 128 queries), so the hardware's in-order dispatch turns
+    // into a longest-job-first schedule: CUs that drew long tiles are topped up with short ones as they finish, and every CU ends
+    // near the mean (pairing long and short tiles inside one workgroup left 384 equal jobs for 512 slots at B=8, T=1024: the CUs that
+    // held two set the time, 36 tile-steps against a mean of 27).
+    const int n_tiles_x = (a.Tq + TQ - 1) / TQ;
+    const int rank = blockIdx.y, h = (int)blockIdx.x % a.heads, b = (int)blockIdx.x / a.heads;      // grid (heads * N, n_tiles): x runs fastest
+    {
+        const int qt = a.causal ? n_tiles_x - 1 - rank : rank;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
         const int Tq = a.Tq, Tk = a.Tk;
         const float *qb = a.q + (long)b * a.q_bs + (long)h * a.q_hs;
@@ -137,7 +152,14 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
         int qrow[QB];                                              // this lane's query in each block
         bf16x8 qh[QB][I::KSTEPS], ql[QB][I::KSTEPS];               // B[k = 32ks + 8lq + e][col = query lr], pre-scaled
         f32x4 o[QB][HD / 16];                                      // O^T[dim = 16m + 4lq + r][query lr]
-        float mrow[QB], lsum[QB];                                  // lsum: this lane's share (its 16 keys per tile) of the normaliser
+        // Softmax reference point: the scores leave the MFMAs already relative to a per-query reference m_ref (its negation is the
+        // accumulator's initial value, so no subtraction and no zeroing per tile), and m_ref is only moved when a tile's maximum exceeds
+        // it by more than REBASE (2^8): the output and the normaliser are rescaled on those tiles alone -- the first one and, on real
+        // score distributions, hardly any other -- instead of on every tile.  Any reference gives the same softmax; p <= 2^8 is exact
+        // headroom for the fp32 sums and for the bf16 probabilities.
+        constexpr float REBASE = 8.0f;
+        float mref[QB], lsum[QB];                                  // lsum: this lane's share (its 16 keys per tile) of the normaliser
+        f32x4 negm[QB];                                            // -m_ref in all four slots (0 while no key has been seen)
     #pragma unroll
         for (int g = 0; g < QB; ++g) {
             qrow[g] = q0 + 16 * g + lr;
@@ -146,30 +168,44 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
             for (int ks = 0; ks < I::KSTEPS; ++ks) load_split8(qp + 32 * ks + 8 * lq, a.scale * LOG2E, qh[g][ks], ql[g][ks]);   // scores in log2 units: exp is one v_exp_f32
     #pragma unroll
             for (int m = 0; m < HD / 16; ++m) o[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mrow[g] = -INFINITY; lsum[g] = 0.f;
+            mref[g] = -INFINITY; lsum[g] = 0.f;
+            negm[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
         int n_ktiles = (klim + 63) / 64;
         if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * TQ + TQ - 1, Tq - 1) + coff) / 64 + 1));
         f32x4 kreg[I::UNITS], vreg[I::UNITS];
-        if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+        int uoff[I::UNITS];
+    #pragma unroll
+        for (int i = 0; i < I::UNITS; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            uoff[i] = (u / (HD / 4)) * (int)a.kv_rs + (u % (HD / 4)) * 4;
+        }
+        auto fetch_kv = [&](int t) {
+            if ((t + 1) * 64 <= Tk) {
+                fetch_tile_inner<HD>(kreg, kb + (long)t * 64 * a.kv_rs, uoff);
+                fetch_tile_inner<HD>(vreg, vb + (long)t * 64 * a.kv_rs, uoff);
+            } else {
+                fetch_tile<HD>(kreg, kb, a.kv_rs, t * 64, Tk);
+                fetch_tile<HD>(vreg, vb, a.kv_rs, t * 64, Tk);
+            }
+        };
+        if (n_ktiles > 0) fetch_kv(0);
         for (int kt = 0; kt < n_ktiles; ++kt) {
             __syncthreads();
             stage_tile<HD, PASSES>(Kimg, kreg);
             stage_tile<HD, PASSES>(Vimg, vreg);
             __syncthreads();
-            if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
-            f32x4 sacc[QB][4];                                     // S^T[key = 64kt + 16n + 4lq + r][query lr]
+            if (kt + 1 < n_ktiles) fetch_kv(kt + 1);
+            f32x4 sacc[QB][4];                                     // S^T[key = 64kt + 16n + 4lq + r][query lr] - m_ref[query]
     #pragma unroll
             for (int n = 0; n < 4; ++n) {
     #pragma unroll
-                for (int g = 0; g < QB; ++g) sacc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
                 for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                    const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
-                    const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                    const bf16x8 kh = row_frag<HD, PASSES>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 kl = PASSES == 3 ? row_frag<HD, PASSES>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
     #pragma unroll
-                    for (int g = 0; g < QB; ++g) sacc[g][n] = mma<PASSES>(sacc[g][n], kh, kl, qh[g][ks], ql[g][ks]);
+                    for (int g = 0; g < QB; ++g) sacc[g][n] = mma<PASSES>(ks == 0 ? negm[g] : sacc[g][n], kh, kl, qh[g][ks], ql[g][ks]);
                 }
             }
             bf16x8 ph[QB][2], pl[QB][2];                           // probabilities as the B operand of the two 32-slot P.V steps
@@ -178,29 +214,46 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
                 // masks only where the tile can need them (wave-uniform): the key-length edge and the causal diagonal
                 if (kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + 16 * g + coff)) {
                     const int kmax = a.causal ? min(klim - 1, qrow[g] + coff) : klim - 1;    // last visible key of this query
+                    const int th = kmax - (kt * 64 + 4 * lq);      // slot 16n + r of this lane is masked iff 16n + r > th
     #pragma unroll
                     for (int n = 0; n < 4; ++n)
     #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (kt * 64 + 16 * n + 4 * lq + r > kmax) sacc[g][n][r] = -INFINITY;
+                            if (16 * n + r > th) sacc[g][n][r] = -INFINITY;
                 }
                 float mx = fmaxf(fmaxf(sacc[g][0][0], sacc[g][0][1]), fmaxf(sacc[g][0][2], sacc[g][0][3]));
     #pragma unroll
                 for (int n = 1; n < 4; ++n) mx = fmaxf(mx, fmaxf(fmaxf(sacc[g][n][0], sacc[g][n][1]), fmaxf(sacc[g][n][2], sacc[g][n][3])));
-                mx = rows4_max(mx);
-                const float mnew = fmaxf(mrow[g], mx);
-                const float msafe = mnew == -INFINITY ? 0.f : mnew;
-                const float alpha = __builtin_amdgcn_exp2f(mrow[g] - msafe);   // 2^(-inf) = 0 on the first tile
-                mrow[g] = mnew;
+                mx = rows4_max(mx);                                // this tile's maximum of the query, relative to m_ref
+                // move the reference?  wave-uniform: when any query of the block has no reference yet or outgrew it by 2^REBASE
+                if (__any((mref[g] == -INFINITY && mx > -INFINITY) || mx > REBASE)) {
+                    const float shift = mref[g] == -INFINITY ? (mx == -INFINITY ? 0.f : mx) : fmaxf(mx, 0.f);
+                    const float mnew = mref[g] == -INFINITY ? (mx == -INFINITY ? -INFINITY : mx) : mref[g] + shift;
+                    const float alpha = __builtin_amdgcn_exp2f(-shift);            // queries that keep their reference: 2^0
+                    if (mref[g] != -INFINITY) {                    // (nothing accumulated yet otherwise)
+                        lsum[g] *= alpha;
+    #pragma unroll
+                        for (int m = 0; m < HD / 16; ++m)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) o[g][m][r] *= alpha;
+                    }
+    #pragma unroll
+                    for (int n = 0; n < 4; ++n)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[g][n][r] -= shift;
+                    mref[g] = mnew;
+                    const float nm = mnew == -INFINITY ? 0.f : -mnew;
+                    negm[g] = f32x4{nm, nm, nm, nm};
+                }
                 float ps = 0.f;
     #pragma unroll
                 for (int n = 0; n < 4; ++n)
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        sacc[g][n][r] = __builtin_amdgcn_exp2f(sacc[g][n][r] - msafe);
+                        sacc[g][n][r] = __builtin_amdgcn_exp2f(sacc[g][n][r]);
                         ps += sacc[g][n][r];
                     }
-                lsum[g] = lsum[g] * alpha + ps;                    // the normaliser keeps the undropped sum
+                lsum[g] += ps;                                     // the normaliser keeps the undropped sum
                 if (DROP && a.use_drop) {
                     const uint64_t base = attn_drop_tile_base(b, a.heads, h, Tq, min(qrow[g], Tq - 1), (Tk + 63) / 64, kt);
     #pragma unroll
@@ -210,10 +263,6 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
                         for (int n = 0; n < 4; ++n) sacc[g][n][r] *= dm[n];
                     }
                 }
-    #pragma unroll
-                for (int m = 0; m < HD / 16; ++m)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[g][m][r] *= alpha;
     #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const float pf[8] = {sacc[g][2 * kk][0], sacc[g][2 * kk][1], sacc[g][2 * kk][2], sacc[g][2 * kk][3],
@@ -226,8 +275,8 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
             for (int kk = 0; kk < 2; ++kk)
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m) {
-                    const bf16x8 vh = tr_frag2<HD>(Vimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                    const bf16x8 vl = PASSES == 3 ? tr_frag2<HD>(Vimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : vh;
+                    const bf16x8 vh = tr_frag2<HD, PASSES>(Vimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 vl = PASSES == 3 ? tr_frag2<HD, PASSES>(Vimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : vh;
     #pragma unroll
                     for (int g = 0; g < QB; ++g) o[g][m] = mma<PASSES>(o[g][m], vh, vl, ph[g][kk], pl[g][kk]);
                 }
@@ -241,7 +290,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m)
                     *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[g][m][0] * inv, o[g][m][1] * inv, o[g][m][2] * inv, o[g][m][3] * inv};
-                if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mrow[g] * LN2 + logf(lrow);
+                if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mref[g] * LN2 + logf(lrow);
             }
         }
     }
@@ -252,7 +301,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
 // lse / delta are lane scalars and dS^T is already the B operand of dQ^T = K^T dS^T (K^T through the transpose read).
 template <int HD, int PASSES, bool DROP>
 __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs a) {
-    using I = Img<HD>;
+    using I = Img<HD, PASSES>;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
     // causal: tile n-1-x (long) then tile x (short): n + 1 key tiles per workgroup, whichever x (see the dK/dV sweep)
@@ -298,10 +347,10 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
                 pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     #pragma unroll
                 for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                    const bf16x8 kh = row_frag<HD>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
-                    const bf16x8 kl = PASSES == 3 ? row_frag<HD>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
-                    const bf16x8 vh = row_frag<HD>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
-                    const bf16x8 vl = PASSES == 3 ? row_frag<HD>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
+                    const bf16x8 kh = row_frag<HD, PASSES>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 kl = PASSES == 3 ? row_frag<HD, PASSES>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                    const bf16x8 vh = row_frag<HD, PASSES>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 vl = PASSES == 3 ? row_frag<HD, PASSES>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
                     sacc[n] = mma<PASSES>(sacc[n], kh, kl, qh[ks], ql[ks]);
                     pacc[n] = mma<PASSES>(pacc[n], vh, vl, doh[ks], dol[ks]);
                 }
@@ -329,8 +378,8 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
                 split8(df, dh, dl);
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m) {
-                    const bf16x8 kh = tr_frag2<HD>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                    const bf16x8 kl = PASSES == 3 ? tr_frag2<HD>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
+                    const bf16x8 kh = tr_frag2<HD, PASSES>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 kl = PASSES == 3 ? tr_frag2<HD, PASSES>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
                     dq[m] = mma<PASSES>(dq[m], kh, kl, dh, dl);
                 }
             }
@@ -349,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
 // leave a lane with 16 queries of one key, and P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
 template <int HD, int PASSES, bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
-    using I = Img<HD>;
+    using I = Img<HD, PASSES>;
     __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // dO tile
     __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
@@ -404,10 +453,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
                 pacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     #pragma unroll
                 for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                    const bf16x8 qfh = row_frag<HD>(Qimg, 16 * n + lr, 32 * ks + 8 * lq);
-                    const bf16x8 qfl = PASSES == 3 ? row_frag<HD>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
-                    const bf16x8 ofh = row_frag<HD>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
-                    const bf16x8 ofl = PASSES == 3 ? row_frag<HD>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
+                    const bf16x8 qfh = row_frag<HD, PASSES>(Qimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 qfl = PASSES == 3 ? row_frag<HD, PASSES>(Qimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : qfh;
+                    const bf16x8 ofh = row_frag<HD, PASSES>(Oimg, 16 * n + lr, 32 * ks + 8 * lq);
+                    const bf16x8 ofl = PASSES == 3 ? row_frag<HD, PASSES>(Oimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : ofh;
                     sacc[n] = mma<PASSES>(sacc[n], qfh, qfl, kh[ks], kl[ks]);
                     pacc[n] = mma<PASSES>(pacc[n], ofh, ofl, vh[ks], vl[ks]);
                 }
@@ -441,10 +490,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
                 split8(df, dh, dl);
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m) {
-                    const bf16x8 oth = tr_frag2<HD>(Oimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                    const bf16x8 otl = PASSES == 3 ? tr_frag2<HD>(Oimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : oth;
-                    const bf16x8 qth = tr_frag2<HD>(Qimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
-                    const bf16x8 qtl = PASSES == 3 ? tr_frag2<HD>(Qimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : qth;
+                    const bf16x8 oth = tr_frag2<HD, PASSES>(Oimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 otl = PASSES == 3 ? tr_frag2<HD, PASSES>(Oimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : oth;
+                    const bf16x8 qth = tr_frag2<HD, PASSES>(Qimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                    const bf16x8 qtl = PASSES == 3 ? tr_frag2<HD, PASSES>(Qimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : qth;
                     dv[m] = mma<PASSES>(dv[m], oth, otl, ph, pl);
                     dk[m] = mma<PASSES>(dk[m], qth, qtl, dh, dl);
                 }
@@ -472,7 +521,7 @@ int launch_fwd(const AttnArgs &a, int N, hipStream_t st) {
     const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
     const bool two = qb2 == 2 || (qb2 == 0 && PASSES == 1 && a.Tq >= 256 && wg128 >= 512);
     const int n2 = (a.Tq + 127) / 128, n1 = (a.Tq + 63) / 64;
-    const dim3 g2(a.causal ? (n2 + 1) / 2 : n2, a.heads, N), g1(a.causal ? (n1 + 1) / 2 : n1, a.heads, N);
+    const dim3 g2(a.heads * N, n2), g1(a.heads * N, n1);
     if (two && a.use_drop) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2, true>), g2, dim3(256), 0, st, a);
     else if (two) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 2, false>), g2, dim3(256), 0, st, a);
     else if (a.use_drop) hipLaunchKernelGGL((attention_fwd_mx_kernel<HD, PASSES, 1, true>), g1, dim3(256), 0, st, a);
