@@ -129,3 +129,47 @@ def test_temporal_classifier_star_branch(hal):
     np.testing.assert_allclose(float(loss.detach()), float(ref), rtol=2e-5)
     np.testing.assert_allclose(rec.classifier.weight.grad.cpu().numpy(), w.grad.numpy(), rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(rec.classifier.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-5)
+
+
+def test_transducer_head_matches_cpu_composition(hal):
+    """recognizer.Transducer (ha/recognizer.py:86-127): LSTM prediction network + linear transcription head + additive joint +
+    transducer loss (mean over the batch), eval mode, against the same composition on the CPU: torch's nn.LSTM / F.linear /
+    log_softmax and the pinned oracle lattice (the reference's live branch needs torchaudio's rnnt_loss, which its own tests equate
+    with the lattice score).  Loss and every parameter gradient."""
+    from haloop_amd import recognizer
+    from oracle import star_ref
+    g = torch.Generator().manual_seed(31)
+    N, T, H, V, U = 3, 12, 48, 20, 5
+    feats = torch.randn(N, T, H, generator=g)
+    tg = torch.randint(1, V, (N, U), generator=g)
+    il, tl = torch.tensor([12, 9, 12]), torch.tensor([5, 3, 4])
+    torch.manual_seed(5)
+    head = recognizer.Transducer(H, V).eval()
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    head = head.to(DEV)
+    loss, stats = head(feats.to(DEV), tg, il, tl)
+    loss.backward()
+    assert stats == {}
+    # CPU composition with the same parameters
+    E = 512
+    lstm = torch.nn.LSTM(E, E, 2)
+    lstm.load_state_dict({k[len('lm.rnn.'):]: v for k, v in sd.items() if k.startswith('lm.rnn.')})
+    emb = sd['lm.embedding.weight'].clone().requires_grad_(True)
+    ob = sd['lm.out_layer.bias'].clone().requires_grad_(True)
+    cw, cb = sd['classifier.weight'].clone().requires_grad_(True), sd['classifier.bias'].clone().requires_grad_(True)
+    lm_in = torch.cat([tg.new_zeros((N, 1)), tg], dim=1)
+    out, _ = lstm(torch.nn.functional.embedding(lm_in, emb).transpose(0, 1))
+    lm_out = torch.nn.functional.linear(out, emb, ob).transpose(0, 1)
+    f = torch.nn.functional.linear(feats, cw, cb)
+    joint = (f[:, :, None, :] + lm_out[:, None, :, :]).log_softmax(-1)
+    jl, tl32 = il.to(torch.int32), tl.to(torch.int32)
+    ref_losses = star_ref.transducer_forward_score(joint.detach(), tg, jl, tl32)
+    joint.backward(gradient=star_ref.transducer_grad(joint.detach(), tg, jl, tl32) / N)
+    np.testing.assert_allclose(float(loss.detach()), float(ref_losses.mean()), rtol=2e-5)
+    np.testing.assert_allclose(head.classifier.weight.grad.cpu().numpy(), cw.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(head.classifier.bias.grad.cpu().numpy(), cb.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(head.lm.embedding.weight.grad.cpu().numpy(), emb.grad.numpy(), rtol=2e-3, atol=2e-5)
+    for k, p_ in head.lm.rnn.named_parameters():
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), getattr(lstm, k).grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+    with pytest.raises(NotImplementedError):
+        head.decode(feats.to(DEV), il)
