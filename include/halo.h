@@ -311,6 +311,18 @@ int halo_ctc_greedy(const float *lp, int N, int T, int C, int64_t *alignments, f
                     int64_t *hyp, int64_t *hyp_len, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 80-mel log filterbank front-end on the device (ha/data.py:136-140: torchaudio.compliance.kaldi.fbank(wav, num_mel_bins=80) with that
+ * function's defaults; haloop_amd/fbank.py chains these with two halo_gemm_f32 products -- the real DFT and the mel filters).
+ *   halo_fbank_frames  waveform [n_samples] -> frames [n_frames][padded]: frame f = samples [f*shift, f*shift + frame_len) (snip edges),
+ *                      minus its mean (remove_dc), pre-emphasised x[i] - c*x[i-1] (x[0] - c*x[0]), times window[i], zero padded
+ *   halo_fbank_power   spectrum [n_frames][2*bins] (real parts, then imaginary parts) -> power [n_frames][ld] (columns >= bins zero)
+ *   halo_fbank_log     x = log(max(x, eps)) in place */
+int halo_fbank_frames(const float *wav, long n_samples, int frame_len, int shift, int padded, float preemphasis, int remove_dc,
+                      const float *window, float *frames, int n_frames, halo_stream_t stream);
+int halo_fbank_power(const float *spectrum, int n_frames, int bins, float *power, int ld, halo_stream_t stream);
+int halo_fbank_log(float *x, long n, float eps, halo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * The reference's two further lattices, one workgroup per utterance, forward score and gradient.
  *   halo_star_ctc_fwd     ha/star.py:65-166 star_ctc_forward_score(emissions [T, N, C] log-probabilities, targets [N, S], lengths,
  *                         star_penalty): losses [N] = -log of the 4S+3-state star lattice (stars are evaluated from the C symbols in

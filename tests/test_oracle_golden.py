@@ -425,3 +425,25 @@ def test_transducer_restatement_matches_reference(name):
     np.testing.assert_allclose(grad.numpy(), g[name + '.grad'][:n], rtol=1e-4, atol=2e-6)
     if name == 'batched':
         np.testing.assert_allclose(losses[0].numpy(), g['batched.score4_seq0'], rtol=1e-5)
+
+
+def test_fbank_restatement_properties():
+    """oracle/fbank_ref.py is parity-unpinned (torchaudio absent); what can be checked without it: frame count, the filter bank's
+    shape / support / partition of unity between the first and last centre, a pure tone landing in the filter that covers it, and
+    invariance to a DC offset."""
+    from oracle import fbank_ref
+    banks = fbank_ref.mel_banks(80, 512, 16000.0)
+    assert banks.shape == (80, 257) and (banks >= 0).all() and (banks[:, 256] == 0).all()
+    mel = fbank_ref.mel_scale(31.25 * np.arange(256))
+    lo, hi = fbank_ref.mel_scale(20.0), fbank_ref.mel_scale(8000.0)
+    delta = (hi - lo) / 81
+    inside = (mel >= lo + delta) & (mel <= hi - delta)
+    np.testing.assert_allclose(banks[:, :256].sum(0)[inside], 1.0, atol=1e-9)      # neighbouring triangles sum to one
+    t = np.arange(16000) / 16000.0
+    tone = 0.5 * np.sin(2 * np.pi * 1000.0 * t)
+    f = fbank_ref.fbank(tone, num_mel_bins=80)
+    assert f.shape == (98, 80)
+    centres = 700.0 * (np.exp((lo + (np.arange(80) + 1) * delta) / 1127.0) - 1.0)
+    assert abs(centres[int(f.mean(0).argmax())] - 1000.0) < 60.0
+    np.testing.assert_allclose(fbank_ref.fbank(tone + 0.25, num_mel_bins=80), f, atol=2e-3)
+    assert fbank_ref.fbank(tone[:399], num_mel_bins=80).shape == (0, 80)
