@@ -216,8 +216,45 @@ __global__ __launch_bounds__(256) void halo_splitk_reduce_kernel(const float *__
     }
 }
 
+// the same sums four columns per thread (N, ldc multiples of 4, 16-byte aligned operands, fewer than 2^31 elements): one 16-byte load
+// per slab and thread, 32-bit index arithmetic, one Philox call per four dropout multipliers; the slabs are summed in the same order,
+// so the results are identical
+__global__ __launch_bounds__(256) void halo_splitk_reduce4_kernel(const float *__restrict__ slab, int ksplit, int M, int N,
+                                                                  float *__restrict__ C, int ldc, const float *bias1,
+                                                                  const float *bias2, int relu, DropoutCfg drop, int use_drop) {
+    const int total4 = M * (N / 4), n4 = N / 4;
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= total4) return;
+    const int row = u / n4, col = (u - row * n4) * 4;
+    const long total = (long)M * N;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(slab + (long)u * 4);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(slab + (long)s * total + (long)u * 4);
+        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    if (bias1) { const f32x4 b = *reinterpret_cast<const f32x4 *>(bias1 + col); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (bias2) { const f32x4 b = *reinterpret_cast<const f32x4 *>(bias2 + col); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gemm_activation(v[i], relu);
+    float *o = C + (long)row * ldc + col;
+    if (use_drop) {
+        const f32x4 dm = dropout_mult4(drop, (uint64_t)((long)row * ldc + col));
+        v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
+    }
+    if (relu & 4) { const f32x4 c = *reinterpret_cast<const f32x4 *>(o); v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3]; }
+    *reinterpret_cast<f32x4 *>(o) = v;
+}
+
 int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, int ldc, const float *bias1,
                        const float *bias2, int relu, const DropoutCfg &drop, int use_drop, hipStream_t st) {
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && (long)M * N < (1L << 31) &&
+                     (((uintptr_t)slab | (uintptr_t)C | (uintptr_t)bias1 | (uintptr_t)bias2) % 16) == 0;
+    if (vec) {
+        const int total4 = M * (N / 4);
+        hipLaunchKernelGGL(halo_splitk_reduce4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, slab, ksplit, M, N, C, ldc,
+                           bias1, bias2, relu, drop, use_drop);
+        return halo_launch_status();
+    }
     long blocks = ((long)M * N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(halo_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, ksplit, M, N, C, ldc, bias1,
