@@ -10,6 +10,7 @@
 //                                           stores, operand read = 32 consecutive floats)
 // The f32 MFMA is an exact k-ordered fmaf chain (MI355X_MICROARCH.md, Matrix cores), so results
 // differ from a CPU sgemm only by summation order.
+#include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
 
@@ -264,11 +265,14 @@ int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, in
 
 // how many K slices make an under-filled grid cover the chip, given the caller-provided scratch
 int halo_pick_ksplit(long tiles, int k_steps, long out_elems) {
+    { static int force = -1; if (force < 0) { const char *e = getenv("HALO_KSPLIT"); force = e ? atoi(e) : 0; } if (force > 0 && tiles < 128 && k_steps >= 8) return force; }
     if (tiles >= 128 || k_steps < 8) return 1;
     void *scratch; size_t bytes;
     halo_get_scratch(&scratch, &bytes);
     if (!scratch) return 1;
-    long s = (256 + tiles - 1) / tiles;
+    // as many slices as still fit ONE round of the 256 CUs (tiles * s <= 256): [1280 x 1024 x 4096], 80 tiles: 3 slices 45.0 us, 4 slices
+    // (320 workgroups: 64 CUs hold two) 53.6 us, 6 slices 46.1 us, GEMM + reduce (tools/ksplit_probe.py)
+    long s = 256 / tiles;
     if (s > k_steps / 4) s = k_steps / 4;
     const long cap = (long)(bytes / (sizeof(float) * (size_t)out_elems));
     if (s > cap) s = cap;
