@@ -353,3 +353,63 @@ class LstmCtcTrainer:
         """The graph's own input buffers (x, input_lengths, targets, target_lengths), available after the first step: fill
         them in place (e.g. as the destination of the host-to-device copy) and pass them to step() to avoid a device copy."""
         return self._static
+
+
+class GraphedTrainStep:
+    """Forward + ``loss.backward()`` of any model built from this package's modules as ONE HIP graph replay.
+
+    The attention ASR / GPT training paths are autograd Functions over many small launches (~1,700 per `transformer:32` step at
+    ~11 us of host time each, against ~12 ms of kernel time): run eagerly they are bound by the host.  ``GraphedTrainStep(forward,
+    params, dropout_streams=...)`` warms ``loss = forward(*inputs)`` up on a side stream, captures forward and backward on private
+    copies of the inputs, and ``step(*inputs)`` refills those copies and replays; the gradients land in the parameters' ``.grad``
+    (the same tensors every replay, so an optimizer can read them in place -- keep ``set_to_none=False``).  A new input shape
+    re-captures.
+
+    Dropout: pass the models' ``DropoutStream`` objects; they are switched to a shared device counter that the graph itself advances
+    once per replay, so every replay draws fresh Philox masks (a captured host-side offset would repeat one mask forever).
+    ``forward`` must be free of host synchronisation (no ``.item()`` / python branching on device values) and must produce the same
+    launch sequence for the same input shapes."""
+
+    def __init__(self, forward, params, dropout_streams=()):
+        self.forward = forward
+        self.params = [p for p in params if p.requires_grad]
+        self.streams = list(dropout_streams)
+        dev = self.params[0].device
+        self.counter = torch.zeros(1, device=dev, dtype=torch.int32)
+        for s in self.streams:
+            s.counter = self.counter
+        self._graph = self._static = self._loss = None
+
+    def _run(self, inputs):
+        loss = self.forward(*inputs)
+        with torch.autograd.set_multithreading_enabled(False):     # the backward's launches come from THIS thread (the capturing one)
+            loss.backward()
+        if self.streams:
+            ops.counter_inc(self.counter)
+        return loss
+
+    def step(self, *inputs):
+        shapes = tuple((tuple(t.shape), t.dtype) for t in inputs)
+        if self._graph is None or self._shapes != shapes:
+            self._shapes = shapes
+            self._static = tuple(t.detach().clone() for t in inputs)
+            for p in self.params:
+                p.grad = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside the capture: operand images, lazy module loads
+                for _ in range(2):
+                    for p in self.params:
+                        p.grad = None
+                    self._run(self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            for p in self.params:
+                p.grad = None                                  # the capture allocates the gradients in the graph's own pool
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._loss = self._run(self._static)
+            self._graph = graph
+        for dst, src in zip(self._static, inputs):
+            dst.copy_(src)
+        self._graph.replay()
+        return self._loss.detach().clone()

@@ -420,7 +420,7 @@ class Decoder(nn.Module):
         # prompt: STX a b c / target: a b c ETX PAD (ha/transformer.py:84-98)
         prompt = nn.functional.pad(targets, (1, 0), value=STX)
         tg = nn.functional.pad(targets, (0, 1), value=0)
-        tg[torch.arange(N, device=dev), target_lengths.to(dev)] = ETX
+        tg.scatter_(1, target_lengths.to(device=dev, dtype=torch.long).view(N, 1), ETX)       # tg[n, target_lengths[n]] = ETX, capture-safe
         T = T + 1
         if (drop_labels is None and self.training) or drop_labels:
             # label dropout (ha/transformer.py:100-103): integer data preparation, drawn from torch's generator like the reference

@@ -427,3 +427,53 @@ def test_attention_two_query_blocks_per_wave_against_exact_kernel(hal, T, causal
     np.testing.assert_allclose(out['bf16'][1], out['f32'][1], atol=5e-2, rtol=1e-3)
     scale = float(np.abs(out['f32'][2]).max())
     np.testing.assert_allclose(out['bf16'][2], out['f32'][2], atol=2e-2 * scale, rtol=0)
+
+
+def test_graphed_train_step_equals_eager(hal):
+    """haloop_amd.train.GraphedTrainStep: forward + backward of the ASR joint loss (dropout 0.2 on) replayed from one HIP graph gives
+    the gradients of the eager launches bit for bit when the device dropout counter holds the same value, draws fresh masks on the
+    next replay, and re-captures on a new input shape."""
+    from oracle import transformer_ref
+    from haloop_amd import train
+    tr, lib = hal['tr'], hal['lib']
+    prev = lib.get_math_mode()
+    lib.set_math_mode('bf16x3')
+    try:
+        V, hd, heads, L, N, T, S = 32, 64, 2, 2, 6, 160, 5
+        pe = transformer_ref.make_encoder_params(hd, heads, L, 80, 64, 3, 41)
+        pd = transformer_ref.make_decoder_params(V, hd, heads, L, 42)
+        enc = tr.AudioEncoder(head_dim=hd, heads=heads, layers=L, p_drop=0.2, input_dim=80, conv_dim=64)
+        dec = tr.CTCAttentionDecoder(vocab=V, head_dim=hd, heads=heads, p_drop=0.2, layers=L)
+        enc.load_state_dict(pe); dec.load_state_dict(pd)
+        enc.to(DEV).train(); dec.to(DEV).train()
+        x, il, tg, tl = transformer_ref.synthetic_asr_batch(N, T, 80, V, S, 7, ragged=True)
+        cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1).to(DEV)
+        xd, ild, tl1 = x.to(DEV), il.to(DEV), (tl + 1).to(DEV)
+        params = list(enc.parameters()) + list(dec.parameters())
+
+        def fwd(xd, ild, cond, tl1):
+            f, fl, _ = enc(xd, ild)
+            loss, _ = dec(f, cond, fl, tl1, drop_labels=False)          # label dropout draws from torch's generator: off for the comparison
+            return loss
+
+        step = train.GraphedTrainStep(fwd, params, dropout_streams=[enc.dropout_stream, dec.decoder.dropout_stream, dec.recognizer.dropout_stream])
+        loss_g = step.step(xd, ild, cond, tl1)
+        used = int(step.counter.item()) - 1                              # the counter value the replay drew its masks with
+        grads_g = [p.grad.clone() for p in params]
+        loss_g2 = step.step(xd, ild, cond, tl1)
+        assert float(loss_g2) != float(loss_g)                           # the next replay: other dropout masks
+        step.counter.fill_(used)
+        for p in params:
+            p.grad = None
+        loss_e = fwd(xd, ild, cond, tl1)
+        loss_e.backward()
+        assert float(loss_e.detach()) == float(loss_g)
+        for (name, p), gg in zip(list(enc.named_parameters()) + list(dec.named_parameters()), grads_g):
+            if name.endswith('wte.weight'):      # the embedding gradient is a float atomic scatter-add: its order varies run to run
+                np.testing.assert_allclose(p.grad.cpu().numpy(), gg.cpu().numpy(), rtol=0, atol=1e-6, err_msg=name)
+            else:
+                assert torch.equal(p.grad, gg), name
+        loss_s = step.step(xd[:4], ild[:4], cond[:4], tl1[:4])           # a new shape re-captures
+        assert torch.isfinite(loss_s) and params[0].grad is not None
+    finally:
+        lib.set_math_mode(prev)

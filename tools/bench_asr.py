@@ -40,14 +40,6 @@ def timed(fn, n=5, warm=2):
     return out, (time.perf_counter() - t0) / n
 
 
-with torch.inference_mode():
-    (feats, flen, _), t_enc = timed(lambda: enc(xd, ild))
-    lp = dec.recognizer.log_probs(feats)
-    (hyp_beam, _), t_beam = timed(lambda: beam.decode_batch(dec.recognizer.log_probs(feats), beam_size=16))
-    (outs, olen, _, lps, _), t_dec = timed(lambda: dec.decode(feats, flen, tld))
-print(f'transformer:32 N={N} math={math_mode}: encoder {t_enc*1e3:.2f} ms ({N/t_enc:,.0f} utt/s) | CTC beam16 {t_beam*1e3:.2f} ms '
-      f'({N/t_beam:,.0f} utt/s) | greedy decode T={int(tl.max())+1} {t_dec*1e3:.2f} ms ({N/t_dec:,.0f} utt/s)')
-
 # training direction (`hala`): encoder -> decoder CE + 0.3 CTC -> backward, dropout 0.2 on, every parameter's gradient
 enc.train(); dec.train()
 cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1).cuda()
@@ -58,8 +50,28 @@ def train_fwd_bwd():
     loss.backward()
     return loss
 loss, t_train = timed(train_fwd_bwd)
+print(f'transformer:32 N={N} joint-loss forward+backward (dropout 0.2), eager launches: {t_train*1e3:.2f} ms ({N/t_train:,.0f} utt/s), loss {loss.item():.4f}')
+# the same forward + backward replayed from one HIP graph (haloop_amd.train.GraphedTrainStep; fresh dropout masks every replay)
+from haloop_amd import train as _train
+tl1 = (tl + 1).cuda()
+def _fwd(xd_, ild_, cond_, tl1_):
+    f, fl, _ = enc(xd_, ild_)
+    return dec(f, cond_, fl, tl1_)[0]
+del loss
+gstep = _train.GraphedTrainStep(_fwd, list(enc.parameters()) + list(dec.parameters()),
+                                dropout_streams=[enc.dropout_stream, dec.decoder.dropout_stream, dec.recognizer.dropout_stream])
+loss_g, t_train_g = timed(lambda: gstep.step(xd, ild, cond, tl1))
+print(f'transformer:32 N={N} joint-loss forward+backward (dropout 0.2), one HIP graph: {t_train_g*1e3:.2f} ms ({N/t_train_g:,.0f} utt/s), loss {loss_g.item():.4f}')
 enc.eval(); dec.eval()
-print(f'transformer:32 N={N} joint-loss forward+backward (dropout 0.2): {t_train*1e3:.2f} ms ({N/t_train:,.0f} utt/s), loss {loss.item():.4f}')
+
+
+with torch.inference_mode():
+    (feats, flen, _), t_enc = timed(lambda: enc(xd, ild))
+    lp = dec.recognizer.log_probs(feats)
+    (hyp_beam, _), t_beam = timed(lambda: beam.decode_batch(dec.recognizer.log_probs(feats), beam_size=16))
+    (outs, olen, _, lps, _), t_dec = timed(lambda: dec.decode(feats, flen, tld))
+print(f'transformer:32 N={N} math={math_mode}: encoder {t_enc*1e3:.2f} ms ({N/t_enc:,.0f} utt/s) | CTC beam16 {t_beam*1e3:.2f} ms '
+      f'({N/t_beam:,.0f} utt/s) | greedy decode T={int(tl.max())+1} {t_dec*1e3:.2f} ms ({N/t_dec:,.0f} utt/s)')
 
 # CPU oracle on the first NCPU utterances: same hypotheses?
 torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))   # the box share; os.cpu_count() reports the whole host
@@ -93,7 +105,7 @@ print(json.dumps({
                                     'batch': N, 'decode_steps': int(tl.max()) + 1, 'beam': 16, 'math': math_mode},
     'stages': {'encoder_utt_per_s': round(N / t_enc, 1), 'ctc_beam16_utt_per_s': round(N / t_beam, 1),
                'greedy_decode_utt_per_s': round(N / t_dec, 1), 'encoder_ms': round(t_enc * 1e3, 3), 'beam_ms': round(t_beam * 1e3, 3),
-               'decode_ms': round(t_dec * 1e3, 3), 'train_fwd_bwd_ms': round(t_train * 1e3, 3),
+               'decode_ms': round(t_dec * 1e3, 3), 'train_fwd_bwd_ms': round(t_train * 1e3, 3), 'train_fwd_bwd_graph_ms': round(t_train_g * 1e3, 3),
                'train_fwd_bwd_utt_per_s': round(N / t_train, 1)},
     'wer_vs_cpu_oracle': {'greedy_errors': errs, 'greedy_words': words, 'beam_errors': berrs, 'beam_words': bwords,
                           'feature_max_abs_diff': float((feats[:NCPU].cpu() - f_ref).abs().max())},
