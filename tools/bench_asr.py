@@ -100,7 +100,7 @@ print(f'CPU oracle ({torch.get_num_threads()} threads, {NCPU} utt): encoder {NCP
 
 print(json.dumps({
     'metric': 'utterances/sec, encoder-decoder attention ASR `transformer:32` (BASELINE config 5): encoder, CTC beam-16, greedy attention decode',
-    'value': round(N / (t_enc + t_dec), 1), 'unit': 'utterances/s', 'n_gpus': 1, 'dtype': 'bf16' if math_mode == 'bf16' else 'f32',
+    'value': round(N / (t_enc + t_dec), 1), 'unit': 'utterances/s', 'n_gpus': 1, 'dtype': {'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)', 'bf16': 'bf16', 'f32': 'f32'}[math_mode],
     'data': 'synthetic', 'config': {'workload': 'AudioEncoder 12L + CTCAttentionDecoder 12L, 8x64 heads, vocab 32, 80 frames x 80 mels',
                                     'batch': N, 'decode_steps': int(tl.max()) + 1, 'beam': 16, 'math': math_mode},
     'stages': {'encoder_utt_per_s': round(N / t_enc, 1), 'ctc_beam16_utt_per_s': round(N / t_beam, 1),

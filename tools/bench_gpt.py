@@ -86,7 +86,7 @@ res = {
     'metric': 'tokens/sec, GPT-2 small LM seq_len 1024 (BASELINE config 3): train step (fwd + bwd + AdamW) and scoring',
     'value': round(B * T / t_train, 1), 'unit': 'tokens/s', 'n_gpus': 1, 'ms_per_step': round(t_train * 1e3, 3),
     'scoring': {'value': round(B * T / t_fwd, 1), 'unit': 'tokens/s', 'ms_per_batch': round(t_fwd * 1e3, 3)},
-    'dtype': 'bf16' if math_mode == 'bf16' else 'f32', 'data': 'synthetic',
+    'dtype': {'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)', 'bf16': 'bf16', 'f32': 'f32'}[math_mode], 'data': 'synthetic',
     'config': {'workload': 'GPT-2 small 12L/12h/768, vocab 50304, tied lm_head, random init', 'batch': B, 'seq_len': T, 'math': math_mode},
     'step_mfma': {'algorithmic_tflop_per_train_step': round(train_flops / 1e12, 3),
                   'achieved_tflops': round(train_flops / t_train / 1e12, 1),
