@@ -53,6 +53,7 @@ SIGNATURES = {
     'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
     'halo_lstm_bwd': (_i, [_vp] * 4 + [_l, _l, _i] + [_vp] * 9 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
     'halo_set_lstm_persistent': (_i, [_i]),
+    'halo_set_lstm_persistent_images': (_i, [_i]),
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),
     'halo_lstm_persist_stamps': (_i, [_vp]),
@@ -189,6 +190,11 @@ def set_lstm_fusion(on):
 def set_lstm_persistent(on):
     """Weight-resident persistent LSTM recurrence (one launch per layer and direction) on / off (include/halo.h)."""
     check(lib().halo_set_lstm_persistent(int(bool(on))), 'halo_set_lstm_persistent')
+
+
+def set_lstm_persistent_images(on):
+    """The persistent LSTM backward emitting the gate gradients' GEMM operand images itself on / off (include/halo.h)."""
+    check(lib().halo_set_lstm_persistent_images(int(bool(on))), 'halo_set_lstm_persistent_images')
 
 
 def lstm_chain_events(ev_begin, ev_end):

@@ -500,15 +500,17 @@ struct PrologueArgs {
     const float *w; void *wdst; long w_units; int wK;
     const float *h0; void *hp0; float *h_rm; const float *c0; float *c_rm; long s_units;
     unsigned *zero; long zero_units;      // 16-byte units
+    unsigned *zero2; long zero2_units;    // a second region to clear (the padded last row tile of an operand image), may be empty
     int H, B;
 };
 template <int WMODE>
 __global__ __launch_bounds__(256) void persist_prologue_kernel(const PrologueArgs a) {
-    const long total = a.w_units + a.s_units + a.zero_units;
+    const long total = a.w_units + a.s_units + a.zero_units + a.zero2_units;
     for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
         if (u < a.w_units) pack_unit<true, WMODE>(u, a.w, a.wdst, a.H, a.B, a.wK, nullptr, nullptr, nullptr);
         else if (u < a.w_units + a.s_units) pack_unit<true, 2>(u - a.w_units, a.h0, a.hp0, a.H, a.B, a.H, a.h_rm, a.c0, a.c_rm);
-        else reinterpret_cast<uint4 *>(a.zero)[u - a.w_units - a.s_units] = make_uint4(0u, 0u, 0u, 0u);
+        else if (u < a.w_units + a.s_units + a.zero_units) reinterpret_cast<uint4 *>(a.zero)[u - a.w_units - a.s_units] = make_uint4(0u, 0u, 0u, 0u);
+        else reinterpret_cast<uint4 *>(a.zero2)[u - a.w_units - a.s_units - a.zero_units] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -1087,6 +1089,16 @@ int halo_set_lstm_persistent(int on) {
     return HALO_OK;
 }
 
+static int g_persist_emit = -1;        // -1: HALO_PERSIST_EMIT from the environment (default on)
+int halo_set_lstm_persistent_images(int on) {
+    g_persist_emit = on ? 1 : 0;
+    return HALO_OK;
+}
+static bool persist_emit_enabled() {
+    if (g_persist_emit < 0) { const char *e = getenv("HALO_PERSIST_EMIT"); g_persist_emit = e ? (atoi(e) != 0) : 1; }
+    return g_persist_emit != 0;
+}
+
 int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B, H) && use_x3(H) ? 1 : 0; }
 
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L) {
@@ -1154,6 +1166,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             pa.h0 = h0l; pa.hp0 = lb.hp; pa.h_rm = lb.h; pa.c0 = c0 ? c0 + (size_t)l * BH : nullptr; pa.c_rm = lb.c;
             pa.s_units = (long)((B + 15) / 16) * (H / 32) * 64;
             pa.zero = flags; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+            pa.zero2 = nullptr; pa.zero2_units = 0;
             pa.H = H; pa.B = B;
             hipLaunchKernelGGL(persist_prologue_kernel<0>, dim3(pack_grid((size_t)(pa.w_units + pa.s_units + pa.zero_units))), dim3(256), 0, st, pa);
             HALO_TRY(halo_launch_status());
@@ -1255,13 +1268,23 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
         const bool persist = !fused && x3 && halo_lstm_persist_ok(B, H);
+        // the chain writes the gate gradients' GEMM operand images itself (three-pass images: hi and lo parts) where its tiles map onto
+        // whole 16-byte chunks of them: B % 32 == 0; what the operand-image launch below then no longer reads is the 4H-wide fp32 dG
+        const int in_dim_l = l == 0 ? in0 : H;
+        const bool need_din_l = (l > 0 && !fused) || (l == 0 && dx);
+        const bool emit = persist && persist_emit_enabled() && halo_math_mode() == HALO_MATH_BF16X3 && B % 32 == 0 && in_dim_l >= 64;
         if (persist) {
             PrologueArgs pa;                                  // packed W_hh^T and zeroed epoch words in one launch
             pa.w = w_hh[l]; pa.wdst = wpT; pa.w_units = (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
             pa.h0 = nullptr; pa.hp0 = nullptr; pa.h_rm = nullptr; pa.c0 = nullptr; pa.c_rm = nullptr; pa.s_units = 0;
             pa.zero = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L)); pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+            pa.zero2 = nullptr; pa.zero2_units = 0;
+            if (emit && need_din_l && (T * B) % 128 != 0) {   // the padded last row tile of dG's row image: cleared whole, the chain fills its real rows
+                const long tile_bytes = (long)(4 * H / 32) * 16384;
+                pa.zero2 = (unsigned *)(img_g + (long)((T * B) / 128) * tile_bytes); pa.zero2_units = tile_bytes / 16;
+            }
             pa.H = H; pa.B = B;
-            hipLaunchKernelGGL(persist_prologue_kernel<1>, dim3(pack_grid((size_t)(pa.w_units + pa.zero_units))), dim3(256), 0, st, pa);
+            hipLaunchKernelGGL(persist_prologue_kernel<1>, dim3(pack_grid((size_t)(pa.w_units + pa.zero_units + pa.zero2_units))), dim3(256), 0, st, pa);
             HALO_TRY(halo_launch_status());
         } else if (!fused) {
             HALO_TRY(launch_pack<1>(w_hh[l], wpT, H, B, 4 * H, H / 16, x3, st));
@@ -1277,6 +1300,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.dcinit = dcn ? dcn + (size_t)l * BH : nullptr;
             a.flags = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L));
             a.stamps = nullptr;
+            a.img_rows = emit && need_din_l ? img_g : nullptr;
+            a.img_cols = emit ? img_gT : nullptr;
             a.T = T; a.B = B; a.H = H;
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_bwd(a, st));
@@ -1329,9 +1354,9 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             HaloPrepJob jobs[4];
             int nj = 0;
             if (need_din) {
-                jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};
+                if (!emit) jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};              // (emit: the chain wrote both)
                 jobs[nj++] = {1, w_ih[l], in_dim, 4 * H, in_dim, img_wT, nullptr};                      // W_ih^T [in][4H]
-            } else {
+            } else if (!emit) {
                 jobs[nj++] = {1, lb.gates, 4 * H, T * B, 4 * H, img_gT, nullptr};                       // dG^T [4H][TB]
             }
             jobs[nj++] = {1, lb.h, H, T * B, H, img_hT, nullptr};                                       // h_prev^T [H][TB]

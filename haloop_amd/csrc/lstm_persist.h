@@ -42,6 +42,12 @@ struct PersistBwd {
     const float *dhinit, *dcinit;   // [B][H] added at t = T-1, may be NULL
     unsigned *flags;
     unsigned long long *stamps;
+    // optional: the split-bf16 tiled GEMM images of the gate gradients, written by the chain itself as each step's gradients leave the
+    // cell update (gemm_bf16x3.hip layout: [row tile 128][k tile 32][hi | lo][64-byte rows, 16-byte chunks XOR-swizzled]), so that the
+    // operand-image launch behind the chain need not read the fp32 gradients again: img_rows = dG as [T*B rows][4H] (the A operand of
+    // the input gradient), img_cols = dG^T as [4H rows][T*B] (both weight gradients).  Either may be NULL.  Needs B % 32 == 0; rows of
+    // img_rows past T*B must have been zeroed by the launch ahead (lstm.hip).
+    char *img_rows, *img_cols;
     int poll_mode;
     int replica_shift, nap;
     int T, B, H;

@@ -158,6 +158,28 @@ def test_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L
         np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, err_msg=k, **tol)
 
 
+@pytest.mark.parametrize('T,B,in0,H,L,p_drop', [
+    (21, 64, 128, 1024, 2, 0.2),            # the benchmark's grid; T*B = 1344 rows: the last 128-row tile of the row image is half padding
+    (8, 32, 64, 256, 2, 0.0),               # T*B = 256: whole tiles, one batch-tile pair
+    (5, 96, 128, 512, 1, 0.0),              # 3 x 2 batch tiles (plain block map), a single layer with dx
+])
+def test_backward_chain_writes_the_same_operand_images(hal, T, B, in0, H, L, p_drop):
+    """The persistent backward writes the split-bf16 GEMM operand images of the gate gradients itself (B % 32 == 0) instead of leaving
+    them to the operand-image launch: the bits must be the same, so every gradient is identical."""
+    hal['lib'].set_math_mode('bf16x3')
+    assert hal['lib'].lib().halo_lstm_persistent_eligible(B, H) == 1
+    hal['lib'].set_lstm_persistent_images(True)
+    a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 6, False)
+    hal['lib'].set_lstm_persistent_images(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, L, p_drop, 6, False)
+    finally:
+        hal['lib'].set_lstm_persistent_images(True)
+    assert st_a == (0, 0) and st_b == (0, 0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_persistent_recurrence_sees_fresh_data_on_every_launch(hal):
     """Hand-off buffers are re-used across launches (torch's allocator returns the same reserve): results must follow the inputs
     of THIS launch, never lines cached from the previous one.  Runs the forward on alternating inputs and compares each result
