@@ -163,10 +163,10 @@ def test_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L
     (8, 32, 64, 256, 2, 0.0),               # T*B = 256: whole tiles, one batch-tile pair
     (5, 96, 128, 512, 1, 0.0),              # 3 x 2 batch tiles (plain block map), a single layer with dx
 ])
-def test_backward_chain_writes_the_same_operand_images(hal, T, B, in0, H, L, p_drop):
+@pytest.mark.parametrize('math_mode', ['bf16x3'], indirect=True)
+def test_backward_chain_writes_the_same_operand_images(hal, math_mode, T, B, in0, H, L, p_drop):
     """The persistent backward writes the split-bf16 GEMM operand images of the gate gradients itself (B % 32 == 0) instead of leaving
     them to the operand-image launch: the bits must be the same, so every gradient is identical."""
-    hal['lib'].set_math_mode('bf16x3')
     assert hal['lib'].lib().halo_lstm_persistent_eligible(B, H) == 1
     hal['lib'].set_lstm_persistent_images(True)
     a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 6, False)
@@ -180,11 +180,11 @@ def test_backward_chain_writes_the_same_operand_images(hal, T, B, in0, H, L, p_d
         assert torch.equal(a[k], b[k]), k
 
 
-def test_persistent_recurrence_sees_fresh_data_on_every_launch(hal):
+@pytest.mark.parametrize('math_mode', ['bf16x3'], indirect=True)
+def test_persistent_recurrence_sees_fresh_data_on_every_launch(hal, math_mode):
     """Hand-off buffers are re-used across launches (torch's allocator returns the same reserve): results must follow the inputs
     of THIS launch, never lines cached from the previous one.  Runs the forward on alternating inputs and compares each result
     with the step-chain result for the same input."""
-    hal['lib'].set_math_mode('bf16x3')
     T, B, in0, H, L = 21, 64, 128, 1024, 1
     ops = hal['ops']
     g = torch.Generator().manual_seed(9)
