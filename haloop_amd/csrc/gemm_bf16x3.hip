@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void image_pair_kernel(const PairArgs p) {
 // launch boundary): block b belongs to the job whose [first, first + gx*gy) range holds it.
 constexpr int PREP_MAX_JOBS = 6;
 struct PrepJobs {
-    PairArgs job[PREP_MAX_JOBS];      // kind 0: row-major source -> img_rm; 1: transposed source -> img_rm; 2: pair (copy) -> img_rm + img_tr
+    PairArgs job[PREP_MAX_JOBS];      // kind 0: row-major source -> img_rm; 1: transposed source -> img_rm; 2: pair (copy) -> img_rm + img_tr;
+                                      // 3: fp32 column sums of src [R][C] -> (float *)img_rm and (float *)img_tr
     int kind[PREP_MAX_JOBS], first[PREP_MAX_JOBS], gx[PREP_MAX_JOBS];
     int n;
 };
@@ -225,7 +226,16 @@ __global__ __launch_bounds__(256) void prep_jobs_kernel(const PrepJobs a) {
     const int kt = local % a.gx[j], rt = local / a.gx[j];
     if (a.kind[j] == 0) prep_rowmajor_block(p.src, p.R, p.C, (int)p.ld, p.img_rm, p.KT_rm, p.with_lo, kt, rt);
     else if (a.kind[j] == 1) prep_transposed_block(p.src, p.R, p.C, (int)p.ld, p.img_rm, p.KT_rm, p.with_lo, kt, rt, reinterpret_cast<float (*)[TR + 1]>(tile));
-    else image_pair_block<PAIR_COPY>(p, kt, rt, reinterpret_cast<float (*)[TK + 1]>(tile));
+    else if (a.kind[j] == 2) image_pair_block<PAIR_COPY>(p, kt, rt, reinterpret_cast<float (*)[TK + 1]>(tile));
+    else {      // kind 3: out[c] (and out2[c]) = sum over the R rows of src [R][C], rows in order: the batch-tile partials of a bias gradient
+        const int c = local * 256 + threadIdx.x;
+        if (c < p.C) {
+            float s = 0.f;
+            for (int r = 0; r < p.R; ++r) s += p.src[(long)r * p.ld + c];
+            reinterpret_cast<float *>(p.img_rm)[c] = s;
+            if (p.img_tr) reinterpret_cast<float *>(p.img_tr)[c] = s;
+        }
+    }
 }
 
 struct TiledGemmArgs {
@@ -579,6 +589,11 @@ int halo_prep_jobs(const HaloPrepJob *jobs, int n, hipStream_t st) {
         p.img_rm = (char *)q.image; p.img_tr = (char *)q.image_tr;
         a.kind[i] = q.kind; a.first[i] = total;
         const int RT = (q.R + TR - 1) / TR;
+        if (q.kind == 3) {                 // column sums of a few rows: one thread per column
+            a.gx[i] = (q.K + 255) / 256;
+            total += a.gx[i];
+            continue;
+        }
         if (q.kind == 2) {
             p.KT_rm = (q.K + TK - 1) / TK;
             p.KT_tr = (q.R + TK - 1) / TK;

@@ -14,7 +14,8 @@ size_t halo_tiled_image_bytes(int R, int K);
 int halo_prep_tiles(const float *src, int R, int K, int ld, int src_transposed, void *image, hipStream_t st);
 int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void *image_tr, hipStream_t st);   // both images, one read
 // several images in one launch.  kind 0: image <- row-major src [R][K]; 1: image <- src stored [K][R] (logical X[r][k] = src[k*ld + r]);
-// 2: image (rows R, k = K) and image_tr (rows K, k = R) from one read of a row-major src [R][K] (halo_prep_pair)
+// 2: image (rows R, k = K) and image_tr (rows K, k = R) from one read of a row-major src [R][K] (halo_prep_pair);
+// 3: not an image: fp32 column sums over the R rows of src [R][K], written to (float *)image and, when given, (float *)image_tr
 struct HaloPrepJob {
     int kind;
     const float *src;

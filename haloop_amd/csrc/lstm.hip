@@ -1110,7 +1110,8 @@ size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
     // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H] + packed gate-gradient images
     // [BT16, 4H] (one per time step) + tiled images for the batched gradient GEMMs + epoch words
-    return bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES;
+    // ... + the batch-tile partials of a layer's bias gradient [ceil(B/16)][4H] (written by the persistent backward)
+    return bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (size_t)((B + 15) / 16) * 4 * H * sizeof(float);
 }
 
 int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
@@ -1302,6 +1303,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.stamps = nullptr;
             a.img_rows = emit && need_din_l ? img_g : nullptr;
             a.img_cols = emit ? img_gT : nullptr;
+            a.bias_part = emit ? (float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES) : nullptr;
             a.T = T; a.B = B; a.H = H;
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_bwd(a, st));
@@ -1351,7 +1353,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         // weight gradients) from one read, W_ih^T, h_prev^T, in^T
         int rc = HALO_OK;
         if (tiled) {
-            HaloPrepJob jobs[4];
+            HaloPrepJob jobs[5];
             int nj = 0;
             if (need_din) {
                 if (!emit) jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};              // (emit: the chain wrote both)
@@ -1359,6 +1361,9 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             } else if (!emit) {
                 jobs[nj++] = {1, lb.gates, 4 * H, T * B, 4 * H, img_gT, nullptr};                       // dG^T [4H][TB]
             }
+            if (emit)       // the bias gradients: the chain left one partial row per batch tile, summed here beside the other jobs
+                jobs[nj++] = {3, (const float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES), (B + 15) / 16, 4 * H,
+                              4 * H, db_ih[l], db_hh[l]};
             jobs[nj++] = {1, lb.h, H, T * B, H, img_hT, nullptr};                                       // h_prev^T [H][TB]
             jobs[nj++] = {1, in, in_dim, T * B, in_dim, img_inT, nullptr};                              // in^T [in][TB]
             HALO_TRY(halo_prep_jobs(jobs, nj, st));
@@ -1387,7 +1392,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             if (!rc) rc = halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
                                         nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
         }
-        if (!rc) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
+        if (!rc && !(emit && tiled)) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
         if (rc) return rc;
     }
     return HALO_OK;

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
     const long BH = (long)B * H;
     const long e0 = (long)b * H + j0 + cj;
     float gv[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cprev = 0.f, dyv = 0.f, dcarry = 0.f, dh0 = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};                 // this thread's (batch row, hidden unit) gate gradients summed over time
     if (cell) {
         const int t = T - 1;
 #pragma unroll
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
                 dg[1] = d_f * fg * (1.f - fg);
                 dg[2] = d_g * (1.f - gg * gg);
                 dg[3] = d_o * og * (1.f - og);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgbuf[g][ci][cj] = dg[g];
@@ -458,6 +461,21 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
         }
     }
     if (cell && p.dc) p.dc[e0] = dcarry;
+    if (p.bias_part) {          // sum over the tile's 16 batch rows (fixed order), one value per (gate, hidden unit) of the workgroup
+        lds_barrier();
+        if (tid < 256) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgbuf[g][ci][cj] = bsum[g];       // rows >= B hold zeros
+        }
+        lds_barrier();
+        if (tid < 64) {
+            const int g = tid >> 4, j = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += dgbuf[g][r][j];
+            p.bias_part[(long)bt * K + (long)g * H + j0 + j] = sum;
+        }
+    }
 }
 
 unsigned long long *g_stamps = nullptr;

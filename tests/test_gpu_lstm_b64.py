@@ -166,7 +166,8 @@ def test_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L
 @pytest.mark.parametrize('math_mode', ['bf16x3'], indirect=True)
 def test_backward_chain_writes_the_same_operand_images(hal, math_mode, T, B, in0, H, L, p_drop):
     """The persistent backward writes the split-bf16 GEMM operand images of the gate gradients itself (B % 32 == 0) instead of leaving
-    them to the operand-image launch: the bits must be the same, so every gradient is identical."""
+    them to the operand-image launch: the bits must be the same, so every weight and input gradient is identical (the bias gradients are
+    then summed inside the chain too, in another order: fp32 rounding apart)."""
     assert hal['lib'].lib().halo_lstm_persistent_eligible(B, H) == 1
     hal['lib'].set_lstm_persistent_images(True)
     a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 6, False)
@@ -177,7 +178,11 @@ def test_backward_chain_writes_the_same_operand_images(hal, math_mode, T, B, in0
         hal['lib'].set_lstm_persistent_images(True)
     assert st_a == (0, 0) and st_b == (0, 0)
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        if k.startswith('db'):      # the bias gradients: summed per batch tile over time in the chain, then over the tiles -- another order
+            scale = float(b[k].abs().max()) + 1e-12
+            np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, rtol=0, atol=2e-6, err_msg=k)
+        else:
+            assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize('math_mode', ['bf16x3'], indirect=True)
