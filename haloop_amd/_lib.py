@@ -131,7 +131,6 @@ SIGNATURES = {
     'halo_cast_bf16_f32': (_i, [_vp, _vp, _f, _sz, _vp]),
     'halo_scale_add_guarded': (_i, [_vp, _vp, _f, _f, _sz, _vp, _vp]),
     'halo_clip_coef_step': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp]),
-    'halo_sumsq_clip_step': (_i, [_vp, _sz, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     'halo_adamw_ranges_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),

@@ -42,51 +42,6 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict_
     }
 }
 
-// sumsq_kernel + clip_coef_kernel in one launch: the block that takes the last ticket runs the second kernel's reduction over the
-// partials (the same order: identical bits) and resets the ticket for the next launch
-__global__ __launch_bounds__(256) void sumsq_clip_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials,
-                                                         unsigned *ticket, float max_norm, float *coef, float *norm_out,
-                                                         uint32_t *applied_steps) {
-    __shared__ float red[4];
-    __shared__ unsigned s_last;
-    float s = 0.f;
-    const size_t n4 = n / 4;
-    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 v = x4[i];
-        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    }
-    if (blockIdx.x == 0)
-        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(partials + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    float t = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = wave_sum(t);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-        const float c = max_norm / (norm + 1e-6f);
-        const bool finite = isfinite(norm);
-        coef[0] = finite ? (c > 1.0f ? 1.0f : c) : NAN;
-        coef[1] = finite ? 1.0f : NAN;
-        if (norm_out) *norm_out = norm;
-        if (applied_steps && finite) *applied_steps += 1u;
-        *ticket = 0u;
-    }
-}
-
 // One AdamW element update (torch.optim.AdamW, _single_tensor).  Every kernel below calls this, with contraction pinned, so that the
 // per-tensor, ranged and multi-tensor launches (and their vector bodies and scalar tails) produce the same bits.
 __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, float decay_mul, float beta1_w, float beta2,
@@ -343,14 +298,6 @@ int halo_clip_coef_step(const float *partials, int count, float max_norm, float 
                         halo_stream_t stream) {
     HALO_CHECK_ARG(partials && coef && count > 0);
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, count, max_norm, coef,
-                       norm_out, applied_steps);
-    return halo_launch_status();
-}
-
-int halo_sumsq_clip_step(const float *x, size_t n, float *partials, uint32_t *ticket, float max_norm, float *coef, float *norm_out,
-                         uint32_t *applied_steps, halo_stream_t stream) {
-    HALO_CHECK_ARG(x && partials && ticket && coef && ((uintptr_t)x % 16 == 0));
-    hipLaunchKernelGGL(sumsq_clip_kernel, dim3(HALO_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, x, n, partials, ticket, max_norm, coef,
                        norm_out, applied_steps);
     return halo_launch_status();
 }

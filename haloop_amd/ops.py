@@ -401,12 +401,6 @@ def sumsq_partials(flat, partials=None):
     return partials
 
 
-def sumsq_clip(flat, partials, ticket, max_norm, coef, norm, applied_steps=None):
-    """sumsq_partials + clip_coef in one launch (same bits); ticket: device int32 zero, left zero."""
-    check(lib().halo_sumsq_clip_step(ptr(flat), flat.numel(), ptr(partials), ptr(ticket), float(max_norm), ptr(coef), ptr(norm),
-                                     ptr(applied_steps), _stream()), 'halo_sumsq_clip_step')
-
-
 def clip_coef(partials, count, max_norm, coef, norm, applied_steps=None):
     """applied_steps: optional device int32 counter advanced when the norm is finite (the Adam step count of applied updates)."""
     check(lib().halo_clip_coef_step(ptr(partials), count, float(max_norm), ptr(coef), ptr(norm), ptr(applied_steps), _stream()),

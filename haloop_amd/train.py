@@ -114,7 +114,6 @@ class LstmCtcTrainer:
         self.loss = torch.zeros((), device=dev, dtype=torch.float32)
         self.step_count = 0                                                # step() calls that reached the optimizer
         self.adam_step = torch.zeros(1, device=dev, dtype=torch.int32)    # APPLIED updates: advanced on the device (clip_coef)
-        self._clip_ticket = torch.zeros(1, device=dev, dtype=torch.int32)
         self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)      # last-workgroup ticket of the fused CTC head
         self.use_graph = use_graph
         self.pg = process_group
@@ -221,7 +220,8 @@ class LstmCtcTrainer:
         parts = torch.zeros(_lib.HALO_SUMSQ_PARTS, device=dev, dtype=torch.float32)
         coef, norm = torch.ones(2, device=dev, dtype=torch.float32), torch.zeros(1, device=dev, dtype=torch.float32)
         cnt = torch.ones(1, device=dev, dtype=torch.int32)
-        ops.sumsq_clip(d[1], parts, torch.zeros(1, device=dev, dtype=torch.int32), self.clip, coef, norm, applied_steps=cnt)
+        ops.sumsq_partials(d[1], parts)
+        ops.clip_coef(parts, _lib.HALO_SUMSQ_PARTS, self.clip, coef, norm, applied_steps=cnt)
         ops.adamw_ranges(d[0], d[1], d[2], d[3], [(0, 8, 0.0, coef[0:1])], self.lr, self.betas[0], self.betas[1], self.eps, cnt)
 
     def _optimizer(self):
@@ -229,7 +229,8 @@ class LstmCtcTrainer:
         in the step graph."""
         f = self.flat
         e0, e1 = f.encoder_range
-        ops.sumsq_clip(f.grads[e0:e1], self.partials, self._clip_ticket, self.clip, self.coef, self.grad_norm, applied_steps=self.adam_step)
+        ops.sumsq_partials(f.grads[e0:e1], self.partials)
+        ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm, applied_steps=self.adam_step)
         # all (decay, clip) ranges and the dropout step counter in one launch
         ranges = [(a, b, self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
                   for a, b, decays, clipped in f.ranges if b > a]

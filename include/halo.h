@@ -588,10 +588,6 @@ int halo_clip_coef(const float *partials, int count, float max_norm, float *coef
  * advances only with an applied update (the reference skips optimizer.step() on a non-finite norm, ha/loop.py:185-189). */
 int halo_clip_coef_step(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                         uint32_t *applied_steps, halo_stream_t stream);
-/* halo_sumsq + halo_clip_coef_step in ONE launch (the block that takes the last ticket reduces the partials, in the same order: the
- * same bits).  ticket: device uint32, 0 before the first call (the kernel leaves it 0). */
-int halo_sumsq_clip_step(const float *x, size_t n, float *partials, uint32_t *ticket, float max_norm, float *coef,
-                         float *norm_out, uint32_t *applied_steps, halo_stream_t stream);
 int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, const float *grad_scale, halo_stream_t stream);
 /* halo_adamw over n_ranges (<= 8) contiguous element ranges [begin[r], end[r]) of the same flat buffers in ONE launch (host
