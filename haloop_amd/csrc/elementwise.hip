@@ -1,5 +1,6 @@
 // Small memory-bound kernels around the GEMMs: dropout, im2col for the stride-4 subsample conv,
 // relu/dropout backward, row-wise log-softmax, column sums, transpose.
+#include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
 
@@ -33,6 +34,80 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
         float v = 0.f;
         if (tt >= 0 && tt < T) v = x[((long)b * T + tt) * F + c];
         col[(long)row * K + k] = v;
+    }
+}
+
+// The whole subsample convolution of the forward in ONE launch: a workgroup builds the im2col tile of 16 output rows in LDS (and, once per
+// row tile, writes it to col for the backward), then its four waves each multiply it with 16 output channels of the weight on the
+// exact-f32 MFMA (16x16x4; a lane's 16-byte load of W and 16-byte read of the tile feed four MFMAs, the k order permuted the same way
+// on both sides) and apply bias, relu and the inverted dropout.  Replaces im2col + product + split-K reduce (17 us at B=64, T=80, F=80,
+// C=128) for K = F*ks a multiple of 16 and C a multiple of 64.  grid (row tiles, C / 64).
+template <int NS>        // NS = K / 16 sixteen-deep k groups (25 at F = 80, ks = 5)
+__global__ __launch_bounds__(256) void subsample_fused_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ y,
+                                                              float *__restrict__ col, int B, int T, int F, int C, int Tp, int ks, int stride,
+                                                              int pad, DropoutCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [16][LDA], LDA = K + 4 = 4 * odd: 16 rows x 16 bytes land on 16 bank groups
+    constexpr int K = 16 * NS, LDA = K + 4;
+    const int rows = Tp * B, row0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    // this lane's weight fragments first: they are in flight while the tile is built
+    const int n = blockIdx.y * 64 + wave * 16 + lr;
+    const float *wr = w + (long)n * K + 4 * lq;
+    f32x4 bw[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) bw[u] = *reinterpret_cast<const f32x4 *>(wr + 16 * u);
+    // im2col tile: unit = (row r, frame kk, four channels c4 .. c4+3), one 16-byte load each (F % 4 == 0), scattered into the
+    // col order k = c*ks + kk; all of a thread's loads are issued before the first is used
+    const int F4 = F / 4, units = 16 * ks * F4;
+    constexpr int MAXU = 8;                                         // 16 * 5 * 20 / 256 = 6.25 at the LC shape
+    f32x4 xv[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < units) {
+            const int r = u / (ks * F4), rem = u - r * (ks * F4), kk = rem / F4, c4 = (rem - kk * F4) * 4, row = row0 + r;
+            if (row < rows) {
+                const int t = row / B, b = row - t * B, tt = t * stride - pad + kk;
+                if (tt >= 0 && tt < T) xv[i] = *reinterpret_cast<const f32x4 *>(x + ((long)b * T + tt) * F + c4);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        if (u < units) {
+            const int r = u / (ks * F4), rem = u - r * (ks * F4), kk = rem / F4, c4 = (rem - kk * F4) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r * LDA + (c4 + j) * ks + kk] = xv[i][j];
+        }
+    }
+    __syncthreads();
+    if (blockIdx.y == 0) {              // the tile, row by row, to col (16-byte stores; K % 16 == 0)
+        for (int u = threadIdx.x; u < 16 * (K / 4); u += 256) {
+            const int r = u / (K / 4), k4 = (u - r * (K / 4)) * 4;
+            if (row0 + r < rows) *reinterpret_cast<f32x4 *>(col + (long)(row0 + r) * K + k4) = *reinterpret_cast<const f32x4 *>(tile + r * LDA + k4);
+        }
+    }
+    const float *ar = tile + lr * LDA + 4 * lq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ar + 16 * u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bw[u][j], acc, 0, 0, 0);
+    }
+    const int colc = blockIdx.y * 64 + wave * 16 + lr;             // D layout: column = lane % 16, rows 4 * (lane / 16) + e
+    const float bv = bias ? bias[colc] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 4 * lq + e;
+        if (row >= rows) continue;
+        const long o = (long)row * C + colc;
+        float v = fmaxf(acc[e] + bv, 0.f);
+        if (drop.threshold) v *= dropout_mult(drop, (uint64_t)o);
+        y[o] = v;
     }
 }
 
@@ -217,6 +292,16 @@ int halo_subsample_fwd(const float *x, const float *w, const float *bias, float 
     HALO_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0 && ks > 0 && stride > 0 && pad >= 0 && T + 2 * pad >= ks);
     const int Tp = subsampled_len(T, ks, stride, pad);
     hipStream_t st = (hipStream_t)stream;
+    const int K = F * ks;
+    static const int fused = getenv("HALO_SUBSAMPLE_FUSED") ? atoi(getenv("HALO_SUBSAMPLE_FUSED")) : 1;
+    // the LC front-end's shape (K = 400): one fused launch; the loads of a workgroup's 16 x ks x F/4 tile units must fit 8 per thread
+    if (fused && K == 400 && F % 4 == 0 && C % 64 == 0 && 16 * ks * (F / 4) <= 8 * 256 &&
+        (((uintptr_t)w | (uintptr_t)x | (uintptr_t)col) % 16 == 0)) {
+        const DropoutCfg d = make_dropout(p_drop, seed, HALO_STREAM_SUBSAMPLE, offset, offset_dev);
+        hipLaunchKernelGGL(subsample_fused_kernel<25>, dim3((Tp * B + 15) / 16, C / 64), dim3(256), (size_t)16 * (K + 4) * sizeof(float), st,
+                           x, w, bias, y, col, B, T, F, C, Tp, ks, stride, pad, d);
+        return halo_launch_status();
+    }
     hipLaunchKernelGGL(im2col_kernel, dim3(Tp * B), dim3(256), 0, st, x, col, B, T, F, Tp, ks, stride, pad);
     int rc = halo_launch_status();
     if (rc) return rc;

@@ -207,3 +207,33 @@ def test_persistent_recurrence_sees_fresh_data_on_every_launch(hal, math_mode):
         for x, ref in zip(xs, refs):
             y = ops.lstm_fwd(x, w_ih, w_hh, b, b)[0]
             np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('B,T,C,p', [(64, 79, 512, 0.0), (64, 79, 512, 0.2), (5, 43, 64, 0.2), (32, 8, 128, 0.0)])
+def test_fused_front_end_launch(B, T, C, p):
+    """The LC front-end shape (F = 80, kernel 5 -> K = 400) runs as ONE launch (csrc/elementwise.hip, subsample_fused_kernel: im2col
+    tile in LDS, fp32 MFMA, bias + relu + dropout): against torch's float64 conv1d (ha/rnn.py:16-19) with the oracle's Philox mask,
+    and the saved im2col image against unfold -- ragged last row tiles ((T' * B) % 16 != 0) and zero-padded frames at both ends."""
+    from haloop_amd import _lib, ops
+    from haloop_amd.ops import Dropout, NO_DROPOUT
+    from oracle import philox
+    from oracle.cpu_ref import STREAM_SUBSAMPLE
+    _lib.lib()
+    F_, ks, stride, pad = 80, 5, 4, 3
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, T, F_, generator=g)
+    w = torch.randn(C, F_, ks, generator=g) / 20
+    bias = torch.randn(C, generator=g)
+    seed, offset = 1234, 7
+    y, col = ops.subsample_fwd(x.cuda(), w.cuda(), bias.cuda(), Dropout(p, seed, offset, None) if p else NO_DROPOUT)
+    Tp = ops.subsampled_length(T, ks, stride, pad)
+    ref = torch.relu(torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=stride, padding=pad))
+    ref = ref.permute(2, 0, 1)                                                          # [T', B, C]
+    if p:
+        mask = torch.from_numpy(philox.dropout_mask(Tp * B * C, p, seed, STREAM_SUBSAMPLE, offset)).view(Tp, B, C)
+        ref = ref * mask.double()
+    assert y.shape == (Tp, B, C)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-6 * float(ref.abs().max()))
+    unf = torch.nn.functional.unfold(torch.nn.functional.pad(x.transpose(1, 2), (pad, pad)).unsqueeze(2), (1, ks), stride=(1, stride))
+    want = unf.view(B, F_ * ks, Tp).permute(2, 0, 1).reshape(Tp * B, F_ * ks)            # k = c * ks + kk
+    assert torch.equal(col.cpu(), want)
