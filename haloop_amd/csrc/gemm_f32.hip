@@ -265,14 +265,19 @@ int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, in
 
 // how many K slices make an under-filled grid cover the chip, given the caller-provided scratch
 int halo_pick_ksplit(long tiles, int k_steps, long out_elems) {
-    { static int force = -1; if (force < 0) { const char *e = getenv("HALO_KSPLIT"); force = e ? atoi(e) : 0; } if (force > 0 && tiles < 128 && k_steps >= 8) return force; }
-    if (tiles >= 128 || k_steps < 8) return 1;
+    { static int force = -1; if (force < 0) { const char *e = getenv("HALO_KSPLIT"); force = e ? atoi(e) : 0; } if (force > 0 && tiles < 256 && k_steps >= 8) return force; }
+    if (tiles >= 256 || k_steps < 8) return 1;
+    if (tiles >= 128 && k_steps < 64) return 1;
     void *scratch; size_t bytes;
     halo_get_scratch(&scratch, &bytes);
     if (!scratch) return 1;
     // as many slices as still fit ONE round of the 256 CUs (tiles * s <= 256): [1280 x 1024 x 4096], 80 tiles: 3 slices 45.0 us, 4 slices
     // (320 workgroups: 64 CUs hold two) 53.6 us, 6 slices 46.1 us, GEMM + reduce (tools/ksplit_probe.py)
     long s = 256 / tiles;
+    // one or two slices leave a long product (K >= 2048) on 100-255 tiles with half-idle CUs or stragglers: go to ~1.7 workgroups per
+    // CU instead, all co-resident (88 tiles, the LSTM input gradient: 2 or 5 slices, the same step time, interleaved x4 -- left at 2).  [768 x 3072 x 8192] (144 tiles, bf16 / bf16x3): 1 slice 85 / 185 us, 2: 77 / 173, 3: 65 / 148,
+    // 4: 73 / 160; [768 x 2304 x 8192] (108 tiles): 2 slices 55.5 / 118, 4: 51.2 / 117.5
+    if (tiles >= 100 && k_steps >= 64 && 448 / tiles > s) s = 448 / tiles;
     if (s > k_steps / 4) s = k_steps / 4;
     const long cap = (long)(bytes / (sizeof(float) * (size_t)out_elems));
     if (s > cap) s = cap;
