@@ -292,7 +292,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // PASSES == 3: split-bf16 (hi*hi + hi*lo + lo*hi);  PASSES == 1: plain bf16 operands (hi parts only: HALO_MATH_BF16)
 // CE: the cross-entropy epilogue is compiled into its own instantiations, so the plain products keep the register count and
 // the epilogue code they had without it
-// EPI: 0 the full epilogue; 1 bias + residual add only (no activation, no dropout, no split-K); 2 a split-K slice (raw sums to its slab).
+// EPI: 0 the full epilogue; 1 bias only; 3 bias + residual add (neither: no activation, no dropout, no split-K); 2 a split-K slice (raw sums to its slab).
 // The plain products run on 1 / 2: the code they do not need costs them 3-6 % when it is compiled in.
 template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
@@ -430,6 +430,42 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                     if (ok1) p.C[(long)row * p.ldc + c1] = v1;
                 }
             }
+        return;
+    }
+    if (EPI == 3) {
+        // bias + C += result (the residual add).  C is read and written through one pointer, so loads written in the store loop each
+        // wait for the store before them ([8192 x 768 x 768] bf16: 21 us plain, 39 us with the add); here the 16 addends of a 32 x 32
+        // block are requested together (30 us).  Element (i, j, r) of this lane: row = m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 lh,
+        // col = n0 + 64 wn + 32 j + lr -- everything but 4 lh and lr is wave-uniform
+        const int urow0 = m0 + wm * 64, ucol0 = n0 + wn * 64;
+        float bias[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = ucol0 + j * 32 + lr;
+            if (col < p.N) {
+                if (p.bias1) bias[j] += p.bias1[col];
+                if (p.bias2) bias[j] += p.bias2[col];
+            }
+        }
+        const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)lr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = q >> 1, j = q & 1;
+            const bool col_ok = ucol0 + j * 32 + lr < p.N;
+            float *cb = p.C + (long)(urow0 + i * 32) * p.ldc + ucol0 + j * 32;       // wave-uniform
+            float rcur[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ur = (r & 3) + 8 * (r >> 2);
+                rcur[r] = (col_ok && urow0 + i * 32 + ur + 4 * lh < p.M) ? (cb + (long)ur * p.ldc)[lane_off] : 0.f;
+            }
+            if (!col_ok) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ur = (r & 3) + 8 * (r >> 2);
+                if (urow0 + i * 32 + ur + 4 * lh < p.M) (cb + (long)ur * p.ldc)[lane_off] = acc[i][j][r] + bias[j] + rcur[r];
+            }
+        }
         return;
     }
 #pragma unroll
@@ -694,6 +730,8 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess)
             return HALO_ELAUNCH;
         nstage = e ? (want == 4 ? 4 : (want == 1 ? 1 : 2)) : 0;      // 0: by tile count (below)
@@ -722,7 +760,8 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
     // epilogue specialisations (same-box A/B: the LSTM-CTC step 1.274 -> 1.247 ms, products 1-7 % faster)
     const bool slice = p.ksplit > 1;                                                     // raw sums: the reduce kernel applies the epilogue
-    const bool lean = p.ksplit == 1 && !p.use_drop && (relu & ~HALO_GEMM_ACCUM) == 0;
+    const bool lean_any = p.ksplit == 1 && !p.use_drop && (relu & ~HALO_GEMM_ACCUM) == 0;
+    const bool lean = lean_any && !(relu & HALO_GEMM_ACCUM), lean_add = lean_any && (relu & HALO_GEMM_ACCUM);   // bias only / bias + C += result
     if (ce) {                       // the epilogue instantiations (kept apart: compiled into the common kernel the extra registers and
                                     // epilogue code cost every product 6-17 % and the LSTM-CTC step 2.6 %, same-box A/B)
         if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, true>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
@@ -730,6 +769,7 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
         else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, true>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     } else
     if (one_pass && nstage1 == 3 && lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (one_pass && nstage1 == 3 && lean_add) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 3>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (one_pass && nstage1 == 3 && slice) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 2>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (one_pass && nstage1 == 3) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (one_pass && nstage1 == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), STAGE_BYTES, st, p);
@@ -740,9 +780,11 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     // two-slot ring at two per CU is faster ([4096 x 1024 x 1344], the LSTM weight gradient: 54 vs 63 us)
     else if (nstage == 1 || (nstage == 0 && (long)p.ntiles * p.ksplit >= 768)) {
         if (lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 1>), grid, dim3(256), STAGE_BYTES, st, p);
+        else if (lean_add) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 3>), grid, dim3(256), STAGE_BYTES, st, p);
         else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3>), grid, dim3(256), STAGE_BYTES, st, p);
     } else if (nstage == 4) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), grid, dim3(256), 4 * STAGE_BYTES, st, p);
     else if (lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 1>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    else if (lean_add) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     else if (slice) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 2>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
