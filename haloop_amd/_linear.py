@@ -53,6 +53,17 @@ class WeightImages:
         # bf16 mode writes only the hi part of an image: keep the images of different modes apart
         return self._lookup('pair:' + _lib.get_math_mode(), weights, lambda: ops.image_pair(self.dense(weights).contiguous()))
 
+    def prefetch_pairs(self, weight_sets):
+        """Build the (image, transposed image) pairs of several Linears that lack a current one in ceil(n / 6) launches instead of one
+        launch each: a training step calls it once with every block's weights, which all went stale at the optimizer step."""
+        kind = 'pair:' + _lib.get_math_mode()
+        todo = [tuple(ws) for ws in weight_sets if not self._has(kind, tuple(ws))]
+        if not todo:
+            return
+        pairs = ops.image_pairs([self.dense(ws).contiguous() for ws in todo])
+        for ws, pr in zip(todo, pairs):
+            self._cache[(kind,) + tuple(id(w) for w in ws)] = (tuple((w._version, w.data_ptr()) for w in ws), pr)
+
     def split(self, weights):
         """The split/tiled image of the (concatenated) weight."""
         if _PAIRS[0] or self._has('pair:' + _lib.get_math_mode(), weights):
@@ -69,12 +80,13 @@ class WeightImages:
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None,
-           shape=None):
+           shape=None, residual=None):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
     ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
     and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add).
     ``a_image``: the split image of x2d when the caller already has it (normed_image, forward_images), used if the split GEMM
-    runs; x2d may then be None with ``shape`` = its shape."""
+    runs; x2d may then be None with ``shape`` = its shape.  ``residual`` [M, sum N_i]: returns residual + result in a new tensor
+    (the residual connection without copying the stream first); ``accumulate`` adds into ``out`` in place."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
     M, K = x2d.shape if x2d is not None else shape
@@ -83,7 +95,9 @@ def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=Fal
     # reads x and W where they lie
     if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64 and M > SMALL_M:
         return ops.gemm_split(a_image if a_image is not None else ops.split_image(x2d), images.split(weights), M, N, K, out=out,
-                              bias1=bias, gelu=gelu, accumulate=accumulate, drop=drop, stream_id=stream_id)
+                              bias1=bias, gelu=gelu, accumulate=accumulate, drop=drop, stream_id=stream_id, residual=residual)
+    if residual is not None:
+        out, accumulate = residual.clone(), True
     return ops.gemm(x2d, images.dense(weights), True, True, M, N, K, out=out, bias1=bias, gelu=gelu, accumulate=accumulate,
                     drop=drop, stream_id=stream_id)
 

@@ -123,6 +123,17 @@ def block_forward(images, blk, x, B, T, cfg):
     return x
 
 
+def prefetch_block_weights(images, blocks, M):
+    """The weight images of every block's four Linears (forward image + the transposed one its backward reads) in a few multi-matrix
+    launches at the head of a training forward, instead of one small launch per Linear on first use: they all went stale together
+    at the optimizer step.  Only where linear() will take the split GEMM."""
+    if _lib.get_math_mode() == 'f32' or M <= SMALL_M:
+        return
+    sets = [(w,) for blk in blocks for w in (blk.attn.c_attn.weight, blk.attn.c_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight)
+            if w.shape[0] >= 64 and w.shape[1] >= 64]
+    images.prefetch_pairs(sets)
+
+
 def block_forward_train(images, blk, x0, B, T, cfg, sites):
     """Training forward: returns (x_out, saved).  Dropout sites in forward order (ha/attention.py:90,127,141): attention
     probabilities, c_proj output, MLP output; the output dropouts are GEMM epilogues."""
@@ -134,12 +145,12 @@ def block_forward_train(images, blk, x0, B, T, cfg, sites):
     # y and gelu(a) each feed one Linear now and its weight gradient later: both operand images come out of one read, and
     # gelu(a) is never written in fp32
     y_img, y_img_t = forward_images(y, C)
-    x1 = linear(images, y, blk.attn.c_proj.weight, bias=blk.attn.c_proj.bias, out=x0.clone(), accumulate=True, drop=s_res[0],
+    x1 = linear(images, y, blk.attn.c_proj.weight, bias=blk.attn.c_proj.bias, residual=x0, drop=s_res[0],
                 stream_id=s_res[1], a_image=y_img)
     a, h2 = ln_linear(images, x1, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, want_normed=True)
     g_img, g_img_t = forward_images(a, C, ops.PAIR_GELU)
     g = ops.gelu_fwd(a) if g_img is None else None
-    x = linear(images, g, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x1.clone(), accumulate=True, drop=s_mlp[0],
+    x = linear(images, g, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, residual=x1, drop=s_mlp[0],
                stream_id=s_mlp[1], a_image=g_img, shape=a.shape)
     return x, (x0, h1, qkv, y, y_img_t, lse, x1, h2, a, g, g_img_t, s_att, s_res, s_mlp)
 
@@ -325,6 +336,7 @@ class GPT(nn.Module):
         x, emb_saved = self._embed(input_ids, 0, keep=True)
         x = drop_rows(x, s_emb)
         blocks = []
+        prefetch_block_weights(self._images, tr.h, B * T)
         for blk in tr.h:
             x, sv = block_forward_train(self._images, blk, x, B, T, cfg, sites)
             blocks.append(sv)

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._linear import DropSites, WeightImages, drop_rows, linear, linear_dw, linear_dx, training_images
-from .attention import Block, LayerNorm, block_backward, block_forward, block_forward_train
+from .attention import Block, LayerNorm, block_backward, block_forward, block_forward_train, prefetch_block_weights
 from .rnn import DropoutStream
 
 
@@ -140,6 +140,7 @@ class AudioEncoder(nn.Module):
         s_emb = sites.next()
         y = drop_rows(y, s_emb)
         blocks = []
+        prefetch_block_weights(self._images, self.transformer.h, B * T)
         for blk in self.transformer.h:
             y, sv = block_forward_train(self._images, blk, y, B, T, cfg, sites)
             blocks.append(sv)

@@ -242,6 +242,8 @@ struct TiledGemmArgs {
     const char *A;     // image of A [M][K]
     const char *B;     // image of B [N][K]
     float *C;
+    const float *R;    // HALO_GEMM_ACCUM: the addend [M][ldr] (C itself for C += result)
+    int ldr;
     const float *bias1;
     const float *bias2;
     int M, N, KT;
@@ -448,16 +450,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             }
         }
         const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)lr;
+        const unsigned lane_off_r = (unsigned)(4 * lh) * (unsigned)p.ldr + (unsigned)lr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = q >> 1, j = q & 1;
             const bool col_ok = ucol0 + j * 32 + lr < p.N;
             float *cb = p.C + (long)(urow0 + i * 32) * p.ldc + ucol0 + j * 32;       // wave-uniform
+            const float *rb = p.R + (long)(urow0 + i * 32) * p.ldr + ucol0 + j * 32;
             float rcur[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ur = (r & 3) + 8 * (r >> 2);
-                rcur[r] = (col_ok && urow0 + i * 32 + ur + 4 * lh < p.M) ? (cb + (long)ur * p.ldc)[lane_off] : 0.f;
+                rcur[r] = (col_ok && urow0 + i * 32 + ur + 4 * lh < p.M) ? (rb + (long)ur * p.ldr)[lane_off_r] : 0.f;
             }
             if (!col_ok) continue;
 #pragma unroll
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 if (EPI == 0) v = gemm_activation(v, p.relu);
                 const long e = (long)row * p.ldc + col;
                 if (EPI == 0 && p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
-                if (p.relu & 4) v += p.C[e];
+                if (p.relu & 4) v += p.R[(long)row * p.ldr + col];
                 p.C[e] = v;
             }
         }
@@ -694,7 +698,7 @@ struct CeEpilogue {
 };
 static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                                   const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
-                                  hipStream_t st);
+                                  hipStream_t st, const float *resid, int ldr);
 
 // both operand images of src [R][C] from one read: image_rm = halo_prep_tiles(src, R, C, ld, 0), image_tr = halo_prep_tiles(src, C, R, ld, 1)
 int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void *image_tr, hipStream_t st) {
@@ -706,12 +710,12 @@ int halo_prep_pair(const float *src, int R, int C, int ld, void *image_rm, void 
 
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st) {
-    return gemm_bf16x3_tiled_impl(Aimg, Bimg, M, N, K, C, ldc, bias1, bias2, relu, drop, nullptr, st);
+    return gemm_bf16x3_tiled_impl(Aimg, Bimg, M, N, K, C, ldc, bias1, bias2, relu, drop, nullptr, st, C, ldc);
 }
 
 static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                                   const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, const CeEpilogue *ce,
-                                  hipStream_t st) {
+                                  hipStream_t st, const float *resid, int ldr) {
     static int nstage = -1, nstage1 = 0;     // nstage: -1 not read yet, 0 chosen per call by tile count, else forced by HALO_GEMM_STAGES
     if (nstage < 0) {
         // three-pass ring depth: 1 slot = 32 KiB (three workgroups per CU), 2 = 64 KiB (two), 4 = 128 KiB (one); opt in to the LDS size once
@@ -742,7 +746,7 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
         if (nstage1 != 8 && nstage1 != 4 && nstage1 != 2) nstage1 = 3;
     }
     TiledGemmArgs p;
-    p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.bias1 = bias1; p.bias2 = bias2;
+    p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.R = resid; p.ldr = ldr; p.bias1 = bias1; p.bias2 = bias2;
     p.M = M; p.N = N; p.KT = (K + TK - 1) / TK; p.ldc = ldc; p.relu = relu;
     p.tiles_n = (N + TR - 1) / TR;
     p.use_drop = drop && drop->threshold != 0u;
@@ -789,6 +793,11 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
     int rc = halo_launch_status();
     if (rc != HALO_OK || p.ksplit == 1) return rc;
+    // the reduce adds into C: an addend held elsewhere is copied there first
+    if ((relu & HALO_GEMM_ACCUM) && resid != C &&
+        hipMemcpy2DAsync(C, (size_t)ldc * sizeof(float), resid, (size_t)ldr * sizeof(float), (size_t)N * sizeof(float), (size_t)M,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return HALO_ELAUNCH;
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);
 }
 
@@ -847,7 +856,7 @@ int halo_gemm_split_ce(const void *a_image, const void *b_image, int M, int N, i
     const int strips = 2 * ((N + TR - 1) / TR);
     CeEpilogue ce;
     ce.target = targets; ce.part = (float *)workspace; ce.tlogit = ce.part + (size_t)M * strips * 2;
-    int rc = gemm_bf16x3_tiled_impl(a_image, b_image, M, N, K, logits, ldc, bias, nullptr, 0, nullptr, &ce, st);
+    int rc = gemm_bf16x3_tiled_impl(a_image, b_image, M, N, K, logits, ldc, bias, nullptr, 0, nullptr, &ce, st, logits, ldc);
     if (rc != HALO_OK) return rc;
     hipLaunchKernelGGL(ce_merge_kernel, dim3((M + 3) / 4), dim3(256), 0, st, ce.part, ce.tlogit, targets, loss, lse, M, strips,
                        ignore_index);
@@ -874,6 +883,35 @@ int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int 
     const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
     return halo_gemm_bf16x3_tiled(a_image, b_image, M, N, K, C, ldc, bias1, bias2, flags & 15, &d,
                                   (hipStream_t)stream);
+}
+
+int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *residual,
+                             int ldr, const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
+                             uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(a_image && b_image && C && residual && M > 0 && N > 0 && K > 0 && ldc >= N && ldr >= N);
+    const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    return gemm_bf16x3_tiled_impl(a_image, b_image, M, N, K, C, ldc, bias1, bias2, (flags & 15) | HALO_GEMM_ACCUM, &d, nullptr,
+                                  (hipStream_t)stream, residual, ldr);
+}
+
+int halo_image_pairs(int n, const float *const *src, const int *rows, const int *cols, const long *ld, void *const *image_rows,
+                     void *const *image_cols, halo_stream_t stream) {
+    HALO_CHECK_ARG(n >= 0 && (n == 0 || (src && rows && cols && ld && image_rows && image_cols)));
+    HaloPrepJob jobs[PREP_MAX_JOBS];
+    for (int done = 0; done < n;) {                    // PREP_MAX_JOBS matrices per launch
+        int m = 0;
+        for (; m < PREP_MAX_JOBS && done + m < n; ++m) {
+            const int i = done + m;
+            HALO_CHECK_ARG(src[i] && rows[i] > 0 && cols[i] > 0 && ld[i] >= cols[i] && image_rows[i] && image_cols[i]);
+            HALO_CHECK_ARG(((uintptr_t)image_rows[i] | (uintptr_t)image_cols[i]) % 16 == 0);
+            HALO_CHECK_ARG(ld[i] <= 0x7fffffffL);
+            jobs[m] = HaloPrepJob{2, src[i], rows[i], cols[i], (int)ld[i], image_rows[i], image_cols[i]};
+        }
+        const int rc = halo_prep_jobs(jobs, m, (hipStream_t)stream);
+        if (rc != HALO_OK) return rc;
+        done += m;
+    }
+    return HALO_OK;
 }
 
 }  // extern "C"

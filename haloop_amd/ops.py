@@ -89,6 +89,25 @@ def image_pair(x2d, op=PAIR_COPY, x2=None, rows_image=True, cols_image=True):
     return rm, tr
 
 
+def image_pairs(mats):
+    """image_pair(PAIR_COPY) of several 2-D fp32 matrices in ceil(n / 6) launches -> [(image, image of the transpose), ...]."""
+    import ctypes as C
+    mats = list(mats)
+    if not mats:
+        return []
+    for t in mats:
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError('image_pairs: expected 2-D float32 HIP tensors with a unit column stride')
+    n = len(mats)
+    dev = mats[0].device
+    rm = [torch.empty(lib().halo_split_image_bytes(t.shape[0], t.shape[1]), device=dev, dtype=torch.uint8) for t in mats]
+    tr = [torch.empty(lib().halo_split_image_bytes(t.shape[1], t.shape[0]), device=dev, dtype=torch.uint8) for t in mats]
+    vp = lambda xs: (C.c_void_p * n)(*[ptr(x) for x in xs])
+    check(lib().halo_image_pairs(n, vp(mats), (C.c_int * n)(*[t.shape[0] for t in mats]), (C.c_int * n)(*[t.shape[1] for t in mats]),
+                                 (C.c_long * n)(*[t.stride(0) for t in mats]), vp(rm), vp(tr), _stream()), 'halo_image_pairs')
+    return list(zip(rm, tr))
+
+
 def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
     """LayerNorm of the rows written directly as the split operand image of the Linear that follows (C % 32 == 0).
     -> (image, y fp32 or None)"""
@@ -101,10 +120,21 @@ def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
 
 
 def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0,
-               gelu=False, accumulate=False):
-    """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate)."""
+               gelu=False, accumulate=False, residual=None):
+    """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate).  ``residual`` [M, N]: the
+    result is added to it and written to ``out`` (a fresh tensor by default); ``accumulate`` adds into ``out`` in place."""
     if out is None:
         out = torch.empty(M, N, device=a_img.device, dtype=torch.float32)
+    if residual is not None:
+        if accumulate:
+            raise ValueError('gemm_split: residual= and accumulate= are alternatives')
+        _f32c(residual, 'residual')
+        if residual.shape != (M, N):
+            raise ValueError('gemm_split: residual must be [M, N]')
+        check(lib().halo_gemm_split_residual(ptr(a_img), ptr(b_img), M, N, K, ptr(out), N, ptr(residual), N, ptr(bias1), ptr(bias2),
+                                             _gemm_flags(relu, gelu, False), drop.p, drop.seed, stream_id, drop.offset,
+                                             drop.counter_ptr, _stream()), 'halo_gemm_split_residual')
+        return out
     check(lib().halo_gemm_split(ptr(a_img), ptr(b_img), M, N, K, ptr(out), N, ptr(bias1), ptr(bias2),
                                 _gemm_flags(relu, gelu, accumulate), drop.p, drop.seed, stream_id, drop.offset,
                                 drop.counter_ptr, _stream()), 'halo_gemm_split')

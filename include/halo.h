@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 8
+#define HALO_ABI_VERSION 9
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -141,9 +141,20 @@ int halo_image_pair(const float *src, const float *src2, int rows, int cols, lon
 int halo_cross_entropy_bwd_images(const float *logits, const int64_t *targets, const float *lse, const float *grad,
                                   long grad_stride, int rows, int V, long ld, long ignore_index, void *image_rows,
                                   void *image_cols, halo_stream_t stream);
+/* halo_image_pairs: HALO_PAIR_COPY image pairs of n matrices (src[i] [rows[i]][cols[i]], row stride ld[i]) in ceil(n / 6) launches
+ * instead of n: the weights of a transformer block, whose forward and input-gradient products read one image each
+ * (ha/attention.py:117-129,141-143), are split once per optimizer step. */
+int halo_image_pairs(int n, const float *const *src, const int *rows, const int *cols, const long *ld, void *const *image_rows,
+                     void *const *image_cols, halo_stream_t stream);
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc,
                     const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                     uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+
+/* halo_gemm_split with the addend of the residual connection read from its own buffer: C = epilogue(A B^T) + residual (row stride
+ * ldr), C need not hold x beforehand -- x1 = x0 + c_proj(y) (ha/attention.py:178-179) without first copying x0 into the output. */
+int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *residual,
+                             int ldr, const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
+                             uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
 
 /* lm_head + cross-entropy without materialising the logits (ha/attention.py:228-231): the split GEMM
  * logits[M,N] = A B^T (+ bias[N]) whose epilogue reduces each 64-column strip of a row to (max, sum exp) and picks out the

@@ -1218,3 +1218,46 @@ def test_adamw_multi_more_tensors_than_one_launch_carries():
             ops.adamw(rp.view(-1), gr.view(-1), rm.view(-1), rv.view(-1), 1e-2, 0.9, 0.99, 1e-8, wd, step)
     for p, rp in zip(params, ref_p):
         assert torch.equal(p.detach(), rp)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
+@pytest.mark.parametrize('M,N,K,gelu,p', [(300, 200, 96, False, 0.0), (1000, 768, 768, False, 0.0), (256, 128, 2048, False, 0.0),
+                                           (300, 200, 96, True, 0.3), (1000, 768, 768, False, 0.3)])
+def test_gemm_split_residual_equals_in_place_accumulate(hal, math_mode, M, N, K, gelu, p):
+    """halo_gemm_split_residual (the addend of ha/attention.py:178-179's residual connection read from its own buffer) against
+    halo_gemm_split's HALO_GEMM_ACCUM into a copy of the addend: BITWISE, on the lean epilogue (bias + add), the full one (GELU /
+    dropout) and the split-K path (2 tiles, K = 2048: the addend is copied to the output ahead of the reduce)."""
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    bias, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ai, bi = ops.split_image(a), ops.split_image(b)
+    drop = ops.Dropout(p, 77, 3, None) if p else ops.NO_DROPOUT
+    want = ops.gemm_split(ai, bi, M, N, K, out=r.clone(), bias1=bias, gelu=gelu, accumulate=True, drop=drop, stream_id=5)
+    keep = r.clone()
+    got = ops.gemm_split(ai, bi, M, N, K, bias1=bias, gelu=gelu, residual=r, drop=drop, stream_id=5)
+    assert torch.equal(got, want) and torch.equal(r, keep)                      # and the addend is left alone
+    ref = (a.double() @ b.double().t() + bias.double()).cpu()
+    if not gelu and not p:
+        tol = 3e-5 if math_mode == 'bf16x3' else 2e-2
+        np.testing.assert_allclose(got.cpu().double().numpy(), (ref + r.cpu().double()).numpy(), rtol=0, atol=tol * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
+def test_image_pairs_equal_single_launches(hal, math_mode):
+    """halo_image_pairs (seven matrices: two launches) against halo_image_pair one by one: the images BITWISE, ragged shapes and a
+    row stride wider than the row included (bf16 mode writes the hi parts only: compared through the products that read them)."""
+    ops = hal['ops']
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 768), (2304, 768), (100, 70), (129, 33), (64, 3072), (3072, 64), (40, 200)]
+    mats = [torch.randn(r, c + (8 if i == 3 else 0), generator=g).to(DEV)[:, :c] for i, (r, c) in enumerate(shapes)]
+    got = ops.image_pairs(mats)
+    for m, (rm, tr) in zip(mats, got):
+        want_rm, want_tr = ops.image_pair(m)
+        if math_mode == 'bf16x3':
+            assert torch.equal(rm, want_rm) and torch.equal(tr, want_tr)
+        R, Cc = m.shape
+        x = torch.randn(96, Cc, generator=g).to(DEV)
+        xt = torch.randn(96, R, generator=g).to(DEV)
+        assert torch.equal(ops.gemm_split(ops.split_image(x), rm, 96, R, Cc), ops.gemm_split(ops.split_image(x), want_rm, 96, R, Cc))
+        assert torch.equal(ops.gemm_split(ops.split_image(xt), tr, 96, Cc, R), ops.gemm_split(ops.split_image(xt), want_tr, 96, Cc, R))
