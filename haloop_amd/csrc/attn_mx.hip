@@ -322,11 +322,11 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
         bf16x8 qh[I::KSTEPS], ql[I::KSTEPS], doh[I::KSTEPS], dol[I::KSTEPS];      // B[k = dims][col = query lr]
     #pragma unroll
         for (int ks = 0; ks < I::KSTEPS; ++ks) {
-            load_split8(qb + (long)qsafe * a.q_rs + 32 * ks + 8 * lq, a.scale, qh[ks], ql[ks]);
+            load_split8(qb + (long)qsafe * a.q_rs + 32 * ks + 8 * lq, a.scale * LOG2E, qh[ks], ql[ks]);   // scores in log2 units: P = exp2(S' - lse')
             load_split8(dyb + (long)qsafe * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
         }
         const long stat = ((long)b * a.heads + h) * Tq + qsafe;
-        const float lse = a.lse[stat], delta = a.delta[stat];
+        const float lse = a.lse[stat] * LOG2E, delta = a.delta[stat];
         f32x4 dq[HD / 16];                                         // dQ^T[dim = 16m + 4lq + r][query lr]
     #pragma unroll
         for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
                     dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe, (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
     #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    float p = __expf(sacc[n][r] - lse);
+                    float p = __builtin_amdgcn_exp2f(sacc[n][r] - lse);
                     if (edge && kt * 64 + 16 * n + 4 * lq + r > kmax) p = 0.f;
                     sacc[n][r] = p * (pacc[n][r] * dm[n] - delta);
                 }
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
 // Here the lane-fixed index is the KEY: S = Q K^T and dP = dO V^T (this wave's 16 keys as the B operand, from registers)
 // leave a lane with 16 queries of one key, and P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
 template <int HD, int PASSES, bool DROP>
-__global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a) {
     using I = Img<HD, PASSES>;
     __shared__ __attribute__((aligned(16))) char Qimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // hi | lo images (hi only in single-pass mode)
     __shared__ __attribute__((aligned(16))) char Oimg[(PASSES == 3 ? 2 : 1) * I::BYTES];      // dO tile
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
             const int krow = min(key, Tk - 1);
     #pragma unroll
             for (int ks = 0; ks < I::KSTEPS; ++ks) {
-                load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale, kh[ks], kl[ks]);
+                load_split8(kb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, a.scale * LOG2E, kh[ks], kl[ks]);   // scores in log2 units
                 load_split8(vb + (long)krow * a.kv_rs + 32 * ks + 8 * lq, 1.0f, vh[ks], vl[ks]);
             }
         }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
             stage_tile<HD, PASSES>(Oimg, oreg);
             if (threadIdx.x < 64) {
                 const int qrow = min(qt * 64 + (int)threadIdx.x, Tq - 1);
-                lse_s[threadIdx.x] = a.lse[stat0 + qrow];
+                lse_s[threadIdx.x] = a.lse[stat0 + qrow] * LOG2E;
                 del_s[threadIdx.x] = a.delta[stat0 + qrow];
             }
             __syncthreads();
@@ -467,10 +467,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_mx_kernel(AttnBwdArgs a
             for (int n = 0; n < 4; ++n) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[16 * n + 4 * lq]);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&del_s[16 * n + 4 * lq]);
+                if (!edge && !(DROP && a.use_drop)) {       // the tile lies inside the mask, no dropout: no compares
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[n][r] - l4[r]);
+                        sacc[n][r] = p * (pacc[n][r] - d4[r]);
+                        pacc[n][r] = p;
+                    }
+                    continue;
+                }
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qrow = qt * 64 + 16 * n + 4 * lq + r;
-                    float p = __expf(sacc[n][r] - l4[r]);
+                    float p = __builtin_amdgcn_exp2f(sacc[n][r] - l4[r]);
                     if (edge && (key >= klim || qrow >= Tq || (a.causal && key > qrow + coff))) p = 0.f;
                     float dm = 1.0f;
                     if (DROP && a.use_drop)
