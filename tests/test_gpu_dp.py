@@ -188,3 +188,79 @@ def test_gpt_under_torch_ddp_averages_gradients():
     model.forward_all(inputs.cuda(), targets.cuda()).backward()
     for k, p in model.named_parameters():
         np.testing.assert_allclose(grads2[k], p.grad.cpu().numpy(), rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def _rccl_worker(port, out, grad_dtype):
+    """ONE rank on the real `nccl` (= RCCL) backend with the trainer's world>1 code path forced on: the broadcast, the AVG probe, the
+    three-graph step with the asynchronous all-reduces between the replays, the bf16 wire format.  An all-reduce over one rank is the
+    identity, so with ReduceOp.AVG the trajectory must equal the plain single-process trainer's."""
+    import datetime
+    import faulthandler
+    import traceback
+    faulthandler.dump_traceback_later(150, exit=True)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device('cuda', 0))
+        from haloop_amd import dp
+        from haloop_amd.train import LstmCtcTrainer
+        from oracle import cpu_ref
+        c = CFG_PERSIST
+        x, il, tg, tl = (t.cuda() for t in cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7))
+        res = {}
+        for forced in (False, True):
+            real = dp.world_size
+            if forced:
+                dp.world_size = lambda group=None: 2              # take every world > 1 branch; the collectives still span one rank
+            try:
+                enc, rec = _build(100, c)
+                tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, grad_dtype=grad_dtype if forced else 'f32')
+                if forced:
+                    assert tr.world == 2 and len(tr.avg_early.buckets) >= 1
+                    if grad_dtype == 'bf16':                       # SUM over one rank, then the 1/world scale: undo the forced halving
+                        tr.avg_early.world = tr.avg_late.world = 1
+                        tr.avg_early.start = lambda s=tr.avg_early: [s.reduce_bucket(i, async_op=True) for i in range(len(s.buckets))]
+                        tr.avg_late.start = lambda s=tr.avg_late: [s.reduce_bucket(i, async_op=True) for i in range(len(s.buckets))]
+                        fin = lambda s: (lambda works: ([w.wait() for w in works], [s._from_wire(i) for i in range(len(s.buckets))]))
+                        tr.avg_early.finish, tr.avg_late.finish = fin(tr.avg_early), fin(tr.avg_late)
+                losses = []
+                for _ in range(3):
+                    losses.append(float(tr.step(x, il, tg, tl).item()))
+                torch.cuda.synchronize()
+                res[forced] = (tr.flat.params.cpu().numpy(), losses, len(tr._graphs), bool(getattr(tr.avg_early, '_avg_op', False)))
+            finally:
+                dp.world_size = real
+        out.put(('ok', res))
+    except Exception:
+        out.put(('error', traceback.format_exc()))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('grad_dtype', ['f32', 'bf16'])
+def test_rccl_backend_runs_the_data_parallel_step(grad_dtype):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out, grad_dtype))
+    p.start()
+    try:
+        msg = out.get(timeout=300)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg[0] == 'ok', msg[1]
+    single, forced = msg[1][False], msg[1][True]
+    assert single[2] == 1 and forced[2] == 3                           # one graph / three graphs with the collectives between them
+    assert all(np.isfinite(forced[1]))
+    if grad_dtype == 'f32' and forced[3]:                              # ReduceOp.AVG over one rank: the identity
+        # the lower layers run on the step-launch chain beside the collective (another summation order of the recurrence)
+        np.testing.assert_allclose(forced[1], single[1], rtol=1e-5)
+        d = np.abs(forced[0] - single[0])
+        assert d.max() <= 1e-4 and (d > 2e-5).mean() < 1e-4
+    else:                                                              # bf16 wire: gradients rounded to bf16 once
+        np.testing.assert_allclose(forced[1][0], single[1][0], rtol=1e-5)
+        np.testing.assert_allclose(forced[1], single[1], rtol=2e-2)
