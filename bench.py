@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / bf16_mode / f32_mode legs')
+    ap.add_argument('--dp-rehearsal', action='store_true',
+                    help='N=1 only, a measurement aid: run the data-parallel code path (three graphs, RCCL all-reduces between them, '
+                         'step-launch chain under the first bucket) on a one-rank RCCL group; the line says so in config.parallelism')
     ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16x3',
                     help="arithmetic of the dense products: 'f32' and 'bf16x3' meet the fp32 parity tolerances; 'bf16' rounds the "
                          "operands to bf16")
@@ -245,6 +248,12 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=device)
+    elif args.dp_rehearsal:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        from haloop_amd import dp
+        dp.world_size = lambda group=None: 2          # every world > 1 branch; an all-reduce (AVG) over one rank is the identity
 
     from haloop_amd import _lib, synth
     from haloop_amd.train import LstmCtcTrainer
@@ -303,7 +312,7 @@ def main():
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}', 'hip_graph': use_graph, 'math': args.math,
+                       'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None},
             'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
