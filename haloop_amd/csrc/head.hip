@@ -58,21 +58,34 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // a chunk = 32 x KC/4 float4 units of the features and as many of W: two of each per thread.  The next chunk's loads are issued
+    // before this chunk is written to LDS and multiplied, so their latency (which a chunk-by-chunk loop paid four times at H = 1024,
+    // ~1.5 us each) runs under it
+    constexpr int UPT = 32 * (KC / 4) / 1024;
+    f32x4 ca[UPT], cb[UPT], na[UPT], nb[UPT];
+    auto load_chunk = [&](int c0, f32x4 (&a)[UPT], f32x4 (&b)[UPT]) {
+        const int kc = min(KC, H - c0);
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int u = tid + 1024 * i, row = u / (KC / 4), k4 = (u % (KC / 4)) * 4;
+            a[i] = f32x4{0.f, 0.f, 0.f, 0.f}; b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k4 < kc) {
+                if (row < T) a[i] = *reinterpret_cast<const f32x4 *>(p.feats + ((long)n * T + row) * H + c0 + k4);
+                if (row < V) b[i] = *reinterpret_cast<const f32x4 *>(p.w + (long)row * H + c0 + k4);
+            }
+        }
+    };
+    load_chunk(0, ca, cb);
     for (int c0 = 0; c0 < H; c0 += KC) {
         const int kc = min(KC, H - c0);                          // H % 64 == 0: a multiple of 64
-        for (int u = tid; u < 32 * (KC / 4); u += 1024) {
-            const int row = u / (KC / 4), k4 = (u % (KC / 4)) * 4;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (k4 < kc) {
-                if (row < T) {
-                    const long e = ((long)n * T + row) * H + c0 + k4;
-                    a = *reinterpret_cast<const f32x4 *>(p.feats + e);
-                    if (p.drop.threshold) a = a * dropout_mult4(p.drop, (uint64_t)e);
-                }
-                if (row < V) b = *reinterpret_cast<const f32x4 *>(p.w + (long)row * H + c0 + k4);
-            }
+        if (c0 + KC < H) load_chunk(c0 + KC, na, nb);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { As[row * LDK + k4 + e] = a[e]; Ws[row * LDK + k4 + e] = b[e]; }
+        for (int i = 0; i < UPT; ++i) {
+            const int u = tid + 1024 * i, row = u / (KC / 4), k4 = (u % (KC / 4)) * 4;
+            f32x4 a = ca[i];
+            if (p.drop.threshold && k4 < kc && row < T) a = a * dropout_mult4(p.drop, (uint64_t)(((long)n * T + row) * H + c0 + k4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { As[row * LDK + k4 + e] = a[e]; Ws[row * LDK + k4 + e] = cb[i][e]; }
         }
         __syncthreads();
         const int kw = wave * (KC / NW);
@@ -82,6 +95,8 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[r * LDK + k], Ws[r * LDK + k], acc, 0, 0, 0);
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r] = acc[e];
@@ -203,6 +218,20 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
             *reinterpret_cast<f32x4 *>(mask_s + 4 * u) = dropout_mult4(p.drop, (uint64_t)(((long)n * T + row) * H + h0 + col));
         }
     }
+    // the operands of this wave's first column tile of the two products (W's and the features' 32 columns) are requested now: they
+    // do not depend on the lattice work below, which hides their latency
+    const int r = lane & 31, kh = lane >> 5;
+    float wv0[16], fv0[16];
+    {
+        const int c0 = h0 + wave * 32;
+        const bool mine = wave < Hs / 32;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int kk = 2 * s2 + kh;
+            wv0[s2] = (mine && kk < V) ? p.w[(long)kk * H + c0 + r] : 0.f;
+            fv0[s2] = (mine && kk < T) ? p.feats[((long)n * T + kk) * H + c0 + r] : 0.f;
+        }
+    }
     const int64_t *tg = p.targets + (long)n * p.tg_stride;
     const int il = max(0, min((int)p.flen[n], T));
     const int tl = max(0, min((int)p.tl[n], p.S));
@@ -267,13 +296,12 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
         p.db_part[(long)n * V + tid] = s;
     }
     // ---- the two products, column tiles of 32 over H: wave w takes tiles w, w + NW, ... ----
-    const int r = lane & 31, kh = lane >> 5;
     for (int nt = wave; nt < Hs / 32; nt += NWB) {
         const int c0 = h0 + nt * 32, m0 = nt * 32;                      // column of the tile in the row / in the slice's mask
         {   // d features[t][c0 + j] = sum_v dl[t][v] * W[v][c0 + j], times the dropout mask of the element
             float wv[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) wv[s] = (2 * s + kh) < V ? p.w[(long)(2 * s + kh) * H + c0 + r] : 0.f;
+            for (int s = 0; s < 16; ++s) wv[s] = nt == wave ? wv0[s] : ((2 * s + kh) < V ? p.w[(long)(2 * s + kh) * H + c0 + r] : 0.f);
             f32x16 dx;
 #pragma unroll
             for (int e = 0; e < 16; ++e) dx[e] = 0.f;
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kk = 2 * s + kh;
-                float f = kk < T ? p.feats[((long)n * T + kk) * H + c0 + r] : 0.f;
+                float f = nt == wave ? fv0[s] : (kk < T ? p.feats[((long)n * T + kk) * H + c0 + r] : 0.f);
                 if (p.drop.threshold && kk < T) f *= mask_s[kk * Hs + m0 + r];
                 fv[s] = f;
             }
