@@ -118,6 +118,85 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__re
         dpre[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
+// The front-end convolution's backward in two launches (relu/dropout mask + weight-gradient product + bias column sums, then the
+// reduction of the row chunks) instead of four (mask, exact-f32 GEMM, split-K reduce, column sum).  Workgroup (chunk, c-tile, n-half):
+// rows [chunk * CH, +CH) of dy / y / col, 16 output channels, half of the K = F * ks columns.  dpre = dy * (y > 0 ? scale : 0) of its
+// rows x 16 channels goes to LDS (it is the A operand, read transposed: A[m = channel][k = row]); the B fragments B[k = row][n] are
+// read straight from col (4 rows x 16 columns = 4 x 64 contiguous bytes per wave instruction); fp32 MFMA 16x16x4, rows in order.
+// part[chunk][c][k] and bias_part[chunk][c] are summed over the chunks, in order, by subsample_bwd_reduce_kernel.
+__global__ __launch_bounds__(256) void subsample_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                    const float *__restrict__ col, float *__restrict__ part,
+                                                                    float *__restrict__ bias_part, int rows, int C, int K, int CH, float scale) {
+    extern __shared__ float dp[];                      // [CH rounded up to 32][17], zero beyond the chunk's rows
+    const int chunk = blockIdx.x, c0 = blockIdx.y * 16, nh = blockIdx.z;
+    const int row0 = chunk * CH, nrows = min(CH, rows - row0), CHP = (CH + 31) / 32 * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    for (int u = threadIdx.x; u < CHP * 16; u += 256) {
+        const int r = u >> 4, c = u & 15;
+        float v = 0.f;
+        if (r < nrows) {
+            const long o = (long)(row0 + r) * C + c0 + c;
+            v = y[o] > 0.f ? dy[o] * scale : 0.f;
+        }
+        dp[r * 17 + c] = v;
+    }
+    __syncthreads();
+    if (nh == 0 && threadIdx.x < 16) {
+        float sum = 0.f;
+        for (int r = 0; r < nrows; ++r) sum += dp[r * 17 + threadIdx.x];
+        bias_part[(long)chunk * C + c0 + threadIdx.x] = sum;
+    }
+    const int ntiles = K / 16, half = (ntiles + 1) / 2;
+    const int t0 = nh == 0 ? 0 : half, t1 = nh == 0 ? half : ntiles;
+    // this wave's n-tiles: t0 + wave, + 4, ... (at most 4 of them: K / 16 <= 32); a tile past the half is computed on the last valid
+    // tile's columns and not stored, rows past the chunk read the last row against a zero A -- so that every load is unconditional
+    // and the 32 loads of eight k-steps are in flight together
+    constexpr int MAXT = 4, KU = 8;
+    f32x4 acc[MAXT];
+    const float *cb[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cb[i] = col + (long)row0 * K + min(t0 + wave + 4 * i, t1 - 1) * 16 + lr;
+    }
+    for (int k0 = 0; k0 < CHP; k0 += 4 * KU) {
+        float a[KU], b[KU][MAXT];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int r = k0 + 4 * u + lq;
+            a[u] = dp[r * 17 + lr];
+            const long ro = (long)min(r, nrows - 1) * K;
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) b[u][i] = cb[i][ro];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][i], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int t = t0 + wave + 4 * i;
+        if (t >= t1) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[((long)chunk * C + c0 + 4 * lq + e) * K + t * 16 + lr] = acc[i][e];    // D: row 4 lq + e, column lr
+    }
+}
+
+__global__ __launch_bounds__(256) void subsample_bwd_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part,
+                                                                   float *__restrict__ dw, float *__restrict__ dbias, int chunks, long CK, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < CK) {
+        float sum = 0.f;
+        for (int q = 0; q < chunks; ++q) sum += part[(long)q * CK + i];
+        dw[i] = sum;
+    } else if (i - CK < C) {
+        float sum = 0.f;
+        for (int q = 0; q < chunks; ++q) sum += bias_part[(long)q * C + (i - CK)];
+        dbias[i - CK] = sum;
+    }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               int rows, int cols) {
@@ -318,6 +397,27 @@ int halo_subsample_bwd(const float *dy, const float *y, const float *col, float 
     const size_t n = (size_t)Tp * B * C;
     hipStream_t st = (hipStream_t)stream;
     const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    {
+        // two launches when the shape fits them and the caller has lent scratch for the row chunks' partial sums
+        const int rows = Tp * B, K = F * ks;
+        int CH = ((rows + 15) / 16 + 3) / 4 * 4;                       // <= 16 chunks, whole 4-row k-steps
+        const int chunks = (rows + CH - 1) / CH;
+        void *scratch; size_t bytes;
+        halo_get_scratch(&scratch, &bytes);
+        static const int fused = getenv("HALO_SUBSAMPLE_BWD_FUSED") ? atoi(getenv("HALO_SUBSAMPLE_BWD_FUSED")) : 1;
+        const size_t need = ((size_t)chunks * C * K + (size_t)chunks * C) * sizeof(float);
+        if (fused && scratch && bytes >= need && K % 16 == 0 && K / 16 <= 32 && C % 16 == 0 && rows >= 64 && CH <= 512) {
+            float *part = (float *)scratch, *bias_part = part + (size_t)chunks * C * K;
+            hipLaunchKernelGGL(subsample_bwd_partial_kernel, dim3(chunks, C / 16, 2), dim3(256), (size_t)((CH + 31) / 32 * 32) * 17 * sizeof(float), st, dy, y,
+                               col, part, bias_part, rows, C, K, CH, scale);
+            int rc = halo_launch_status();
+            if (rc) return rc;
+            const long CK = (long)C * K;
+            hipLaunchKernelGGL(subsample_bwd_reduce_kernel, dim3((unsigned)((CK + C + 255) / 256)), dim3(256), 0, st, part, bias_part, dw,
+                               dbias, chunks, CK, C);
+            return halo_launch_status();
+        }
+    }
     hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, y, dpre, n, scale);
     int rc = halo_launch_status();
     if (rc) return rc;

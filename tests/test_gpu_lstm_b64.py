@@ -237,3 +237,38 @@ def test_fused_front_end_launch(B, T, C, p):
     unf = torch.nn.functional.unfold(torch.nn.functional.pad(x.transpose(1, 2), (pad, pad)).unsqueeze(2), (1, ks), stride=(1, stride))
     want = unf.view(B, F_ * ks, Tp).permute(2, 0, 1).reshape(Tp * B, F_ * ks)            # k = c * ks + kk
     assert torch.equal(col.cpu(), want)
+
+
+@pytest.mark.parametrize('B,T,C,p', [(64, 79, 128, 0.2), (64, 80, 512, 0.0), (5, 43, 64, 0.2), (32, 8, 128, 0.0), (3, 30, 48, 0.2)])
+def test_front_end_backward_in_two_launches(B, T, C, p):
+    """halo_subsample_bwd with scratch lent (csrc/elementwise.hip, subsample_bwd_partial_kernel + subsample_bwd_reduce_kernel: mask,
+    weight-gradient product and bias sums over row chunks, then their sum) against torch's float64 autograd of
+    conv1d -> relu -> dropout (ha/rnn.py:16-19) with the mask read off the forward output, and against the four-launch path (no
+    scratch lent): ragged chunks, rows % 4 != 0, fewer than 64 rows (falls back)."""
+    from haloop_amd import _lib, ops
+    _lib.lib()
+    F_, ks, stride, pad = 80, 5, 4, 3
+    g = torch.Generator().manual_seed(B * 3 + T)
+    x = torch.randn(B, T, F_, generator=g)
+    w = (torch.randn(C, F_, ks, generator=g) / 20).requires_grad_(True)
+    bias = torch.randn(C, generator=g).requires_grad_(True)
+    drop = ops.Dropout(p, 4321, 2, None) if p else ops.NO_DROPOUT
+    y, col = ops.subsample_fwd(x.cuda(), w.detach().cuda(), bias.detach().cuda(), drop)
+    Tp = y.shape[0]
+    dy = torch.randn(Tp, B, C, generator=g)
+    # reference: the same mask (y > 0 <=> relu passed and not dropped), float64
+    pre = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=stride, padding=pad).permute(2, 0, 1)
+    mask = (y.cpu() > 0).double() * (1.0 / (1.0 - p) if p else 1.0)
+    (pre * mask * dy.double()).sum().backward()
+    res = {}
+    for lend in (False, True):
+        if lend:
+            _lib.lend_scratch()
+        else:
+            _lib.check(_lib.lib().halo_set_scratch(None, 0), 'halo_set_scratch'); _lib._scratch = None
+        dw, db = ops.subsample_bwd(dy.cuda(), y, col, B, T, F_, C, p)
+        res[lend] = (dw.cpu(), db.cpu())
+    for dw, db in res.values():
+        np.testing.assert_allclose(dw.double().numpy(), w.grad.numpy(), rtol=0, atol=3e-6 * float(w.grad.abs().max()))
+        np.testing.assert_allclose(db.double().numpy(), bias.grad.numpy(), rtol=0, atol=3e-6 * float(bias.grad.abs().max()))
+    np.testing.assert_allclose(res[True][0].numpy(), res[False][0].numpy(), rtol=0, atol=2e-6 * float(w.grad.abs().max()))
