@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         return;
     }
     if (EPI == 3) {
-        // bias + C += result (the residual add).  C is read and written through one pointer, so loads written in the store loop each
-        // wait for the store before them ([8192 x 768 x 768] bf16: 21 us plain, 39 us with the add); here the 16 addends of a 32 x 32
+        // bias + addend R + result (the residual add; R may be C itself).  With loads and stores through possibly one buffer, loads
+        // written in the store loop each wait for the store before them ([8192 x 768 x 768] bf16: 21 us plain, 39 us with the add); here the 16 addends of a 32 x 32
         // block are requested together (30 us).  Element (i, j, r) of this lane: row = m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 lh,
         // col = n0 + 64 wn + 32 j + lr -- everything but 4 lh and lr is wave-uniform
         const int urow0 = m0 + wm * 64, ucol0 = n0 + wn * 64;
