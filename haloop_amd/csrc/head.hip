@@ -24,6 +24,21 @@ __device__ __forceinline__ float log_add_exp_fast2(float a, float b) {       // 
     return m + __logf(1.0f + __expf(-fabsf(a - b)));
 }
 __device__ __forceinline__ int ext_label2(const int64_t *tg, int s) { return (s & 1) ? (int)tg[s >> 1] : 0; }
+// log(e^a + e^b + e^c) the way ATen's CTC loss writes it (max, three exponentials, one log: LossCTC.cpp): the exponentials are
+// independent, so a lattice step pays one exp and one log latency instead of two of each.  All -inf -> -inf.
+__device__ __forceinline__ float log_add_exp_fast3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+// the whole wave shifted by one lane on the VALU (DPP wave_shr:1 / wave_shl:1) instead of through the LDS crossbar of a
+// ds_bpermute-based __shfl_up / __shfl_down; lane 0 (63) keeps `x` itself, like the shuffles
+__device__ __forceinline__ float wave_up1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_down1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
 
 struct HeadFwdArgs {
     const float *feats, *w, *bias;
@@ -141,16 +156,15 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
         if (lane < S_) alpha[lane] = prev;
         float ra = 0.f, rb = 0.f;
         if (tlast == 0) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
+        float em = tile[min(1, T - 1)][lab];                 // the emission of the next frame: fetched ahead of the dependent chain
         for (int t = 1; t < T; ++t) {
-            const float p1 = __shfl_up(prev, 1, 64), p2 = __shfl_up(prev, 2, 64);
+            const float p1 = wave_up1(prev), p2 = wave_up1(p1);
+            const float e = em;
+            em = tile[min(t + 1, T - 1)][lab];
             float v = -INFINITY;
             if (t < il && lane < states) {
-                if (lane == 0) v = prev + tile[t][0];
-                else {
-                    float a2 = log_add_exp_fast2(prev, p1);
-                    if (lane >= 2 && can_skip) a2 = log_add_exp_fast2(a2, p2);
-                    v = a2 + tile[t][lab];
-                }
+                if (lane == 0) v = prev + e;
+                else v = log_add_exp_fast3(prev, p1, (lane >= 2 && can_skip) ? p2 : -INFINITY) + e;
             }
             prev = v;
             if (lane < S_) alpha[(long)t * S_ + lane] = v;
@@ -249,16 +263,17 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
         const int labn2 = __shfl_down(lab, 2, 64);
         const bool can_skip = lane + 2 < states && labn2 != 0 && labn2 != lab;
         float nxt = -INFINITY;
+        float em = lps[il - 1][lab];
         for (int t = il - 1; t >= 0; --t) {
-            const float n1 = __shfl_down(nxt, 1, 64), n2 = __shfl_down(nxt, 2, 64);
+            const float n1 = wave_down1(nxt), n2 = wave_down1(n1);
+            const float e = em;
+            em = lps[max(t - 1, 0)][lab];
             float v = -INFINITY;
             if (lane < states) {
                 if (t == il - 1) {
-                    if (lane == states - 1 || lane == states - 2) v = lps[t][lab];
+                    if (lane == states - 1 || lane == states - 2) v = e;
                 } else {
-                    float a2 = log_add_exp_fast2(nxt, lane + 1 < states ? n1 : -INFINITY);
-                    if (can_skip) a2 = log_add_exp_fast2(a2, n2);
-                    v = a2 + lps[t][lab];
+                    v = log_add_exp_fast3(nxt, lane + 1 < states ? n1 : -INFINITY, can_skip ? n2 : -INFINITY) + e;
                 }
                 ab[t][lane] += v;
             }
