@@ -1273,7 +1273,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         // whole 16-byte chunks of them: B % 32 == 0; what the operand-image launch below then no longer reads is the 4H-wide fp32 dG
         const int in_dim_l = l == 0 ? in0 : H;
         const bool need_din_l = (l > 0 && !fused) || (l == 0 && dx);
-        const bool emit = persist && persist_emit_enabled() && halo_math_mode() == HALO_MATH_BF16X3 && B % 32 == 0 && in_dim_l >= 64;
+        const bool emit = persist && persist_emit_enabled() && halo_math_mode() != HALO_MATH_F32 && B % 32 == 0 && in_dim_l >= 64;
         if (persist) {
             PrologueArgs pa;                                  // packed W_hh^T and zeroed epoch words in one launch
             pa.w = w_hh[l]; pa.wdst = wpT; pa.w_units = (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;

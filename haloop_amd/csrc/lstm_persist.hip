@@ -429,13 +429,14 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
             old = __builtin_amdgcn_readfirstlane(old);
             if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
             // ---- off the hand-off path: this tile of dG_t in the two GEMM operand images (plain stores, read by later launches) ----
-            if (p.img_rows) {           // rows t*B + b, k = g*H + j0 + cj: item (g, part, kg = which 8 of the 16 columns, row = batch row)
+            // (single-pass mode reads the hi parts only: the lo halves of the threads skip the images)
+            if (p.img_rows && !(ONE && part)) {           // rows t*B + b, k = g*H + j0 + cj: item (g, part, kg = which 8 of the 16 columns, row = batch row)
                 const int grow = t * B + bt * 16 + row, kcol = g * H + j0 + kg * 8;
                 const long blk = ((long)(grow >> 7) * nkb4 + (kcol >> 5)) * 2 + part;
                 const int r = grow & 127, c = (kcol & 31) >> 3;
                 *reinterpret_cast<bf16x8 *>(p.img_rows + blk * 8192 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = part ? lo : hi;
             }
-            if (p.img_cols) {           // rows g*H + j0 + cj, k = t*B + b: item (g, part, kg = which 8 of the 16 batch rows, row = hidden unit)
+            if (p.img_cols && !(ONE && part)) {           // rows g*H + j0 + cj, k = t*B + b: item (g, part, kg = which 8 of the 16 batch rows, row = hidden unit)
                 float xt[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xt[e] = dgbuf[g][kg * 8 + e][row];

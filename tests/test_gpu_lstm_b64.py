@@ -163,7 +163,7 @@ def test_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L
     (8, 32, 64, 256, 2, 0.0),               # T*B = 256: whole tiles, one batch-tile pair
     (5, 96, 128, 512, 1, 0.0),              # 3 x 2 batch tiles (plain block map), a single layer with dx
 ])
-@pytest.mark.parametrize('math_mode', ['bf16x3'], indirect=True)
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)     # bf16: the hi parts only
 def test_backward_chain_writes_the_same_operand_images(hal, math_mode, T, B, in0, H, L, p_drop):
     """The persistent backward writes the split-bf16 GEMM operand images of the gate gradients itself (B % 32 == 0) instead of leaving
     them to the operand-image launch: the bits must be the same, so every weight and input gradient is identical (the bias gradients are
