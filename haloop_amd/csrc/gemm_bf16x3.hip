@@ -244,6 +244,12 @@ struct TiledGemmArgs {
     float *C;
     const float *R;    // HALO_GEMM_ACCUM: the addend [M][ldr] (C itself for C += result)
     int ldr;
+    // IO & 1: A is not an image but row-major bf16 [M][lda] (hi, and lo with three passes), K % 32 == 0
+    const __bf16 *Arm_hi, *Arm_lo;
+    long lda;
+    // IO & 2: the result also (C != NULL) or only (C == NULL) goes out as row-major bf16 [M][ldo]: hi = bf16(v), lo = bf16(v - hi)
+    __bf16 *Ohi, *Olo;
+    long ldo;
     const float *bias1;
     const float *bias2;
     int M, N, KT;
@@ -272,6 +278,23 @@ __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int
     }
 }
 
+// The same LDS slot filled from a ROW-MAJOR bf16 matrix instead of a tiled image.  LDS-DMA puts lane l's 16 bytes at l * 16 of the
+// piece, i.e. at (row = 16 piece + l / 4, position l % 4) of the slot's 64-byte rows; the swizzled image holds logical chunk
+// pos ^ ((row >> 2) & 3) there -- so the lane simply FETCHES that chunk: the swizzle is applied on the source side and no operand-image
+// pass over the activations is needed.  Rows past M read row M - 1 (their products are never stored).
+template <int PASSES>
+__device__ __forceinline__ void stage_rowmajor(const __bf16 *hi, const __bf16 *lo, long lda, int row0, int k0, int M, char *lds_dst, int wave,
+                                               int lane) {
+#pragma unroll
+    for (int i = 0; i < (PASSES == 3 ? 4 : 2); ++i) {
+        const int piece = i * 4 + wave;                        // 0..7: hi part, 8..15: lo part (as stage_block)
+        const int row = (piece & 7) * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const __bf16 *src = (piece < 8 ? hi : lo) + (long)min(row0 + row, M - 1) * lda + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
+    }
+}
+
 constexpr int STAGE_BYTES = 2 * BLOCK_BYTES;    // one ring slot: A block | B block = 32 KiB
 constexpr int LOADS_PER_STAGE = 8;              // global_load_lds per thread and stage (hi + lo; half of it when only hi is staged)
 
@@ -296,7 +319,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // the epilogue code they had without it
 // EPI: 0 the full epilogue; 1 bias only; 3 bias + residual add (neither: no activation, no dropout, no split-K); 2 a split-K slice (raw sums to its slab).
 // The plain products run on 1 / 2: the code they do not need costs them 3-6 % when it is compiled in.
-template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0>
+// IO: bit 0 = A staged from row-major bf16 (stage_rowmajor), bit 1 = bf16 row-major output; both only in their own instantiations
+template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0, int IO = 0>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
     constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
     // ring slot: [A block | B block]; with one pass only the hi parts are staged, so a slot is half the size and the
@@ -346,11 +370,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
         const int t = min(s, nkt - 1);
-        stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * SLOT, wave, lane);
+        if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, lds + s * SLOT, wave, lane);
+        else stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * SLOT, wave, lane);
         stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * SLOT + OPER, wave, lane);
     }
     if (NSTAGE == 1) {      // single slot: filled here, refilled each iteration once every wave holds its fragments in registers
-        stage_block<PASSES>(Ablk, lds, wave, lane);
+        if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, kt0 * TK, p.M, lds, wave, lane);
+        else stage_block<PASSES>(Ablk, lds, wave, lane);
         stage_block<PASSES>(Bblk, lds + OPER, wave, lane);
     }
     for (int t = 0; t < nkt; ++t) {
@@ -359,7 +385,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         if (NSTAGE >= 2) {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
             const int tn = min(t + NSTAGE - 1, nkt - 1);
             char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * SLOT;
-            stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
+            if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + tn) * TK, p.M, slot, wave, lane);
+            else stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
             stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, slot + OPER, wave, lane);
         }
         const char *cur = lds + (t % NSTAGE) * SLOT;
@@ -381,7 +408,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             // every wave has its fragments: the slot is free, the next tile streams in under this tile's MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int tn = min(t + 1, nkt - 1);
-            stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, lds, wave, lane);
+            if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + tn) * TK, p.M, lds, wave, lane);
+            else stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, lds, wave, lane);
             stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, lds + OPER, wave, lane);
         }
 #pragma unroll
@@ -467,7 +495,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ur = (r & 3) + 8 * (r >> 2);
-                if (urow0 + i * 32 + ur + 4 * lh < p.M) (cb + (long)ur * p.ldc)[lane_off] = acc[i][j][r] + bias[j] + rcur[r];
+                if (urow0 + i * 32 + ur + 4 * lh < p.M) {
+                    const float v = acc[i][j][r] + bias[j] + rcur[r];
+                    if (IO & 2) {
+                        const long o = (long)(urow0 + i * 32 + ur + 4 * lh) * p.ldo + ucol0 + j * 32 + lr;
+                        const __bf16 h = (__bf16)v;
+                        p.Ohi[o] = h;
+                        if (PASSES == 3) p.Olo[o] = (__bf16)(v - (float)h);
+                    }
+                    if (!(IO & 2) || p.C) (cb + (long)ur * p.ldc)[lane_off] = v;
+                }
             }
         }
         return;
@@ -499,7 +536,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 const long e = (long)row * p.ldc + col;
                 if (EPI == 0 && p.use_drop) v *= dropout_mult(p.drop, (uint64_t)e);
                 if (p.relu & 4) v += p.R[(long)row * p.ldr + col];
-                p.C[e] = v;
+                if (IO & 2) {
+                    const long o = (long)row * p.ldo + col;
+                    const __bf16 h = (__bf16)v;
+                    p.Ohi[o] = h;
+                    if (PASSES == 3) p.Olo[o] = (__bf16)(v - (float)h);
+                }
+                if (!(IO & 2) || p.C) p.C[e] = v;
             }
         }
     }
@@ -745,7 +788,7 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
         nstage1 = e1 ? atoi(e1) : 3;
         if (nstage1 != 8 && nstage1 != 4 && nstage1 != 2) nstage1 = 3;
     }
-    TiledGemmArgs p;
+    TiledGemmArgs p = {};
     p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.R = resid; p.ldr = ldr; p.bias1 = bias1; p.bias2 = bias2;
     p.M = M; p.N = N; p.KT = (K + TK - 1) / TK; p.ldc = ldc; p.relu = relu;
     p.tiles_n = (N + TR - 1) / TR;
@@ -801,6 +844,49 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);
 }
 
+
+// The tiled product with row-major bf16 on either side (IO instantiations of the kernel): A from a row-major bf16 matrix (a_hi [, a_lo])
+// instead of an image, and / or the result as row-major bf16 (o_hi [, o_lo]) beside or instead of fp32 C.  No split-K, no dropout.
+template <int EPI, int IO>
+static int launch_io(const TiledGemmArgs &p, bool one_pass, hipStream_t st) {
+    const dim3 grid((unsigned)p.ntiles);
+    if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, EPI, IO>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (p.ntiles >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, EPI, IO>), grid, dim3(256), STAGE_BYTES, st, p);
+    else {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, EPI, IO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * STAGE_BYTES) != hipSuccess)
+                return HALO_ELAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, EPI, IO>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    }
+    return halo_launch_status();
+}
+
+static int gemm_bf16x3_io(const void *Aimg, const void *a_hi, const void *a_lo, long lda, const void *Bimg, int M, int N, int K, float *C,
+                          int ldc, void *o_hi, void *o_lo, long ldo, const float *resid, int ldr, const float *bias1, const float *bias2,
+                          int flags, hipStream_t st) {
+    const bool one_pass = halo_math_mode() == HALO_MATH_BF16;
+    const int io = (a_hi ? 1 : 0) | (o_hi ? 2 : 0);
+    TiledGemmArgs p = {};
+    p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.R = resid ? resid : C; p.ldr = resid ? ldr : ldc;
+    p.Arm_hi = (const __bf16 *)a_hi; p.Arm_lo = (const __bf16 *)a_lo; p.lda = lda;
+    p.Ohi = (__bf16 *)o_hi; p.Olo = (__bf16 *)o_lo; p.ldo = ldo;
+    p.bias1 = bias1; p.bias2 = bias2;
+    p.M = M; p.N = N; p.KT = (K + TK - 1) / TK; p.ldc = ldc; p.relu = flags;
+    p.tiles_n = (N + TR - 1) / TR;
+    p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
+    p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
+    p.ksplit = 1; p.ktper = p.KT;
+    const bool act = (flags & ~HALO_GEMM_ACCUM) != 0, add = (flags & HALO_GEMM_ACCUM) != 0;
+    if (io == 2 && act && !add) return launch_io<0, 2>(p, one_pass, st);
+    if (io == 2 && !act && !add) return launch_io<1, 2>(p, one_pass, st);
+    if (io == 1 && !act && add) return launch_io<3, 1>(p, one_pass, st);
+    if (io == 1 && !act && !add) return launch_io<1, 1>(p, one_pass, st);
+    return HALO_ENOTSUP;
+}
 
 // ---- public entry points (include/halo.h) -----------------------------------------------------
 extern "C" {
@@ -892,6 +978,20 @@ int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, in
     const DropoutCfg d = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
     return gemm_bf16x3_tiled_impl(a_image, b_image, M, N, K, C, ldc, bias1, bias2, (flags & 15) | HALO_GEMM_ACCUM, &d, nullptr,
                                   (hipStream_t)stream, residual, ldr);
+}
+
+int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, long lda, const void *b_image, int M, int N, int K, float *C,
+                       int ldc, void *out_hi, void *out_lo, long ldo, const float *residual, int ldr, const float *bias1,
+                       const float *bias2, int flags, halo_stream_t stream) {
+    HALO_CHECK_ARG(b_image && M > 0 && N > 0 && K > 0 && (a_image != nullptr) != (a_hi != nullptr) && (C || out_hi));
+    HALO_CHECK_ARG(!C || ldc >= N);
+    HALO_CHECK_ARG(halo_math_mode() != HALO_MATH_F32);
+    const bool x3 = halo_math_mode() != HALO_MATH_BF16;
+    if (a_hi) HALO_CHECK_ARG(K % 32 == 0 && lda >= K && lda % 8 == 0 && (uintptr_t)a_hi % 16 == 0 && (!x3 || (a_lo && (uintptr_t)a_lo % 16 == 0)));
+    if (out_hi) HALO_CHECK_ARG(ldo >= N && (!x3 || out_lo));
+    HALO_CHECK_ARG(!(flags & HALO_GEMM_ACCUM) || ((residual || C) && (!residual || ldr >= N)));
+    return gemm_bf16x3_io(a_image, a_hi, a_lo, lda, b_image, M, N, K, C, ldc, out_hi, out_lo, ldo, residual, ldr, bias1, bias2, flags & 15,
+                          (hipStream_t)stream);
 }
 
 int halo_image_pairs(int n, const float *const *src, const int *rows, const int *cols, const long *ld, void *const *image_rows,

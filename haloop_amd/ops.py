@@ -141,6 +141,36 @@ def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=Fal
     return out
 
 
+def gemm_split_io(a, b_img, M, N, K, out=None, out_rowmajor=False, bias1=None, bias2=None, relu=False, gelu=False, accumulate=False,
+                  residual=None):
+    """gemm_split with row-major bf16 activations on either side (halo_gemm_split_io).  ``a``: an operand image (uint8 tensor) or a
+    (hi, lo) pair of row-major bf16 [M, K] tensors (lo None in bf16 mode).  ``out_rowmajor``: return the result as a (hi, lo) pair of
+    bf16 [M, N] tensors (lo None in bf16 mode) and write no fp32 unless ``out`` is given.  -> out, or (hi, lo)."""
+    x3 = lib().halo_get_math_mode() != _lib.HALO_MATH_BF16
+    a_img = a_hi = a_lo = None
+    lda = 0
+    if isinstance(a, (tuple, list)):
+        a_hi, a_lo = a
+        if a_hi.dtype != torch.bfloat16 or a_hi.shape != (M, K) or a_hi.stride(1) != 1 or (x3 and (a_lo is None or a_lo.shape != (M, K) or a_lo.stride() != a_hi.stride())):
+            raise ValueError('gemm_split_io: a = (hi, lo) row-major bf16 [M, K] tensors with equal strides')
+        lda = a_hi.stride(0)
+    else:
+        a_img = a
+    dev = b_img.device
+    o_hi = o_lo = None
+    if out_rowmajor:
+        o_hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        o_lo = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if x3 else None
+    elif out is None:
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    if residual is not None:
+        _f32c(residual, 'residual')
+    check(lib().halo_gemm_split_io(ptr(a_img), ptr(a_hi), ptr(a_lo), lda, ptr(b_img), M, N, K, ptr(out), N if out is not None else 0,
+                                   ptr(o_hi), ptr(o_lo), N, ptr(residual), N if residual is not None else 0, ptr(bias1), ptr(bias2),
+                                   _gemm_flags(relu, gelu, accumulate or residual is not None), _stream()), 'halo_gemm_split_io')
+    return (o_hi, o_lo) if out_rowmajor else out
+
+
 def gemm_split_ce(a_img, b_img, M, N, K, targets, ignore_index=0, bias=None, want_logits=False, want_lse=False):
     """Per-row cross-entropy of logits = A B^T (+ bias) straight from the split GEMM's epilogue: -> (loss [M], lse [M] or None,
     logits [M, N] or None).  Without want_logits nothing of size M x N is written."""

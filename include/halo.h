@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 9
+#define HALO_ABI_VERSION 10
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -155,6 +155,17 @@ int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int 
 int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *residual,
                              int ldr, const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                              uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+
+/* halo_gemm_split with row-major bf16 activations on either side, so that consecutive Linears hand their activations on without an
+ * operand-image pass (ha/attention.py:136-143: c_fc -> gelu -> c_proj).  A comes either from an image (a_image) or from a row-major
+ * bf16 matrix a_hi [M][lda] (and a_lo, its split remainder, in bf16x3 mode; K % 32 == 0, lda % 8 == 0, 16-byte aligned): the kernel's
+ * LDS staging fetches each 16-byte chunk from where the swizzled image would hold it.  The result goes to fp32 C (may be NULL when
+ * out_hi is given) and / or to row-major bf16 out_hi [M][ldo] = bf16(v) (and out_lo = bf16(v - out_hi) in bf16x3 mode).
+ * flags: HALO_GEMM_RELU / GELU* / ACCUM (adds residual [M][ldr], or C itself when residual is NULL).  No dropout, no split-K.
+ * Combinations built: image -> bf16 (with or without activation), bf16 -> fp32 (with or without ACCUM); others HALO_ENOTSUP. */
+int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, long lda, const void *b_image, int M, int N, int K, float *C,
+                       int ldc, void *out_hi, void *out_lo, long ldo, const float *residual, int ldr, const float *bias1,
+                       const float *bias2, int flags, halo_stream_t stream);
 
 /* lm_head + cross-entropy without materialising the logits (ha/attention.py:228-231): the split GEMM
  * logits[M,N] = A B^T (+ bias[N]) whose epilogue reduces each 64-column strip of a row to (max, sum exp) and picks out the

@@ -1261,3 +1261,54 @@ def test_image_pairs_equal_single_launches(hal, math_mode):
         xt = torch.randn(96, R, generator=g).to(DEV)
         assert torch.equal(ops.gemm_split(ops.split_image(x), rm, 96, R, Cc), ops.gemm_split(ops.split_image(x), want_rm, 96, R, Cc))
         assert torch.equal(ops.gemm_split(ops.split_image(xt), tr, 96, Cc, R), ops.gemm_split(ops.split_image(xt), want_tr, 96, Cc, R))
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
+@pytest.mark.parametrize('M,N,K,N2', [(4096, 1024, 768, 1024), (4000, 1056, 96, 1024), (300, 224, 96, 128)])
+def test_gemm_split_io_rowmajor_bf16_on_either_side(hal, math_mode, M, N, K, N2):
+    """halo_gemm_split_io: (1) the result written as row-major bf16 is the split of the fp32 result of the same launch, BITWISE
+    (hi = bf16(v), lo = bf16(v - hi)), and that fp32 result is halo_gemm_split's (bitwise where that runs without split-K: >= 256
+    tiles; to rounding otherwise, and through the GELU epilogue); (2) a product whose A operand is staged from those row-major
+    bf16 matrices (source-side swizzle in the LDS-DMA, no operand image) equals the product from the image of the same values, with
+    bias and residual add -- ragged M (rows past M are fetched from row M - 1 and never stored)."""
+    ops = hal['ops']
+    x3 = math_mode == 'bf16x3'
+    g = torch.Generator().manual_seed(M + N)
+    a, b = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ai, bi = ops.split_image(a), ops.split_image(b)
+    nosplit = ((M + 127) // 128) * ((N + 127) // 128) >= 256
+
+    def same(x, y):
+        if nosplit:
+            assert torch.equal(x, y)
+        else:
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=2e-5 * float(y.abs().max()))
+
+    for gelu in (False, True):
+        want = ops.gemm_split(ai, bi, M, N, K, bias1=bias, gelu=gelu)
+        c = torch.empty(M, N, device=DEV)
+        hi, lo = ops.gemm_split_io(ai, bi, M, N, K, out=c, out_rowmajor=True, bias1=bias, gelu=gelu)
+        if gelu:        # the activation's multiply-adds may be contracted differently in the two instantiations: one ulp
+            np.testing.assert_allclose(c.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=2e-6)
+        else:
+            same(c, want)
+        assert torch.equal(hi, c.bfloat16())
+        if x3:
+            assert torch.equal(lo, (c - hi.float()).bfloat16())
+        else:
+            assert lo is None
+        hi2, lo2 = ops.gemm_split_io(ai, bi, M, N, K, out_rowmajor=True, bias1=bias, gelu=gelu)       # bf16 only: no fp32 written
+        assert torch.equal(hi2, hi) and (not x3 or torch.equal(lo2, lo))
+    # second Linear: A = the bf16 activations of the first, [M, N] x [N2, N]^T with a residual
+    hi, lo = ops.gemm_split_io(ai, bi, M, N, K, out_rowmajor=True, bias1=bias)
+    act = hi.float() + (lo.float() if x3 else 0.0)                  # what the image of the same values is built from
+    w2 = (torch.randn(N2, N, generator=g) / N ** 0.5).to(DEV)
+    w2i = ops.split_image(w2)
+    r = torch.randn(M, N2, generator=g).to(DEV)
+    b2 = torch.randn(N2, generator=g).to(DEV)
+    # bf16x3: re-splitting hi + lo gives another (hi, lo) on exact rounding ties (~0.1 % of the elements), so the image path multiplies
+    # slightly different operands there; bf16 mode has no such freedom and must agree bitwise
+    nosplit = ((M + 127) // 128) * ((N2 + 127) // 128) >= 256 and not x3
+    same(ops.gemm_split_io((hi, lo), w2i, M, N2, N, bias1=b2, residual=r), ops.gemm_split(ops.split_image(act), w2i, M, N2, N, bias1=b2, residual=r))
+    same(ops.gemm_split_io((hi, lo), w2i, M, N2, N, bias1=b2), ops.gemm_split(ops.split_image(act), w2i, M, N2, N, bias1=b2))
