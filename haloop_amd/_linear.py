@@ -80,19 +80,23 @@ class WeightImages:
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None,
-           shape=None, residual=None):
+           shape=None, residual=None, a_rowmajor=None):
     """x2d [M, K] times the row-concatenation of ``weights`` (each [N_i, K]) -> [M, sum N_i].
     ``weights`` must be the long-lived nn.Parameter objects themselves (the cache is keyed on their identity
     and version), not views made per call.  ``drop``: inverted dropout on the result (before the residual add).
     ``a_image``: the split image of x2d when the caller already has it (normed_image, forward_images), used if the split GEMM
     runs; x2d may then be None with ``shape`` = its shape.  ``residual`` [M, sum N_i]: returns residual + result in a new tensor
-    (the residual connection without copying the stream first); ``accumulate`` adds into ``out`` in place."""
+    (the residual connection without copying the stream first); ``accumulate`` adds into ``out`` in place.
+    ``a_rowmajor``: x2d as the (hi, lo) row-major bf16 pair a previous Linear wrote (ln_linear(..., out_rowmajor=True)); no operand
+    image of it is built (inference paths: no dropout)."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
     M, K = x2d.shape if x2d is not None else shape
     N = sum(w.shape[0] for w in weights)
     # a handful of rows (one decode step): the operand-image pass would cost more than the product; the exact-f32 kernel
     # reads x and W where they lie
+    if a_rowmajor is not None:
+        return ops.gemm_split_io(a_rowmajor, images.split(weights), M, N, K, out=out, bias1=bias, accumulate=accumulate, residual=residual)
     if _lib.get_math_mode() != 'f32' and K >= 64 and N >= 64 and M > SMALL_M:
         return ops.gemm_split(a_image if a_image is not None else ops.split_image(x2d), images.split(weights), M, N, K, out=out,
                               bias1=bias, gelu=gelu, accumulate=accumulate, drop=drop, stream_id=stream_id, residual=residual)
@@ -172,15 +176,23 @@ def drop_rows(x2d, site):
     return ops.dropout_fwd(x2d, drop, sid) if drop.p > 0 else x2d
 
 
-def ln_linear(images, x2d, ln_weight, ln_bias, weights, bias=None, gelu=False, want_normed=False, eps=1e-5):
+def rowmajor_ok(M, N, K):
+    """Whether a Linear [M, K] -> [M, N] can hand its result on as row-major bf16 to a Linear that contracts over N (gemm_split_io)."""
+    return use_split(M, N, K) and M > SMALL_M and K % 32 == 0 and N % 32 == 0
+
+
+def ln_linear(images, x2d, ln_weight, ln_bias, weights, bias=None, gelu=False, want_normed=False, eps=1e-5, out_rowmajor=False):
     """linear(layer_norm(x2d), weights) with the normalisation written straight into the GEMM's operand image when the split
-    GEMM will run (saves the pass that re-reads the normalised rows to split them).  -> (out, normed fp32 rows or None)"""
+    GEMM will run (saves the pass that re-reads the normalised rows to split them).  -> (out, normed fp32 rows or None).
+    ``out_rowmajor`` (callers check rowmajor_ok first): out is the (hi, lo) row-major bf16 pair for linear(..., a_rowmajor=)."""
     if isinstance(weights, torch.Tensor):
         weights = (weights,)
     M, K = x2d.shape
     N = sum(w.shape[0] for w in weights)
     if use_split(M, N, K) and M > SMALL_M and K % 32 == 0:
         a_img, h = ops.layernorm_image(x2d, ln_weight, ln_bias, eps, want_y=want_normed)
+        if out_rowmajor:
+            return ops.gemm_split_io(a_img, images.split(weights), M, N, K, out_rowmajor=True, bias1=bias, gelu=gelu), h
         return ops.gemm_split(a_img, images.split(weights), M, N, K, bias1=bias, gelu=gelu), h
     h = ops.layernorm_fwd(x2d, ln_weight, ln_bias, eps)
     return linear(images, h, weights, bias=bias, gelu=gelu), (h if want_normed else None)

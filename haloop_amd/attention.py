@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._linear import (SMALL_M, DropSites, training_images, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx,
+from ._linear import (SMALL_M, DropSites, training_images, WeightImages, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, rowmajor_ok,
                       ln_linear, use_split)
 from .rnn import DropoutStream
 
@@ -118,6 +118,12 @@ def block_forward(images, blk, x, B, T, cfg):
     qkv, _ = ln_linear(images, x, blk.ln_1.weight, blk.ln_1.bias, blk.attn.c_attn.weight, bias=blk.attn.c_attn.bias)
     y, _, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
     linear(images, y, blk.attn.c_proj.weight, bias=blk.attn.c_proj.bias, out=x, accumulate=True)           # x += c_proj(y)
+    if rowmajor_ok(B * T, 4 * C, C) and C % 32 == 0:
+        # gelu(c_fc(ln_2(x))) leaves its GEMM as row-major bf16 (hi, lo) and the c_proj GEMM stages it from there: neither the fp32
+        # activations nor an operand image of them are written
+        h, _ = ln_linear(images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True, out_rowmajor=True)
+        linear(images, None, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x, accumulate=True, a_rowmajor=h, shape=(B * T, 4 * C))
+        return x
     h, _ = ln_linear(images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True)
     linear(images, h, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x, accumulate=True)              # x += mlp(h)
     return x
@@ -278,6 +284,12 @@ class GPT(nn.Module):
             else:
                 y, _, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
             self._linear(y, blk.attn.c_proj, out=x, accumulate=True)                     # x += c_proj(y)
+            if rowmajor_ok(B * T, 4 * C, C) and C % 32 == 0:          # as block_forward: the MLP's activations as row-major bf16
+                h, _ = ln_linear(self._images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True,
+                                 out_rowmajor=True)
+                linear(self._images, None, blk.mlp.c_proj.weight, bias=blk.mlp.c_proj.bias, out=x, accumulate=True, a_rowmajor=h,
+                       shape=(B * T, 4 * C))
+                continue
             h, _ = ln_linear(self._images, x, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, bias=blk.mlp.c_fc.bias, gelu=True)
             self._linear(h, blk.mlp.c_proj, out=x, accumulate=True)                      # x += mlp(h)
         return ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias), present
