@@ -178,7 +178,10 @@ def drop_rows(x2d, site):
 
 def rowmajor_ok(M, N, K):
     """Whether a Linear [M, K] -> [M, N] can hand its result on as row-major bf16 to a Linear that contracts over N (gemm_split_io)."""
-    return use_split(M, N, K) and M > SMALL_M and K % 32 == 0 and N % 32 == 0
+    # halo_gemm_split_io runs without split-K: both products must fill the chip with whole-K tiles (the attention-ASR blocks at
+    # 1280 rows do not: 40 tiles, 1.2 -> 1.8 ms per encoder pass when forced)
+    tiles = lambda r, c: ((r + 127) // 128) * ((c + 127) // 128)
+    return use_split(M, N, K) and M > SMALL_M and K % 32 == 0 and N % 32 == 0 and tiles(M, N) >= 200 and tiles(M, K) >= 200
 
 
 def ln_linear(images, x2d, ln_weight, ln_bias, weights, bias=None, gelu=False, want_normed=False, eps=1e-5, out_rowmajor=False):

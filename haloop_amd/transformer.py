@@ -33,7 +33,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._linear import (NO_SITES, DropSites, WeightImages, training_images, drop_rows, forward_images, grad_images, linear, linear_dw, linear_dx, ln_linear,
-                      normed_image, use_split)
+                      normed_image, rowmajor_ok, use_split)
 from .attention import LayerNorm
 from .conv import ConvEncoder
 from .recognizer import TemporalClassifier
@@ -321,6 +321,11 @@ class Block(nn.Module):
         t, t_ent = mt._attend2d(x_norm, None, N, T, T, key_lengths=time_lengths, causal=causal and time_lengths is None, rope=True,
                                 measure_entropy=measure_entropy, x_img=x_img)                    # the SAME x_norm (:476-494)
         linear(mt._images, t, mt.proj.weight, out=x2d, accumulate=True)
+        M, C = x2d.shape
+        if rowmajor_ok(M, 4 * C, C) and C % 32 == 0:        # the MLP's activations go on as row-major bf16 (halo_gemm_split_io)
+            h, _ = ln_linear(self._images, x2d, self.ln_chan.weight, None, self.mix_chan[0].weight, gelu='erf', out_rowmajor=True)
+            linear(self._images, None, self.mix_chan[2].weight, out=x2d, accumulate=True, a_rowmajor=h, shape=(M, 4 * C))
+            return m_ent, t_ent
         h, _ = ln_linear(self._images, x2d, self.ln_chan.weight, None, self.mix_chan[0].weight, gelu='erf')
         linear(self._images, h, self.mix_chan[2].weight, out=x2d, accumulate=True)
         return m_ent, t_ent
