@@ -719,7 +719,7 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
                    y_row_stride % 4 == 0 && y_batch_stride % 4 == 0);
     HALO_CHECK_ARG(N <= 65535 && heads <= 65535 && y_batch_stride == y_row_stride * Tq);
     AttnBwdArgs a;
-    a.q = q; a.k = k; a.v = v; a.dy = dy; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.q = q; a.k = k; a.v = v; a.dy = dy; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.y = nullptr; a.delta_w = nullptr;
     a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
     a.dy_rs = y_row_stride; a.dy_bs = y_batch_stride; a.dq_rs = dq_row_stride; a.dq_bs = dq_batch_stride;
     a.dkv_rs = dkv_row_stride; a.dkv_bs = dkv_batch_stride; a.key_len = key_lengths;
@@ -729,11 +729,12 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
     a.use_drop = p_drop > 0.f;
     hipStream_t st = (hipStream_t)stream;
     if (halo_math_mode() != HALO_MATH_F32 && (head_dim == 64 || head_dim == 32)) {
-        if (head_dim == 64)
-            hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
-        else
-            hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
-        const int rc = halo_attention_bwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
+        // the matrix-core sweeps: the dQ sweep computes delta = rowsum(dy * y) itself and leaves it in `delta` for the dK/dV sweep
+        AttnBwdArgs m = a;
+        if ((uintptr_t)y % 16 == 0) { m.y = y; m.delta_w = delta; }
+        else if (head_dim == 64) hipLaunchKernelGGL(attention_delta_kernel<64>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
+        else hipLaunchKernelGGL(attention_delta_kernel<32>, dim3(N * Tq), dim3(256), 0, st, dy, y_row_stride, y, y_row_stride, delta, Tq, heads);
+        const int rc = halo_attention_bwd_mx(m, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, st);
         if (rc != HALO_ENOTSUP) return rc;           // unaligned gradient views: the exact-f32 kernels take them
     }
     switch (head_dim) {

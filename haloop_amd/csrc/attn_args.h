@@ -26,6 +26,10 @@ __device__ __forceinline__ uint64_t attn_drop_tile_base(int n, int H, int h, int
 struct AttnBwdArgs {
     const float *q, *k, *v, *dy, *lse, *delta;
     float *dq, *dk, *dv;
+    // attn_mx.hip: when y (the forward output, laid out like dy) is given, the dQ sweep computes delta = rowsum(dy * y) of its own
+    // queries, uses it and writes it to delta_w for the dK/dV sweep behind it -- no separate delta launch
+    const float *y;
+    float *delta_w;
     long q_rs, q_bs, kv_rs, kv_bs, dy_rs, dy_bs, dq_rs, dq_bs, dkv_rs, dkv_bs;
     const int *key_len;
     int Tq, Tk, heads, causal;

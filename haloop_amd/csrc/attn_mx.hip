@@ -326,7 +326,27 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
             load_split8(dyb + (long)qsafe * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[ks], dol[ks]);
         }
         const long stat = ((long)b * a.heads + h) * Tq + qsafe;
-        const float lse = a.lse[stat] * LOG2E, delta = a.delta[stat];
+        float delta;
+        if (a.y) {          // delta = sum_d dy[q][d] * y[q][d]: this lane's 8 * KSTEPS dims, then the four lanes that share the query
+            const float *yb = a.y + (long)b * a.dy_bs + (long)h * HD + (long)qsafe * a.dy_rs;
+            const float *db = dyb + (long)qsafe * a.dy_rs;
+            float part = 0.f;
+    #pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const int d0 = 32 * ks + 8 * lq;
+                const f32x4 y0 = *reinterpret_cast<const f32x4 *>(yb + d0), y1 = *reinterpret_cast<const f32x4 *>(yb + d0 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(db + d0), g1 = *reinterpret_cast<const f32x4 *>(db + d0 + 4);
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) part += g0[e] * y0[e] + g1[e] * y1[e];
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            delta = part;
+            if (lq == 0 && qrow < Tq) a.delta_w[stat] = delta;
+        } else {
+            delta = a.delta[stat];
+        }
+        const float lse = a.lse[stat] * LOG2E;
         f32x4 dq[HD / 16];                                         // dQ^T[dim = 16m + 4lq + r][query lr]
     #pragma unroll
         for (int m = 0; m < HD / 16; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
