@@ -235,8 +235,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
  * byte offset halo_lstm_status_offset() of the reserve (backward != 0: of the backward workspace) is set to 1 and the results
  * of that call are invalid.  It reads 0 after a good call. */
 int halo_set_lstm_persistent(int on);
-/* The persistent backward writes the gate gradients' split-bf16 GEMM operand images itself (B % 32 == 0, HALO_MATH_BF16X3) instead of
- * leaving them to the operand-image launch behind it: same bits, one 4H-wide fp32 re-read less per layer.  On by default
+/* The persistent backward writes the gate gradients' split-bf16 GEMM operand images itself (B % 32 == 0, split-bf16 and bf16 modes) instead of
+ * leaving them to the operand-image launch behind it (bf16 mode: the hi parts only): same bits, one 4H-wide fp32 re-read less per layer.  On by default
  * (HALO_PERSIST_EMIT=0 / halo_set_lstm_persistent_images(0): off). */
 int halo_set_lstm_persistent_images(int on);
 int halo_lstm_persistent_eligible(int B, int H);
