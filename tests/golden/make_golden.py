@@ -568,11 +568,39 @@ def save_transducer():
     print('g9_transducer batched', d['batched.losses'][:4], 'score4', d['batched.score4_seq0'], 'ragged', d['ragged.losses'])
 
 
+def save_fbank():
+    """g11_fbank: the 80-mel kaldi filterbank of ha/data.py:136-140 (torchaudio.compliance.kaldi.fbank(wav, num_mel_bins=80)).
+    torchaudio is not installed here, so the vectors come from the Hugging Face transformers port of that function -- the numpy
+    path Speech2TextFeatureExtractor._extract_fbank_features takes when torchaudio is absent (transformers.audio_utils.spectrogram
+    with the povey window, kaldi mel scale, pre-emphasis 0.97, DC removal, log floored at float32 eps), which transformers keeps
+    equal to ta_kaldi.fbank.  Inputs: waveforms in the 16-bit integer range torchaudio's callers feed (a tone + noise + offset, white
+    noise, a chirp, a 401-sample clip = one frame); the port multiplies by 2**15 itself, so it gets wav / 2**15."""
+    import transformers
+    from transformers import Speech2TextFeatureExtractor
+    fe = Speech2TextFeatureExtractor(feature_size=80, num_mel_bins=80, sampling_rate=16000, dither=0.0)
+    rng = np.random.default_rng(11)
+    t = np.arange(16000) / 16000.0
+    waves = {
+        'tone': 0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * rng.standard_normal(16000) + 0.01,
+        'noise': 0.1 * rng.standard_normal(12345),
+        'chirp': 0.5 * np.sin(2 * np.pi * (100.0 + 3000.0 * t[:8000]) * t[:8000]),
+        'one_frame': 0.2 * rng.standard_normal(401),
+    }
+    d = {'transformers_version': np.array(transformers.__version__)}
+    for k, w in waves.items():
+        w16 = (w * 2 ** 15).astype(np.float32)                          # what torchaudio.compliance.kaldi.fbank is handed
+        d[f'{k}.wav'] = w16
+        d[f'{k}.fbank'] = fe._extract_fbank_features((w16 / 2 ** 15).astype(np.float32)).astype(np.float32)
+        print('g11_fbank', k, d[f'{k}.fbank'].shape, float(np.abs(d[f'{k}.fbank']).max()))
+    np.savez_compressed(os.path.join(OUT, 'g11_fbank.npz'), **d)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                       # e.g. `make_golden.py save_lc2x1024_b64`: regenerate the named fixtures only
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
+    save_fbank()
     save_star()
     save_transducer()
     save_rnn_decoder()

@@ -1,5 +1,6 @@
 """GPU check of the 80-mel filterbank front-end (haloop_amd.fbank, ha/data.py:136-140) against oracle/fbank_ref.py -- a restatement of
-torchaudio.compliance.kaldi.fbank's published algorithm, PARITY UNPINNED (torchaudio is not installable here; see the oracle's header).
+torchaudio.compliance.kaldi.fbank's published algorithm -- and against g11_fbank, vectors of the Hugging Face transformers port of that
+function (torchaudio itself is not installable here; see the oracle's header).
 Log-mel features <= 2e-3 abs (the DFT runs as one exact-f32 product of depth 512 instead of an FFT)."""
 import numpy as np
 import pytest
@@ -24,6 +25,16 @@ def test_fbank_matches_restatement(n, seed):
         if n == 16000:        # the 440 Hz tone: the loudest filter is the one whose triangle covers 440 Hz
             centers = 700.0 * (np.exp((fbank_ref.mel_scale(20.0) + (np.arange(80) + 1) * (fbank_ref.mel_scale(8000.0) - fbank_ref.mel_scale(20.0)) / 81) / 1127.0) - 1.0)
             assert abs(centers[int(got.mean(0).argmax())] - 440.0) < 40.0
+
+
+def test_fbank_matches_the_transformers_port_vectors():
+    from haloop_amd import fbank
+    from conftest import load_golden
+    g = load_golden('g11_fbank')
+    for k in ('tone', 'noise', 'chirp', 'one_frame'):
+        got = fbank.fbank(torch.from_numpy(g[f'{k}.wav'])[None].cuda(), num_mel_bins=80)
+        assert tuple(got.shape) == g[f'{k}.fbank'].shape
+        np.testing.assert_allclose(got.cpu().numpy(), g[f'{k}.fbank'], rtol=0, atol=2e-3, err_msg=k)
 
 
 def test_fbank_refusals():

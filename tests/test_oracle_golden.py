@@ -427,8 +427,21 @@ def test_transducer_restatement_matches_reference(name):
         np.testing.assert_allclose(losses[0].numpy(), g['batched.score4_seq0'], rtol=1e-5)
 
 
+def test_fbank_restatement_matches_the_transformers_port():
+    """oracle/fbank_ref.py against g11_fbank: vectors of the Hugging Face transformers port of torchaudio.compliance.kaldi.fbank (the
+    numpy path of Speech2TextFeatureExtractor; tests/golden/make_golden.py save_fbank).  torchaudio itself, the reference's dependency,
+    is not installable here, so this pins the restatement to an independent published implementation of the same function rather than
+    to torchaudio's own output.  float32 log-mels of magnitude ~25: 4e-6 abs = 2 ulp."""
+    from oracle import fbank_ref
+    g = load_golden('g11_fbank')
+    for k in ('tone', 'noise', 'chirp', 'one_frame'):
+        got = fbank_ref.fbank(g[f'{k}.wav'], num_mel_bins=80)
+        assert got.shape == g[f'{k}.fbank'].shape
+        np.testing.assert_allclose(got, g[f'{k}.fbank'], rtol=0, atol=4e-6, err_msg=k)
+
+
 def test_fbank_restatement_properties():
-    """oracle/fbank_ref.py is parity-unpinned (torchaudio absent); what can be checked without it: frame count, the filter bank's
+    """What can be checked of oracle/fbank_ref.py without any vectors: frame count, the filter bank's
     shape / support / partition of unity between the first and last centre, a pure tone landing in the filter that covers it, and
     invariance to a DC offset."""
     from oracle import fbank_ref
