@@ -33,8 +33,15 @@ def test_fbank_matches_the_transformers_port_vectors():
     g = load_golden('g11_fbank')
     for k in ('tone', 'noise', 'chirp', 'one_frame'):
         got = fbank.fbank(torch.from_numpy(g[f'{k}.wav'])[None].cuda(), num_mel_bins=80)
-        assert tuple(got.shape) == g[f'{k}.fbank'].shape
-        np.testing.assert_allclose(got.cpu().numpy(), g[f'{k}.fbank'], rtol=0, atol=2e-3, err_msg=k)
+        ref = g[f'{k}.fbank'].astype(np.float64)
+        assert tuple(got.shape) == ref.shape
+        got = got.cpu().numpy().astype(np.float64)
+        # the DFT runs in fp32 here (and in torchaudio) and in float64 in the port: mel energies agree to fp32 rounding of the frame's
+        # LARGEST energy, so the logs agree tightly only within a few nepers of the frame maximum (the noiseless chirp spans e^35)
+        peak = np.exp(ref).max(axis=1, keepdims=True)
+        assert (np.abs(np.exp(got) - np.exp(ref)) / peak).max() <= 1e-5, k
+        near = ref >= ref.max(axis=1, keepdims=True) - 6.0
+        assert np.abs(got - ref)[near].max() <= 2e-3, k
 
 
 def test_fbank_refusals():
