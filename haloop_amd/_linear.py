@@ -10,6 +10,28 @@ SMALL_M = int(__import__('os').environ.get('HALO_SMALL_M', '64'))
 
 
 _PAIRS = [False]
+# Inside a GraphedTrainStep run (train.py) this holds a number unique to that run: cached weight operands then count as current
+# only for the run that built them, so every captured step records the image-building launches (into buffers of the graph's
+# own pool) and a replay re-derives the images from the weights as the optimizer left them.  None: eager calls, cache by version.
+_RUN_EPOCH = [None]
+_EPOCHS = [0]
+
+
+class graphed_run:
+    """One forward + backward that is, or will be, replayed from a HIP graph: weight operand images are rebuilt inside it."""
+
+    def __enter__(self):
+        self.prev = _RUN_EPOCH[0]
+        _EPOCHS[0] += 1
+        _RUN_EPOCH[0] = _EPOCHS[0]
+
+    def __exit__(self, *exc):
+        _RUN_EPOCH[0] = self.prev
+        return False
+
+
+def _stamp(weights):
+    return (_RUN_EPOCH[0],) + tuple((w._version, w.data_ptr()) for w in weights)
 
 
 class training_images:
@@ -33,7 +55,7 @@ class WeightImages:
 
     def _lookup(self, kind, weights, build):
         key = (kind,) + tuple(id(w) for w in weights)
-        stamp = tuple((w._version, w.data_ptr()) for w in weights)
+        stamp = _stamp(weights)
         hit = self._cache.get(key)
         if hit is None or hit[0] != stamp:
             hit = (stamp, build())
@@ -62,7 +84,7 @@ class WeightImages:
             return
         pairs = ops.image_pairs([self.dense(ws).contiguous() for ws in todo])
         for ws, pr in zip(todo, pairs):
-            self._cache[(kind,) + tuple(id(w) for w in ws)] = (tuple((w._version, w.data_ptr()) for w in ws), pr)
+            self._cache[(kind,) + tuple(id(w) for w in ws)] = (_stamp(ws), pr)
 
     def split(self, weights):
         """The split/tiled image of the (concatenated) weight."""
@@ -76,7 +98,7 @@ class WeightImages:
 
     def _has(self, kind, weights):
         hit = self._cache.get((kind,) + tuple(id(w) for w in weights))
-        return hit is not None and hit[0] == tuple((w._version, w.data_ptr()) for w in weights)
+        return hit is not None and hit[0] == _stamp(weights)
 
 
 def linear(images, x2d, weights, bias=None, out=None, gelu=False, accumulate=False, drop=ops.NO_DROPOUT, stream_id=0, a_image=None,

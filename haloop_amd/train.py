@@ -13,7 +13,7 @@ semantics of DistributedDataParallel in ha/attention_loop.py:154.
 """
 import torch
 
-from . import _lib, dp, ops
+from . import _lib, _linear, dp, ops
 from .ops import Dropout, NO_DROPOUT
 from .rnn import lstm_param_list
 
@@ -363,7 +363,8 @@ class GraphedTrainStep:
     params, dropout_streams=...)`` warms ``loss = forward(*inputs)`` up on a side stream, captures forward and backward on private
     copies of the inputs, and ``step(*inputs)`` refills those copies and replays; the gradients land in the parameters' ``.grad``
     (the same tensors every replay, so an optimizer can read them in place -- keep ``set_to_none=False``).  A new input shape
-    re-captures.
+    re-captures.  The weights' GEMM operand images are rebuilt by launches inside the graph, so a replay after an in-place
+    optimizer step sees the new weights.
 
     Dropout: pass the models' ``DropoutStream`` objects; they are switched to a shared device counter that the graph itself advances
     once per replay, so every replay draws fresh Philox masks (a captured host-side offset would repeat one mask forever).
@@ -381,9 +382,12 @@ class GraphedTrainStep:
         self._graph = self._static = self._loss = None
 
     def _run(self, inputs):
-        loss = self.forward(*inputs)
-        with torch.autograd.set_multithreading_enabled(False):     # the backward's launches come from THIS thread (the capturing one)
-            loss.backward()
+        # weight operand images are part of the run (not a host-side cache hit recorded as nothing): a replay after an optimizer
+        # step must multiply by the updated weights
+        with _linear.graphed_run():
+            loss = self.forward(*inputs)
+            with torch.autograd.set_multithreading_enabled(False):     # the backward's launches come from THIS thread (the capturing one)
+                loss.backward()
         if self.streams:
             ops.counter_inc(self.counter)
         return loss

@@ -477,3 +477,55 @@ def test_graphed_train_step_equals_eager(hal):
         assert torch.isfinite(loss_s) and params[0].grad is not None
     finally:
         lib.set_math_mode(prev)
+
+
+def test_graphed_train_step_sees_optimizer_updates(hal):
+    """A replay after an in-place optimizer step multiplies by the UPDATED weights: the GEMM operand images of the weights are built
+    by launches inside the graph, not cached from the warm-up (a host-side cache hit records no launch, and the graph would go on
+    reading the warm-up's images).  step(), update every parameter in place, step(): loss and every gradient equal the eager
+    launches' on the updated weights bit for bit."""
+    from oracle import transformer_ref
+    from haloop_amd import train
+    tr, lib = hal['tr'], hal['lib']
+    prev = lib.get_math_mode()
+    lib.set_math_mode('bf16x3')
+    try:
+        V, hd, heads, L, N, T, S = 32, 64, 2, 2, 6, 160, 5
+        pe = transformer_ref.make_encoder_params(hd, heads, L, 80, 64, 3, 43)
+        pd = transformer_ref.make_decoder_params(V, hd, heads, L, 44)
+        enc = tr.AudioEncoder(head_dim=hd, heads=heads, layers=L, p_drop=0.0, input_dim=80, conv_dim=64)
+        dec = tr.CTCAttentionDecoder(vocab=V, head_dim=hd, heads=heads, p_drop=0.0, layers=L)
+        enc.load_state_dict(pe); dec.load_state_dict(pd)
+        enc.to(DEV).train(); dec.to(DEV).train()
+        dec.recognizer.dropout.p = 0.0                       # the CTC head's own dropout (recognizer.py:41) off too: no masks in this test
+        x, il, tg, tl = transformer_ref.synthetic_asr_batch(N, T, 80, V, S, 9, ragged=True)
+        cond = torch.cat([torch.full((N, 1), 5, dtype=torch.long), tg], dim=1).to(DEV)
+        xd, ild, tl1 = x.to(DEV), il.to(DEV), (tl + 1).to(DEV)
+        named = list(enc.named_parameters()) + list(dec.named_parameters())
+        params = [p for _, p in named]
+
+        def fwd(xd, ild, cond, tl1):
+            f, fl, _ = enc(xd, ild)
+            loss, _ = dec(f, cond, fl, tl1, drop_labels=False)
+            return loss
+
+        step = train.GraphedTrainStep(fwd, params)
+        loss0 = float(step.step(xd, ild, cond, tl1))
+        with torch.no_grad():
+            for p in params:                                 # a plain SGD step, in place like every optimizer of this package
+                p.add_(p.grad, alpha=-0.5)
+        loss_g = float(step.step(xd, ild, cond, tl1))
+        assert loss_g != loss0
+        grads_g = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss_e = fwd(xd, ild, cond, tl1)
+        loss_e.backward()
+        assert float(loss_e.detach()) == loss_g
+        for (name, p), gg in zip(named, grads_g):
+            if name.endswith('wte.weight'):
+                np.testing.assert_allclose(p.grad.cpu().numpy(), gg.cpu().numpy(), rtol=0, atol=1e-6, err_msg=name)
+            else:
+                assert torch.equal(p.grad, gg), name
+    finally:
+        lib.set_math_mode(prev)
