@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 10
+HALO_ABI_VERSION = 11
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -58,6 +58,8 @@ SIGNATURES = {
     'halo_set_lstm_persistent': (_i, [_i]),
     'halo_set_lstm_persistent_images': (_i, [_i]),
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
+    'halo_set_lstm_persistent2': (_i, [_i]),
+    'halo_lstm_persistent2_eligible': (_i, [_i, _i, _i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),
     'halo_lstm_persist_stamps': (_i, [_vp]),
     'halo_lstm_chain_events': (_i, [_vp, _vp]),
@@ -193,6 +195,11 @@ def set_lstm_fusion(on):
 def set_lstm_persistent(on):
     """Weight-resident persistent LSTM recurrence (one launch per layer and direction) on / off (include/halo.h)."""
     check(lib().halo_set_lstm_persistent(int(bool(on))), 'halo_set_lstm_persistent')
+
+
+def set_lstm_persistent2(on):
+    """Both layers of a 2-layer LSTM in one persistent launch per direction (bf16 mode; include/halo.h) on / off."""
+    check(lib().halo_set_lstm_persistent2(int(bool(on))), 'halo_set_lstm_persistent2')
 
 
 def set_lstm_persistent_images(on):

@@ -514,6 +514,34 @@ __global__ __launch_bounds__(256) void persist_prologue_kernel(const PrologueArg
     }
 }
 
+// The same for the two-layer persistent launch (lstm_persist2.hip): three weight images (W_hh0, W_hh1, W_ih1; transposed for the
+// backward), both layers' initial states, the epoch words.
+struct Prologue2Args {
+    const float *w[3]; void *wdst[3]; long w_units; int wK;         // w_units per matrix
+    const float *h0[2]; void *hp0[2]; float *h_rm[2]; const float *c0[2]; float *c_rm[2]; long s_units;   // per layer (forward only)
+    unsigned *zero; long zero_units;
+    unsigned *zero2; long zero2_units;
+    int H, B;
+};
+template <int WMODE>
+__global__ __launch_bounds__(256) void persist2_prologue_kernel(const Prologue2Args a) {
+    const long nw = 3 * a.w_units, ns = 2 * a.s_units;
+    const long total = nw + ns + a.zero_units + a.zero2_units;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        if (u < nw) {
+            const int m = (int)(u / a.w_units);
+            pack_unit<true, WMODE>(u - m * a.w_units, a.w[m], a.wdst[m], a.H, a.B, a.wK, nullptr, nullptr, nullptr);
+        } else if (u < nw + ns) {
+            const int l = (int)((u - nw) / a.s_units);
+            pack_unit<true, 2>(u - nw - l * a.s_units, a.h0[l], a.hp0[l], a.H, a.B, a.H, a.h_rm[l], a.c0[l], a.c_rm[l]);
+        } else if (u < nw + ns + a.zero_units) {
+            reinterpret_cast<uint4 *>(a.zero)[u - nw - ns] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            reinterpret_cast<uint4 *>(a.zero2)[u - nw - ns - a.zero_units] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
 // =================================================================================================
 // Layer-diagonal ("wavefront") fusion.  Step t of layer l only needs step t of layer l-1 and step
 // t-1 of layer l, so ONE launch runs step d-l of every layer l (grid.z = layer): a 2-layer, T=21
@@ -1059,6 +1087,145 @@ inline size_t bwd_flags_offset(int T, int B, int in0, int H, int L) {
     return (n + 255) & ~(size_t)255;
 }
 
+// What follows a layer's backward chain: every operand image of its gradient GEMMs in ONE launch (dG [TB][4H] for the input
+// gradient and dG^T [4H][TB] for both weight gradients unless the chain wrote them itself: ``emit``; W_ih^T, h_prev^T, in^T; the
+// bias gradients from the chain's partial rows), then the input gradient (feeds layer l-1's recurrence or the caller's dx) and
+// the parameter gradients over all frames at once.
+int lstm_bwd_layer_tail(const float *x, const float *const *w_ih, float *reserve, int l, int in0, int T, int B, int H, int L, float p_drop,
+                        uint64_t seed, uint32_t offset, const uint32_t *offset_dev, bool fused, bool emit, char *img_g, char *img_gT,
+                        char *img_hT, char *img_inT, char *img_wT, const float *bias_part, float *din, float *dx, float *const *dw_ih,
+                        float *const *dw_hh, float *const *db_ih, float *const *db_hh, bool need_din, hipStream_t st) {
+    const size_t BH = (size_t)B * H;
+    const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
+    hipStream_t side = st;
+    const float *in;
+    int in_dim;
+    if (l == 0) { in = x; in_dim = in0; }
+    else {
+        const LayerBufs pb = layer_bufs(reserve, l - 1, T, B, H);
+        in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
+        in_dim = H;
+    }
+    (void)fused;
+    float *din_out = l > 0 ? din : dx;
+    const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
+                                          offset, offset_dev);
+    const bool tiled = halo_math_mode() != HALO_MATH_F32 && in_dim >= 64;
+    int rc = HALO_OK;
+    if (tiled) {
+        HaloPrepJob jobs[5];
+        int nj = 0;
+        if (need_din) {
+            if (!emit) jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};              // (emit: the chain wrote both)
+            jobs[nj++] = {1, w_ih[l], in_dim, 4 * H, in_dim, img_wT, nullptr};                      // W_ih^T [in][4H]
+        } else if (!emit) {
+            jobs[nj++] = {1, lb.gates, 4 * H, T * B, 4 * H, img_gT, nullptr};                       // dG^T [4H][TB]
+        }
+        if (emit)       // the bias gradients: the chain left one partial row per batch tile, summed here beside the other jobs
+            jobs[nj++] = {3, bias_part, (B + 15) / 16, 4 * H, 4 * H, db_ih[l], db_hh[l]};
+        jobs[nj++] = {1, lb.h, H, T * B, H, img_hT, nullptr};                                       // h_prev^T [H][TB]
+        jobs[nj++] = {1, in, in_dim, T * B, in_dim, img_inT, nullptr};                              // in^T [in][TB]
+        HALO_TRY(halo_prep_jobs(jobs, nj, st));
+    }
+    // (1) the gradient w.r.t. this layer's input feeds layer l-1's recurrence
+    if (need_din) {
+        if (tiled) {
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
+                                            &ddrop, st));
+        } else {
+            HALO_TRY(halo_gemm_f32(1, 0, T * B, in_dim, 4 * H, lb.gates, 4 * H, w_ih[l], in_dim, din_out, in_dim,
+                                   nullptr, nullptr, 0, l > 0 ? p_drop : 0.f, seed,
+                                   HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0), offset, offset_dev, (halo_stream_t)st));
+        }
+    }
+    // (2) this layer's parameter gradients
+    if (tiled) {
+        rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
+        if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
+                                             nullptr, side);
+    } else {
+        // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
+        rc = halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f, 0, 0,
+                           0, nullptr, (halo_stream_t)side);
+        // dW_ih[4H,in] = dG^T * in
+        if (!rc) rc = halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
+                                    nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
+    }
+    if (!rc && !(emit && tiled)) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
+    return rc;
+}
+
+
+// ---- both layers in one persistent launch (lstm_persist2.hip; bf16 arithmetic, L = 2) ------------------------------------------
+// layer 0's input projection (one batched GEMM), one prologue launch, ONE launch for the 2 T time steps of the stack
+int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+                      const float *const *b_hh, const float *h0, const float *c0, float *y, long y_stride_t, long y_stride_b,
+                      int y_relu, float *hn, float *cn, float *reserve, float *extra, char *img_in, char *img_w, int T, int B,
+                      int in0, int H, float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev, hipStream_t st) {
+    const int L = 2;
+    const size_t BH = (size_t)B * H;
+    const LayerBufs l0 = layer_bufs(reserve, 0, T, B, H), l1 = layer_bufs(reserve, 1, T, B, H);
+    if (in0 >= 64) {
+        const HaloPrepJob jobs[2] = {{0, x, T * B, in0, in0, img_in, nullptr}, {0, w_ih[0], 4 * H, in0, in0, img_w, nullptr}};
+        HALO_TRY(halo_prep_jobs(jobs, 2, st));
+        HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in0, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
+    } else {
+        HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in0, x, in0, w_ih[0], in0, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0, 0,
+                               nullptr, (halo_stream_t)st));
+    }
+    float *wp0 = reserve, *wp1 = fused_wpk(extra, 1, H), *wpi = wp1 + (size_t)4 * H * H;
+    unsigned *flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
+    Prologue2Args pa;
+    pa.w[0] = w_hh[0]; pa.wdst[0] = wp0; pa.w[1] = w_hh[1]; pa.wdst[1] = wp1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpi;
+    pa.w_units = (long)(H / 16) * 4 * (H / 32) * 64; pa.wK = H;
+    for (int l = 0; l < 2; ++l) {
+        const LayerBufs lb = l ? l1 : l0;
+        pa.h0[l] = h0 ? h0 + (size_t)l * BH : nullptr; pa.hp0[l] = lb.hp; pa.h_rm[l] = lb.h;
+        pa.c0[l] = c0 ? c0 + (size_t)l * BH : nullptr; pa.c_rm[l] = lb.c;
+    }
+    pa.s_units = (long)((B + 15) / 16) * (H / 32) * 64;
+    pa.zero = flags; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+    pa.zero2 = nullptr; pa.zero2_units = 0;
+    pa.H = H; pa.B = B;
+    hipLaunchKernelGGL(persist2_prologue_kernel<0>, dim3(pack_grid((size_t)(3 * pa.w_units + 2 * pa.s_units + pa.zero_units))), dim3(256),
+                       0, st, pa);
+    HALO_TRY(halo_launch_status());
+    Persist2Fwd a;
+    a.wp0 = (const char *)wp0; a.wp1 = (const char *)wp1; a.wpi = (const char *)wpi;
+    a.hp0 = (char *)l0.hp; a.hp1 = (char *)l1.hp;
+    a.xp = p_drop > 0.f ? (char *)fused_yp(extra, 0, T, B, H, L) : nullptr;
+    a.gates0 = l0.gates; a.h0 = l0.h; a.c0 = l0.c;
+    a.gates1 = l1.gates; a.h1 = l1.h; a.c1 = l1.c;
+    a.b_ih1 = b_ih[1]; a.b_hh1 = b_hh[1];
+    a.ydrop = p_drop > 0.f ? l0.ydrop : nullptr;
+    a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y ? (y_relu ? 2 : 1) : 0;
+    a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+    a.flags = flags;
+    a.stamps = nullptr;
+    a.T = T; a.B = B; a.H = H;
+    chain_begin(st);
+    HALO_TRY(halo_lstm_persist2_fwd(a, st));
+    chain_end(st, 0, 1, "lstm_persist2_fwd_kernel");
+    for (int l = 0; l < 2; ++l) {
+        const LayerBufs lb = l ? l1 : l0;
+        if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
+        if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
+    }
+    return HALO_OK;
+}
+
+
+// the two-layer persistent backward (lstm_persist2.hip) keeps both layers' gate-gradient images alive at once: appended to the
+// workspace are layer 1's bias partials [ceil(B/16)][4H], its packed images [T] and its dG^T GEMM operand image
+inline size_t bwd_p2_offset(int T, int B, int in0, int H, int L) {
+    const size_t n = bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (size_t)((B + 15) / 16) * 4 * H * sizeof(float);
+    return (n + 255) & ~(size_t)255;
+}
+inline size_t bwd_p2_bytes(int T, int B, int H) {
+    return (((size_t)((B + 15) / 16) * 4 * H * sizeof(float) + 255) & ~(size_t)255) + (size_t)T * bt16(B) * 4 * H * sizeof(float) +
+           halo_tiled_image_bytes(4 * H, T * B);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1101,6 +1268,12 @@ static bool persist_emit_enabled() {
 
 int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B, H) && use_x3(H) ? 1 : 0; }
 
+int halo_set_lstm_persistent2(int on) {
+    halo_lstm_persist2_enable(on);
+    return HALO_OK;
+}
+int halo_lstm_persistent2_eligible(int T, int B, int H, int L) { return !fused_ok(H, L) && use_x3(H) && halo_lstm_persist2_ok(T, B, H, L) ? 1 : 0; }
+
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
     return backward ? bwd_flags_offset(T, B, in0, H, L) : reserve_flags_offset(T, B, in0, H, L);
@@ -1108,6 +1281,7 @@ size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
+    if (L == 2) return bwd_p2_offset(T, B, in0, H, L) + bwd_p2_bytes(T, B, H);
     // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H] + packed gate-gradient images
     // [BT16, 4H] (one per time step) + tiled images for the batched gradient GEMMs + epoch words
     // ... + the batch-tile partials of a layer's bias gradient [ceil(B/16)][4H] (written by the persistent backward)
@@ -1130,6 +1304,11 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     char *img_in = (char *)(reserve + (size_t)4 * H * H + (size_t)L * layer_floats(T, B, H));
     char *img_w = img_in + halo_tiled_image_bytes(T * B, kin);
     for (int l = 0; l < L; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
+    if (!fused_ok(H, L) && x3 && halo_lstm_persist2_ok(T, B, H, L)) {
+        float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
+        return lstm_fwd_persist2(x, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra, img_in,
+                                 img_w, T, B, in0, H, p_drop, seed, offset, offset_dev, st);
+    }
     if (fused_ok(H, L)) {
         float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
         return lstm_fwd_fused(x, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra,
@@ -1264,6 +1443,62 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_TRY(lstm_bwd_fused_chain(w_ih, w_hh, dy, y_stride_t, y_stride_b, y_relu, dhn, dcn, reserve, extra, T, B, H, L,
                                       p_drop, seed, offset, offset_dev, st));
     }
+    if (!fused && x3 && L == 2 && layer_begin == 0 && layer_end == 2 && halo_lstm_persist2_ok(T, B, H, L)) {
+        // both layers' chains in ONE persistent launch (lstm_persist2.hip), layer 1's input gradient formed inside it
+        for (int l = 0; l < 2; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
+        const LayerBufs l0 = layer_bufs(reserve, 0, T, B, H), l1 = layer_bufs(reserve, 1, T, B, H);
+        float *extra = (float *)(img_wT + halo_tiled_image_bytes(kin, 4 * H));
+        float *wpT1 = extra, *wpTi = extra + (size_t)4 * H * H, *dcarry1 = extra + (size_t)8 * H * H;
+        char *flag_base = (char *)workspace + bwd_flags_offset(T, B, in0, H, L);
+        float *bias_part0 = (float *)(flag_base + PERSIST_FLAG_BYTES);
+        char *p2 = (char *)workspace + bwd_p2_offset(T, B, in0, H, L);
+        float *bias_part1 = (float *)p2;
+        float *dgp1 = (float *)(p2 + (((size_t)((B + 15) / 16) * 4 * H * sizeof(float) + 255) & ~(size_t)255));
+        char *img_gT1 = (char *)(dgp1 + (size_t)T * PG);
+        const bool can_emit = persist_emit_enabled() && B % 32 == 0;
+        const bool emit0 = can_emit && in0 >= 64, emit1 = can_emit;
+        const bool need_dx = dx != nullptr;
+        Prologue2Args pa;
+        pa.w[0] = w_hh[0]; pa.wdst[0] = wpT; pa.w[1] = w_hh[1]; pa.wdst[1] = wpT1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpTi;
+        pa.w_units = (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
+        for (int l = 0; l < 2; ++l) { pa.h0[l] = nullptr; pa.hp0[l] = nullptr; pa.h_rm[l] = nullptr; pa.c0[l] = nullptr; pa.c_rm[l] = nullptr; }
+        pa.s_units = 0;
+        pa.zero = (unsigned *)flag_base; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
+        pa.zero2 = nullptr; pa.zero2_units = 0;
+        if (emit0 && need_dx && (T * B) % 128 != 0) {   // the padded last row tile of dG0's row image
+            const long tile_bytes = (long)(4 * H / 32) * 16384;
+            pa.zero2 = (unsigned *)(img_g + (long)((T * B) / 128) * tile_bytes); pa.zero2_units = tile_bytes / 16;
+        }
+        pa.H = H; pa.B = B;
+        hipLaunchKernelGGL(persist2_prologue_kernel<1>, dim3(pack_grid((size_t)(3 * pa.w_units + pa.zero_units + pa.zero2_units))), dim3(256), 0,
+                           st, pa);
+        HALO_TRY(halo_launch_status());
+        Persist2Bwd a;
+        a.wpT0 = (const char *)wpT; a.wpT1 = (const char *)wpT1; a.wpTi = (const char *)wpTi;
+        a.dgp0 = (char *)dgp; a.dgp1 = (char *)dgp1;
+        a.gates0 = l0.gates; a.gates1 = l1.gates; a.c0 = l0.c; a.c1 = l1.c;
+        a.dc0 = dcarry; a.dc1 = dcarry1;
+        a.dy = dy; a.dy_stride_t = y_stride_t; a.dy_stride_b = y_stride_b; a.dy_relu = y_relu;
+        a.dhinit0 = dhn; a.dcinit0 = dcn;
+        a.dhinit1 = dhn ? dhn + BH : nullptr; a.dcinit1 = dcn ? dcn + BH : nullptr;
+        a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+        a.flags = (unsigned *)flag_base;
+        a.stamps = nullptr;
+        a.img_rows0 = emit0 && need_dx ? img_g : nullptr;
+        a.img_cols0 = emit0 ? img_gT : nullptr;
+        a.img_cols1 = emit1 ? img_gT1 : nullptr;
+        a.bias_part0 = emit0 ? bias_part0 : nullptr;
+        a.bias_part1 = emit1 ? bias_part1 : nullptr;
+        a.T = T; a.B = B; a.H = H;
+        chain_begin(st);
+        HALO_TRY(halo_lstm_persist2_bwd(a, st));
+        chain_end(st, 1, 1, "lstm_persist2_bwd_kernel");
+        HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 1, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g, emit1 ? img_gT1 : img_gT,
+                                     img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));
+        HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 0, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit0, img_g, img_gT, img_hT,
+                                     img_inT, img_wT, bias_part0, din, dx, dw_ih, dw_hh, db_ih, db_hh, need_dx, st));
+        return HALO_OK;
+    }
     for (int l = layer_end - 1; l >= layer_begin; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
@@ -1336,64 +1571,9 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         }
         if (!fused && !persist) chain_end(st, 1, T, "lstm_step_bwd_kernel");
         // parameter gradients over all frames at once
-        const float *in;
-        int in_dim;
-        if (l == 0) { in = x; in_dim = in0; }
-        else {
-            const LayerBufs pb = layer_bufs(reserve, l - 1, T, B, H);
-            in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
-            in_dim = H;
-        }
-        const bool need_din = (l > 0 && !fused) || (l == 0 && dx);   // fused: upper layers fold it into their steps
-        float *din_out = l > 0 ? din : dx;
-        const DropoutCfg ddrop = make_dropout(l > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0),
-                                              offset, offset_dev);
-        const bool tiled = halo_math_mode() != HALO_MATH_F32 && in_dim >= 64;
-        // every operand image of this layer's gradient GEMMs in ONE launch: dG [TB][4H] (input gradient) and dG^T [4H][TB] (both
-        // weight gradients) from one read, W_ih^T, h_prev^T, in^T
-        int rc = HALO_OK;
-        if (tiled) {
-            HaloPrepJob jobs[5];
-            int nj = 0;
-            if (need_din) {
-                if (!emit) jobs[nj++] = {2, lb.gates, T * B, 4 * H, 4 * H, img_g, img_gT};              // (emit: the chain wrote both)
-                jobs[nj++] = {1, w_ih[l], in_dim, 4 * H, in_dim, img_wT, nullptr};                      // W_ih^T [in][4H]
-            } else if (!emit) {
-                jobs[nj++] = {1, lb.gates, 4 * H, T * B, 4 * H, img_gT, nullptr};                       // dG^T [4H][TB]
-            }
-            if (emit)       // the bias gradients: the chain left one partial row per batch tile, summed here beside the other jobs
-                jobs[nj++] = {3, (const float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES), (B + 15) / 16, 4 * H,
-                              4 * H, db_ih[l], db_hh[l]};
-            jobs[nj++] = {1, lb.h, H, T * B, H, img_hT, nullptr};                                       // h_prev^T [H][TB]
-            jobs[nj++] = {1, in, in_dim, T * B, in_dim, img_inT, nullptr};                              // in^T [in][TB]
-            HALO_TRY(halo_prep_jobs(jobs, nj, st));
-        }
-        // (1) the gradient w.r.t. this layer's input feeds layer l-1's recurrence
-        if (need_din) {
-            if (tiled) {
-                HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_dim, 4 * H, din_out, in_dim, nullptr, nullptr, 0,
-                                                &ddrop, st));
-            } else {
-                HALO_TRY(halo_gemm_f32(1, 0, T * B, in_dim, 4 * H, lb.gates, 4 * H, w_ih[l], in_dim, din_out, in_dim,
-                                       nullptr, nullptr, 0, l > 0 ? p_drop : 0.f, seed,
-                                       HALO_STREAM_LSTM_LAYER0 + (uint32_t)(l > 0 ? l - 1 : 0), offset, offset_dev, stream));
-            }
-        }
-        // (2) this layer's parameter gradients
-        if (tiled) {
-            rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
-            if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
-                                                 nullptr, side);
-        } else {
-            // dW_hh[4H,H] = dG[T*B,4H]^T * h_{t-1}[T*B,H]   (h buffer rows 0..T-1 are the previous states)
-            rc = halo_gemm_f32(0, 0, 4 * H, H, T * B, lb.gates, 4 * H, lb.h, H, dw_hh[l], H, nullptr, nullptr, 0, 0.f, 0, 0,
-                               0, nullptr, (halo_stream_t)side);
-            // dW_ih[4H,in] = dG^T * in
-            if (!rc) rc = halo_gemm_f32(0, 0, 4 * H, in_dim, T * B, lb.gates, 4 * H, in, in_dim, dw_ih[l], in_dim, nullptr,
-                                        nullptr, 0, 0.f, 0, 0, 0, nullptr, (halo_stream_t)side);
-        }
-        if (!rc && !(emit && tiled)) rc = halo_colsum2(lb.gates, T * B, 4 * H, 4 * H, db_ih[l], db_hh[l], side);
-        if (rc) return rc;
+        HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, l, in0, T, B, H, L, p_drop, seed, offset, offset_dev, fused, emit, img_g, img_gT, img_hT,
+                                     img_inT, img_wT, emit ? (const float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES) : nullptr,
+                                     din, dx, dw_ih, dw_hh, db_ih, db_hh, (l > 0 && !fused) || (l == 0 && dx), st));
     }
     return HALO_OK;
 }

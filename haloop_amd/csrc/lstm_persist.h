@@ -61,3 +61,54 @@ bool halo_lstm_persist_ok(int B, int H);        // shape, arithmetic mode, CU co
 void halo_lstm_persist_enable(int on);
 int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st);
 int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st);
+
+// ---- both layers of a 2-layer stack in ONE persistent launch (lstm_persist2.hip; single-pass bf16 arithmetic only) ----
+// Combined step s = 0 .. T runs layer 0's time step s and layer 1's time step s - 1 in the same workgroup (waves 0-3: layer 0,
+// waves 4-7: layer 1), so the T + 1 combined steps need ONE hand-off each instead of the 2 T of two chains run back to back, and
+// layer 1's input projection (dropout(h0_t) W_ih1^T) is part of its step: no batched GEMM, no operand images between the layers.
+struct Persist2Fwd {
+    const char *wp0, *wp1, *wpi;   // packed W_hh0, W_hh1, W_ih1 (lstm.hip Packed<true>, tile jt*4 + gate, H/32 blocks of 2 KiB; hi halves used)
+    char *hp0, *hp1;               // packed h images of the layers, [T+1][ceil(B/16)][H/32] blocks; image 0 = initial state
+    char *xp;                      // packed dropout(h0_t) images [T][ceil(B/16)][H/32] blocks, or NULL (no dropout: layer 1 reads hp0)
+    float *gates0, *h0, *c0;       // layer 0: gates [T][B][4H] in: x W_ih0^T + b_ih0 + b_hh0, out: activated i,f,g,o; h, c [T+1][B][H]
+    float *gates1, *h1, *c1;       // layer 1: gates out only
+    const float *b_ih1, *b_hh1;
+    float *ydrop;                  // [T][B][H] row-major dropout(h0_t) (operand of layer 1's weight gradient); NULL without dropout
+    float *y;                      // layer 1's second output (features), may be NULL with y_mode 0
+    long y_stride_t, y_stride_b;
+    int y_mode;                    // 0 none, 1 plain, 2 relu
+    DropoutCfg drop;               // layer 0's output dropout (the stream of lstm.hip's Y_DROPOUT epilogue)
+    unsigned *flags;
+    unsigned long long *stamps;
+    int poll_mode, replica_shift, nap;
+    int T, B, H;
+};
+
+// Combined step s = 0 .. T of the backward runs layer 1's time step T-1-s and layer 0's time step T-s: the gate gradients of
+// layer 1 at time T-s feed BOTH layer 1's recurrence (times W_hh1) and layer 0's incoming gradient (times W_ih1, its dropout
+// mask applied), from one set of fragment loads.
+struct Persist2Bwd {
+    const char *wpT0, *wpT1, *wpTi;   // packed W_hh0^T, W_hh1^T, W_ih1^T (tile jt, 4H/32 blocks; hi halves used)
+    char *dgp0, *dgp1;                // packed gate-gradient images per layer [T][ceil(B/16)][4H/32] blocks
+    float *gates0, *gates1;           // in: activated gates, out: gradients w.r.t. the pre-activations
+    const float *c0, *c1;             // [T+1][B][H]
+    float *dc0, *dc1;                 // final cell-gradient carries [B][H] (may be NULL)
+    const float *dy;                  // gradient w.r.t. layer 1's output, dy[t*stride_t + b*stride_b + j]
+    long dy_stride_t, dy_stride_b;
+    int dy_relu;
+    const float *dhinit0, *dcinit0, *dhinit1, *dcinit1;   // [B][H], may be NULL
+    DropoutCfg drop;                  // layer 0's output dropout mask (applied to the gradient arriving from layer 1)
+    unsigned *flags;
+    unsigned long long *stamps;
+    // optional GEMM operand images of the gate gradients (see PersistBwd): rows image of layer 0 only (layer 1's input gradient
+    // is formed in this kernel), column images of both
+    char *img_rows0, *img_cols0, *img_cols1;
+    float *bias_part0, *bias_part1;   // [ceil(B/16)][4H] per layer, may be NULL
+    int poll_mode, replica_shift, nap;
+    int T, B, H;
+};
+
+bool halo_lstm_persist2_ok(int T, int B, int H, int L);   // shape, arithmetic mode (bf16), CU count, switch
+void halo_lstm_persist2_enable(int on);
+int halo_lstm_persist2_fwd(const Persist2Fwd &a, hipStream_t st);
+int halo_lstm_persist2_bwd(const Persist2Bwd &a, hipStream_t st);

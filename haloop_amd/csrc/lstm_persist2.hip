@@ -1,0 +1,531 @@
+// Both layers of a 2-layer LSTM stack in ONE weight-resident persistent launch per direction (gfx950; SURVEY.md K3 and section 7,
+// "layer-wavefront pipelining: layer 1 step t overlaps layer 0 step t+1"; ha/rnn.py:11,25 is the 2-layer nn.LSTM this replaces).
+//
+// Why.  lstm_persist.hip runs one layer per launch: 21 dependent steps per layer and direction, each ending in a group-wide
+// hand-off that costs more than the step's arithmetic, so the four chains of a training step are 84 hand-offs
+// back to back while the matrix pipes idle.  Layer 1's step t needs layer 0's step t and its own step t-1 only, so here a
+// COMBINED step s computes layer 0 at time s and layer 1 at time s-1 in the same workgroup, and the T+1 combined steps pay
+// ONE hand-off each: the pieces of h0_s, dropout(h0_s) and h1_{s-1} are published together behind one epoch word.
+//
+// Decomposition.  Workgroup (jt, bt) owns hidden units [16 jt, +16) of batch rows [16 bt, +16) of BOTH layers, as in
+// lstm_persist.hip.  Waves 0-3 are layer 0 (each holds a K-quarter of W_hh0's 64 gate rows in registers), waves 4-7 are layer 1
+// (a K-quarter of W_hh1 in registers; the K-quarter of W_ih1 in LDS, one k-block per gate in registers at H=1024 so that the
+// 128 KiB tile leaves room for the reduction buffers).  Single-pass bf16 only (HALO_MATH_BF16): three split-bf16 weight tiles
+// of 256 KiB each do not fit a CU's 512 KiB register file + 160 KiB LDS; three bf16 tiles of 128 KiB do.
+// In the backward the gate gradients of layer 1 at time t feed both layer 1's recurrence (times W_hh1) and the gradient arriving
+// at layer 0 (times W_ih1): waves 4-7 multiply the SAME fragments by both matrices (W_hh1^T in registers, W_ih1^T in LDS), so
+// the batched input-gradient GEMM between the chains and its operand images disappear too.
+//
+// Hand-off protocol, epoch words, block placement: lstm_persist.hip / lstm_persist_dev.h, unchanged.
+#include <stdlib.h>
+#include "halo_common.h"
+#include "halo_internal.h"
+#include "lstm_persist.h"
+#include "lstm_persist_dev.h"
+
+namespace {
+
+// ================================================================================================================
+// forward
+// ================================================================================================================
+// KBQ: k-blocks (32 deep) per wave = H / 128 (a K-quarter).
+template <int KBQ>
+__global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist2Fwd p) {
+    constexpr int WREG = KBQ >= 8 ? 1 : 0;            // k-blocks of W_ih1 per gate that stay in registers
+    constexpr int WLDS = KBQ - WREG;                  // ... and in LDS
+    __shared__ float red[2][4][4][256];               // [layer][K-quarter][gate][batch row * 16 + hidden unit]
+    __shared__ __attribute__((aligned(16))) float hbuf[3][16][16];   // h0_t, dropout(h0_t), h1_t of the tile
+    __shared__ int s_abort;
+    __shared__ unsigned s_published;
+    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][gate][WLDS] W_ih1 fragments of 1 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wq = wave & 3;        // half 0: layer 0, half 1: layer 1
+    const int H = p.H, B = p.B, T = p.T;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb = H / 32;
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
+    const int j0 = jt * 16;
+
+    // this wave's K-quarter of its layer's recurrent matrix: gates 0..3, k-blocks [wq*KBQ, +KBQ), hi halves
+    bf16x8 wr[4][KBQ];
+    {
+        const char *wsrc = half ? p.wp1 : p.wp0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i)
+                wr[g][i] = *reinterpret_cast<const bf16x8 *>(wsrc + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
+    }
+    bf16x8 wir[4][WREG > 0 ? WREG : 1];
+    char *my_wi = wi_lds + (long)wq * 4 * WLDS * 1024 + lane * 16;      // + (g * WLDS + i) * 1024: this lane's 16 bytes
+    if (half) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
+                if (i < WREG) wir[g][i < WREG ? i : 0] = v;
+                else *reinterpret_cast<bf16x8 *>(my_wi + (g * WLDS + (i - WREG)) * 1024) = v;   // read back by this lane only
+            }
+    }
+
+    const int u = tid & 255, ci = u >> 4, cj = u & 15;   // cell threads of a layer: (batch row, hidden unit) of the tile
+    const int b = bt * 16 + ci;
+    const bool cell = b < B;
+    const long BH = (long)B * H;
+    const long e0 = (long)b * H + j0 + cj;
+    float cst = 0.f;                                     // c_{t-1} of this thread's layer
+    float gin[4] = {0.f, 0.f, 0.f, 0.f};                 // layer 0: next step's pre-activations; layer 1: b_ih1 + b_hh1
+    if (cell) {
+        cst = half ? p.c1[e0] : p.c0[e0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gin[g] = half ? p.b_ih1[(long)g * H + j0 + cj] + p.b_hh1[(long)g * H + j0 + cj]
+                          : p.gates0[(long)b * 4 * H + (long)g * H + j0 + cj];
+    }
+    const __amdgpu_buffer_rsrc_t hp0_rsrc = make_rsrc(p.hp0), hp1_rsrc = make_rsrc(p.hp1);
+    const __amdgpu_buffer_rsrc_t x_rsrc = p.xp ? make_rsrc(p.xp) : hp0_rsrc;
+    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
+    if (tid == 0) { s_abort = 0; s_published = 0; }
+
+    for (int s = 0; s <= T; ++s) {
+        if (wave == 0) stamp(p.stamps, T + 1, s, 0, lane);
+        const bool act = half ? (s >= 1) : (s < T);      // this wave's layer has a time step in combined step s ...
+        const int t = half ? s - 1 : s;                   // ... namely this one
+        // ---- epoch s: every workgroup of the batch group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-2} ----
+        bool ok = true;
+        if (s > 0 && wave == 5) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (!ok && lane == 0) {
+            s_abort = 1;
+            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();                                                             // (A)
+        if (s_abort) return;
+        if (wave == 0) stamp(p.stamps, T + 1, s, 1, lane);
+        if (act) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!half) {
+                // image s of layer 0 = h0_{s-1}, this wave's K-quarter
+                const int img = (int)((((long)s * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+                bf16x8 ah[KBQ];
+#pragma unroll
+                for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1(hp0_rsrc, img + i * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < KBQ; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wr[g][i], acc[g], 0, 0, 0);
+            } else {
+                // layer 1 at time t: input dropout(h0_t) = image t of xp (or image t+1 of layer 0 when there is no dropout),
+                // recurrent state h1_{t-1} = image t of layer 1
+                const int ximg = (int)((((long)(p.xp ? t : t + 1) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+                const int himg = (int)((((long)t * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+                // four chunks of KBQ/2 fragments -- X0, X1 (input), H0, H1 (state) -- through three register buffers: the last chunk is
+                // requested when the first has been multiplied (all 2 KBQ fragments in flight at once would not fit beside the weights)
+                constexpr int HC = KBQ / 2;
+                bf16x8 fb[3][HC];
+                auto loadx = [&](int buf, int c) {
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) fb[buf][i] = load_sc1(x_rsrc, ximg + (c * HC + i) * 2048);
+                };
+                auto loadh = [&](int buf, int c) {
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) fb[buf][i] = load_sc1(hp1_rsrc, himg + (c * HC + i) * 2048);
+                };
+                auto mmax = [&](int buf, int c) {
+#pragma unroll
+                    for (int i = 0; i < HC; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int kb = c * HC + i;
+                            const bf16x8 w = kb < WREG ? wir[g][kb < WREG ? kb : 0]
+                                                       : *reinterpret_cast<const bf16x8 *>(my_wi + (g * WLDS + (kb - WREG)) * 1024);
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][i], w, acc[g], 0, 0, 0);
+                        }
+                };
+                auto mmah = [&](int buf, int c) {
+#pragma unroll
+                    for (int i = 0; i < HC; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][i], wr[g][c * HC + i], acc[g], 0, 0, 0);
+                };
+                loadx(0, 0); loadx(1, 1); loadh(2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mmax(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                loadh(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mmax(1, 1);
+                mmah(2, 0);
+                mmah(0, 1);
+            }
+            // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + reg (batch row)
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[half][wq][g][(4 * q + e) * 16 + r] = acc[g][e];
+        }
+        lds_barrier();                                                             // (B)
+        if (wave == 0) stamp(p.stamps, T + 1, s, 2, lane);
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f, xv = 0.f;
+        if (act) {
+            if (cell) {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sum += red[half][k][g][u];
+                    pre[g] = sum + gin[g];
+                }
+                ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
+                cst = fg * cst + ig * gg;
+                h = og * fast_tanh(cst);
+                if (!half && p.xp) xv = h * dropout_mult(p.drop, (uint64_t)t * BH + (uint64_t)e0);
+            }
+            hbuf[half ? 2 : 0][ci][cj] = h;              // rows >= B: zeros
+            if (!half && p.xp) hbuf[1][ci][cj] = xv;
+        }
+        lds_barrier();                                                             // (C)
+        if (act && wq == 3) {
+            // waves 3 and 7 publish: lanes 0-31 the hi image piece of h (layer 0: image s+1; layer 1: image t+1 = s), lanes 32-63 of
+            // wave 3 the piece of dropout(h0_s) (image s of xp).  This tile is k-groups 2 (jt & 1), 2 (jt & 1) + 1 of k-block jt / 2.
+            const int sel = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
+            const float(*src)[16] = half ? hbuf[2] : hbuf[sel];
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = src[row][kg * 8 + e];
+            bf16x8 hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hi[e] = (__bf16)x[e];
+            const int within = (jt >> 1) * 2048 + (((jt & 1) * 2 + kg) * 16 + row) * 16;
+            if (!half) {
+                if (sel == 0) store_sc1(hp0_rsrc, (int)((((long)(s + 1) * NBT + bt) * nkb) * 2048) + within, hi);
+                else if (p.xp) store_sc1(x_rsrc, (int)((((long)s * NBT + bt) * nkb) * 2048) + within, hi);
+            } else if (sel == 0) {
+                store_sc1(hp1_rsrc, (int)((((long)s * NBT + bt) * nkb) * 2048) + within, hi);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
+            // the last storing wave of the step to get here signals for the workgroup (counter in LDS: Guideline 16); through
+            // combined step s layer 0 has stored min(s + 1, T) times, layer 1 s times
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(&s_published, 1u);
+            old = __builtin_amdgcn_readfirstlane(old);
+            const unsigned target = (unsigned)((s + 1 < T ? s + 1 : T) + s);
+            if (old + 1u == target) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+        }
+        if (act && cell) {
+            float *gp = (half ? p.gates1 : p.gates0) + ((long)t * B + b) * 4 * H + j0 + cj;
+            gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
+            (half ? p.c1 : p.c0)[(long)(t + 1) * BH + e0] = cst;
+            (half ? p.h1 : p.h0)[(long)(t + 1) * BH + e0] = h;
+            if (!half) {
+                if (p.ydrop) p.ydrop[(long)t * BH + e0] = xv;
+                if (t + 1 < T) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((long)(t + 1) * B + b) * 4 * H + (long)g * H + j0 + cj];
+                }
+            } else if (p.y_mode != 0) {
+                p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
+            }
+        }
+    }
+}
+
+// ================================================================================================================
+// backward
+// ================================================================================================================
+// KC: chunks of 4 k-blocks per wave = (4H / 32 / 4) / 4 = H / 128.
+template <int KC>
+__global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist2Bwd p) {
+    constexpr int KBW = 4 * KC;                          // k-blocks per wave (a quarter of the 4H-deep contraction)
+    __shared__ float red[3][4][256];                     // [layer 0 recurrent | layer 1 recurrent | from layer 1 into layer 0][K-quarter]
+    __shared__ __attribute__((aligned(16))) float dgbuf[2][4][16][16];
+    __shared__ int s_abort;
+    __shared__ unsigned s_published;
+    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][KBW] W_ih1^T fragments of 1 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wq = wave & 3;
+    const int H = p.H, B = p.B, T = p.T, K = 4 * H;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb4 = K / 32;
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
+    const int j0 = jt * 16;
+
+    // this wave's K-quarter of its layer's W_hh^T: columns j0..j0+15, k-blocks [wq*KBW, +KBW)
+    bf16x8 wr[KBW];
+    {
+        const char *wsrc = half ? p.wpT1 : p.wpT0;
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) wr[i] = *reinterpret_cast<const bf16x8 *>(wsrc + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
+    }
+    char *my_wi = wi_lds + (long)wq * KBW * 1024 + lane * 16;
+    if (half) {
+#pragma unroll
+        for (int i = 0; i < KBW; ++i)
+            *reinterpret_cast<bf16x8 *>(my_wi + i * 1024) =
+                *reinterpret_cast<const bf16x8 *>(p.wpTi + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
+    }
+
+    const int u = tid & 255, ci = u >> 4, cj = u & 15;
+    const int b = bt * 16 + ci;
+    const bool cell = b < B;
+    const long BH = (long)B * H;
+    const long e0 = (long)b * H + j0 + cj;
+    float *gates = half ? p.gates1 : p.gates0;
+    const float *cbuf = half ? p.c1 : p.c0;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cprev = 0.f, dyv = 0.f, dcarry = 0.f, dh0 = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cell) {
+        const int t = T - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = gates[((long)t * B + b) * K + (long)g * H + j0 + cj];
+        cc = cbuf[(long)(t + 1) * BH + e0];
+        cprev = cbuf[(long)t * BH + e0];
+        if (half && p.dy) dyv = p.dy[(long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+        const float *dci = half ? p.dcinit1 : p.dcinit0, *dhi = half ? p.dhinit1 : p.dhinit0;
+        if (dci) dcarry = dci[e0];
+        if (dhi) dh0 = dhi[e0];
+    }
+    const __amdgpu_buffer_rsrc_t dg_rsrc = make_rsrc(half ? p.dgp1 : p.dgp0);     // the image this wave READS (its own layer's)
+    const __amdgpu_buffer_rsrc_t dg0_rsrc = make_rsrc(p.dgp0), dg1_rsrc = make_rsrc(p.dgp1);
+    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
+    if (tid == 0) { s_abort = 0; s_published = 0; }
+
+    for (int s = 0; s <= T; ++s) {
+        if (wave == 0) stamp(p.stamps, T + 1, s, 0, lane);
+        const bool act = half ? (s < T) : (s >= 1);      // this half's layer has a cell update in combined step s ...
+        const int t = half ? T - 1 - s : T - s;           // ... at this time
+        // layer 1's waves contract dG1 of time T-s (steps 1 .. T): for their own recurrence (s < T) and for layer 0 (always);
+        // layer 0's waves contract dG0 of time T-s+1 (steps 2 .. T)
+        const bool mm = half ? (s >= 1) : (s >= 2);
+        const int timg = half ? T - s : T - s + 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        bool ok = true;
+        if (s > 0 && wave == 7) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (!ok && lane == 0) {
+            s_abort = 1;
+            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();                                                             // (A)
+        if (s_abort) return;
+        if (mm) {
+            const int img = (int)((((long)timg * NBT + bt) * nkb4 + wq * KBW) * 2048) + lane * 16;
+            bf16x8 ah[2][4];
+            auto load4 = [&](int buf, int c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ah[buf][i] = load_sc1(dg_rsrc, img + (c * 4 + i) * 2048);
+            };
+            load4(0, 0);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) load4((c + 1) & 1, c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c & 1][i], wr[c * 4 + i], acc, 0, 0, 0);
+                    if (half) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(my_wi + (c * 4 + i) * 1024);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c & 1][i], w, acc2, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        {
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[half][wq][(4 * q + e) * 16 + r] = acc[e];
+                if (half) red[2][wq][(4 * q + e) * 16 + r] = acc2[e];
+            }
+        }
+        lds_barrier();                                                             // (B)
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            if (cell) {
+                float dh = 0.f;
+                if (half) {
+                    if (s == 0) dh = dh0;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dh += red[1][k][u];
+                    }
+                } else {
+                    float rec = 0.f, above = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { rec += red[0][k][u]; above += red[2][k][u]; }
+                    above *= dropout_mult(p.drop, (uint64_t)t * BH + (uint64_t)e0);       // layer 0's own output mask
+                    dh = (s == 1 ? dh0 : rec) + above;
+                }
+                const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+                const float tc = fast_tanh(cc);
+                if (half && p.dy) {
+                    float d = dyv;
+                    if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
+                    dh += d;
+                }
+                const float dcc = dcarry + dh * og * (1.f - tc * tc);
+                const float d_o = dh * tc;
+                const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
+                dcarry = dcc * fg;
+                dg[0] = d_i * ig * (1.f - ig);
+                dg[1] = d_f * fg * (1.f - fg);
+                dg[2] = d_g * (1.f - gg * gg);
+                dg[3] = d_o * og * (1.f - og);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgbuf[half][g][ci][cj] = dg[g];
+        }
+        lds_barrier();                                                             // (C)
+        if (half) {
+            // waves 4-7 pack: wave 4 + g takes gate g; lanes 0-31 layer 1's piece (time T-1-s, steps 0 .. T-1), lanes 32-63 layer
+            // 0's (time T-s, steps 1 .. T).  Gate g's columns j0..j0+15 are k-groups 2 (jt & 1), 2 (jt & 1) + 1 of k-block g H/32 + jt/2.
+            const int g = wq, lay = lane < 32 ? 1 : 0, kg = (lane >> 4) & 1, row = lane & 15;
+            const bool on = lay ? (s < T) : (s >= 1);
+            const int tt = lay ? T - 1 - s : T - s;
+            bf16x8 hi;
+            if (on) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = dgbuf[lay][g][row][kg * 8 + e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hi[e] = (__bf16)x[e];
+                const int dst = (int)((((long)tt * NBT + bt) * nkb4 + g * (H / 32) + (jt >> 1)) * 2048) + (((jt & 1) * 2 + kg) * 16 + row) * 16;
+                if (lay) store_sc1(dg1_rsrc, dst, hi);
+                else store_sc1(dg0_rsrc, dst, hi);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(&s_published, 1u);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            // ---- off the hand-off path: the tile in the GEMM operand images (hi parts; gemm_bf16x3.hip layout) ----
+            if (on) {
+                char *img_rows = lay ? nullptr : p.img_rows0;
+                char *img_cols = lay ? p.img_cols1 : p.img_cols0;
+                if (img_rows) {          // rows tt*B + b, k = g*H + j0 + 8 kg ..
+                    const int grow = tt * B + bt * 16 + row, kcol = g * H + j0 + kg * 8;
+                    const long blk = ((long)(grow >> 7) * nkb4 + (kcol >> 5)) * 2;
+                    const int r = grow & 127, c = (kcol & 31) >> 3;
+                    *reinterpret_cast<bf16x8 *>(img_rows + blk * 8192 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = hi;
+                }
+                if (img_cols) {          // rows g*H + j0 + row (hidden unit), k = tt*B + bt*16 + 8 kg ..
+                    bf16x8 hit;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hit[e] = (__bf16)dgbuf[lay][g][kg * 8 + e][row];
+                    const int grow = g * H + j0 + row, kcol = tt * B + bt * 16 + kg * 8;
+                    const int KT = (T * B + 31) >> 5;
+                    const long blk = ((long)(grow >> 7) * KT + (kcol >> 5)) * 2;
+                    const int r = grow & 127, c = (kcol & 31) >> 3;
+                    *reinterpret_cast<bf16x8 *>(img_cols + blk * 8192 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = hit;
+                }
+            }
+        }
+        if (act && cell) {
+            float *gp = gates + ((long)t * B + b) * K + j0 + cj;
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
+            if (t > 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv[g] = gates[((long)(t - 1) * B + b) * K + (long)g * H + j0 + cj];
+                cc = cprev;
+                cprev = cbuf[(long)(t - 1) * BH + e0];
+                if (half && p.dy) dyv = p.dy[(long)(t - 1) * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+            }
+        }
+    }
+    {
+        float *dc = half ? p.dc1 : p.dc0;
+        if (cell && dc) dc[e0] = dcarry;
+    }
+    float *bias_part = half ? p.bias_part1 : p.bias_part0;
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dgbuf[half][g][ci][cj] = bsum[g];              // rows >= B hold zeros
+    lds_barrier();
+    if (bias_part && u < 64) {
+        const int g = u >> 4, j = u & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += dgbuf[half][g][r][j];
+        bias_part[(long)bt * K + (long)g * H + j0 + j] = sum;
+    }
+}
+
+int g_cu_count2 = 0;
+int g_persist2_enabled = 1;
+inline int cu_count2() {
+    if (!g_cu_count2) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count2 = prop.multiProcessorCount;
+        else g_cu_count2 = -1;
+    }
+    return g_cu_count2;
+}
+
+constexpr size_t MIN_DYN_LDS = 64 * 1024;             // with the static arrays: more than half a CU's LDS -> one workgroup per CU
+
+template <typename K, typename A>
+int launch2(K kernel, const A &a0, int blocks, size_t dyn, hipStream_t st) {
+    static_assert(sizeof(A) <= 4096, "kernel arguments");
+    A a = a0;
+    static const int shift = getenv("HALO_PERSIST_REPLICA_SHIFT") ? atoi(getenv("HALO_PERSIST_REPLICA_SHIFT")) : 3;
+    static const int nap = getenv("HALO_PERSIST_NAP") ? atoi(getenv("HALO_PERSIST_NAP")) : 2;
+    a.poll_mode = 0; a.replica_shift = shift; a.nap = nap;
+    if (dyn < MIN_DYN_LDS) dyn = MIN_DYN_LDS;
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return HALO_ELAUNCH;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), dyn, st, a);
+    return halo_launch_status();
+}
+
+}  // namespace
+
+void halo_lstm_persist2_enable(int on) { g_persist2_enabled = on ? 1 : 0; }
+
+bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
+    static const bool env_off = getenv("HALO_LSTM_PERSIST2") && atoi(getenv("HALO_LSTM_PERSIST2")) == 0;
+    if (env_off || !g_persist2_enabled) return false;
+    if (!halo_lstm_persist_ok(B, H)) return false;                         // the per-layer recurrence's shape / switch / CU rules
+    if (halo_math_mode() != HALO_MATH_BF16 || L != 2) return false;
+    if (H % 128 != 0 || H > 1024 || T < 1) return false;
+    // image byte offsets are 32-bit (buffer addressing): the largest is the backward's, (T + 1) images of ceil(B/16) * 4H/32 blocks
+    const long nbt = (B + 15) / 16;
+    if ((long)(T + 1) * nbt * (4 * H / 32) * 2048 >= (1L << 31)) return false;
+    return (H / 16) * nbt <= cu_count2();
+}
+
+int halo_lstm_persist2_fwd(const Persist2Fwd &a, hipStream_t st) {
+    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
+    const int kbq = a.H / 128;
+    const size_t dyn = (size_t)16 * 1024 * (kbq >= 8 ? kbq - 1 : kbq);
+    switch (kbq) {
+        case 2: return launch2(lstm_persist2_fwd_kernel<2>, a, blocks, dyn, st);
+        case 4: return launch2(lstm_persist2_fwd_kernel<4>, a, blocks, dyn, st);
+        case 6: return launch2(lstm_persist2_fwd_kernel<6>, a, blocks, dyn, st);
+        case 8: return launch2(lstm_persist2_fwd_kernel<8>, a, blocks, dyn, st);
+        default: return HALO_ENOTSUP;
+    }
+}
+
+int halo_lstm_persist2_bwd(const Persist2Bwd &a, hipStream_t st) {
+    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
+    const int kc = a.H / 128;
+    const size_t dyn = (size_t)4 * 4 * kc * 1024;     // 4 quarters x KBW fragments of 1 KiB
+    switch (kc) {
+        case 2: return launch2(lstm_persist2_bwd_kernel<2>, a, blocks, dyn, st);
+        case 4: return launch2(lstm_persist2_bwd_kernel<4>, a, blocks, dyn, st);
+        case 6: return launch2(lstm_persist2_bwd_kernel<6>, a, blocks, dyn, st);
+        case 8: return launch2(lstm_persist2_bwd_kernel<8>, a, blocks, dyn, st);
+        default: return HALO_ENOTSUP;
+    }
+}

@@ -185,7 +185,9 @@ class LstmCtcTrainer:
         B, T, F, Cc, H, Tp, L = dims
         ws = ops.lstm_bwd_workspace(y_sub, w_hh)
         dy_sub = torch.empty_like(y_sub)
-        top = L - 1 if L > 1 else 0
+        # one process: the whole stack in one call (a 2-layer stack in bf16 mode then runs as ONE two-layer persistent launch,
+        # csrc/lstm_persist2.hip); data parallel: the top layer first, so that the first gradient bucket is final early
+        top = (L - 1 if L > 1 else 0) if self.world > 1 else 0
         ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(top, L),
                      workspace=ws, dx=dy_sub)
         return (y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 10
+#define HALO_ABI_VERSION 11
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -240,6 +240,13 @@ int halo_set_lstm_persistent(int on);
  * (HALO_PERSIST_EMIT=0 / halo_set_lstm_persistent_images(0): off). */
 int halo_set_lstm_persistent_images(int on);
 int halo_lstm_persistent_eligible(int B, int H);
+/* Two-layer persistent recurrence (csrc/lstm_persist2.hip): for L == 2 in the single-pass bf16 arithmetic mode (HALO_MATH_BF16) and a
+ * shape the persistent recurrence takes, halo_lstm_fwd runs BOTH layers' T steps in one launch of T + 1 combined steps (layer 0 at
+ * time s beside layer 1 at time s - 1: one hand-off per combined step, layer 1's input projection inside its step), and halo_lstm_bwd
+ * called with layer_begin = 0, layer_end = 2 likewise (layer 1's input gradient formed inside the launch).  Same reserve contents as
+ * the per-layer path, so either backward follows either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
+int halo_set_lstm_persistent2(int on);
+int halo_lstm_persistent2_eligible(int T, int B, int H, int L);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 
 /* Diagnostic: device buffer of uint64 [blocks][T][16] that the persistent forward fills with 100 MHz time stamps of its phases

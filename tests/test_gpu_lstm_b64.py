@@ -272,3 +272,67 @@ def test_front_end_backward_in_two_launches(B, T, C, p):
         np.testing.assert_allclose(dw.double().numpy(), w.grad.numpy(), rtol=0, atol=3e-6 * float(w.grad.abs().max()))
         np.testing.assert_allclose(db.double().numpy(), bias.grad.numpy(), rtol=0, atol=3e-6 * float(bias.grad.abs().max()))
     np.testing.assert_allclose(res[True][0].numpy(), res[False][0].numpy(), rtol=0, atol=2e-6 * float(w.grad.abs().max()))
+
+
+def _normalised_close(a, b, rtol, atol):
+    for k in a:
+        scale = float(b[k].abs().max()) + 1e-12
+        np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, err_msg=k, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,p_drop,with_state', [
+    (7, 5, 40, 256, 0.0, True),             # 16 workgroups, one ragged batch tile, carried state, exact-f32 input projection (in0 < 64)
+    (6, 16, 128, 768, 0.25, False),         # inter-layer dropout: layer 1 reads the dropped image, the backward applies the mask
+    (9, 33, 64, 512, 0.0, False),           # 3 batch tiles (plain block map), no dropout: layer 1 reads layer 0's own images
+    (21, 64, 128, 1024, 0.2, False),        # the benchmark's grid: 256 workgroups, W_ih1 split between registers and LDS
+    (1, 32, 128, 1024, 0.2, True),          # a single time step: combined steps 0 and 1 only
+])
+def test_two_layer_launch_equals_layer_launches(hal, math_mode, T, B, in0, H, p_drop, with_state):
+    """csrc/lstm_persist2.hip (both layers in one persistent launch per direction, bf16 mode) computes what the two per-layer
+    persistent launches with the batched GEMMs between them compute: the same bf16 operands, fp32 sums in another order (a state
+    element whose fp32 value moves across a bf16 rounding boundary moves its bf16 image by one unit: the bounds below)."""
+    lib = hal['lib']
+    assert lib.lib().halo_lstm_persistent2_eligible(T, B, H, 2) == 1
+    a, st_a = _lstm_case(hal, T, B, in0, H, 2, p_drop, 5, with_state)
+    lib.set_lstm_persistent2(False)
+    try:
+        assert lib.lib().halo_lstm_persistent2_eligible(T, B, H, 2) == 0
+        b, st_b = _lstm_case(hal, T, B, in0, H, 2, p_drop, 5, with_state)
+    finally:
+        lib.set_lstm_persistent2(True)
+    assert st_a == (0, 0) and st_b == (0, 0)
+    _normalised_close(a, b, rtol=5e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_split_backward_follows_the_two_layer_forward(hal, math_mode):
+    """The two-layer forward leaves the reserve the per-layer backward expects: backward called layer by layer (the data-parallel
+    step does, haloop_amd/train.py) after the fused forward equals the one-call two-layer backward."""
+    ops, lib = hal['ops'], hal['lib']
+    T, B, in0, H, L = 8, 32, 128, 512, 2
+    g = torch.Generator().manual_seed(11)
+    k = 1.0 / H ** 0.5
+    x = torch.randn(T, B, in0, generator=g).to(DEV)
+    w_ih = [((torch.rand(4 * H, in0 if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_ih = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_hh = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    dy = torch.randn(T, B, H, generator=g).to(DEV)
+    drop = ops.Dropout(0.2, 77, 1)
+    outs = []
+    for split in (False, True):
+        y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, drop=drop)
+        ws = ops.lstm_bwd_workspace(x, w_hh)
+        if split:
+            _, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, drop=drop, workspace=ws, layers=(1, 2))
+            dx, grads = ops.lstm_bwd(x, w_ih, w_hh, None, (B * H, H), False, reserve, drop=drop, workspace=ws, layers=(0, 1), grads=grads,
+                                     want_dx=True)
+        else:
+            dx, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, drop=drop, workspace=ws, want_dx=True)
+        out = {'y': y.cpu(), 'dx': dx.cpu()}
+        for name, lst in grads.items():
+            for l, t in enumerate(lst):
+                out[f'{name}{l}'] = t.cpu()
+        outs.append(out)
+    _normalised_close(outs[0], outs[1], rtol=5e-3, atol=2e-3)
