@@ -1201,7 +1201,7 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y ? (y_relu ? 2 : 1) : 0;
     a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
     a.flags = flags;
-    a.stamps = nullptr;
+    a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 2][16] here
     a.T = T; a.B = B; a.H = H;
     chain_begin(st);
     HALO_TRY(halo_lstm_persist2_fwd(a, st));

@@ -31,13 +31,16 @@ namespace {
 // KBQ: k-blocks (32 deep) per wave = H / 128 (a K-quarter).
 template <int KBQ>
 __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist2Fwd p) {
-    constexpr int WREG = KBQ >= 8 ? 1 : 0;            // k-blocks of W_ih1 per gate that stay in registers
-    constexpr int WLDS = KBQ - WREG;                  // ... and in LDS
+    // W_ih1's K-quarter is 4 KBQ fragments of 1 KiB per layer-1 wave, kept in LDS; at KBQ = 8 the four quarters (128 KiB) and the
+    // reduction buffers (32 KiB) would be the whole 160 KiB, so the first NWREG fragments (gates 0 .. NWREG-1 of k-block 0) stay
+    // in registers -- as few as make room for hbuf: the register file is as full as the LDS
+    constexpr int NWREG = KBQ >= 8 ? 2 : 0;
+    constexpr int NWLDS = 4 * KBQ - NWREG;
     __shared__ float red[2][4][4][256];               // [layer][K-quarter][gate][batch row * 16 + hidden unit]
     __shared__ __attribute__((aligned(16))) float hbuf[3][16][16];   // h0_t, dropout(h0_t), h1_t of the tile
     __shared__ int s_abort;
     __shared__ unsigned s_published;
-    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][gate][WLDS] W_ih1 fragments of 1 KiB
+    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][NWLDS] W_ih1 fragments of 1 KiB (k-block major, gate minor)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, wq = wave & 3;        // half 0: layer 0, half 1: layer 1
@@ -57,32 +60,31 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
             for (int i = 0; i < KBQ; ++i)
                 wr[g][i] = *reinterpret_cast<const bf16x8 *>(wsrc + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
     }
-    bf16x8 wir[4][WREG > 0 ? WREG : 1];
-    char *my_wi = wi_lds + (long)wq * 4 * WLDS * 1024 + lane * 16;      // + (g * WLDS + i) * 1024: this lane's 16 bytes
+    bf16x8 wir[NWREG > 0 ? NWREG : 1];
+    char *my_wi = wi_lds + (long)wq * NWLDS * 1024 + lane * 16;         // + (i * 4 + g - NWREG) * 1024: this lane's 16 bytes
     if (half) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int i = 0; i < KBQ; ++i)
 #pragma unroll
-            for (int i = 0; i < KBQ; ++i) {
+            for (int g = 0; g < 4; ++g) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
-                if (i < WREG) wir[g][i < WREG ? i : 0] = v;
-                else *reinterpret_cast<bf16x8 *>(my_wi + (g * WLDS + (i - WREG)) * 1024) = v;   // read back by this lane only
+                if (i * 4 + g < NWREG) wir[i * 4 + g < NWREG ? i * 4 + g : 0] = v;
+                else *reinterpret_cast<bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024) = v;       // read back by this lane only
             }
     }
 
     const int u = tid & 255, ci = u >> 4, cj = u & 15;   // cell threads of a layer: (batch row, hidden unit) of the tile
     const int b = bt * 16 + ci;
     const bool cell = b < B;
-    const long BH = (long)B * H;
-    const long e0 = (long)b * H + j0 + cj;
+    const int BH = B * H;                                // element counts of a layer fit 31 bits (halo_lstm_persist2_ok)
+    const int e0 = b * H + j0 + cj;
     float cst = 0.f;                                     // c_{t-1} of this thread's layer
     float gin[4] = {0.f, 0.f, 0.f, 0.f};                 // layer 0: next step's pre-activations; layer 1: b_ih1 + b_hh1
     if (cell) {
         cst = half ? p.c1[e0] : p.c0[e0];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            gin[g] = half ? p.b_ih1[(long)g * H + j0 + cj] + p.b_hh1[(long)g * H + j0 + cj]
-                          : p.gates0[(long)b * 4 * H + (long)g * H + j0 + cj];
+            gin[g] = half ? p.b_ih1[g * H + j0 + cj] + p.b_hh1[g * H + j0 + cj] : p.gates0[b * 4 * H + g * H + j0 + cj];
     }
     const __amdgpu_buffer_rsrc_t hp0_rsrc = make_rsrc(p.hp0), hp1_rsrc = make_rsrc(p.hp1);
     const __amdgpu_buffer_rsrc_t x_rsrc = p.xp ? make_rsrc(p.xp) : hp0_rsrc;
@@ -90,80 +92,47 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
     const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
     if (tid == 0) { s_abort = 0; s_published = 0; }
 
-    for (int s = 0; s <= T; ++s) {
-        if (wave == 0) stamp(p.stamps, T + 1, s, 0, lane);
-        const bool act = half ? (s >= 1) : (s < T);      // this wave's layer has a time step in combined step s ...
-        const int t = half ? s - 1 : s;                   // ... namely this one
-        // ---- epoch s: every workgroup of the batch group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-2} ----
+    // Combined step s = 0 .. T+1: layer 0 at time s, layer 1 at time s - 2.  Layer 1 lags TWO steps so that its input half,
+    // dropout(h0_t) W_ih1^T, is not on the hand-off path: the image of dropout(h0_{s-1}) was complete when this step's poll matched,
+    // so waves 4-7 multiply it at the END of step s, in the shadow of the next hand-off (when every wave would otherwise sit at the
+    // barrier), and the sums (xacc) seed the accumulators of layer 1's step s+1.  On the path a layer-1 wave then does what a
+    // layer-0 wave does: KBQ fragment loads and 4 KBQ MFMAs against register-resident weights.  Both layers' pieces are packed
+    // and published by layer-0 waves (2: h1, 3: h0 and dropout(h0)), so the layer-1 waves go from the cell update straight to
+    // their input fragments: those loads are then under way before the epoch stores and polls of the hand-off use the CU's
+    // memory queue.
+    f32x4 xacc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s <= T + 1; ++s) {
+        if (wave == 0) stamp(p.stamps, T + 2, s, 0, lane);
+        if (wave == 4) stamp(p.stamps, T + 2, s, 8, lane);
+        const bool act0 = s < T, act1 = s >= 2;          // layer 0 at time s, layer 1 at time s - 2
+        const bool act = half ? act1 : act0;              // this wave's layer has a time step in combined step s ...
+        const int t = half ? s - 2 : s;                   // ... namely this one
+        // ---- epoch s: every workgroup of the batch group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-3} ----
         bool ok = true;
-        if (s > 0 && wave == 5) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
             s_abort = 1;
             __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();                                                             // (A)
         if (s_abort) return;
-        if (wave == 0) stamp(p.stamps, T + 1, s, 1, lane);
+        if (wave == 0) stamp(p.stamps, T + 2, s, 1, lane);
         if (act) {
+            // layer 0: image s = h0_{s-1}; layer 1: image t = h1_{t-1}; this wave's K-quarter
+            const int img = (int)((((long)(half ? t : s) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+            bf16x8 ah[KBQ];
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1(half ? hp1_rsrc : hp0_rsrc, img + i * 2048);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!half) {
-                // image s of layer 0 = h0_{s-1}, this wave's K-quarter
-                const int img = (int)((((long)s * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
-                bf16x8 ah[KBQ];
+            for (int g = 0; g < 4; ++g) acc[g] = half ? xacc[g] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1(hp0_rsrc, img + i * 2048);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < KBQ; ++i)
 #pragma unroll
-                for (int i = 0; i < KBQ; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wr[g][i], acc[g], 0, 0, 0);
-            } else {
-                // layer 1 at time t: input dropout(h0_t) = image t of xp (or image t+1 of layer 0 when there is no dropout),
-                // recurrent state h1_{t-1} = image t of layer 1
-                const int ximg = (int)((((long)(p.xp ? t : t + 1) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
-                const int himg = (int)((((long)t * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
-                // four chunks of KBQ/2 fragments -- X0, X1 (input), H0, H1 (state) -- through three register buffers: the last chunk is
-                // requested when the first has been multiplied (all 2 KBQ fragments in flight at once would not fit beside the weights)
-                constexpr int HC = KBQ / 2;
-                bf16x8 fb[3][HC];
-                auto loadx = [&](int buf, int c) {
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) fb[buf][i] = load_sc1(x_rsrc, ximg + (c * HC + i) * 2048);
-                };
-                auto loadh = [&](int buf, int c) {
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) fb[buf][i] = load_sc1(hp1_rsrc, himg + (c * HC + i) * 2048);
-                };
-                auto mmax = [&](int buf, int c) {
-#pragma unroll
-                    for (int i = 0; i < HC; ++i)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int kb = c * HC + i;
-                            const bf16x8 w = kb < WREG ? wir[g][kb < WREG ? kb : 0]
-                                                       : *reinterpret_cast<const bf16x8 *>(my_wi + (g * WLDS + (kb - WREG)) * 1024);
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][i], w, acc[g], 0, 0, 0);
-                        }
-                };
-                auto mmah = [&](int buf, int c) {
-#pragma unroll
-                    for (int i = 0; i < HC; ++i)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][i], wr[g][c * HC + i], acc[g], 0, 0, 0);
-                };
-                loadx(0, 0); loadx(1, 1); loadh(2, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mmax(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                loadh(0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mmax(1, 1);
-                mmah(2, 0);
-                mmah(0, 1);
-            }
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wr[g][i], acc[g], 0, 0, 0);
             // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + reg (batch row)
             const int r = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -172,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
                 for (int e = 0; e < 4; ++e) red[half][wq][g][(4 * q + e) * 16 + r] = acc[g][e];
         }
         lds_barrier();                                                             // (B)
-        if (wave == 0) stamp(p.stamps, T + 1, s, 2, lane);
+        if (wave == 0) stamp(p.stamps, T + 2, s, 2, lane);
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f, xv = 0.f;
         if (act) {
             if (cell) {
@@ -187,17 +156,19 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
                 ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
                 cst = fg * cst + ig * gg;
                 h = og * fast_tanh(cst);
-                if (!half && p.xp) xv = h * dropout_mult(p.drop, (uint64_t)t * BH + (uint64_t)e0);
+                if (!half && p.xp) xv = h * dropout_mult(p.drop, (uint64_t)((long)t * BH + e0));
             }
             hbuf[half ? 2 : 0][ci][cj] = h;              // rows >= B: zeros
             if (!half && p.xp) hbuf[1][ci][cj] = xv;
         }
         lds_barrier();                                                             // (C)
-        if (act && wq == 3) {
-            // waves 3 and 7 publish: lanes 0-31 the hi image piece of h (layer 0: image s+1; layer 1: image t+1 = s), lanes 32-63 of
-            // wave 3 the piece of dropout(h0_s) (image s of xp).  This tile is k-groups 2 (jt & 1), 2 (jt & 1) + 1 of k-block jt / 2.
+        if (wave == 0) stamp(p.stamps, T + 2, s, 3, lane);
+        if ((wave == 3 && act0) || (wave == 2 && act1)) {
+            // wave 3: lanes 0-31 the hi image piece of h0_s (image s+1 of layer 0), lanes 32-63 the piece of dropout(h0_s) (image s of
+            // xp); wave 2: lanes 0-31 the piece of h1_{s-2} (image s-1 of layer 1).  The tile is k-groups 2 (jt & 1), 2 (jt & 1) + 1 of
+            // k-block jt / 2.
             const int sel = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
-            const float(*src)[16] = half ? hbuf[2] : hbuf[sel];
+            const float(*src)[16] = wave == 2 ? hbuf[2] : hbuf[sel];
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = src[row][kg * 8 + e];
@@ -205,35 +176,62 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
 #pragma unroll
             for (int e = 0; e < 8; ++e) hi[e] = (__bf16)x[e];
             const int within = (jt >> 1) * 2048 + (((jt & 1) * 2 + kg) * 16 + row) * 16;
-            if (!half) {
+            if (wave == 3) {
                 if (sel == 0) store_sc1(hp0_rsrc, (int)((((long)(s + 1) * NBT + bt) * nkb) * 2048) + within, hi);
                 else if (p.xp) store_sc1(x_rsrc, (int)((((long)s * NBT + bt) * nkb) * 2048) + within, hi);
             } else if (sel == 0) {
-                store_sc1(hp1_rsrc, (int)((((long)s * NBT + bt) * nkb) * 2048) + within, hi);
+                store_sc1(hp1_rsrc, (int)((((long)(s - 1) * NBT + bt) * nkb) * 2048) + within, hi);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
             // the last storing wave of the step to get here signals for the workgroup (counter in LDS: Guideline 16); through
-            // combined step s layer 0 has stored min(s + 1, T) times, layer 1 s times
+            // combined step s layer 0 has stored min(s + 1, T) times, layer 1 max(s - 1, 0) times
             unsigned old = 0;
             if (lane == 0) old = atomicAdd(&s_published, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
-            const unsigned target = (unsigned)((s + 1 < T ? s + 1 : T) + s);
+            const unsigned target = (unsigned)((s + 1 < T ? s + 1 : T) + (s >= 2 ? s - 1 : 0));
             if (old + 1u == target) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            stamp(p.stamps, T + 2, s, wave == 3 ? 4 : 5, lane);
+        } else if (wave == 3 && !act0 && !act1) {
+            publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
         }
         if (act && cell) {
-            float *gp = (half ? p.gates1 : p.gates0) + ((long)t * B + b) * 4 * H + j0 + cj;
-            gp[0] = ig; gp[H] = fg; gp[2 * (long)H] = gg; gp[3 * (long)H] = og;
-            (half ? p.c1 : p.c0)[(long)(t + 1) * BH + e0] = cst;
-            (half ? p.h1 : p.h0)[(long)(t + 1) * BH + e0] = h;
+            float *gp = (half ? p.gates1 : p.gates0) + (t * B + b) * 4 * H + j0 + cj;
+            gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            (half ? p.c1 : p.c0)[(t + 1) * BH + e0] = cst;
+            (half ? p.h1 : p.h0)[(t + 1) * BH + e0] = h;
             if (!half) {
-                if (p.ydrop) p.ydrop[(long)t * BH + e0] = xv;
+                if (p.ydrop) p.ydrop[t * BH + e0] = xv;
                 if (t + 1 < T) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((long)(t + 1) * B + b) * 4 * H + (long)g * H + j0 + cj];
+                    for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((t + 1) * B + b) * 4 * H + g * H + j0 + cj];
                 }
             } else if (p.y_mode != 0) {
                 p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
             }
+        }
+        // ---- in the shadow of the hand-off: layer 1's input half for its NEXT step (time s - 1), from the image of dropout(h0_{s-1})
+        //      (image s-1 of xp; without dropout image s of layer 0) that this step's poll has already seen complete ----
+        if (half && s >= 1 && s <= T) {
+            const int ximg = (int)((((long)(p.xp ? s - 1 : s) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+            bf16x8 ax[KBQ];
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) ax[i] = load_sc1(x_rsrc, ximg + i * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave == 4) stamp(p.stamps, T + 2, s, 7, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) {
+                bf16x8 w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    w[g] = i * 4 + g < NWREG ? wir[i * 4 + g < NWREG ? i * 4 + g : 0]
+                                             : *reinterpret_cast<const bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[i], w[g], xacc[g], 0, 0, 0);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // at most two k-blocks' LDS fragments in flight: the registers are full
+            }
+            if (wave == 4) stamp(p.stamps, T + 2, s, 6, lane);
         }
     }
 }
@@ -500,14 +498,15 @@ bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     if (H % 128 != 0 || H > 1024 || T < 1) return false;
     // image byte offsets are 32-bit (buffer addressing): the largest is the backward's, (T + 1) images of ceil(B/16) * 4H/32 blocks
     const long nbt = (B + 15) / 16;
-    if ((long)(T + 1) * nbt * (4 * H / 32) * 2048 >= (1L << 31)) return false;
+    if ((long)(T + 2) * nbt * (4 * H / 32) * 2048 >= (1L << 31)) return false;
+    if ((long)(T + 1) * B * 4 * H >= (1L << 31)) return false;             // 32-bit element indices inside the kernels
     return (H / 16) * nbt <= cu_count2();
 }
 
 int halo_lstm_persist2_fwd(const Persist2Fwd &a, hipStream_t st) {
     const int blocks = (a.H / 16) * ((a.B + 15) / 16);
     const int kbq = a.H / 128;
-    const size_t dyn = (size_t)16 * 1024 * (kbq >= 8 ? kbq - 1 : kbq);
+    const size_t dyn = (size_t)4 * 1024 * (4 * kbq - (kbq >= 8 ? 2 : 0));      // 4 quarters x NWLDS fragments of 1 KiB
     switch (kbq) {
         case 2: return launch2(lstm_persist2_fwd_kernel<2>, a, blocks, dyn, st);
         case 4: return launch2(lstm_persist2_fwd_kernel<4>, a, blocks, dyn, st);
