@@ -136,7 +136,12 @@ SIGNATURES = {
     'halo_cast_bf16_f32': (_i, [_vp, _vp, _f, _sz, _vp]),
     'halo_scale_add_guarded': (_i, [_vp, _vp, _f, _f, _sz, _vp, _vp]),
     'halo_clip_coef_step': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp]),
-    'halo_adamw_ranges_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    'halo_adamw_ranges_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    'halo_ctx_create': (_vp, []),
+    'halo_ctx_destroy': (None, [_vp]),
+    'halo_ctx_use': (_i, [_vp]),
+    'halo_set_status_word': (_i, [_vp]),
+    'halo_debug_mute_workgroup': (_i, [_i]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw_multi_tensor_bytes': (_sz, []),
@@ -244,6 +249,54 @@ def lend_scratch(nbytes=64 << 20, device=None):
         _scratch = torch.empty(nbytes, dtype=torch.uint8, device=device or 'cuda')
         check(lib().halo_set_scratch(_scratch.data_ptr(), _scratch.numel()), 'halo_set_scratch')
     return _scratch
+
+
+class Context:
+    """A caller-owned settings record (include/halo.h, "Contexts"): created as a copy of the calling thread's current settings;
+    ``with ctx:`` makes it the record this thread's halo_* calls read and halo_set_* calls write, and restores the previous
+    selection on exit.  Two trainers (or a trainer and a recognizer) on different threads then do not share switches."""
+    _current = __import__('threading').local()
+
+    def __init__(self):
+        self.handle = lib().halo_ctx_create()
+        if not self.handle:
+            raise HaloError('halo_ctx_create failed')
+        self._prev = []
+
+    def use(self):
+        global _mode
+        check(lib().halo_ctx_use(self.handle), 'halo_ctx_use')
+        Context._current.ctx = self
+        _mode = None                      # re-read the arithmetic mode of the selected record
+
+    def __enter__(self):
+        self._prev.append(getattr(Context._current, 'ctx', None))
+        self.use()
+        return self
+
+    def __exit__(self, *exc):
+        global _mode
+        prev = self._prev.pop()
+        check(lib().halo_ctx_use(prev.handle if prev is not None else None), 'halo_ctx_use')
+        Context._current.ctx = prev
+        _mode = None
+        return False
+
+    def close(self):
+        if self.handle:
+            lib().halo_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_status_tensor = None
+
+
+def set_status_word(t):
+    """Lend the library a device int32/uint32 tensor of one element as its sticky status word (None: none); include/halo.h.
+    The tensor is kept alive here for as long as it is the registered word."""
+    global _status_tensor
+    check(lib().halo_set_status_word(ptr(t)), 'halo_set_status_word')
+    _status_tensor = t
 
 
 def check(rc, what):

@@ -11,6 +11,7 @@
 // updated iff p < s"; since the updated value total[p] + e[blank] does not depend on the loop,
 // all prefixes are processed in parallel with that rule applied explicitly.
 #include "halo_common.h"
+#include "halo_internal.h"
 
 namespace {
 
@@ -527,13 +528,12 @@ __global__ __launch_bounds__(256) void beam_kernel(const BeamArgs p) {
 
 }  // namespace
 
-static int g_beam_vec_chunk = 32;
 
 extern "C" {
 
 int halo_set_beam_vector_chunk(int elements) {
     if (elements != 0 && elements != 16 && elements != 32) return HALO_EINVAL;
-    g_beam_vec_chunk = elements;
+    halo_ctx_cur().beam_vec_chunk = elements;
     return HALO_OK;
 }
 
@@ -542,7 +542,7 @@ int halo_logaddexp_aten(const float *a, const float *b, float *out, size_t n, ha
     if (n == 0) return HALO_OK;
     size_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(logaddexp_probe_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, g_beam_vec_chunk);
+    hipLaunchKernelGGL(logaddexp_probe_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, halo_ctx_cur().beam_vec_chunk);
     return halo_launch_status();
 }
 
@@ -582,7 +582,7 @@ int halo_ctc_beam(const float *em, int N, int T, int V, int beam, int log_domain
     a.ws_taken = (int32_t *)(a.ws_cand + (size_t)N * beam * (1 + V));
     a.ws_qv = (float *)(a.ws_taken + (size_t)N * beam * (1 + V));
     a.queue_in_lds = queue_in_lds;
-    a.vec_chunk = g_beam_vec_chunk;
+    a.vec_chunk = halo_ctx_cur().beam_vec_chunk;
     hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(256), shmem, (hipStream_t)stream, a);
     return halo_launch_status();
 }

@@ -26,6 +26,23 @@ int halo_prep_jobs(const HaloPrepJob *jobs, int n, hipStream_t st);
 // C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);
+// ---- settings record (include/halo.h, "Contexts"): every switch the halo_set_* entries change lives here.  A thread that has selected
+// a caller-owned context with halo_ctx_use() reads and writes THAT record; every other thread the process-wide default one.
+struct HaloCtx {
+    int math_mode = 0;
+    int lstm_fusion = 0;
+    int lstm_persistent = 1, lstm_persistent2 = 1;
+    int persist_emit = -1;               // -1: HALO_PERSIST_EMIT from the environment (default on)
+    int beam_vec_chunk = 32;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int scratch_slot = 0;
+    unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
+    hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
+    unsigned long long *stamps = nullptr;
+    int mute_block = -1;                 // test hook (halo_debug_mute_workgroup): this workgroup of a persistent forward never publishes
+};
+HaloCtx &halo_ctx_cur();
 int halo_math_mode();
 int halo_lstm_fusion();   // 1: run multi-layer LSTMs as layer-diagonal fused launches (halo_set_lstm_fusion)   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
 

@@ -891,12 +891,11 @@ inline unsigned pack_grid(size_t units) {
 
 // ---- measurement hook (halo_lstm_chain_events): two events recorded on the launch stream right around a layer's recurrent
 // chain, so a caller can time the chain without the batched GEMMs / operand preparation of the same call ----
-hipEvent_t g_chain_ev0 = nullptr, g_chain_ev1 = nullptr;
 struct ChainInfo { int launches; const char *kernel; };
 ChainInfo g_chain_info[2] = {{0, ""}, {0, ""}};      // [0] forward, [1] backward: what the last chain ran as
-inline void chain_begin(hipStream_t st) { if (g_chain_ev0) (void)hipEventRecord(g_chain_ev0, st); }
+inline void chain_begin(hipStream_t st) { if (halo_ctx_cur().chain_ev0) (void)hipEventRecord(halo_ctx_cur().chain_ev0, st); }
 inline void chain_end(hipStream_t st, int dir, int launches, const char *kernel) {
-    if (g_chain_ev1) (void)hipEventRecord(g_chain_ev1, st);
+    if (halo_ctx_cur().chain_ev1) (void)hipEventRecord(halo_ctx_cur().chain_ev1, st);
     g_chain_info[dir].launches = launches;
     g_chain_info[dir].kernel = kernel;
 }
@@ -1231,8 +1230,8 @@ inline size_t bwd_p2_bytes(int T, int B, int H) {
 extern "C" {
 
 int halo_lstm_chain_events(void *ev_begin, void *ev_end) {
-    g_chain_ev0 = (hipEvent_t)ev_begin;
-    g_chain_ev1 = (hipEvent_t)ev_end;
+    halo_ctx_cur().chain_ev0 = (hipEvent_t)ev_begin;
+    halo_ctx_cur().chain_ev1 = (hipEvent_t)ev_end;
     return HALO_OK;
 }
 
@@ -1256,14 +1255,14 @@ int halo_set_lstm_persistent(int on) {
     return HALO_OK;
 }
 
-static int g_persist_emit = -1;        // -1: HALO_PERSIST_EMIT from the environment (default on)
 int halo_set_lstm_persistent_images(int on) {
-    g_persist_emit = on ? 1 : 0;
+    halo_ctx_cur().persist_emit = on ? 1 : 0;
     return HALO_OK;
 }
 static bool persist_emit_enabled() {
-    if (g_persist_emit < 0) { const char *e = getenv("HALO_PERSIST_EMIT"); g_persist_emit = e ? (atoi(e) != 0) : 1; }
-    return g_persist_emit != 0;
+    int &v = halo_ctx_cur().persist_emit;
+    if (v < 0) { const char *e = getenv("HALO_PERSIST_EMIT"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
 }
 
 int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B, H) && use_x3(H) ? 1 : 0; }

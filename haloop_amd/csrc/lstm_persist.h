@@ -23,6 +23,8 @@ struct PersistFwd {
     int y_mode;          // 0 none, 1 plain, 2 relu, 3 dropout
     DropoutCfg drop;
     unsigned *flags;     // PERSIST_FLAG_BYTES, zeroed by the launch ahead of this one (lstm.hip, persist_prologue_kernel)
+    unsigned *status;    // optional caller-owned sticky word (halo_set_status_word): set to 1 when a bounded wait times out; set by the launcher
+    int mute;            // test hook (halo_debug_mute_workgroup): the workgroup with this blockIdx never publishes (-1: none); set by the launcher
     unsigned long long *stamps;   // diagnostic: [block][T][16] s_memrealtime stamps (halo_lstm_persist_stamps), normally NULL
     int poll_mode;       // set by the launcher
     int replica_shift;   // copy of the epoch words polled = (XCC id + replica_shift) % PERSIST_REPLICAS
@@ -41,6 +43,7 @@ struct PersistBwd {
     int dy_relu;
     const float *dhinit, *dcinit;   // [B][H] added at t = T-1, may be NULL
     unsigned *flags;
+    unsigned *status;    // see PersistFwd
     unsigned long long *stamps;
     // optional: the split-bf16 tiled GEMM images of the gate gradients, written by the chain itself as each step's gradients leave the
     // cell update (gemm_bf16x3.hip layout: [row tile 128][k tile 32][hi | lo][64-byte rows, 16-byte chunks XOR-swizzled]), so that the
@@ -79,6 +82,8 @@ struct Persist2Fwd {
     int y_mode;                    // 0 none, 1 plain, 2 relu
     DropoutCfg drop;               // layer 0's output dropout (the stream of lstm.hip's Y_DROPOUT epilogue)
     unsigned *flags;
+    unsigned *status;              // see PersistFwd
+    int mute;                      // see PersistFwd
     unsigned long long *stamps;
     int poll_mode, replica_shift, nap;
     int T, B, H;
@@ -99,6 +104,7 @@ struct Persist2Bwd {
     const float *dhinit0, *dcinit0, *dhinit1, *dcinit1;   // [B][H], may be NULL
     DropoutCfg drop;                  // layer 0's output dropout mask (applied to the gradient arriving from layer 1)
     unsigned *flags;
+    unsigned *status;                 // see PersistFwd
     unsigned long long *stamps;
     // optional GEMM operand images of the gate gradients (see PersistBwd): rows image of layer 0 only (layer 1's input gradient
     // is formed in this kernel), column images of both

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
         }
         if (!ok && lane == 0) {
             s_abort = 1;
-            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_abort(p.flags, p.status);
         }
         if (wave == 5) stamp(p.stamps, T, t, 9, lane);
         if (p.poll_mode != 2) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_fwd_kernel(const PersistF
             store_sc1(hp_rsrc, dst, part ? lo : hi);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
             stamp(p.stamps, T, t, 6, lane);
-            publish_epoch(p.flags, bt * NJ + jt, (unsigned)(t + 1), lane);
+            if ((int)blockIdx.x != p.mute) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(t + 1), lane);
             stamp(p.stamps, T, t, 7, lane);
         }
         if (cell) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
             else if (wave == 7) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
             if (!ok && lane == 0) {
                 s_abort = 1;
-                __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                raise_abort(p.flags, p.status);
             }
             if (p.poll_mode != 2) {
                 lds_barrier();                                                     // (A)
@@ -394,13 +394,11 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
     }
 }
 
-unsigned long long *g_stamps = nullptr;
 int g_cu_count = 0;
 inline int poll_mode() {
     static const int m = getenv("HALO_PERSIST_POLL") ? atoi(getenv("HALO_PERSIST_POLL")) : 0;
     return m;
 }
-int g_persist_enabled = 1;
 
 inline int cu_count() {
     if (!g_cu_count) {
@@ -414,6 +412,9 @@ inline int cu_count() {
 
 constexpr size_t FORCE_ONE_PER_CU_LDS = 64 * 1024;    // dynamic LDS request on top of the static arrays: one workgroup per CU
 
+inline void set_mute(PersistFwd &a) { a.mute = halo_ctx_cur().mute_block; }
+inline void set_mute(PersistBwd &) {}
+
 template <typename K, typename A>
 int launch_persist(K kernel, const A &a0, int blocks, hipStream_t st) {
     static_assert(sizeof(A) <= 4096, "kernel arguments");
@@ -422,6 +423,8 @@ int launch_persist(K kernel, const A &a0, int blocks, hipStream_t st) {
     static const int shift = getenv("HALO_PERSIST_REPLICA_SHIFT") ? atoi(getenv("HALO_PERSIST_REPLICA_SHIFT")) : 3;
     static const int nap = getenv("HALO_PERSIST_NAP") ? atoi(getenv("HALO_PERSIST_NAP")) : 2;
     a.replica_shift = shift; a.nap = nap;
+    a.status = halo_ctx_cur().status;
+    set_mute(a);
     // a.flags is zeroed by the caller's prologue launch (lstm.hip, persist_prologue_kernel)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), FORCE_ONE_PER_CU_LDS, st, a);
     return halo_launch_status();
@@ -435,16 +438,20 @@ int allow_lds(K kernel) {
 
 }  // namespace
 
-void halo_lstm_persist_enable(int on) { g_persist_enabled = on ? 1 : 0; }
-unsigned long long *halo_lstm_persist_stamp_buffer() { return g_stamps; }
+void halo_lstm_persist_enable(int on) { halo_ctx_cur().lstm_persistent = on ? 1 : 0; }
+unsigned long long *halo_lstm_persist_stamp_buffer() { return halo_ctx_cur().stamps; }
+extern "C" int halo_debug_mute_workgroup(int block) {
+    halo_ctx_cur().mute_block = block;
+    return HALO_OK;
+}
 extern "C" int halo_lstm_persist_stamps(void *buf) {
-    g_stamps = (unsigned long long *)buf;
+    halo_ctx_cur().stamps = (unsigned long long *)buf;
     return HALO_OK;
 }
 
 bool halo_lstm_persist_ok(int B, int H) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST") && atoi(getenv("HALO_LSTM_PERSIST")) == 0;
-    if (env_off || !g_persist_enabled) return false;
+    if (env_off || !halo_ctx_cur().lstm_persistent) return false;
     if (halo_math_mode() == HALO_MATH_F32) return false;
     if (H % 256 != 0 || H > 1024 || B <= 0) return false;
     const int blocks = (H / 16) * ((B + 15) / 16);

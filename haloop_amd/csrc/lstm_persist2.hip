@@ -29,137 +29,100 @@ namespace {
 // forward
 // ================================================================================================================
 // KBQ: k-blocks (32 deep) per wave = H / 128 (a K-quarter).
-template <int KBQ>
-__global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist2Fwd p) {
-    // W_ih1's K-quarter is 4 KBQ fragments of 1 KiB per layer-1 wave, kept in LDS; at KBQ = 8 the four quarters (128 KiB) and the
-    // reduction buffers (32 KiB) would be the whole 160 KiB, so the first NWREG fragments (gates 0 .. NWREG-1 of k-block 0) stay
-    // in registers -- as few as make room for hbuf: the register file is as full as the LDS
-    constexpr int NWREG = KBQ >= 8 ? 2 : 0;
-    constexpr int NWLDS = 4 * KBQ - NWREG;
-    __shared__ float red[2][4][4][256];               // [layer][K-quarter][gate][batch row * 16 + hidden unit]
-    __shared__ __attribute__((aligned(16))) float hbuf[3][16][16];   // h0_t, dropout(h0_t), h1_t of the tile
-    __shared__ int s_abort;
-    __shared__ unsigned s_published;
-    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][NWLDS] W_ih1 fragments of 1 KiB (k-block major, gate minor)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, wq = wave & 3;        // half 0: layer 0, half 1: layer 1
-    const int H = p.H, B = p.B, T = p.T;
-    const int NJ = H / 16, NBT = (B + 15) / 16, nkb = H / 32;
-    int jt, bt;
-    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
-    const int j0 = jt * 16;
+//
+// Combined step s = 0 .. T+1: layer 0 at time s, layer 1 at time s - 2.  Layer 1 lags TWO steps so that its input half,
+// dropout(h0_t) W_ih1^T, is not on the hand-off path: the image of dropout(h0_{s-1}) was complete when step s's poll matched, so
+// waves 4-7 request its fragments at the start of step s (with the step's own) and multiply them at the END of the step, in the
+// shadow of the next hand-off (when every wave would otherwise sit at the barrier); the sums (xacc) seed the accumulators of layer
+// 1's step s+1.  On the path a layer-1 wave then does what a layer-0 wave does: KBQ fragment loads and 4 KBQ MFMAs against
+// register-resident weights.  Both layers' pieces are packed and published by layer-0 waves (2: h1, 3: h0 and dropout(h0)).
+// The two halves run DIFFERENT loop bodies (same three barriers per step): the compiler then allocates registers per half, and
+// layer 1's 32 extra fragment registers do not have to coexist with layer 0's packing code.
+struct Fwd2Shared {
+    float (*red)[4][4][256];          // [layer][K-quarter][gate][batch row * 16 + hidden unit]
+    float (*hbuf)[16][16];            // h0_t, dropout(h0_t), h1_t of the tile
+    int *s_abort;
+    unsigned *s_published;
+};
 
-    // this wave's K-quarter of its layer's recurrent matrix: gates 0..3, k-blocks [wq*KBQ, +KBQ), hi halves
-    bf16x8 wr[4][KBQ];
-    {
-        const char *wsrc = half ? p.wp1 : p.wp0;
+template <int KBQ>
+__device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fwd2Shared sh, int jt, int bt, int wave, int lane, int u) {
+    const int wq = wave & 3;
+    const int H = p.H, B = p.B, T = p.T;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb = H / 32, j0 = jt * 16;
+    bf16x8 wr[4][KBQ];                               // K-quarter wq of W_hh0: gates 0..3, k-blocks [wq*KBQ, +KBQ), hi halves
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = 0; i < KBQ; ++i)
-                wr[g][i] = *reinterpret_cast<const bf16x8 *>(wsrc + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
-    }
-    bf16x8 wir[NWREG > 0 ? NWREG : 1];
-    char *my_wi = wi_lds + (long)wq * NWLDS * 1024 + lane * 16;         // + (i * 4 + g - NWREG) * 1024: this lane's 16 bytes
-    if (half) {
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < KBQ; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
-                if (i * 4 + g < NWREG) wir[i * 4 + g < NWREG ? i * 4 + g : 0] = v;
-                else *reinterpret_cast<bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024) = v;       // read back by this lane only
-            }
-    }
-
-    const int u = tid & 255, ci = u >> 4, cj = u & 15;   // cell threads of a layer: (batch row, hidden unit) of the tile
+            wr[g][i] = *reinterpret_cast<const bf16x8 *>(p.wp0 + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
+    const int ci = u >> 4, cj = u & 15;              // cell thread: (batch row, hidden unit) of the tile
     const int b = bt * 16 + ci;
     const bool cell = b < B;
-    const int BH = B * H;                                // element counts of a layer fit 31 bits (halo_lstm_persist2_ok)
+    const int BH = B * H;                            // element counts of a layer fit 31 bits (halo_lstm_persist2_ok)
     const int e0 = b * H + j0 + cj;
-    float cst = 0.f;                                     // c_{t-1} of this thread's layer
-    float gin[4] = {0.f, 0.f, 0.f, 0.f};                 // layer 0: next step's pre-activations; layer 1: b_ih1 + b_hh1
+    float cst = 0.f, gin[4] = {0.f, 0.f, 0.f, 0.f};  // c_{t-1}; the step's pre-activations x W_ih0^T + biases
     if (cell) {
-        cst = half ? p.c1[e0] : p.c0[e0];
+        cst = p.c0[e0];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            gin[g] = half ? p.b_ih1[g * H + j0 + cj] + p.b_hh1[g * H + j0 + cj] : p.gates0[b * 4 * H + g * H + j0 + cj];
+        for (int g = 0; g < 4; ++g) gin[g] = p.gates0[b * 4 * H + g * H + j0 + cj];
     }
     const __amdgpu_buffer_rsrc_t hp0_rsrc = make_rsrc(p.hp0), hp1_rsrc = make_rsrc(p.hp1);
     const __amdgpu_buffer_rsrc_t x_rsrc = p.xp ? make_rsrc(p.xp) : hp0_rsrc;
     const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
     const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
-    if (tid == 0) { s_abort = 0; s_published = 0; }
-
-    // Combined step s = 0 .. T+1: layer 0 at time s, layer 1 at time s - 2.  Layer 1 lags TWO steps so that its input half,
-    // dropout(h0_t) W_ih1^T, is not on the hand-off path: the image of dropout(h0_{s-1}) was complete when this step's poll matched,
-    // so waves 4-7 multiply it at the END of step s, in the shadow of the next hand-off (when every wave would otherwise sit at the
-    // barrier), and the sums (xacc) seed the accumulators of layer 1's step s+1.  On the path a layer-1 wave then does what a
-    // layer-0 wave does: KBQ fragment loads and 4 KBQ MFMAs against register-resident weights.  Both layers' pieces are packed
-    // and published by layer-0 waves (2: h1, 3: h0 and dropout(h0)), so the layer-1 waves go from the cell update straight to
-    // their input fragments: those loads are then under way before the epoch stores and polls of the hand-off use the CU's
-    // memory queue.
-    f32x4 xacc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s <= T + 1; ++s) {
         if (wave == 0) stamp(p.stamps, T + 2, s, 0, lane);
-        if (wave == 4) stamp(p.stamps, T + 2, s, 8, lane);
-        const bool act0 = s < T, act1 = s >= 2;          // layer 0 at time s, layer 1 at time s - 2
-        const bool act = half ? act1 : act0;              // this wave's layer has a time step in combined step s ...
-        const int t = half ? s - 2 : s;                   // ... namely this one
+        const bool act0 = s < T, act1 = s >= 2;
         // ---- epoch s: every workgroup of the batch group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-3} ----
         bool ok = true;
         if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
-            s_abort = 1;
-            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *sh.s_abort = 1;
+            raise_abort(p.flags, p.status);
         }
         lds_barrier();                                                             // (A)
-        if (s_abort) return;
+        if (*sh.s_abort) return;
         if (wave == 0) stamp(p.stamps, T + 2, s, 1, lane);
-        if (act) {
-            // layer 0: image s = h0_{s-1}; layer 1: image t = h1_{t-1}; this wave's K-quarter
-            const int img = (int)((((long)(half ? t : s) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
+        if (act0) {
+            const int img = ((s * NBT + bt) * nkb + wq * KBQ) * 2048;              // image s = h0_{s-1}; wave-uniform: the loads' scalar offset
             bf16x8 ah[KBQ];
 #pragma unroll
-            for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1(half ? hp1_rsrc : hp0_rsrc, img + i * 2048);
+            for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp0_rsrc, lane * 16, img + i * 2048);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = half ? xacc[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < KBQ; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wr[g][i], acc[g], 0, 0, 0);
-            // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + reg (batch row)
-            const int r = lane & 15, q = lane >> 4;
+            const int r = lane & 15, q = lane >> 4;      // D layout: col = lane & 15 (hidden unit), row = 4 (lane >> 4) + reg (batch row)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) red[half][wq][g][(4 * q + e) * 16 + r] = acc[g][e];
+                for (int e = 0; e < 4; ++e) sh.red[0][wq][g][(4 * q + e) * 16 + r] = acc[g][e];
         }
         lds_barrier();                                                             // (B)
         if (wave == 0) stamp(p.stamps, T + 2, s, 2, lane);
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f, xv = 0.f;
-        if (act) {
+        if (act0) {
             if (cell) {
                 float pre[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sum += red[half][k][g][u];
+                    for (int k = 0; k < 4; ++k) sum += sh.red[0][k][g][u];
                     pre[g] = sum + gin[g];
                 }
                 ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
                 cst = fg * cst + ig * gg;
                 h = og * fast_tanh(cst);
-                if (!half && p.xp) xv = h * dropout_mult(p.drop, (uint64_t)((long)t * BH + e0));
+                if (p.xp) xv = h * dropout_mult(p.drop, (uint64_t)((long)s * BH + e0));
             }
-            hbuf[half ? 2 : 0][ci][cj] = h;              // rows >= B: zeros
-            if (!half && p.xp) hbuf[1][ci][cj] = xv;
+            sh.hbuf[0][ci][cj] = h;                      // rows >= B: zeros
+            if (p.xp) sh.hbuf[1][ci][cj] = xv;
         }
         lds_barrier();                                                             // (C)
         if (wave == 0) stamp(p.stamps, T + 2, s, 3, lane);
@@ -168,58 +131,148 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
             // xp); wave 2: lanes 0-31 the piece of h1_{s-2} (image s-1 of layer 1).  The tile is k-groups 2 (jt & 1), 2 (jt & 1) + 1 of
             // k-block jt / 2.
             const int sel = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
-            const float(*src)[16] = wave == 2 ? hbuf[2] : hbuf[sel];
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = src[row][kg * 8 + e];
+            const float(*src)[16] = wave == 2 ? sh.hbuf[2] : sh.hbuf[sel];
             bf16x8 hi;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hi[e] = (__bf16)x[e];
+            for (int e = 0; e < 8; ++e) hi[e] = (__bf16)src[row][kg * 8 + e];
             const int within = (jt >> 1) * 2048 + (((jt & 1) * 2 + kg) * 16 + row) * 16;
             if (wave == 3) {
-                if (sel == 0) store_sc1(hp0_rsrc, (int)((((long)(s + 1) * NBT + bt) * nkb) * 2048) + within, hi);
-                else if (p.xp) store_sc1(x_rsrc, (int)((((long)s * NBT + bt) * nkb) * 2048) + within, hi);
+                if (sel == 0) store_sc1(hp0_rsrc, (((s + 1) * NBT + bt) * nkb) * 2048 + within, hi);
+                else if (p.xp) store_sc1(x_rsrc, ((s * NBT + bt) * nkb) * 2048 + within, hi);
             } else if (sel == 0) {
-                store_sc1(hp1_rsrc, (int)((((long)(s - 1) * NBT + bt) * nkb) * 2048) + within, hi);
+                store_sc1(hp1_rsrc, (((s - 1) * NBT + bt) * nkb) * 2048 + within, hi);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the write-through stores have left
             // the last storing wave of the step to get here signals for the workgroup (counter in LDS: Guideline 16); through
             // combined step s layer 0 has stored min(s + 1, T) times, layer 1 max(s - 1, 0) times
             unsigned old = 0;
-            if (lane == 0) old = atomicAdd(&s_published, 1u);
+            if (lane == 0) old = atomicAdd(sh.s_published, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
             const unsigned target = (unsigned)((s + 1 < T ? s + 1 : T) + (s >= 2 ? s - 1 : 0));
-            if (old + 1u == target) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            if (old + 1u == target && (int)blockIdx.x != p.mute) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
             stamp(p.stamps, T + 2, s, wave == 3 ? 4 : 5, lane);
         } else if (wave == 3 && !act0 && !act1) {
             publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
         }
-        if (act && cell) {
-            float *gp = (half ? p.gates1 : p.gates0) + (t * B + b) * 4 * H + j0 + cj;
+        if (act0 && cell) {
+            float *gp = p.gates0 + (s * B + b) * 4 * H + j0 + cj;
             gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-            (half ? p.c1 : p.c0)[(t + 1) * BH + e0] = cst;
-            (half ? p.h1 : p.h0)[(t + 1) * BH + e0] = h;
-            if (!half) {
-                if (p.ydrop) p.ydrop[t * BH + e0] = xv;
-                if (t + 1 < T) {
+            p.c0[(s + 1) * BH + e0] = cst;
+            p.h0[(s + 1) * BH + e0] = h;
+            if (p.ydrop) p.ydrop[s * BH + e0] = xv;
+            if (s + 1 < T) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((t + 1) * B + b) * 4 * H + g * H + j0 + cj];
-                }
-            } else if (p.y_mode != 0) {
-                p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
+                for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((s + 1) * B + b) * 4 * H + g * H + j0 + cj];
             }
         }
-        // ---- in the shadow of the hand-off: layer 1's input half for its NEXT step (time s - 1), from the image of dropout(h0_{s-1})
-        //      (image s-1 of xp; without dropout image s of layer 0) that this step's poll has already seen complete ----
-        if (half && s >= 1 && s <= T) {
-            const int ximg = (int)((((long)(p.xp ? s - 1 : s) * NBT + bt) * nkb + wq * KBQ) * 2048) + lane * 16;
-            bf16x8 ax[KBQ];
+    }
+}
+
+template <int KBQ>
+__device__ __forceinline__ void fwd2_layer1_waves(const Persist2Fwd &p, const Fwd2Shared sh, char *wi_lds, int jt, int bt, int wave, int lane,
+                                                  int u) {
+    // W_ih1's K-quarter is 4 KBQ fragments of 1 KiB per layer-1 wave, kept in LDS; at KBQ = 8 the four quarters (128 KiB) and the
+    // reduction buffers (32 KiB) would be the whole 160 KiB, so the first NWREG fragments (gates 0 .. NWREG-1 of k-block 0) stay
+    // in registers -- as few as make room for hbuf: the register file is as full as the LDS
+    constexpr int NWREG = KBQ >= 8 ? 2 : 0;
+    constexpr int NWLDS = 4 * KBQ - NWREG;
+    const int wq = wave & 3;
+    const int H = p.H, B = p.B, T = p.T;
+    const int NBT = (B + 15) / 16, nkb = H / 32, j0 = jt * 16;
+    bf16x8 wr[4][KBQ];                               // K-quarter wq of W_hh1
 #pragma unroll
-            for (int i = 0; i < KBQ; ++i) ax[i] = load_sc1(x_rsrc, ximg + i * 2048);
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < KBQ; ++i)
+            wr[g][i] = *reinterpret_cast<const bf16x8 *>(p.wp1 + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
+    bf16x8 wir[NWREG > 0 ? NWREG : 1];
+    char *my_wi = wi_lds + (long)wq * NWLDS * 1024 + lane * 16;         // + (i * 4 + g - NWREG) * 1024: this lane's 16 bytes
+#pragma unroll
+    for (int i = 0; i < KBQ; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
+            if (i * 4 + g < NWREG) wir[i * 4 + g < NWREG ? i * 4 + g : 0] = v;
+            else *reinterpret_cast<bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024) = v;           // read back by this lane only
+        }
+    const int ci = u >> 4, cj = u & 15;
+    const int b = bt * 16 + ci;
+    const bool cell = b < B;
+    const int BH = B * H;
+    const int e0 = b * H + j0 + cj;
+    float cst = 0.f, bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cell) {
+        cst = p.c1[e0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = p.b_ih1[g * H + j0 + cj] + p.b_hh1[g * H + j0 + cj];
+    }
+    const __amdgpu_buffer_rsrc_t hp1_rsrc = make_rsrc(p.hp1);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(p.xp ? p.xp : p.hp0);
+    f32x4 xacc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s <= T + 1; ++s) {
+        if (wave == 4) stamp(p.stamps, T + 2, s, 8, lane);
+        const bool act1 = s >= 2, xin = s >= 1 && s <= T;
+        const int t = s - 2;
+        lds_barrier();                                                             // (A)
+        if (*sh.s_abort) return;
+        // the input fragments of the NEXT step (time s - 1: image s-1 of xp; without dropout image s of layer 0), complete since this
+        // step's poll matched, are requested with the step's own: nothing of them is left for the hand-off window, where loads
+        // would sit in front of the epoch stores and polls in the CU's memory queue
+        bf16x8 ax[KBQ];
+        if (xin) {
+            const int ximg = (((p.xp ? s - 1 : s) * NBT + bt) * nkb + wq * KBQ) * 2048;
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) ax[i] = load_sc1_u(x_rsrc, lane * 16, ximg + i * 2048);
+        }
+        if (act1) {
+            const int img = ((t * NBT + bt) * nkb + wq * KBQ) * 2048;              // image t = h1_{t-1}
+            bf16x8 ah[KBQ];
+#pragma unroll
+            for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp1_rsrc, lane * 16, img + i * 2048);
             __builtin_amdgcn_sched_barrier(0);
-            if (wave == 4) stamp(p.stamps, T + 2, s, 7, lane);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < KBQ; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], wr[g][i], xacc[g], 0, 0, 0);
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh.red[1][wq][g][(4 * q + e) * 16 + r] = xacc[g][e];
+        }
+        lds_barrier();                                                             // (B)
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
+        if (act1) {
+            if (cell) {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sum += sh.red[1][k][g][u];
+                    pre[g] = sum + bias[g];
+                }
+                ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
+                cst = fg * cst + ig * gg;
+                h = og * fast_tanh(cst);
+            }
+            sh.hbuf[2][ci][cj] = h;
+        }
+        lds_barrier();                                                             // (C)
+        if (act1 && cell) {
+            float *gp = p.gates1 + (t * B + b) * 4 * H + j0 + cj;
+            gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            p.c1[(t + 1) * BH + e0] = cst;
+            p.h1[(t + 1) * BH + e0] = h;
+            if (p.y_mode != 0) p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
+        }
+        // ---- in the shadow of the hand-off: layer 1's input half for its next step ----
+        if (wave == 4) stamp(p.stamps, T + 2, s, 7, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xin) {
 #pragma unroll
             for (int i = 0; i < KBQ; ++i) {
                 bf16x8 w[4];
@@ -229,11 +282,29 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
                                              : *reinterpret_cast<const bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[i], w[g], xacc[g], 0, 0, 0);
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // at most two k-blocks' LDS fragments in flight: the registers are full
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two k-blocks' LDS fragments in flight at a time: the registers are full
             }
-            if (wave == 4) stamp(p.stamps, T + 2, s, 6, lane);
         }
+        if (wave == 4) stamp(p.stamps, T + 2, s, 6, lane);
     }
+}
+
+template <int KBQ>
+__global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist2Fwd p) {
+    __shared__ float red[2][4][4][256];
+    __shared__ __attribute__((aligned(16))) float hbuf[3][16][16];
+    __shared__ int s_abort;
+    __shared__ unsigned s_published;
+    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][NWLDS] W_ih1 fragments of 1 KiB (k-block major, gate minor)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
+    if (tid == 0) { s_abort = 0; s_published = 0; }
+    const Fwd2Shared sh = {red, hbuf, &s_abort, &s_published};
+    // (the first barrier of either loop orders the two initialisations above before any use)
+    if (wave < 4) fwd2_layer0_waves<KBQ>(p, sh, jt, bt, wave, lane, tid & 255);
+    else fwd2_layer1_waves<KBQ>(p, sh, wi_lds, jt, bt, wave, lane, tid & 255);
 }
 
 // ================================================================================================================
@@ -311,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
         if (s > 0 && wave == 7) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
             s_abort = 1;
-            __hip_atomic_store(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_abort(p.flags, p.status);
         }
         lds_barrier();                                                             // (A)
         if (s_abort) return;
@@ -460,7 +531,6 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
 }
 
 int g_cu_count2 = 0;
-int g_persist2_enabled = 1;
 inline int cu_count2() {
     if (!g_cu_count2) {
         int dev = 0;
@@ -473,6 +543,9 @@ inline int cu_count2() {
 
 constexpr size_t MIN_DYN_LDS = 64 * 1024;             // with the static arrays: more than half a CU's LDS -> one workgroup per CU
 
+inline void set_mute(Persist2Fwd &a) { a.mute = halo_ctx_cur().mute_block; }
+inline void set_mute(Persist2Bwd &) {}
+
 template <typename K, typename A>
 int launch2(K kernel, const A &a0, int blocks, size_t dyn, hipStream_t st) {
     static_assert(sizeof(A) <= 4096, "kernel arguments");
@@ -480,6 +553,8 @@ int launch2(K kernel, const A &a0, int blocks, size_t dyn, hipStream_t st) {
     static const int shift = getenv("HALO_PERSIST_REPLICA_SHIFT") ? atoi(getenv("HALO_PERSIST_REPLICA_SHIFT")) : 3;
     static const int nap = getenv("HALO_PERSIST_NAP") ? atoi(getenv("HALO_PERSIST_NAP")) : 2;
     a.poll_mode = 0; a.replica_shift = shift; a.nap = nap;
+    a.status = halo_ctx_cur().status;
+    set_mute(a);
     if (dyn < MIN_DYN_LDS) dyn = MIN_DYN_LDS;
     if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return HALO_ELAUNCH;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), dyn, st, a);
@@ -488,11 +563,11 @@ int launch2(K kernel, const A &a0, int blocks, size_t dyn, hipStream_t st) {
 
 }  // namespace
 
-void halo_lstm_persist2_enable(int on) { g_persist2_enabled = on ? 1 : 0; }
+void halo_lstm_persist2_enable(int on) { halo_ctx_cur().lstm_persistent2 = on ? 1 : 0; }
 
 bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST2") && atoi(getenv("HALO_LSTM_PERSIST2")) == 0;
-    if (env_off || !g_persist2_enabled) return false;
+    if (env_off || !halo_ctx_cur().lstm_persistent2) return false;
     if (!halo_lstm_persist_ok(B, H)) return false;                         // the per-layer recurrence's shape / switch / CU rules
     if (halo_math_mode() != HALO_MATH_BF16 || L != 2) return false;
     if (H % 128 != 0 || H > 1024 || T < 1) return false;

@@ -22,6 +22,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
 __device__ __forceinline__ bf16x8 load_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
+// the same with the wave-uniform part of the offset in an SGPR (soffset): the lane part (voffset) is then ONE register for all loads
+__device__ __forceinline__ bf16x8 load_sc1_u(__amdgpu_buffer_rsrc_t r, int lane_off, int uniform_off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 16));
+}
 __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, bf16x8 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
 }
@@ -53,6 +57,12 @@ __device__ __forceinline__ bool poll_group(const unsigned *grp_flags, int first,
         else if (nap == 3) __builtin_amdgcn_s_sleep(16);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) return false;
     }
+}
+
+// a bounded wait timed out: the call's own abort word (read by tests, zeroed by the next prologue) and the caller's sticky status word
+__device__ __forceinline__ void raise_abort(unsigned *flags, unsigned *status) {
+    __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int xcc_id() {

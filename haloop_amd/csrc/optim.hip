@@ -1,6 +1,7 @@
 // Gradient-norm clipping and AdamW on flat fp32 buffers (one pass each over the parameters).
 #include <math.h>
 #include "halo_common.h"
+#include "halo_internal.h"
 
 namespace {
 
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
 }
 
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ partials, int count, float max_norm,
-                                                        float *coef, float *norm_out, uint32_t *applied_steps) {
+                                                        float *coef, float *norm_out, uint32_t *applied_steps, const uint32_t *status) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
@@ -32,9 +33,10 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict_
     if (threadIdx.x == 0) {
         const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
         const float c = max_norm / (norm + 1e-6f);
-        const bool finite = isfinite(norm);
         // a non-finite norm poisons both scales: halo_adamw skips the update when its scale is NaN
-        // (the reference skips the batch on a NaN/Inf loss or gradient norm, ha/loop.py:167-189)
+        // (the reference skips the batch on a NaN/Inf loss or gradient norm, ha/loop.py:167-189); so does a raised status word
+        // (halo_set_status_word: a persistent recurrence of this step gave up a bounded wait, its gradients are not to be applied)
+        const bool finite = isfinite(norm) && !(status && *status != 0u);
         coef[0] = finite ? (c > 1.0f ? 1.0f : c) : NAN;
         coef[1] = finite ? 1.0f : NAN;
         if (norm_out) *norm_out = norm;
@@ -115,6 +117,8 @@ struct AdamRangesArgs {
     float beta1_w, beta2, beta2_w, step_size, bc2_sqrt, eps;
     uint32_t *counter;
     const uint32_t *step_dev;     // optional: 1-based update count on the device (halo_clip_coef_step); overrides step_size / bc2_sqrt
+    const float *lr_dev;          // optional (with step_dev): the learning rate read from the device, so a schedule reaches a captured launch
+    float weight_decay[ADAM_MAX_RANGES];
     float lr, beta1;
 };
 
@@ -122,16 +126,17 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(const AdamRangesArgs 
     f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);
     float step_size = a.step_size, bc2_sqrt = a.bc2_sqrt;
+    const float lr = a.lr_dev ? *a.lr_dev : a.lr;
     if (a.step_dev) {
         // the same scalar preparation as the host path (double, like torch's python-side bias corrections), from the device counter
         const double t = (double)max(*a.step_dev, 1u);
-        step_size = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
+        step_size = (float)((double)lr / (1.0 - pow((double)a.beta1, t)));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
     }
     for (int r = 0; r < a.n_ranges; ++r) {
         const float gs = a.grad_scale[r] ? *a.grad_scale[r] : 1.0f;
         if (gs != gs) continue;                                   // NaN scale: this range's update is skipped
-        const float decay_mul = a.decay_mul[r];
+        const float decay_mul = a.lr_dev ? (float)(1.0 - (double)lr * (double)a.weight_decay[r]) : a.decay_mul[r];
         for (size_t i = a.begin4[r] + blockIdx.x * (size_t)256 + threadIdx.x; i < a.end4[r]; i += (size_t)gridDim.x * 256) {
             f32x4 p = p4[i], m = m4[i], v = v4[i];
             const f32x4 g = g4[i];
@@ -298,7 +303,7 @@ int halo_clip_coef_step(const float *partials, int count, float max_norm, float 
                         halo_stream_t stream) {
     HALO_CHECK_ARG(partials && coef && count > 0);
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, count, max_norm, coef,
-                       norm_out, applied_steps);
+                       norm_out, applied_steps, (const uint32_t *)halo_ctx_cur().status);
     return halo_launch_status();
 }
 
@@ -354,19 +359,20 @@ int halo_adamw_multi(const void *tensor_table, const void *chunk_table, int n_ch
 
 static int adamw_ranges_impl(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
                       const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps, int step,
-                      const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream) {
+                      const uint32_t *step_dev, const float *lr_dev, uint32_t *counter, halo_stream_t stream) {
     HALO_CHECK_ARG(p && g && m && v && begin && end && weight_decay && grad_scale && n_ranges > 0 && n_ranges <= ADAM_MAX_RANGES &&
-                   (step >= 1 || step_dev));
+                   (step >= 1 || step_dev) && (!lr_dev || step_dev));
     HALO_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0));
     AdamRangesArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n_ranges = n_ranges; a.counter = counter;
-    a.step_dev = step_dev; a.lr = lr; a.beta1 = beta1;
+    a.step_dev = step_dev; a.lr_dev = lr_dev; a.lr = lr; a.beta1 = beta1;
     if (step < 1) step = 1;
     size_t biggest = 0;
     for (int r = 0; r < n_ranges; ++r) {
         HALO_CHECK_ARG(begin[r] % 4 == 0 && end[r] % 4 == 0 && begin[r] <= end[r]);
         a.begin4[r] = begin[r] / 4; a.end4[r] = end[r] / 4;
         a.decay_mul[r] = (float)(1.0 - (double)lr * (double)weight_decay[r]);
+        a.weight_decay[r] = weight_decay[r];
         a.grad_scale[r] = grad_scale[r];
         if (a.end4[r] - a.begin4[r] > biggest) biggest = a.end4[r] - a.begin4[r];
     }
@@ -388,16 +394,16 @@ static int adamw_ranges_impl(float *p, const float *g, float *m, float *v, int n
 int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
                       const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps, int step,
                       uint32_t *counter, halo_stream_t stream) {
-    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, step, nullptr, counter,
-                             stream);
+    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, step, nullptr, nullptr,
+                             counter, stream);
 }
 
 int halo_adamw_ranges_dev(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
-                          const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2, float eps,
-                          const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream) {
+                          const float *weight_decay, const float *const *grad_scale, float lr, const float *lr_dev, float beta1, float beta2,
+                          float eps, const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream) {
     HALO_CHECK_ARG(step_dev);
-    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, 0, step_dev, counter,
-                             stream);
+    return adamw_ranges_impl(p, g, m, v, n_ranges, begin, end, weight_decay, grad_scale, lr, beta1, beta2, eps, 0, step_dev, lr_dev,
+                             counter, stream);
 }
 
 }  // extern "C"

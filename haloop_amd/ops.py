@@ -477,15 +477,17 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None
 
 def adamw_ranges(p, g, m, v, ranges, lr, beta1, beta2, eps, step, counter=None):
     """One-launch AdamW over ``ranges`` = [(begin, end, weight_decay, grad_scale tensor or None), ...] of flat buffers.
-    ``step``: the 1-based update count as a python int, or a device int32 tensor holding it (no host scalar: graph-capturable)."""
+    ``step``: the 1-based update count as a python int, or a device int32 tensor holding it (no host scalar: graph-capturable).
+    ``lr``: a python float, or (with a device ``step``) a one-element float32 device tensor the launch reads it from."""
     n = len(ranges)
     begin = (C.c_size_t * n)(*[r[0] for r in ranges])
     end = (C.c_size_t * n)(*[r[1] for r in ranges])
     wd = (C.c_float * n)(*[float(r[2]) for r in ranges])
     gs = (C.c_void_p * n)(*[ptr(r[3]) for r in ranges])
     if torch.is_tensor(step):
-        check(lib().halo_adamw_ranges_dev(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, ptr(step),
-                                          ptr(counter), _stream()), 'halo_adamw_ranges_dev')
+        lr_dev = lr if torch.is_tensor(lr) else None
+        check(lib().halo_adamw_ranges_dev(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, 0.0 if lr_dev is not None else lr,
+                                          ptr(lr_dev), beta1, beta2, eps, ptr(step), ptr(counter), _stream()), 'halo_adamw_ranges_dev')
     else:
         check(lib().halo_adamw_ranges(ptr(p), ptr(g), ptr(m), ptr(v), n, begin, end, wd, gs, lr, beta1, beta2, eps, step, ptr(counter),
                                       _stream()), 'halo_adamw_ranges')

@@ -101,9 +101,17 @@ class LstmCtcTrainer:
         self.encoder, self.recognizer = encoder, recognizer
         self.accumulate = int(accumulate)
         self._micro = 0
-        self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip_grad_norm
+        self.betas, self.eps, self.weight_decay, self.clip = betas, eps, weight_decay, clip_grad_norm
         self.flat = FlatParams(encoder, recognizer)
         dev = self.flat.params.device
+        # the learning rate lives on the device: the optimizer launch (captured in the step graph) reads it there, so assigning
+        # ``trainer.lr`` between steps -- the reference applies its schedule every step, ha/loop.py:191 -- takes effect on replay
+        self._lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.lr = lr
+        # sticky status word of the persistent recurrences (include/halo.h): a timed-out wait sets it, the clip kernel then
+        # suppresses every update, and check_status() turns it into an exception
+        self.status = torch.zeros(1, device=dev, dtype=torch.int32)
+        _lib.set_status_word(self.status)
         _lib.lend_scratch(device=dev)                      # split-K slabs for the under-filled GEMMs
         self.device = dev
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -125,6 +133,24 @@ class LstmCtcTrainer:
         self._graphs = None
         self._static = None
         self._accum = torch.zeros_like(self.flat.grads) if self.accumulate > 1 else None
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self._lr_dev.fill_(self._lr)
+
+    def check_status(self):
+        """Raise if a persistent recurrence of any step so far gave up a bounded wait (its workgroups were not all resident: a
+        CU mask, another process on the GPU, a profiler).  One device read: call it at logging intervals, not every step.
+        No update has been applied since the word was raised (halo_clip_coef_step)."""
+        if int(self.status.item()) != 0:
+            raise _lib.HaloError('a persistent LSTM recurrence timed out waiting for its peer workgroups (they were not all resident); '
+                                 'no optimizer update has been applied since.  Free the GPU of other work, or select the step-launch '
+                                 'chain with haloop_amd._lib.set_lstm_persistent(False), then zero trainer.status and continue.')
 
     # ---- pieces -------------------------------------------------------------------------------
     def _dropout(self):
@@ -236,7 +262,7 @@ class LstmCtcTrainer:
         # all (decay, clip) ranges and the dropout step counter in one launch
         ranges = [(a, b, self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
                   for a, b, decays, clipped in f.ranges if b > a]
-        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self.lr, self.betas[0], self.betas[1], self.eps,
+        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self._lr_dev, self.betas[0], self.betas[1], self.eps,
                          self.adam_step, counter=self.counter)
 
     # ---- public -------------------------------------------------------------------------------

@@ -226,6 +226,25 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                   int layer_begin, int layer_end, float p_drop, uint64_t seed, uint32_t offset,
                   const uint32_t *offset_dev, halo_stream_t stream);
 
+/* Contexts.  Every halo_set_* switch (arithmetic mode, scratch, LSTM schedule switches, measurement hooks, the status word, the beam
+ * search's reference ISA) lives in a settings record.  There is one process-wide default record; halo_ctx_create() makes a caller-owned
+ * copy of the calling thread's current record, and halo_ctx_use(ctx) makes it the record that THIS thread's later halo_* calls read and
+ * halo_set_* calls write (NULL: back to the default).  Two trainers, or a trainer and a recognizer, on different threads therefore do
+ * not see each other's switches; within one thread, select the context before a group of calls.  Work launched on distinct streams from
+ * distinct threads with distinct contexts (and distinct scratch buffers) is independent; calls that share one record, or the default
+ * one, must be serialised by the caller. */
+typedef struct halo_ctx halo_ctx;
+halo_ctx *halo_ctx_create(void);
+void halo_ctx_destroy(halo_ctx *ctx);
+int halo_ctx_use(halo_ctx *ctx);
+/* A caller-owned device uint32 that the persistent recurrences (csrc/lstm_persist*.hip) set to 1 when one of their bounded waits times
+ * out (co-residency lost: a CU mask, another tenant, a profiler).  It is sticky -- the library only ever sets it -- and
+ * halo_clip_coef_step treats a raised word like a non-finite gradient norm (no update is applied).  NULL (default): no word. */
+int halo_set_status_word(uint32_t *device_word);
+/* Test hook: the workgroup with this blockIdx of every persistent LSTM forward launched afterwards never publishes its epoch, so its
+ * peers run into their bounded waits (0.2 s), raise the abort and status words and leave; -1 (default): none. */
+int halo_debug_mute_workgroup(int block);
+
 /* Weight-resident persistent recurrence (csrc/lstm_persist.hip): when the shape is eligible (split-bf16 arithmetic modes,
  * H in {256, 512, 768, 1024}, (H/16) * ceil(B/16) <= number of CUs) a layer's T dependent step launches become ONE launch
  * whose workgroups keep their W_hh slice in registers and hand h_t (forward) / the gate gradients (backward) to each other
@@ -614,7 +633,8 @@ int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
 int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                    halo_stream_t stream);
 /* halo_clip_coef that also advances a device-side update counter (uint32) when the norm is finite: torch's AdamW step count
- * advances only with an applied update (the reference skips optimizer.step() on a non-finite norm, ha/loop.py:185-189). */
+ * advances only with an applied update (the reference skips optimizer.step() on a non-finite norm, ha/loop.py:185-189).
+ * A raised status word (halo_set_status_word) counts as a non-finite norm: the update is skipped on the device. */
 int halo_clip_coef_step(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                         uint32_t *applied_steps, halo_stream_t stream);
 int halo_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
@@ -628,9 +648,11 @@ int halo_adamw_ranges(float *p, const float *g, float *m, float *v, int n_ranges
 
 /* halo_adamw_ranges with the 1-based update count read from the device (the counter halo_clip_coef_step advances), so that a
  * whole training step -- optimizer included -- has no host-side scalar and replays from one hipGraph. */
+/* lr_dev (optional, device float): the learning rate is read from there instead of ``lr`` -- a schedule (the reference applies
+ * lr.apply_lr_ every step, ha/loop.py:191) then reaches a captured launch: the caller writes the device scalar between replays. */
 int halo_adamw_ranges_dev(float *p, const float *g, float *m, float *v, int n_ranges, const size_t *begin, const size_t *end,
-                          const float *weight_decay, const float *const *grad_scale, float lr, float beta1, float beta2,
-                          float eps, const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream);
+                          const float *weight_decay, const float *const *grad_scale, float lr, const float *lr_dev, float beta1,
+                          float beta2, float eps, const uint32_t *step_dev, uint32_t *counter, halo_stream_t stream);
 
 /* halo_adamw over MANY tensors in one launch (what torch.optim.AdamW(fused=True) does for a parameter list, ha/attention_loop.py:
  * 141-147).  tensor_table (device, built once): n_tensors records of halo_adamw_multi_tensor_bytes() bytes each:
