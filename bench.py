@@ -4,10 +4,14 @@
 Workload: 2-layer H=1024 LSTM-CTC ("LC-2x1024"), 64 utterances of 80 frames x
 80 mels per GPU, char vocab 32, dropout 0.2 on, full step = forward + CTC loss + backward +
 encoder-only clip + AdamW (ha/loop.py:176-196).  Synthetic inputs resident in HBM.  Arithmetic of the
-headline number: `bf16x3` -- every dense operand split x = hi + lo (two bf16), three bf16 MFMAs per
-product, fp32 accumulate, fp32 state / gates / CTC / optimizer; it meets the fp32 parity tolerances of
-tests/test_gpu_parity.py.  The exact-f32-MFMA step (`f32_mode`) and the single-pass bf16 step
-(`bf16_mode`) are reported beside it.
+headline number: `bf16` -- the operands of the dense products (input / recurrent / classifier GEMMs)
+rounded to bf16, one MFMA per product, fp32 accumulate; cell state, gates, CTC lattice, softmax, clip and
+AdamW in fp32 on fp32 master weights: the precision the contract names (the reference's own GPU runs
+use fp16 autocast, ha/loop.py:125) at BASELINE.md's bf16-MFMA parity gate (loss rel <= 2e-2; tested at
+this very configuration, dropout on, against the CPU oracle with the same masks:
+tests/test_gpu_lstm_b64.py).  The same step in the fp32-grade split-bf16 arithmetic (`bf16x3_mode`:
+three MFMAs per product, meets the fp32 tolerances) and on the exact-f32 MFMA (`f32_mode`) is
+reported beside it, as are larger per-GPU batches (`b_sweep`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -16,10 +20,13 @@ With --gpus N > 1 and no torch.distributed environment, this process starts
 touched the GPU) and forwards its JSON line and exit code; under torchrun it is one of the N ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- the dominant kernel (the recurrent chain of one LSTM layer's backward: one persistent
-                  launch, or T' step launches on the fallback path) against the HBM roof; bytes follow
-                  SURVEY.md 8d (parameters once per pass + per-step activations), duration measured
-                  here with HIP events recorded by the library on the launch stream;
+  roofline     -- the dominant kernel (the recurrent chain of the backward: in bf16 mode ONE persistent launch
+                  for both layers, otherwise one per layer, or T' step launches on the fallback path)
+                  against the HBM roof; bytes follow SURVEY.md 8d (parameters once per pass + per-step
+                  activations), duration measured here with HIP events recorded by the library on the
+                  launch stream;
+  gpt2_small, asr_transformer32 -- BASELINE configs 3 and 5 (tools/bench_gpt.py, tools/bench_asr.py run as
+                  child processes after the timed region, bounded);
   cpu_baseline -- the CPU restatement of the reference path (oracle/, kind "port") timed on this
                   box's host cores on a bounded sample of the same workload (B=64, and B=4 = config 1).
 """
@@ -37,7 +44,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 B_PER_GPU, T, F, C_SUB, H, L, V, S = 64, 80, 80, 128, 1024, 2, 32, 10
 T_SUB = (T + 6 - 5) // 4 + 1   # 21
-MATH_DTYPE = {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)', 'bf16': 'bf16'}
+MATH_DTYPE = {'f32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)',
+              'bf16': 'bf16 (dense operands rounded to bf16, 1 MFMA per product, fp32 accumulate; fp32 state, CTC, optimizer and master weights)'}
 
 
 def parse_args():
@@ -51,9 +59,13 @@ def parse_args():
     ap.add_argument('--dp-rehearsal', action='store_true',
                     help='N=1 only, a measurement aid: run the data-parallel code path (three graphs, RCCL all-reduces between them, '
                          'step-launch chain under the first bucket) on a one-rank RCCL group; the line says so in config.parallelism')
-    ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16x3',
-                    help="arithmetic of the dense products: 'f32' and 'bf16x3' meet the fp32 parity tolerances; 'bf16' rounds the "
-                         "operands to bf16")
+    ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16',
+                    help="arithmetic of the dense products: 'bf16' rounds the operands to bf16 (one MFMA per product); 'f32' and "
+                         "'bf16x3' meet the fp32 parity tolerances")
+    ap.add_argument('--no-configs', action='store_true', help='skip the GPT-2 small / attention-ASR legs (BASELINE configs 3 and 5)')
+    ap.add_argument('--dp-algo', choices=['allreduce', 'rs_ag'], default='rs_ag',
+                    help='N > 1: allreduce = every rank averages the whole gradient and updates every parameter (DistributedDataParallel); '
+                         'rs_ag = reduce-scatter, each rank updates its 1/N of the flat parameters, all-gather')
     ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
                     help='wire format of the data-parallel gradient all-reduce (N > 1)')
     return ap.parse_args()
@@ -80,14 +92,17 @@ def algorithmic_step_bytes(B):
     return 10 * 4 * P + 2_120_000 * B
 
 
-def chain_algorithmic_bytes(B, direction):
-    """Bytes ONE layer's recurrent chain must move over its T' steps, SURVEY.md 8d accounting: the recurrent weight matrix
-    once per pass, plus per step and utterance the fp32 activations that enter or leave the chain.
+def chain_algorithmic_bytes(B, direction, layers=1):
+    """Bytes ONE launch of the recurrent chain must move over its T' steps, SURVEY.md 8d accounting: every weight matrix the launch
+    multiplies by once per pass (4 bytes per parameter), plus per step, utterance and layer the fp32 activations that enter or leave.
     forward : W_hh [4H,H]; per step: gate pre-activations in [4H], activated gates out [4H], c_t out [H], h_t out [H]
     backward: W_hh^T;      per step: activated gates in [4H], c_t in [H] (c_{t-1} is the same array), dh from above in [H],
-                           gate gradients out [4H]"""
+                           gate gradients out [4H]
+    layers = 2 (the two-layer launch, csrc/lstm_persist2.hip): both layers' terms plus W_ih of layer 1 [4H,H], which that launch
+    multiplies by as well (forward: the input projection; backward: the input gradient)"""
     per_step = (4 * H + 4 * H + H + H) if direction == 'fwd' else (4 * H + H + H + 4 * H)
-    return 4 * (4 * H * H) + 4 * T_SUB * B * per_step
+    weights = 1 if layers == 1 else 3
+    return 4 * weights * (4 * H * H) + 4 * T_SUB * B * per_step * layers
 
 
 def build_model(device, seed=42):
@@ -100,30 +115,34 @@ def build_model(device, seed=42):
     return enc.to(device).train(), rec.to(device).train(), (enc_p, rec_p)
 
 
-def time_chain(device, direction, reps=20):
-    """Average duration of the dominant kernel: the recurrent chain of one H=1024, B=64, T'=21 layer.  The library records
-    two HIP events on its launch stream right around the chain (halo_lstm_chain_events), so the batched GEMMs and operand
-    preparation of the same call are outside the bracket.  Returns (microseconds per chain, launches per chain, kernel name)."""
+def time_chain(device, direction, layers, reps=20):
+    """Median duration of the dominant kernel: the recurrent chain of the H=1024, B=64, T'=21 stack (layers = 2: the two-layer
+    persistent launch; 1: one layer's chain).  The library records two HIP events on its launch stream right around the chain
+    (halo_lstm_chain_events), so the batched GEMMs and operand preparation of the same call are outside the bracket.
+    Returns (microseconds per chain, launches per chain, kernel name)."""
     import torch
     from haloop_amd import _lib, ops
     g = torch.Generator().manual_seed(0)
-    x = (torch.randn(T_SUB, B_PER_GPU, H, generator=g) * 0.1).to(device)
-    w = [(torch.rand(4 * H, H, generator=g) - 0.5).mul(0.06).to(device)]
-    b = [torch.zeros(4 * H, device=device)]
+    in0 = C_SUB if layers == 2 else H
+    x = (torch.randn(T_SUB, B_PER_GPU, in0, generator=g) * 0.1).to(device)
+    w_ih = [(torch.rand(4 * H, in0 if l == 0 else H, generator=g) - 0.5).mul(0.06).to(device) for l in range(layers)]
+    w_hh = [(torch.rand(4 * H, H, generator=g) - 0.5).mul(0.06).to(device) for l in range(layers)]
+    b = [torch.zeros(4 * H, device=device) for l in range(layers)]
     dy = (torch.randn(B_PER_GPU, T_SUB, H, generator=g) * 0.01).to(device)
+    drop = ops.Dropout(0.2, 1, 0) if layers == 2 else ops.NO_DROPOUT
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); e1.record()
     torch.cuda.synchronize()
-    grads = {k: [torch.zeros_like(w[0])] for k in ('dw_ih', 'dw_hh')}
-    grads.update({k: [torch.zeros_like(b[0])] for k in ('db_ih', 'db_hh')})
+    grads = {'dw_ih': [torch.zeros_like(w) for w in w_ih], 'dw_hh': [torch.zeros_like(w) for w in w_hh],
+             'db_ih': [torch.zeros_like(v) for v in b], 'db_hh': [torch.zeros_like(v) for v in b]}
     ts = []
     for i in range(reps + 3):
         if direction == 'fwd':
             _lib.lstm_chain_events(e0, e1)
-        y, _, _, reserve = ops.lstm_fwd(x, w, w, b, b, y_strides=None, y_relu=False)
+        y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b, y_strides=None, y_relu=False, drop=drop)
         if direction == 'bwd':
             _lib.lstm_chain_events(e0, e1)
-            ops.lstm_bwd(x, w, w, dy, (H, T_SUB * H), False, reserve, grads=grads)
+            ops.lstm_bwd(x, w_ih, w_hh, dy, (H, T_SUB * H), False, reserve, grads=grads, drop=drop)
         _lib.lstm_chain_events(None, None)
         torch.cuda.synchronize()
         if i >= 3:
@@ -154,7 +173,7 @@ def time_inference(enc, rec, x, steps):
 
 
 def time_other_mode(mode, device, batch, warmup, steps, use_graph):
-    """The same training step in another arithmetic mode (own model + trainer, same seeds and batch)."""
+    """The same training step in another arithmetic mode, or at another batch size (own model + trainer, same seeds)."""
     import torch
     from haloop_amd import _lib
     from haloop_amd.train import LstmCtcTrainer
@@ -170,8 +189,41 @@ def time_other_mode(mode, device, batch, warmup, steps, use_graph):
         tr.step(*b2)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
-    return {'value': round(B_PER_GPU * steps / dt, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt / steps, 4),
-            'dtype': MATH_DTYPE[mode], 'final_loss': round(tr.loss.item(), 5), 'steps_trained': warmup + steps}
+    tr.check_status()
+    B = batch[0].shape[0]
+    nbytes = algorithmic_step_bytes(B)
+    return {'value': round(B * steps / dt, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt / steps, 4), 'batch': B,
+            'dtype': MATH_DTYPE[mode], 'final_loss': round(tr.loss.item(), 5), 'steps_trained': warmup + steps,
+            'step_frac_of_hbm_peak': round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def batch_sweep(mode, device, warmup, steps, use_graph):
+    """'larger B raises the achieved fraction.  Report both.'  The same step at B = 128 and 256 per GPU
+    (bytes(B) = 10*4*P + 2.12e6*B); the persistent recurrences take (H/16) * ceil(B/16) <= 256 workgroups, larger batches
+    run the step-launch chain."""
+    from haloop_amd import _lib, synth
+    out = {}
+    for B in (128, 256):
+        batch = tuple(t.to(device) for t in synth.synthetic_batch(B, T, F, V, S, 42))
+        r = time_other_mode(mode, device, batch, warmup, steps, use_graph)
+        r['recurrence'] = _lib.lstm_chain_info('bwd')['kernel']
+        out[f'B{B}'] = r
+    return out
+
+
+def run_config_leg(script, mode, timeout_s):
+    """BASELINE configs 3 / 5: the tool's own process (its JSON line is its last line of output), after this process's timed
+    region; a failure or a timeout is recorded, never fatal to the headline."""
+    env = dict(os.environ, HALO_MATH=mode)
+    try:
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', script)], env=env, capture_output=True, text=True,
+                              timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {'error': f'{script} exceeded {timeout_s} s'}
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    if proc.returncode != 0 or not lines:
+        return {'error': f'{script} exit code {proc.returncode}', 'stderr_tail': proc.stderr[-400:]}
+    return json.loads(lines[-1])
 
 
 def host_cores():

