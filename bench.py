@@ -304,8 +304,9 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
-        from haloop_amd import dp
-        dp.world_size = lambda group=None: 2          # every world > 1 branch; an all-reduce (AVG) over one rank is the identity
+        if args.dp_algo == 'allreduce':
+            from haloop_amd import dp
+            dp.world_size = lambda group=None: 2      # every world > 1 branch; an all-reduce (AVG) over one rank is the identity
 
     from haloop_amd import _lib, synth
     from haloop_amd.train import LstmCtcTrainer
@@ -313,7 +314,8 @@ def main():
     _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
-    trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True)
+    dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo == 'rs_ag')
+    trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True, **dp_kw)
     x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
     use_graph = not args.no_graph
@@ -327,7 +329,7 @@ def main():
         print(f'[bench rank {rank}] graph mode failed ({type(e).__name__}: {e}); falling back to eager launches', file=sys.stderr, flush=True)
         use_graph = False
         enc, rec, params = build_model(device)
-        trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=False, grad_dtype=args.grad_dtype, alias_loss=True)
+        trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=False, grad_dtype=args.grad_dtype, alias_loss=True, **dp_kw)
         for _ in range(args.warmup):
             trainer.step(x, il, tg, tl)
     if trainer.static_inputs() is not None:                 # inputs resident in the step graph's own buffers (no per-step copy)
@@ -351,6 +353,7 @@ def main():
         dist.all_reduce(ones)                                # every rank that really took part adds one
         n_ranks_seen = int(ones.item())
     loss = trainer.loss.item()
+    trainer.check_status()        # a persistent recurrence that gave up a wait during the run: fail the bench, loudly
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -365,7 +368,9 @@ def main():
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
                        'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'math': args.math,
-                       'grad_allreduce_dtype': args.grad_dtype if world > 1 else None},
+                       'grad_allreduce_dtype': args.grad_dtype if world > 1 else None,
+                       'dp_algo': trainer.dp_algo if (world > 1 or args.dp_rehearsal) else None,
+                       'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None},
             'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
             'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
@@ -374,33 +379,47 @@ def main():
                               'note': 'whole training step against SURVEY.md 8d bytes(B) = 10*4*P + 2.12e6*B'},
         }
         if world == 1:
-            # dominant kernel: the backward recurrent chain (2 per step); the forward twin beside it
-            us_b, launches_b, name_b = time_chain(device, 'bwd')
-            us_f, launches_f, name_f = time_chain(device, 'fwd')
-            kb, kf = chain_algorithmic_bytes(B_PER_GPU, 'bwd'), chain_algorithmic_bytes(B_PER_GPU, 'fwd')
+            # dominant kernel: the backward recurrent chain (bf16 mode: ONE launch for both layers, otherwise one per layer); the
+            # forward twin beside it
+            two = bool(_lib.lib().halo_lstm_persistent2_eligible(T_SUB, B_PER_GPU, H, L))
+            cl = 2 if two else 1
+            us_b, launches_b, name_b = time_chain(device, 'bwd', cl)
+            us_f, launches_f, name_f = time_chain(device, 'fwd', cl)
+            kb, kf = chain_algorithmic_bytes(B_PER_GPU, 'bwd', cl), chain_algorithmic_bytes(B_PER_GPU, 'fwd', cl)
+            chains = L // cl
             ach = kb / launches_b / (us_b / launches_b * 1e-6) / 1e9
             out['roofline'] = {
-                'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': L,
+                'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': chains, 'layers_per_chain': cl,
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                 'traffic': read_traffic(name_b),
                 'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
-                'accounting': 'SURVEY.md 8d: W_hh^T once per pass + per step the fp32 activations entering/leaving the chain '
-                              '(gates in, c in, dh in, gate gradients out), divided over the launches of the chain',
-                'share_of_step': round(L * us_b * 1e-3 / ms_per_step, 3),
+                'accounting': 'SURVEY.md 8d: every weight matrix the launch multiplies by once per pass (W_hh^T per layer; the two-layer '
+                              'launch also W_ih of layer 1) + per step and layer the fp32 activations entering/leaving the chain (gates in, '
+                              'c in, dh in, gate gradients out), divided over the launches of the chain',
+                'share_of_step': round(chains * us_b * 1e-3 / ms_per_step, 3),
                 'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
                                  'algorithmic_bytes_per_launch': kf // launches_f,
                                  'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
                                  'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': read_traffic(name_f),
-                                 'share_of_step': round(L * us_f * 1e-3 / ms_per_step, 3)}}
+                                 'share_of_step': round(chains * us_f * 1e-3 / ms_per_step, 3)}}
         if world == 1 and not args.no_extras:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
             n2 = max(20, args.steps // 2)
-            for mode in ('bf16', 'f32'):
+            for mode in ('bf16', 'bf16x3', 'f32'):
                 if mode != args.math:
                     out[mode + '_mode'] = time_other_mode(mode, device, (x, il, tg, tl), args.warmup, n2, not args.no_graph)
+            out['b_sweep'] = batch_sweep(args.math, device, args.warmup, max(20, args.steps // 4), not args.no_graph)
+            out['b_sweep'][f'B{B_PER_GPU}'] = {'value': out['value'], 'unit': 'utterances/s', 'ms_per_step': out['ms_per_step'], 'batch': B_PER_GPU,
+                                               'step_frac_of_hbm_peak': out['step_roofline']['frac_of_hbm_peak'],
+                                               'recurrence': out.get('roofline', {}).get('kernel')}
             _lib.set_math_mode(args.math)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(params)
+        if world == 1 and not args.no_extras and not args.no_configs:
+            # BASELINE configs 3 and 5, each in its own process after everything of this one is timed
+            torch.cuda.synchronize()
+            out['gpt2_small'] = run_config_leg('bench_gpt.py', 'bf16', 240)
+            out['asr_transformer32'] = run_config_leg('bench_asr.py', 'bf16x3', 240)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

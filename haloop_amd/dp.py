@@ -125,3 +125,66 @@ class GradientAverager:
 
     def average(self):
         self.finish(self.start())
+
+
+class ShardedUpdate:
+    """The collectives of the sharded-optimizer data-parallel step ("prefer direct reduce-scatter + all-gather
+    across the 7 links over ring"; the gradient semantics are DistributedDataParallel's, ha/attention_loop.py:154,203):
+
+        reduce_scatter()   flat_grads[span of this rank] <- mean over ranks   (every rank receives 1/world of the reduced buffer)
+        all_reduce_sum(t)  a few floats summed over ranks (the squared-norm partials of the clipped range: the clip needs the
+                           GLOBAL gradient norm although each rank holds 1/world of the gradient)
+        all_gather()       flat_params <- every rank's updated span
+
+    between them each rank runs clip + AdamW on its span only (1/world of the optimizer's 28 bytes per parameter).  The flat
+    buffers must be ``padded_numel(n, world)`` long so that the spans are equal and 16-byte aligned.  ``nccl`` (= RCCL) runs
+    reduce_scatter_tensor / all_gather_into_tensor in place on the flat buffers; ``gloo`` (the CPU tests) has no reduce-scatter:
+    there the mean is an all-reduce of which each rank keeps its span -- the same values."""
+
+    def __init__(self, flat_params, flat_grads, group=None, always=False):
+        """always: issue the collectives on a one-rank group too (where each is the identity) -- how a single GPU rehearses the
+        sharded step on the real backend, captured graphs included."""
+        self.params, self.grads, self.group = flat_params, flat_grads, group
+        self.always = bool(always) and dist.is_available() and dist.is_initialized()
+        self.world = world_size(group)
+        self.rank = dist.get_rank(group) if (self.world > 1 or self.always) else 0
+        n = flat_grads.numel()
+        if n % (4 * self.world) or flat_params.numel() != n:
+            raise ValueError(f'flat buffers must hold padded_numel(n, world) elements, got {n} for world {self.world}')
+        self.shard = n // self.world
+        self.span = (self.rank * self.shard, (self.rank + 1) * self.shard)
+        self._native = (self.world > 1 or self.always) and dist.get_backend(group) == 'nccl'
+        self._avg_op = self._native and _avg_supported(flat_grads, group)
+
+    @staticmethod
+    def padded_numel(n, world):
+        q = 4 * world
+        return (n + q - 1) // q * q
+
+    def reduce_scatter(self):
+        if self.world == 1 and not self.always:
+            return
+        lo, hi = self.span
+        if self._native:
+            op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+            dist.reduce_scatter_tensor(self.grads[lo:hi], self.grads, op=op, group=self.group)     # in place: out = in + rank * count
+            if not self._avg_op:
+                self.grads[lo:hi].mul_(1.0 / self.world)
+        else:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+            self.grads[lo:hi].mul_(1.0 / self.world)
+
+    def all_reduce_sum(self, t):
+        if self.world > 1 or self.always:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self):
+        if self.world == 1 and not self.always:
+            return
+        lo, hi = self.span
+        if self._native:
+            dist.all_gather_into_tensor(self.params, self.params[lo:hi], group=self.group)         # in place
+        else:
+            # (gloo copies into the list's tensors: contiguous slices of the flat buffer are written where they belong)
+            dist.all_gather([self.params[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], self.params[lo:hi].clone(),
+                            group=self.group)

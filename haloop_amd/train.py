@@ -11,6 +11,8 @@ Data parallel: one process per GPU, parameters broadcast 
 gradients averaged with one RCCL all-reduce per step over the flat gradient buffer -- the
 semantics of DistributedDataParallel in ha/attention_loop.py:154.
 """
+import os
+
 import torch
 
 from . import _lib, _linear, dp, ops
@@ -41,7 +43,8 @@ class FlatParams:
     are final first in backward -- recognizer and top LSTM layer -- form one contiguous suffix,
     the first all-reduce bucket of the data-parallel step."""
 
-    def __init__(self, encoder, recognizer):
+    def __init__(self, encoder, recognizer, pad_to=4):
+        """pad_to: the buffers' length is rounded up to a multiple of it (the sharded data-parallel update wants equal spans)."""
         decay, no_decay = decay_groups(encoder, recognizer)
         top = getattr(encoder, 'lstm', None)
         top_tag = f'_l{top.num_layers - 1}' if top is not None and top.num_layers > 1 else None
@@ -67,10 +70,11 @@ class FlatParams:
         # AdamW ranges: (begin, end, weight-decayed, clipped)
         self.ranges = [(bounds[0][0], bounds[0][1], False, True), (bounds[1][0], bounds[2][1], True, True),
                        (bounds[3][0], bounds[3][1], True, False), (bounds[4][0], bounds[4][1], False, False)]
-        self.params = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.padded = (off + pad_to - 1) // pad_to * pad_to
+        self.params = torch.zeros(self.padded, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(self.padded, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(self.padded, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(self.padded, device=dev, dtype=torch.float32)
         self.grad_views = {}
         with torch.no_grad():
             for n, p, o in self.slots:
@@ -87,7 +91,7 @@ class FlatParams:
 class LstmCtcTrainer:
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
-                 alias_loss=False, fused_head=True):
+                 alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False):
         """accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
         forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call.
         A micro-batch whose loss is NaN/Inf contributes nothing (the reference skips it, loop.py:167-174; here it still counts
@@ -95,14 +99,27 @@ class LstmCtcTrainer:
         skipped on the device and does not advance the Adam step count (loop.py:185-189).
         grad_dtype: wire format of the data-parallel all-reduce ('f32' = DistributedDataParallel's; 'bf16' halves the bytes).
         alias_loss: step() returns ``self.loss`` itself -- ONE device scalar that every later step overwrites -- instead of a
-        copy the caller owns (for loops that read each loss before the next step, or never)."""
+        copy the caller owns (for loops that read each loss before the next step, or never).
+        dp_algo (more than one rank): 'rs_ag' -- the gradients are reduce-scattered, every rank clips and updates ITS 1/world span of
+        the flat parameters (the squared-norm partials are summed over the ranks first: the clip uses the global norm), and the
+        spans are all-gathered; forward + backward stay ONE graph (a 2-layer stack in bf16 mode: the two-layer persistent launches).
+        (rehearse_dp: take this path on ONE rank of an initialised process group, every collective issued over that one rank --
+        how a single GPU exercises the real backend, captured graphs included.)
+        'allreduce' -- DistributedDataParallel's shape: every rank averages the whole gradient (two buckets, the first overlapped
+        with the lower layers' backward) and updates every parameter.  Both give the single-process step on the concatenated batch."""
         self.alias_loss = bool(alias_loss)
         self.fused_head = fused_head
         self.encoder, self.recognizer = encoder, recognizer
         self.accumulate = int(accumulate)
         self._micro = 0
         self.betas, self.eps, self.weight_decay, self.clip = betas, eps, weight_decay, clip_grad_norm
-        self.flat = FlatParams(encoder, recognizer)
+        if dp_algo not in ('rs_ag', 'allreduce'):
+            raise ValueError(f"dp_algo must be 'rs_ag' or 'allreduce', got {dp_algo!r}")
+        self.world = dp.world_size(process_group)
+        # gradient accumulation and the bf16 wire format live on the all-reduce path
+        self.dp_algo = dp_algo if ((self.world > 1 or rehearse_dp) and self.accumulate == 1 and grad_dtype == 'f32') else 'allreduce'
+        self._rehearse_dp = bool(rehearse_dp)
+        self.flat = FlatParams(encoder, recognizer, pad_to=4 * self.world if self.dp_algo == 'rs_ag' else 4)
         dev = self.flat.params.device
         # the learning rate lives on the device: the optimizer launch (captured in the step graph) reads it there, so assigning
         # ``trainer.lr`` between steps -- the reference applies its schedule every step, ha/loop.py:191 -- takes effect on replay
@@ -125,8 +142,9 @@ class LstmCtcTrainer:
         self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)      # last-workgroup ticket of the fused CTC head
         self.use_graph = use_graph
         self.pg = process_group
-        self.world = dp.world_size(process_group)
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
+        self.sharded = (dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp)
+                        if self.dp_algo == 'rs_ag' else None)
         # two buckets in readiness order: [top layer + recognizer] then [the rest]
         self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range, wire_dtype=grad_dtype)
         self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range, wire_dtype=grad_dtype)
@@ -213,7 +231,7 @@ class LstmCtcTrainer:
         dy_sub = torch.empty_like(y_sub)
         # one process: the whole stack in one call (a 2-layer stack in bf16 mode then runs as ONE two-layer persistent launch,
         # csrc/lstm_persist2.hip); data parallel: the top layer first, so that the first gradient bucket is final early
-        top = (L - 1 if L > 1 else 0) if self.world > 1 else 0
+        top = (L - 1 if L > 1 else 0) if (self.world > 1 and self.dp_algo == 'allreduce') else 0
         ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(top, L),
                      workspace=ws, dx=dy_sub)
         return (y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L))
@@ -255,15 +273,43 @@ class LstmCtcTrainer:
     def _optimizer(self):
         """clip + AdamW; the update count lives on the device, so these three launches have no host scalar and are captured
         in the step graph."""
+        self._norm_partials()
+        self._apply_update()
+
+    def _span(self):
+        return self.sharded.span if self.sharded is not None else (0, self.flat.padded)
+
+    def _norm_partials(self):
+        """Squared-norm partials of the clipped (encoder) range -- of this rank's span of it under the sharded update."""
         f = self.flat
-        e0, e1 = f.encoder_range
-        ops.sumsq_partials(f.grads[e0:e1], self.partials)
+        lo, hi = self._span()
+        e0, e1 = max(f.encoder_range[0], lo), min(f.encoder_range[1], hi)
+        if e1 > e0:
+            ops.sumsq_partials(f.grads[e0:e1], self.partials)
+        else:
+            self.partials.zero_()
+
+    def _apply_update(self):
+        f = self.flat
+        lo, hi = self._span()
         ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm, applied_steps=self.adam_step)
-        # all (decay, clip) ranges and the dropout step counter in one launch
-        ranges = [(a, b, self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
-                  for a, b, decays, clipped in f.ranges if b > a]
-        ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self._lr_dev, self.betas[0], self.betas[1], self.eps,
-                         self.adam_step, counter=self.counter)
+        # all (decay, clip) ranges (cut to this rank's span) and the dropout step counter in one launch
+        ranges = [(max(a, lo), min(b, hi), self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
+                  for a, b, decays, clipped in f.ranges if min(b, hi) > max(a, lo)]
+        if ranges:
+            ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self._lr_dev, self.betas[0], self.betas[1], self.eps,
+                             self.adam_step, counter=self.counter)
+        else:
+            ops.counter_inc(self.counter)
+
+    def _sharded_tail(self):
+        """reduce-scatter -> partial norms -> their sum over the ranks -> clip + AdamW on this rank's span -> all-gather."""
+        sh = self.sharded
+        sh.reduce_scatter()
+        self._norm_partials()
+        sh.all_reduce_sum(self.partials)
+        self._apply_update()
+        sh.all_gather()
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):
@@ -276,6 +322,8 @@ class LstmCtcTrainer:
         if self.accumulate > 1:
             return self._accumulating_step(x, input_lengths, targets, target_lengths)
         self.step_count += 1
+        if self.sharded is not None:
+            return self._sharded_step(x, input_lengths, targets, target_lengths)
         if not self.use_graph:
             st = self._forward_backward_top(x, input_lengths, targets, target_lengths)
             w1 = self.avg_early.start()          # overlaps the rest of backward (world > 1)
@@ -286,6 +334,36 @@ class LstmCtcTrainer:
             self._optimizer()
             return self.loss
         return self._graph_step(x, input_lengths, targets, target_lengths)
+
+    def _sharded_step(self, x, il, tg, tl):
+        """world > 1, dp_algo 'rs_ag'.  Graph mode: forward + backward replay from one graph; the tail -- three collectives with two
+        short optimizer pieces between them -- is captured in a second graph when the collective backend can be captured (RCCL
+        can: its kernels are ordinary stream work), else it runs eagerly."""
+        if not self.use_graph:
+            self._forward_backward(x, il, tg, tl)
+            self._sharded_tail()
+            return self.loss
+        self._replay_forward_backward(x, il, tg, tl)
+        self._tail_calls = getattr(self, '_tail_calls', 0) + 1
+        if self._tail_calls == 2 and self.sharded._native and os.environ.get('HALO_DP_CAPTURE', '1') != '0':
+            # the first tail ran eagerly (communicator and kernels warm); record the second
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._sharded_tail()
+                self._tail_graph = g
+            except Exception as e:                       # a backend that cannot live inside a capture: eager collectives
+                import logging
+                logging.getLogger(__name__).warning('haloop_amd.train: capturing the collectives failed (%s: %s); they run eagerly',
+                                                    type(e).__name__, e)
+                torch.cuda.synchronize()
+                self._tail_graph = None
+        if getattr(self, '_tail_graph', None) is not None:
+            self._tail_graph.replay()
+        else:
+            self._sharded_tail()
+        return self.loss
 
     def _accumulating_step(self, x, il, tg, tl):
         # forward/backward writes this micro-batch's gradients into the flat buffer; they are folded into the running sum

@@ -47,8 +47,26 @@ def _worker(rank, world, port, out):
         avg.average()
         avg16 = dp.GradientAverager(g16, bucket_bytes=4096, boundaries=[1000, 5000], wire_dtype='bf16')     # bf16 on the wire
         avg16.average()
+        # the sharded update (dp.ShardedUpdate): reduce-scatter the gradient, clip by the GLOBAL norm (partials summed over the ranks),
+        # a plain SGD step on this rank's span only, all-gather the parameters
+        n = flat.numel()
+        npad = dp.ShardedUpdate.padded_numel(n, world)
+        P, G = torch.zeros(npad), torch.zeros(npad)
+        P[:n] = flat
+        G[:n] = torch.cat([(pe[k] if w == 'e' else pr[k]).grad.reshape(-1) for w, k in names])     # this rank's own gradient again
+        sh = dp.ShardedUpdate(P, G)
+        lo, hi = sh.span
+        assert hi - lo == npad // world and sh.rank == rank
+        sh.reduce_scatter()
+        part = torch.tensor([float((G[lo:hi].double() ** 2).sum())], dtype=torch.float64)
+        sh.all_reduce_sum(part)
+        coef = min(1.0, 0.05 / (float(part.sqrt()) + 1e-6))
+        P[lo:hi] -= 0.1 * coef * G[lo:hi]
+        other = (lo - 1) % npad if lo else hi            # an element of another rank's span: untouched until the all-gather
+        before = float(P[other])
+        sh.all_gather()
         if rank == 0:
-            out.put((flat.numpy(), grads.numpy(), float(loss), g16.numpy()))
+            out.put((flat.numpy(), grads.numpy(), float(loss), g16.numpy(), P[:n].numpy(), float(part.sqrt()), before != float(P[other])))
     finally:
         dist.destroy_process_group()
 
@@ -62,7 +80,7 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    flat, grads, _, g16 = out.get()
+    flat, grads, _, g16, p_sharded, norm_sharded, moved = out.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -80,6 +98,11 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     # the bf16 wire format: each rank's contribution rounded to 8 significant bits, summed in bf16, averaged in fp32
     np.testing.assert_allclose(g16, want, rtol=2e-2, atol=1e-2 * np.abs(want).max())
     assert np.abs(g16 - want).max() > 0                                   # it really went through bf16
+    # the sharded update == the single-process clipped step on the concatenated batch
+    norm = float(np.sqrt((want.astype(np.float64) ** 2).sum()))
+    np.testing.assert_allclose(norm_sharded, norm, rtol=1e-4)
+    np.testing.assert_allclose(p_sharded, want_flat - 0.1 * min(1.0, 0.05 / (norm + 1e-6)) * want, rtol=1e-4, atol=1e-7)
+    assert moved                                                          # the other rank's span arrived through the all-gather
 
 
 def test_shard_slice_and_buckets():

@@ -32,7 +32,7 @@ def _build(seed, c=None):
     return enc.to('cuda:0').eval(), rec.to('cuda:0').eval()
 
 
-def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32'):
+def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32', dp_algo='allreduce'):
     import datetime
     import faulthandler
     import traceback
@@ -40,7 +40,7 @@ def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
-        _worker_body(rank, world, out, use_graph, cfg or CFG, grad_dtype)
+        _worker_body(rank, world, out, use_graph, cfg or CFG, grad_dtype, dp_algo)
     except Exception:                                   # a dead rank must not leave its peer (or pytest) waiting
         out.put(('error', rank, traceback.format_exc()))
         raise
@@ -48,33 +48,37 @@ def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32'):
         dist.destroy_process_group()
 
 
-def _worker_body(rank, world, out, use_graph, c, grad_dtype):
+def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
     if True:
         from haloop_amd import dp
         from haloop_amd.train import LstmCtcTrainer
         from oracle import cpu_ref
         enc, rec = _build(100 + rank, c)                   # different init per rank: rank 0's must win
-        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype)
+        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype, dp_algo=dp_algo)
+        assert tr.dp_algo == dp_algo
         x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
             tr.step(x[sl].cuda(), il[sl].cuda(), tg[sl].cuda(), tl[sl].cuda())
         torch.cuda.synchronize()
         if rank == 0:
-            out.put(('ok', tr.flat.params.cpu().numpy(), float(tr.grad_norm.item())))
+            out.put(('ok', tr.flat.params[:tr.flat.total].cpu().numpy(), float(tr.grad_norm.item())))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('use_graph,cfg_name,grad_dtype', [(False, 'tiny', 'f32'), (True, 'tiny', 'f32'),      # True: three captured graphs, all-reduces between them
-                                                           (True, 'persist', 'f32'), (True, 'persist', 'bf16')])
-def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype):
+@pytest.mark.parametrize('use_graph,cfg_name,grad_dtype,dp_algo', [
+    (False, 'tiny', 'f32', 'allreduce'), (True, 'tiny', 'f32', 'allreduce'),      # True: three captured graphs, all-reduces between them
+    (True, 'persist', 'f32', 'allreduce'), (True, 'persist', 'bf16', 'allreduce'),
+    # the sharded update: reduce-scatter, each rank clips (global norm) and updates its half of the flat parameters, all-gather
+    (False, 'tiny', 'f32', 'rs_ag'), (True, 'tiny', 'f32', 'rs_ag'), (True, 'persist', 'f32', 'rs_ag')])
+def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype, dp_algo):
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
     cfg = CFG if cfg_name == 'tiny' else CFG_PERSIST
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph, cfg, grad_dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph, cfg, grad_dtype, dp_algo)) for r in range(2)]
     for p in procs:
         p.start()
     import time
@@ -101,16 +105,16 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_nam
         tr.step(x.cuda(), il.cuda(), tg.cuda(), tl.cuda())
     if grad_dtype == 'bf16':          # gradients rounded to 8 significant bits on the wire: the update direction survives, not its bits
         np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=2e-2)
-        diff = np.abs(params2 - tr.flat.params.cpu().numpy())
+        diff = np.abs(params2 - tr.flat.params[:tr.flat.total].cpu().numpy())
         # two Adam steps at lr = 3e-3: an element whose tiny gradient changes sign on the wire moves the other way (<= 4 lr apart)
         assert diff.max() <= 4.2 * 3e-3 and (diff > 2e-3).mean() < 1e-3, (diff.max(), (diff > 2e-3).mean())
     else:
         np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=1e-4)
         if cfg_name == 'tiny':
-            np.testing.assert_allclose(params2, tr.flat.params.cpu().numpy(), atol=5e-6)
+            np.testing.assert_allclose(params2, tr.flat.params[:tr.flat.total].cpu().numpy(), atol=5e-6)
         else:       # H = 256 products run split-bf16 with shape-dependent K slicing: the two batch splits round differently, and Adam's
                     # normalised update carries that into a few near-zero-gradient elements (11 of 865 k above 2e-5 when this was set)
-            diff = np.abs(params2 - tr.flat.params.cpu().numpy())
+            diff = np.abs(params2 - tr.flat.params[:tr.flat.total].cpu().numpy())
             assert diff.max() <= 1e-4 and (diff > 2e-5).mean() < 1e-4, (diff.max(), (diff > 2e-5).mean())
 
 
@@ -214,7 +218,7 @@ def _rccl_worker(port, out, grad_dtype):
                 dp.world_size = lambda group=None: 2              # take every world > 1 branch; the collectives still span one rank
             try:
                 enc, rec = _build(100, c)
-                tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, grad_dtype=grad_dtype if forced else 'f32')
+                tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, grad_dtype=grad_dtype if forced else 'f32', dp_algo='allreduce')
                 if forced:
                     assert tr.world == 2 and len(tr.avg_early.buckets) >= 1
                     if grad_dtype == 'bf16':                       # SUM over one rank, then the 1/world scale: undo the forced halving
@@ -264,3 +268,60 @@ def test_rccl_backend_runs_the_data_parallel_step(grad_dtype):
     else:                                                              # bf16 wire: gradients rounded to bf16 once
         np.testing.assert_allclose(forced[1][0], single[1][0], rtol=1e-5)
         np.testing.assert_allclose(forced[1], single[1], rtol=2e-2)
+
+
+def _rccl_sharded_worker(port, out, math_mode):
+    """ONE rank on the real `nccl` (= RCCL) backend running the sharded data-parallel step (dp_algo 'rs_ag') with every collective issued
+    over that one rank: reduce_scatter_tensor and all_gather_into_tensor in place on the flat buffers, the all-reduce of the norm partials,
+    and -- from the second step on -- all three captured in a HIP graph with the two optimizer pieces between them."""
+    import datetime
+    import faulthandler
+    import traceback
+    faulthandler.dump_traceback_later(150, exit=True)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device('cuda', 0))
+        from haloop_amd import _lib
+        from haloop_amd.train import LstmCtcTrainer
+        from oracle import cpu_ref
+        _lib.set_math_mode(math_mode)
+        c = CFG_PERSIST
+        x, il, tg, tl = (t.cuda() for t in cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7))
+        res = {}
+        for rehearse in (False, True):
+            enc, rec = _build(100, c)
+            tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=rehearse)
+            assert (tr.sharded is not None) == rehearse
+            losses = [float(tr.step(x, il, tg, tl).item()) for _ in range(4)]
+            torch.cuda.synchronize()
+            tr.check_status()
+            res[rehearse] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None)
+        out.put(('ok', res))
+    except Exception:
+        out.put(('error', traceback.format_exc()))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'])
+def test_rccl_backend_runs_the_sharded_step(math_mode):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_sharded_worker, args=(_free_port(), out, math_mode))
+    p.start()
+    try:
+        msg = out.get(timeout=300)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg[0] == 'ok', msg[1]
+    plain, sharded = msg[1][False], msg[1][True]
+    # over one rank every collective is the identity and the span is the whole buffer: the same launches on the same data
+    assert sharded[1] == plain[1]
+    assert np.array_equal(sharded[0], plain[0])
+    assert sharded[2], 'the collectives were not captured (they ran eagerly): see the warning in the log'

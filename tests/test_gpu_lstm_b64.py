@@ -378,7 +378,10 @@ def test_two_train_mode_steps_at_config2_match_the_oracle_with_the_same_masks(ha
     for k, v in sd.items():
         a, b = v.reshape(-1)[::997].cpu().numpy(), want[k].detach().reshape(-1)[::997].numpy()
         if exact:
-            np.testing.assert_allclose(a, b, atol=2e-5, err_msg=k)
+            # (Adam's normalised update makes an element whose gradient is within rounding of zero move by up to lr either way:
+            # nearly all elements within 2e-5, none further than 1e-4)
+            assert (np.abs(a - b) <= 2e-5).mean() >= 0.999, (k, (np.abs(a - b) <= 2e-5).mean())
+            np.testing.assert_allclose(a, b, atol=1e-4, err_msg=k)
         else:
             d = np.abs(a - b)
             assert d.max() <= 4 * lr * 1.01 + 1e-6, (k, d.max())
