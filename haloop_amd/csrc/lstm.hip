@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(const StepBwdArg
 // wpT : tile = jt,         row r -> W[k][jt*16 + r]                  (k over 4H)
 // rows: tile = bt,         row r -> x[bt*16 + r][k] (0 beyond B)     (k over W)
 // MODE 2 also initialises the layer's row-major state rows: h_rm <- src (or 0), c_rm <- csrc (or 0)
-template <bool X3, int MODE>   // MODE 0: wp, 1: wpT, 2: rows
+template <bool X3, int MODE, bool HI_ONLY = false>   // MODE 0: wp, 1: wpT, 2: rows; HI_ONLY: the lo halves are not written (single-pass bf16 readers)
 __device__ __forceinline__ void pack_unit(long u, const float *__restrict__ src, void *__restrict__ dst, int H, int B, int Kdim,
                                           float *__restrict__ h_rm, const float *__restrict__ csrc, float *__restrict__ c_rm) {
     using PK = Packed<X3>;
@@ -477,7 +477,7 @@ __device__ __forceinline__ void pack_unit(long u, const float *__restrict__ src,
             lo[e] = (__bf16)(x[e] - (float)hh);
         }
         *reinterpret_cast<bf16x8 *>(base + lane * 16) = hi;
-        *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
+        if (!HI_ONLY) *reinterpret_cast<bf16x8 *>(base + 1024 + lane * 16) = lo;
     } else {
         f32x4 v4;
 #pragma unroll
@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256) void persist_prologue_kernel(const PrologueArg
 }
 
 // The same for the two-layer persistent launch (lstm_persist2.hip): three weight images (W_hh0, W_hh1, W_ih1; transposed for the
-// backward), both layers' initial states, the epoch words.
+// backward), both layers' initial states, the epoch words.  That launch runs in single-pass bf16 and reads the hi halves only: the lo
+// halves of the packed blocks are not written (a third of the prologue's bytes).
 struct Prologue2Args {
     const float *w[3]; void *wdst[3]; long w_units; int wK;         // w_units per matrix
     const float *h0[2]; void *hp0[2]; float *h_rm[2]; const float *c0[2]; float *c_rm[2]; long s_units;   // per layer (forward only)
@@ -530,10 +531,10 @@ __global__ __launch_bounds__(256) void persist2_prologue_kernel(const Prologue2A
     for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
         if (u < nw) {
             const int m = (int)(u / a.w_units);
-            pack_unit<true, WMODE>(u - m * a.w_units, a.w[m], a.wdst[m], a.H, a.B, a.wK, nullptr, nullptr, nullptr);
+            pack_unit<true, WMODE, true>(u - m * a.w_units, a.w[m], a.wdst[m], a.H, a.B, a.wK, nullptr, nullptr, nullptr);
         } else if (u < nw + ns) {
             const int l = (int)((u - nw) / a.s_units);
-            pack_unit<true, 2>(u - nw - l * a.s_units, a.h0[l], a.hp0[l], a.H, a.B, a.H, a.h_rm[l], a.c0[l], a.c_rm[l]);
+            pack_unit<true, 2, true>(u - nw - l * a.s_units, a.h0[l], a.hp0[l], a.H, a.B, a.H, a.h_rm[l], a.c0[l], a.c_rm[l]);
         } else if (u < nw + ns + a.zero_units) {
             reinterpret_cast<uint4 *>(a.zero)[u - nw - ns] = make_uint4(0u, 0u, 0u, 0u);
         } else {

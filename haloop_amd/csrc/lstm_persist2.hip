@@ -194,6 +194,7 @@ __device__ __forceinline__ void fwd2_layer1_waves(const Persist2Fwd &p, const Fw
             const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
             if (i * 4 + g < NWREG) wir[i * 4 + g < NWREG ? i * 4 + g : 0] = v;
             else *reinterpret_cast<bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024) = v;           // read back by this lane only
+            if (g == 3 && (i & 1)) __builtin_amdgcn_sched_barrier(0);      // eight fragments in flight at a time: the registers are half full already
         }
     const int ci = u >> 4, cj = u & 15;
     const int b = bt * 16 + ci;
@@ -311,173 +312,141 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
 // backward
 // ================================================================================================================
 // KC: chunks of 4 k-blocks per wave = (4H / 32 / 4) / 4 = H / 128.
+//
+// Combined step s = 0 .. T: layer 1 at time T-1-s, layer 0 at time T-s.  The gate gradients of layer 1 at time T-s (image T-s of dgp1)
+// feed layer 1's recurrence (times W_hh1^T, registers) AND the gradient arriving at layer 0 (times W_ih1^T, LDS) from ONE set of
+// fragment loads in waves 4-7; waves 0-3 contract layer 0's own gate gradients (image T-s+1 of dgp0) and, having half the matrix
+// work, pack and publish both layers' pieces and write the GEMM operand images.  As in the forward the halves run different loop
+// bodies with the same barriers.
+struct Bwd2Shared {
+    float (*red)[4][256];             // [layer 0 recurrent | layer 1 recurrent | from layer 1 into layer 0][K-quarter]
+    float (*dgbuf)[4][16][16];        // [layer][gate][batch row][hidden unit]
+    int *s_abort;
+    unsigned *s_published;
+};
+
+// one layer's cell update of the backward: dh -> gate gradients (and the carried cell gradient)
+struct Bwd2Cell {
+    float gv[4], cc, cprev, dcarry;
+    __device__ __forceinline__ void update(float dh, float (&dg)[4]) {
+        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+        const float tc = fast_tanh(cc);
+        const float dcc = dcarry + dh * og * (1.f - tc * tc);
+        const float d_o = dh * tc;
+        const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
+        dcarry = dcc * fg;
+        dg[0] = d_i * ig * (1.f - ig);
+        dg[1] = d_f * fg * (1.f - fg);
+        dg[2] = d_g * (1.f - gg * gg);
+        dg[3] = d_o * og * (1.f - og);
+    }
+};
+
 template <int KC>
-__global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist2Bwd p) {
-    constexpr int KBW = 4 * KC;                          // k-blocks per wave (a quarter of the 4H-deep contraction)
-    __shared__ float red[3][4][256];                     // [layer 0 recurrent | layer 1 recurrent | from layer 1 into layer 0][K-quarter]
-    __shared__ __attribute__((aligned(16))) float dgbuf[2][4][16][16];
-    __shared__ int s_abort;
-    __shared__ unsigned s_published;
-    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][KBW] W_ih1^T fragments of 1 KiB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, wq = wave & 3;
+__device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bwd2Shared sh, int jt, int bt, int wave, int lane, int u) {
+    constexpr int KBW = 4 * KC, CH = 4, NCH = KBW / CH, NBUF = 3;     // three buffers of 4 fragments: 12 loads of 1 KiB in flight per wave
+    const int wq = wave & 3;
     const int H = p.H, B = p.B, T = p.T, K = 4 * H;
-    const int NJ = H / 16, NBT = (B + 15) / 16, nkb4 = K / 32;
-    int jt, bt;
-    map_block(blockIdx.x, gridDim.x, NJ, NBT, jt, bt);
-    const int j0 = jt * 16;
-
-    // this wave's K-quarter of its layer's W_hh^T: columns j0..j0+15, k-blocks [wq*KBW, +KBW)
-    bf16x8 wr[KBW];
-    {
-        const char *wsrc = half ? p.wpT1 : p.wpT0;
+    const int NJ = H / 16, NBT = (B + 15) / 16, nkb4 = K / 32, j0 = jt * 16;
+    bf16x8 wr[KBW];                                  // K-quarter wq of W_hh0^T: columns j0..j0+15, k-blocks [wq*KBW, +KBW)
 #pragma unroll
-        for (int i = 0; i < KBW; ++i) wr[i] = *reinterpret_cast<const bf16x8 *>(wsrc + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
-    }
-    char *my_wi = wi_lds + (long)wq * KBW * 1024 + lane * 16;
-    if (half) {
-#pragma unroll
-        for (int i = 0; i < KBW; ++i)
-            *reinterpret_cast<bf16x8 *>(my_wi + i * 1024) =
-                *reinterpret_cast<const bf16x8 *>(p.wpTi + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
-    }
-
-    const int u = tid & 255, ci = u >> 4, cj = u & 15;
+    for (int i = 0; i < KBW; ++i) wr[i] = *reinterpret_cast<const bf16x8 *>(p.wpT0 + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
+    const int ci = u >> 4, cj = u & 15;
     const int b = bt * 16 + ci;
     const bool cell = b < B;
-    const long BH = (long)B * H;
-    const long e0 = (long)b * H + j0 + cj;
-    float *gates = half ? p.gates1 : p.gates0;
-    const float *cbuf = half ? p.c1 : p.c0;
-    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cprev = 0.f, dyv = 0.f, dcarry = 0.f, dh0 = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int BH = B * H;
+    const int e0 = b * H + j0 + cj;
+    Bwd2Cell c;
+    c.cc = c.cprev = c.dcarry = 0.f;
+    float dh0 = 0.f, bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c.gv[g] = 0.f;
     if (cell) {
         const int t = T - 1;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gv[g] = gates[((long)t * B + b) * K + (long)g * H + j0 + cj];
-        cc = cbuf[(long)(t + 1) * BH + e0];
-        cprev = cbuf[(long)t * BH + e0];
-        if (half && p.dy) dyv = p.dy[(long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
-        const float *dci = half ? p.dcinit1 : p.dcinit0, *dhi = half ? p.dhinit1 : p.dhinit0;
-        if (dci) dcarry = dci[e0];
-        if (dhi) dh0 = dhi[e0];
+        for (int g = 0; g < 4; ++g) c.gv[g] = p.gates0[(t * B + b) * K + g * H + j0 + cj];
+        c.cc = p.c0[(t + 1) * BH + e0];
+        c.cprev = p.c0[t * BH + e0];
+        if (p.dcinit0) c.dcarry = p.dcinit0[e0];
+        if (p.dhinit0) dh0 = p.dhinit0[e0];
     }
-    const __amdgpu_buffer_rsrc_t dg_rsrc = make_rsrc(half ? p.dgp1 : p.dgp0);     // the image this wave READS (its own layer's)
     const __amdgpu_buffer_rsrc_t dg0_rsrc = make_rsrc(p.dgp0), dg1_rsrc = make_rsrc(p.dgp1);
     const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
     const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
-    if (tid == 0) { s_abort = 0; s_published = 0; }
-
     for (int s = 0; s <= T; ++s) {
         if (wave == 0) stamp(p.stamps, T + 1, s, 0, lane);
-        const bool act = half ? (s < T) : (s >= 1);      // this half's layer has a cell update in combined step s ...
-        const int t = half ? T - 1 - s : T - s;           // ... at this time
-        // layer 1's waves contract dG1 of time T-s (steps 1 .. T): for their own recurrence (s < T) and for layer 0 (always);
-        // layer 0's waves contract dG0 of time T-s+1 (steps 2 .. T)
-        const bool mm = half ? (s >= 1) : (s >= 2);
-        const int timg = half ? T - s : T - s + 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const bool act = s >= 1;                     // layer 0 has a cell update in combined step s ...
+        const int t = T - s;                          // ... at this time
         bool ok = true;
-        if (s > 0 && wave == 7) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
-            s_abort = 1;
+            *sh.s_abort = 1;
             raise_abort(p.flags, p.status);
         }
         lds_barrier();                                                             // (A)
-        if (s_abort) return;
-        if (mm) {
-            const int img = (int)((((long)timg * NBT + bt) * nkb4 + wq * KBW) * 2048) + lane * 16;
-            bf16x8 ah[2][4];
-            auto load4 = [&](int buf, int c) {
+        if (*sh.s_abort) return;
+        if (wave == 0) stamp(p.stamps, T + 1, s, 1, lane);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s >= 2) {                                 // dG0 of time t + 1 (image T-s+1): layer 0's recurrent term
+            const int img = (((T - s + 1) * NBT + bt) * nkb4 + wq * KBW) * 2048;
+            bf16x8 ah[NBUF][CH];
+            auto loadc = [&](int buf, int cidx) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ah[buf][i] = load_sc1(dg_rsrc, img + (c * 4 + i) * 2048);
+                for (int i = 0; i < CH; ++i) ah[buf][i] = load_sc1_u(dg0_rsrc, lane * 16, img + (cidx * CH + i) * 2048);
             };
-            load4(0, 0);
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                if (c + 1 < KC) load4((c + 1) & 1, c + 1);
+            for (int cidx = 0; cidx < NBUF - 1 && cidx < NCH; ++cidx) loadc(cidx, cidx);
+#pragma unroll
+            for (int cidx = 0; cidx < NCH; ++cidx) {
+                if (cidx + NBUF - 1 < NCH) loadc((cidx + NBUF - 1) % NBUF, cidx + NBUF - 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c & 1][i], wr[c * 4 + i], acc, 0, 0, 0);
-                    if (half) {
-                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(my_wi + (c * 4 + i) * 1024);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c & 1][i], w, acc2, 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cidx % NBUF][i], wr[cidx * CH + i], acc, 0, 0, 0);
             }
         }
         {
             const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[half][wq][(4 * q + e) * 16 + r] = acc[e];
-                if (half) red[2][wq][(4 * q + e) * 16 + r] = acc2[e];
-            }
+            for (int e = 0; e < 4; ++e) sh.red[0][wq][(4 * q + e) * 16 + r] = acc[e];
         }
         lds_barrier();                                                             // (B)
+        if (wave == 0) stamp(p.stamps, T + 1, s, 2, lane);
         float dg[4] = {0.f, 0.f, 0.f, 0.f};
         if (act) {
             if (cell) {
-                float dh = 0.f;
-                if (half) {
-                    if (s == 0) dh = dh0;
-                    else {
+                float rec = 0.f, above = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) dh += red[1][k][u];
-                    }
-                } else {
-                    float rec = 0.f, above = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { rec += red[0][k][u]; above += red[2][k][u]; }
-                    above *= dropout_mult(p.drop, (uint64_t)t * BH + (uint64_t)e0);       // layer 0's own output mask
-                    dh = (s == 1 ? dh0 : rec) + above;
-                }
-                const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-                const float tc = fast_tanh(cc);
-                if (half && p.dy) {
-                    float d = dyv;
-                    if (p.dy_relu && !(og * tc > 0.f)) d = 0.f;
-                    dh += d;
-                }
-                const float dcc = dcarry + dh * og * (1.f - tc * tc);
-                const float d_o = dh * tc;
-                const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
-                dcarry = dcc * fg;
-                dg[0] = d_i * ig * (1.f - ig);
-                dg[1] = d_f * fg * (1.f - fg);
-                dg[2] = d_g * (1.f - gg * gg);
-                dg[3] = d_o * og * (1.f - og);
+                for (int k = 0; k < 4; ++k) { rec += sh.red[0][k][u]; above += sh.red[2][k][u]; }
+                above *= dropout_mult(p.drop, (uint64_t)((long)t * BH + e0));       // layer 0's own output mask
+                c.update((s == 1 ? dh0 : rec) + above, dg);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dgbuf[half][g][ci][cj] = dg[g];
+            for (int g = 0; g < 4; ++g) sh.dgbuf[0][g][ci][cj] = dg[g];
         }
         lds_barrier();                                                             // (C)
-        if (half) {
-            // waves 4-7 pack: wave 4 + g takes gate g; lanes 0-31 layer 1's piece (time T-1-s, steps 0 .. T-1), lanes 32-63 layer
-            // 0's (time T-s, steps 1 .. T).  Gate g's columns j0..j0+15 are k-groups 2 (jt & 1), 2 (jt & 1) + 1 of k-block g H/32 + jt/2.
+        if (wave == 0) stamp(p.stamps, T + 1, s, 3, lane);
+        {
+            // pack: wave g takes gate g; lanes 0-31 layer 1's piece (time T-1-s, steps 0 .. T-1), lanes 32-63 layer 0's (time T-s,
+            // steps 1 .. T).  Gate g's columns j0..j0+15 are k-groups 2 (jt & 1), 2 (jt & 1) + 1 of k-block g H/32 + jt/2.
             const int g = wq, lay = lane < 32 ? 1 : 0, kg = (lane >> 4) & 1, row = lane & 15;
             const bool on = lay ? (s < T) : (s >= 1);
             const int tt = lay ? T - 1 - s : T - s;
             bf16x8 hi;
             if (on) {
-                float x[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = dgbuf[lay][g][row][kg * 8 + e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hi[e] = (__bf16)x[e];
-                const int dst = (int)((((long)tt * NBT + bt) * nkb4 + g * (H / 32) + (jt >> 1)) * 2048) + (((jt & 1) * 2 + kg) * 16 + row) * 16;
+                for (int e = 0; e < 8; ++e) hi[e] = (__bf16)sh.dgbuf[lay][g][row][kg * 8 + e];
+                const int dst = ((tt * NBT + bt) * nkb4 + g * (H / 32) + (jt >> 1)) * 2048 + (((jt & 1) * 2 + kg) * 16 + row) * 16;
                 if (lay) store_sc1(dg1_rsrc, dst, hi);
                 else store_sc1(dg0_rsrc, dst, hi);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned old = 0;
-            if (lane == 0) old = atomicAdd(&s_published, 1u);
+            if (lane == 0) old = atomicAdd(sh.s_published, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
             if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            if (wave == 3) stamp(p.stamps, T + 1, s, 4, lane);
             // ---- off the hand-off path: the tile in the GEMM operand images (hi parts; gemm_bf16x3.hip layout) ----
             if (on) {
                 char *img_rows = lay ? nullptr : p.img_rows0;
@@ -485,49 +454,184 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
                 if (img_rows) {          // rows tt*B + b, k = g*H + j0 + 8 kg ..
                     const int grow = tt * B + bt * 16 + row, kcol = g * H + j0 + kg * 8;
                     const long blk = ((long)(grow >> 7) * nkb4 + (kcol >> 5)) * 2;
-                    const int r = grow & 127, c = (kcol & 31) >> 3;
-                    *reinterpret_cast<bf16x8 *>(img_rows + blk * 8192 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = hi;
+                    const int r = grow & 127, cc = (kcol & 31) >> 3;
+                    *reinterpret_cast<bf16x8 *>(img_rows + blk * 8192 + r * 64 + ((cc ^ ((r >> 2) & 3)) << 4)) = hi;
                 }
                 if (img_cols) {          // rows g*H + j0 + row (hidden unit), k = tt*B + bt*16 + 8 kg ..
                     bf16x8 hit;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hit[e] = (__bf16)dgbuf[lay][g][kg * 8 + e][row];
+                    for (int e = 0; e < 8; ++e) hit[e] = (__bf16)sh.dgbuf[lay][g][kg * 8 + e][row];
                     const int grow = g * H + j0 + row, kcol = tt * B + bt * 16 + kg * 8;
                     const int KT = (T * B + 31) >> 5;
                     const long blk = ((long)(grow >> 7) * KT + (kcol >> 5)) * 2;
-                    const int r = grow & 127, c = (kcol & 31) >> 3;
-                    *reinterpret_cast<bf16x8 *>(img_cols + blk * 8192 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = hit;
+                    const int r = grow & 127, cc = (kcol & 31) >> 3;
+                    *reinterpret_cast<bf16x8 *>(img_cols + blk * 8192 + r * 64 + ((cc ^ ((r >> 2) & 3)) << 4)) = hit;
                 }
             }
         }
         if (act && cell) {
-            float *gp = gates + ((long)t * B + b) * K + j0 + cj;
-            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
+            float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
             if (t > 0) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gv[g] = gates[((long)(t - 1) * B + b) * K + (long)g * H + j0 + cj];
-                cc = cprev;
-                cprev = cbuf[(long)(t - 1) * BH + e0];
-                if (half && p.dy) dyv = p.dy[(long)(t - 1) * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+                for (int g = 0; g < 4; ++g) c.gv[g] = p.gates0[((t - 1) * B + b) * K + g * H + j0 + cj];
+                c.cc = c.cprev;
+                c.cprev = p.c0[(t - 1) * BH + e0];
             }
         }
     }
-    {
-        float *dc = half ? p.dc1 : p.dc0;
-        if (cell && dc) dc[e0] = dcarry;
-    }
-    float *bias_part = half ? p.bias_part1 : p.bias_part0;
+    if (cell && p.dc0) p.dc0[e0] = c.dcarry;
     lds_barrier();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dgbuf[half][g][ci][cj] = bsum[g];              // rows >= B hold zeros
+    for (int g = 0; g < 4; ++g) sh.dgbuf[0][g][ci][cj] = bsum[g];              // rows >= B hold zeros
     lds_barrier();
-    if (bias_part && u < 64) {
+    if (p.bias_part0 && u < 64) {
         const int g = u >> 4, j = u & 15;
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum += dgbuf[half][g][r][j];
-        bias_part[(long)bt * K + (long)g * H + j0 + j] = sum;
+        for (int r = 0; r < 16; ++r) sum += sh.dgbuf[0][g][r][j];
+        p.bias_part0[(long)bt * K + g * H + j0 + j] = sum;
     }
+}
+
+template <int KC>
+__device__ __forceinline__ void bwd2_layer1_waves(const Persist2Bwd &p, const Bwd2Shared sh, char *wi_lds, int jt, int bt, int wave, int lane,
+                                                  int u) {
+    constexpr int KBW = 4 * KC, CH = 4, NCH = KBW / CH, NBUF = 3;     // three buffers of 4: 12 loads in flight (the registers also hold LDS fragments)
+    const int wq = wave & 3;
+    const int H = p.H, B = p.B, T = p.T, K = 4 * H;
+    const int NBT = (B + 15) / 16, nkb4 = K / 32, j0 = jt * 16;
+    bf16x8 wr[KBW];                                  // K-quarter wq of W_hh1^T
+#pragma unroll
+    for (int i = 0; i < KBW; ++i) wr[i] = *reinterpret_cast<const bf16x8 *>(p.wpT1 + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
+    char *my_wi = wi_lds + (long)wq * KBW * 1024 + lane * 16;                     // K-quarter wq of W_ih1^T: read back by this lane only
+#pragma unroll
+    for (int i = 0; i < KBW; ++i) {
+        *reinterpret_cast<bf16x8 *>(my_wi + i * 1024) =
+            *reinterpret_cast<const bf16x8 *>(p.wpTi + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // eight fragments in flight at a time: W_hh1^T already fills half the registers
+    }
+    const int ci = u >> 4, cj = u & 15;
+    const int b = bt * 16 + ci;
+    const bool cell = b < B;
+    const int BH = B * H;
+    const int e0 = b * H + j0 + cj;
+    Bwd2Cell c;
+    c.cc = c.cprev = c.dcarry = 0.f;
+    float dh0 = 0.f, dyv = 0.f, bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c.gv[g] = 0.f;
+    if (cell) {
+        const int t = T - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c.gv[g] = p.gates1[(t * B + b) * K + g * H + j0 + cj];
+        c.cc = p.c1[(t + 1) * BH + e0];
+        c.cprev = p.c1[t * BH + e0];
+        if (p.dy) dyv = p.dy[(long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+        if (p.dcinit1) c.dcarry = p.dcinit1[e0];
+        if (p.dhinit1) dh0 = p.dhinit1[e0];
+    }
+    const __amdgpu_buffer_rsrc_t dg1_rsrc = make_rsrc(p.dgp1);
+    for (int s = 0; s <= T; ++s) {
+        const bool act = s < T;                      // layer 1 has a cell update in combined step s ...
+        const int t = T - 1 - s;                      // ... at this time
+        lds_barrier();                                                             // (A)
+        if (*sh.s_abort) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        if (s >= 1) {                                 // dG1 of time T-s: layer 1's recurrent term (acc) and layer 0's incoming gradient (acc2)
+            const int img = (((T - s) * NBT + bt) * nkb4 + wq * KBW) * 2048;
+            bf16x8 ah[NBUF][CH];
+            auto loadc = [&](int buf, int cidx) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) ah[buf][i] = load_sc1_u(dg1_rsrc, lane * 16, img + (cidx * CH + i) * 2048);
+            };
+#pragma unroll
+            for (int cidx = 0; cidx < NBUF - 1 && cidx < NCH; ++cidx) loadc(cidx, cidx);
+#pragma unroll
+            for (int cidx = 0; cidx < NCH; ++cidx) {
+                if (cidx + NBUF - 1 < NCH) loadc((cidx + NBUF - 1) % NBUF, cidx + NBUF - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8 *>(my_wi + (cidx * CH + i) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cidx % NBUF][i], wr[cidx * CH + i], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cidx % NBUF][i], w, acc2, 0, 0, 0);
+                }
+            }
+        }
+        {
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sh.red[1][wq][(4 * q + e) * 16 + r] = acc[e];
+                sh.red[2][wq][(4 * q + e) * 16 + r] = acc2[e];
+            }
+        }
+        lds_barrier();                                                             // (B)
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            if (cell) {
+                float dh = 0.f;
+                if (s == 0) dh = dh0;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dh += sh.red[1][k][u];
+                }
+                if (p.dy) {
+                    const float tc = fast_tanh(c.cc);
+                    float d = dyv;
+                    if (p.dy_relu && !(c.gv[3] * tc > 0.f)) d = 0.f;
+                    dh += d;
+                }
+                c.update(dh, dg);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sh.dgbuf[1][g][ci][cj] = dg[g];
+        }
+        lds_barrier();                                                             // (C)
+        if (act && cell) {
+            float *gp = p.gates1 + (t * B + b) * K + j0 + cj;
+            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
+            if (t > 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) c.gv[g] = p.gates1[((t - 1) * B + b) * K + g * H + j0 + cj];
+                c.cc = c.cprev;
+                c.cprev = p.c1[(t - 1) * BH + e0];
+                if (p.dy) dyv = p.dy[(long)(t - 1) * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj];
+            }
+        }
+    }
+    if (cell && p.dc1) p.dc1[e0] = c.dcarry;
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sh.dgbuf[1][g][ci][cj] = bsum[g];
+    lds_barrier();
+    if (p.bias_part1 && u < 64) {
+        const int g = u >> 4, j = u & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += sh.dgbuf[1][g][r][j];
+        p.bias_part1[(long)bt * K + g * H + j0 + j] = sum;
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist2Bwd p) {
+    __shared__ float red[3][4][256];
+    __shared__ __attribute__((aligned(16))) float dgbuf[2][4][16][16];
+    __shared__ int s_abort;
+    __shared__ unsigned s_published;
+    extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][4 KC] W_ih1^T fragments of 1 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int jt, bt;
+    map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
+    if (tid == 0) { s_abort = 0; s_published = 0; }
+    const Bwd2Shared sh = {red, dgbuf, &s_abort, &s_published};
+    if (wave < 4) bwd2_layer0_waves<KC>(p, sh, jt, bt, wave, lane, tid & 255);
+    else bwd2_layer1_waves<KC>(p, sh, wi_lds, jt, bt, wave, lane, tid & 255);
 }
 
 int g_cu_count2 = 0;
