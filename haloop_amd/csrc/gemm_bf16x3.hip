@@ -265,6 +265,10 @@ struct TiledGemmArgs {
     const int64_t *ce_target;
     float *ce_part, *ce_tlogit;
     int ce_strips;               // strips per row = 2 * tiles_n
+    // IO & 4: the result's columns [n_split, N) go to a second matrix C2 (leading dimension ldc2) from its column 0 on; n_split is a
+    // multiple of the 128-column tile.  Two products that share their A operand run as ONE launch over the stacked B operands.
+    float *C2;
+    int n_split, ldc2;
 };
 
 template <int PASSES>
@@ -527,6 +531,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             float bias = 0.f;
             if (p.bias1) bias += p.bias1[col];
             if (p.bias2) bias += p.bias2[col];
+            if (IO & 4) {       // two output matrices, cut at a tile boundary (n0 is workgroup-uniform); no bias, activation or addend
+                float *cq = n0 >= p.n_split ? p.C2 : p.C;
+                const int ldq = n0 >= p.n_split ? p.ldc2 : p.ldc, colq = n0 >= p.n_split ? col - p.n_split : col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < p.M) cq[(long)row * ldq + colq] = acc[i][j][r];
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -844,6 +858,34 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);
 }
 
+
+// C [M][n_split] | C2 [M][N - n_split] = A [M][K] x (B [n_split][K] stacked on B2 [N - n_split][K])^T in ONE launch: the image of the
+// stacked operand is the two images one after the other when n_split is a multiple of the 128-row tile.  The LSTM's two weight-gradient
+// products of a layer share dG^T this way (lstm.hip).  Plain sums: no bias, activation, dropout or split-K.
+int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
+                                  hipStream_t st) {
+    if (n_split % TR != 0 || n_split <= 0 || n_split >= N) return HALO_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<1, 3, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<3, 1, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    TiledGemmArgs p = {};
+    p.A = (const char *)Aimg; p.B = (const char *)Bimg; p.C = C; p.C2 = C2; p.n_split = n_split; p.ldc2 = ldc2;
+    p.M = M; p.N = N; p.KT = (K + TK - 1) / TK; p.ldc = ldc;
+    p.tiles_n = (N + TR - 1) / TR;
+    p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
+    p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
+    p.ksplit = 1; p.ktper = p.KT;
+    const dim3 grid((unsigned)p.ntiles);
+    if (halo_math_mode() == HALO_MATH_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (p.ntiles >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 1, 4>), grid, dim3(256), STAGE_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 1, 4>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    return halo_launch_status();
+}
 
 // The tiled product with row-major bf16 on either side (IO instantiations of the kernel): A from a row-major bf16 matrix (a_hi [, a_lo])
 // instead of an image, and / or the result as row-major bf16 (o_hi [, o_lo]) beside or instead of fp32 C.  No split-K, no dropout.

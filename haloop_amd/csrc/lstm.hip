@@ -1087,6 +1087,11 @@ inline size_t bwd_flags_offset(int T, int B, int in0, int H, int L) {
     return (n + 255) & ~(size_t)255;
 }
 
+inline bool pair_dw_enabled() {
+    static const bool on = !(getenv("HALO_LSTM_PAIR_DW") && atoi(getenv("HALO_LSTM_PAIR_DW")) == 0);
+    return on;
+}
+
 // What follows a layer's backward chain: every operand image of its gradient GEMMs in ONE launch (dG [TB][4H] for the input
 // gradient and dG^T [4H][TB] for both weight gradients unless the chain wrote them itself: ``emit``; W_ih^T, h_prev^T, in^T; the
 // bias gradients from the chain's partial rows), then the input gradient (feeds layer l-1's recurrence or the caller's dx) and
@@ -1139,7 +1144,11 @@ int lstm_bwd_layer_tail(const float *x, const float *const *w_ih, float *reserve
         }
     }
     // (2) this layer's parameter gradients
-    if (tiled) {
+    if (tiled && H % 128 == 0 && img_inT == img_hT + halo_tiled_image_bytes(H, T * B) && pair_dw_enabled()) {
+        // dW_hh | dW_ih = dG^T x (h_prev^T stacked on in^T)^T: ONE launch over the two images, which lie one after the other
+        // (512 tiles at H = 1024 instead of 2 x 256: one launch's fill and drain instead of two)
+        rc = halo_gemm_bf16x3_tiled_nsplit(img_gT, img_hT, 4 * H, H + in_dim, T * B, dw_hh[l], H, H, dw_ih[l], in_dim, side);
+    } else if (tiled) {
         rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);
         if (!rc) rc = halo_gemm_bf16x3_tiled(img_gT, img_inT, 4 * H, in_dim, T * B, dw_ih[l], in_dim, nullptr, nullptr, 0,
                                              nullptr, side);
@@ -1483,7 +1492,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         a.dhinit1 = dhn ? dhn + BH : nullptr; a.dcinit1 = dcn ? dcn + BH : nullptr;
         a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
         a.flags = (unsigned *)flag_base;
-        a.stamps = nullptr;
+        a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 1][16] here
         a.img_rows0 = emit0 && need_dx ? img_g : nullptr;
         a.img_cols0 = emit0 ? img_gT : nullptr;
         a.img_cols1 = emit1 ? img_gT1 : nullptr;

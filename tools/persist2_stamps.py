@@ -39,3 +39,26 @@ print(f'per combined step (loop top to loop top), mean over workgroups: {np.diff
 for k in (0, 8, 1, 2, 3, 4, 5, 7, 6):
     d = s[:, steps, k] - base
     print(f'  {names[k]:52s} +{d.mean():7.3f} us  (min {d.min():6.2f}  max {d.max():6.2f})')
+
+# ---- backward ----
+dy = (torch.randn(T, B, H, generator=g) * 0.01).to(dev)
+y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b, drop=drop)
+ws = ops.lstm_bwd_workspace(x, w_hh)
+for _ in range(2):
+    ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, drop=drop, workspace=ws)
+stamps.zero_()
+_lib.check(_lib.lib().halo_lstm_persist_stamps(stamps.data_ptr()), 'stamps')
+ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, drop=drop, workspace=ws)
+torch.cuda.synchronize()
+_lib.lib().halo_lstm_persist_stamps(None)
+Sb = T + 1
+s = stamps.cpu().numpy()[:nblk * Sb * 16].reshape(nblk, Sb, 16).astype(np.float64) * 0.01
+names = {0: 'loop top (wave 0)', 1: 'after barrier A: poll matched', 2: 'after barrier B: MFMAs done, partials written',
+         3: 'after barrier C: cell updates done', 4: 'pieces drained (+ flag), wave 3'}
+steps = slice(3, T - 1)
+base = s[:, steps, 0]
+print(f'BACKWARD kernel span (first loop top to last): {(s[:, -1, 0].max() - s[:, 0, 0].min()):.1f} us')
+print(f'per combined step (loop top to loop top), mean over workgroups: {np.diff(s[:, 2:T, 0], axis=1).mean():.3f} us')
+for k in (0, 1, 2, 3, 4):
+    d = s[:, steps, k] - base
+    print(f'  {names[k]:52s} +{d.mean():7.3f} us  (min {d.min():6.2f}  max {d.max():6.2f})')
