@@ -59,6 +59,7 @@ SIGNATURES = {
     'halo_set_lstm_persistent_images': (_i, [_i]),
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
+    'halo_set_lstm_expect_backward': (_i, [_i]),
     'halo_lstm_persistent2_eligible': (_i, [_i, _i, _i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),
     'halo_lstm_persist_stamps': (_i, [_vp]),
@@ -205,6 +206,11 @@ def set_lstm_persistent(on):
 def set_lstm_persistent2(on):
     """Both layers of a 2-layer LSTM in one persistent launch per direction (bf16 mode; include/halo.h) on / off."""
     check(lib().halo_set_lstm_persistent2(int(bool(on))), 'halo_set_lstm_persistent2')
+
+
+def set_lstm_expect_backward(on):
+    """Whether a backward follows the LSTM forwards issued next (include/halo.h): inference switches it off."""
+    check(lib().halo_set_lstm_expect_backward(int(bool(on))), 'halo_set_lstm_expect_backward')
 
 
 def set_lstm_persistent_images(on):

@@ -40,6 +40,8 @@ struct HaloCtx {
     unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
     hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
     unsigned long long *stamps = nullptr;
+    int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)
+    const float *packT_reserve = nullptr, *packT_w[3] = {nullptr, nullptr, nullptr};   // ... into this reserve, from these weights (host bookkeeping)
     int mute_block = -1;                 // test hook (halo_debug_mute_workgroup): this workgroup of a persistent forward never publishes
 };
 HaloCtx &halo_ctx_cur();

@@ -543,6 +543,68 @@ __global__ __launch_bounds__(256) void persist2_prologue_kernel(const Prologue2A
     }
 }
 
+// The two-layer launches' six weight images -- W_hh0, W_hh1, W_ih1 packed for the forward (pack MODE 0) AND transposed for the backward
+// (MODE 1), hi halves -- from ONE read of the three matrices at the head of the forward: a wave takes a 32 x 32 tile of W [4H][H], writes
+// its two forward blocks (16 rows x 32 k each) straight from the registers it loaded, turns the tile through LDS and writes the two
+// transposed blocks (32 k x 16 columns each).  The backward of the same step then packs nothing (halo_lstm_bwd finds the images in the
+// reserve).  The states and the epoch words ride along in the tail blocks of the same launch.
+struct PackPairArgs {
+    const float *w[3];
+    char *fwd[3], *tr[3];
+    int H;
+    int tile_blocks;          // workgroups that pack tiles (4 tiles each); the rest run the prologue's unit loop
+    Prologue2Args rest;       // w_units = 0: states + zeroed words
+};
+__global__ __launch_bounds__(256) void persist2_pack_pair_kernel(const PackPairArgs a) {
+    __shared__ float tile[4][32][33];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= a.tile_blocks) {
+        const Prologue2Args &r = a.rest;
+        const long ns = 2 * r.s_units, total = ns + r.zero_units + r.zero2_units;
+        for (long u = (blockIdx.x - a.tile_blocks) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - a.tile_blocks) * 256) {
+            if (u < ns) {
+                const int l = (int)(u / r.s_units);
+                pack_unit<true, 2, true>(u - l * r.s_units, r.h0[l], r.hp0[l], r.H, r.B, r.H, r.h_rm[l], r.c0[l], r.c_rm[l]);
+            } else if (u < ns + r.zero_units) {
+                reinterpret_cast<uint4 *>(r.zero)[u - ns] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                reinterpret_cast<uint4 *>(r.zero2)[u - ns - r.zero_units] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        return;
+    }
+    const int H = a.H, nkb = H / 32, nkb4 = 4 * H / 32;
+    const int tiles_c = H / 32, tiles_per = (4 * H / 32) * tiles_c;
+    const long t = (long)blockIdx.x * 4 + wave;                  // tile index over the three matrices (tile_blocks * 4 == 3 * tiles_per)
+    const int m = (int)(t / tiles_per), tt = (int)(t % tiles_per);
+    const int R0 = (tt / tiles_c) * 32, C0 = (tt % tiles_c) * 32;
+    const float *w = a.w[m];
+    const int i = lane & 15, kg = lane >> 4;
+    const int g = R0 / H, jt = (R0 % H) / 16;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float *src = w + (long)(R0 + half * 16 + i) * H + C0 + kg * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+        bf16x8 hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (__bf16)v0[e]; hi[4 + e] = (__bf16)v1[e];
+            tile[wave][half * 16 + i][kg * 8 + e] = v0[e];
+            tile[wave][half * 16 + i][kg * 8 + 4 + e] = v1[e];
+        }
+        *reinterpret_cast<bf16x8 *>(a.fwd[m] + (((long)(jt + half) * 4 + g) * nkb + C0 / 32) * 2048 + lane * 16) = hi;
+    }
+    __builtin_amdgcn_wave_barrier();                             // the tile is this wave's own: LDS program order within the wave suffices
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bf16x8 hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hi[e] = (__bf16)tile[wave][kg * 8 + e][c * 16 + i];
+        *reinterpret_cast<bf16x8 *>(a.tr[m] + ((long)(C0 / 16 + c) * nkb4 + R0 / 32) * 2048 + lane * 16) = hi;
+    }
+}
+
 // =================================================================================================
 // Layer-diagonal ("wavefront") fusion.  Step t of layer l only needs step t of layer l-1 and step
 // t-1 of layer l, so ONE launch runs step d-l of every layer l (grid.z = layer): a 2-layer, T=21
@@ -1196,9 +1258,26 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     pa.zero = flags; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
     pa.zero2 = nullptr; pa.zero2_units = 0;
     pa.H = H; pa.B = B;
-    hipLaunchKernelGGL(persist2_prologue_kernel<0>, dim3(pack_grid((size_t)(3 * pa.w_units + 2 * pa.s_units + pa.zero_units))), dim3(256),
-                       0, st, pa);
-    HALO_TRY(halo_launch_status());
+    HaloCtx &ctx = halo_ctx_cur();
+    ctx.packT_reserve = nullptr;
+    if (ctx.lstm_expect_backward && H % 32 == 0) {
+        // a backward will follow (halo_set_lstm_expect_backward): its three transposed images come out of the same read of the weights
+        float *wT = (float *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES);
+        PackPairArgs pp;
+        for (int m = 0; m < 3; ++m) { pp.w[m] = pa.w[m]; pp.fwd[m] = (char *)pa.wdst[m]; pp.tr[m] = (char *)(wT + (size_t)m * 4 * H * H); }
+        pp.H = H;
+        pp.tile_blocks = 3 * (4 * H / 32) * (H / 32) / 4;
+        pp.rest = pa; pp.rest.w_units = 0;
+        const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units));
+        hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)pp.tile_blocks + rest_blocks), dim3(256), 0, st, pp);
+        HALO_TRY(halo_launch_status());
+        ctx.packT_reserve = reserve;
+        for (int m = 0; m < 3; ++m) ctx.packT_w[m] = pa.w[m];
+    } else {
+        hipLaunchKernelGGL(persist2_prologue_kernel<0>, dim3(pack_grid((size_t)(3 * pa.w_units + 2 * pa.s_units + pa.zero_units))), dim3(256),
+                           0, st, pa);
+        HALO_TRY(halo_launch_status());
+    }
     Persist2Fwd a;
     a.wp0 = (const char *)wp0; a.wp1 = (const char *)wp1; a.wpi = (const char *)wpi;
     a.hp0 = (char *)l0.hp; a.hp1 = (char *)l1.hp;
@@ -1257,7 +1336,8 @@ int halo_lstm_chain_info(int backward, int *launches, char *kernel, int kernel_l
 
 size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
-    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES;
+    // L == 2: behind the epoch words, the three transposed weight images the two-layer forward leaves for the backward of the same step
+    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (L == 2 ? (size_t)3 * 4 * H * H * sizeof(float) : 0);
 }
 
 int halo_set_lstm_persistent(int on) {
@@ -1279,6 +1359,10 @@ int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B,
 
 int halo_set_lstm_persistent2(int on) {
     halo_lstm_persist2_enable(on);
+    return HALO_OK;
+}
+int halo_set_lstm_expect_backward(int on) {
+    halo_ctx_cur().lstm_expect_backward = on ? 1 : 0;
     return HALO_OK;
 }
 int halo_lstm_persistent2_eligible(int T, int B, int H, int L) { return !fused_ok(H, L) && use_x3(H) && halo_lstm_persist2_ok(T, B, H, L) ? 1 : 0; }
@@ -1457,7 +1541,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         for (int l = 0; l < 2; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs l0 = layer_bufs(reserve, 0, T, B, H), l1 = layer_bufs(reserve, 1, T, B, H);
         float *extra = (float *)(img_wT + halo_tiled_image_bytes(kin, 4 * H));
-        float *wpT1 = extra, *wpTi = extra + (size_t)4 * H * H, *dcarry1 = extra + (size_t)8 * H * H;
+        float *wpT1 = extra, *wpTi = extra + (size_t)4 * H * H, *dcarry1 = extra + (size_t)8 * H * H;      // (or the reserve's: below)
         char *flag_base = (char *)workspace + bwd_flags_offset(T, B, in0, H, L);
         float *bias_part0 = (float *)(flag_base + PERSIST_FLAG_BYTES);
         char *p2 = (char *)workspace + bwd_p2_offset(T, B, in0, H, L);
@@ -1467,9 +1551,16 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         const bool can_emit = persist_emit_enabled() && B % 32 == 0;
         const bool emit0 = can_emit && in0 >= 64, emit1 = can_emit;
         const bool need_dx = dx != nullptr;
+        // the forward of this step may have left the three transposed images in the reserve (one read of the weights for all six)
+        const HaloCtx &ctx = halo_ctx_cur();
+        const bool have_T = ctx.packT_reserve == reserve && ctx.packT_w[0] == w_hh[0] && ctx.packT_w[1] == w_hh[1] && ctx.packT_w[2] == w_ih[1];
+        if (have_T) {
+            float *wT = (float *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES);
+            wpT = wT; wpT1 = wT + (size_t)4 * H * H; wpTi = wT + (size_t)8 * H * H;
+        }
         Prologue2Args pa;
         pa.w[0] = w_hh[0]; pa.wdst[0] = wpT; pa.w[1] = w_hh[1]; pa.wdst[1] = wpT1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpTi;
-        pa.w_units = (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
+        pa.w_units = have_T ? 0 : (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
         for (int l = 0; l < 2; ++l) { pa.h0[l] = nullptr; pa.hp0[l] = nullptr; pa.h_rm[l] = nullptr; pa.c0[l] = nullptr; pa.c_rm[l] = nullptr; }
         pa.s_units = 0;
         pa.zero = (unsigned *)flag_base; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);

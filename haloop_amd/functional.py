@@ -21,7 +21,7 @@ class _Encoder(torch.autograd.Function):
         Tp = y_sub.shape[0]
         feats = torch.empty(B, Tp, H, device=x.device, dtype=torch.float32)
         _, _, _, reserve = ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True,
-                                        drop=drop)
+                                        drop=drop, expect_backward=any(ctx.needs_input_grad))
         ctx.save_for_backward(y_sub, col, reserve, *lstm_params)
         ctx.meta = (B, T, F, conv_w.shape[0], L, H, Tp, drop)
         return feats
@@ -52,7 +52,7 @@ class _LSTM(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh = _lstm_lists(lstm_params, L)
         x_tm = x_tm.contiguous()
         y, hn, cn, reserve = ops.lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=h0.contiguous(), c0=c0.contiguous(),
-                                          want_state=True, drop=drop)
+                                          want_state=True, drop=drop, expect_backward=any(ctx.needs_input_grad))
         ctx.save_for_backward(x_tm, reserve, *lstm_params)
         ctx.meta = (L, w_hh[0].shape[1], drop, x_tm.requires_grad)
         return y, hn, cn

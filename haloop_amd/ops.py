@@ -219,8 +219,9 @@ def subsample_bwd(dy, y, col, B, T, F, Cc, p_drop, dw=None, dbias=None, ks=5, st
 
 
 def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=None, y_relu=False,
-             want_state=False, drop=NO_DROPOUT):
+             want_state=False, drop=NO_DROPOUT, expect_backward=True):
     """x_tm [T,B,in] time-major.  Returns (y, hn, cn, reserve).
+    expect_backward=False (inference): the two-layer launch packs only the forward's weight images (include/halo.h).
 
     y defaults to a time-major [T,B,H] tensor; pass a preallocated ``y`` with ``y_strides`` =
     (stride_t, stride_b) in elements to have the last layer write e.g. batch-first."""
@@ -240,9 +241,15 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     if h0 is not None:
         _f32c(h0, 'h0'); _f32c(c0, 'c0')
     a_ih, a_hh, a_bi, a_bh = ptr_array(w_ih), ptr_array(w_hh), ptr_array(b_ih), ptr_array(b_hh)
-    check(lib().halo_lstm_fwd(ptr(x_tm), a_ih, a_hh, a_bi, a_bh, ptr(h0), ptr(c0), ptr(y), y_strides[0], y_strides[1],
-                              int(y_relu), ptr(hn), ptr(cn), ptr(reserve), T, B, in0, H, L, drop.p, drop.seed,
-                              drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_fwd')
+    if not expect_backward:
+        lib().halo_set_lstm_expect_backward(0)
+    try:
+        check(lib().halo_lstm_fwd(ptr(x_tm), a_ih, a_hh, a_bi, a_bh, ptr(h0), ptr(c0), ptr(y), y_strides[0], y_strides[1],
+                                  int(y_relu), ptr(hn), ptr(cn), ptr(reserve), T, B, in0, H, L, drop.p, drop.seed,
+                                  drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_fwd')
+    finally:
+        if not expect_backward:
+            lib().halo_set_lstm_expect_backward(1)
     return y, hn, cn, reserve
 
 

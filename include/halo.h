@@ -265,6 +265,10 @@ int halo_lstm_persistent_eligible(int B, int H);
  * called with layer_begin = 0, layer_end = 2 likewise (layer 1's input gradient formed inside the launch).  Same reserve contents as
  * the per-layer path, so either backward follows either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
 int halo_set_lstm_persistent2(int on);
+/* The two-layer forward packs its three weight images; when a backward of the same step will follow (the default) it writes the
+ * backward's three transposed images from the same read of the weights, into the reserve, and halo_lstm_bwd called with that reserve
+ * and those weight pointers packs nothing.  Inference callers switch it off (0): the forward then packs its own three only. */
+int halo_set_lstm_expect_backward(int on);
 int halo_lstm_persistent2_eligible(int T, int B, int H, int L);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 
