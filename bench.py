@@ -273,12 +273,13 @@ def cpu_baseline(params):
 def read_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py writes the
     file from the FETCH_SIZE / WRITE_SIZE CSVs with the guide's gfx950 corrections); null unless it is for THIS kernel."""
-    tpath = os.path.join(ROOT, 'profiles', 'lstm_chain_traffic.json')
-    if not os.path.exists(tpath):
-        return None
-    for rec in json.load(open(tpath)).get('kernels', []):
-        if rec.get('kernel') and (rec['kernel'] in kernel_name or kernel_name in rec['kernel']):
-            return rec.get('hbm_bytes_per_launch')
+    for fname in ('r03_lstm2_chain_traffic.json', 'lstm_chain_traffic.json'):      # round 3: the two-layer launches; round 2: one layer per launch
+        tpath = os.path.join(ROOT, 'profiles', fname)
+        if not os.path.exists(tpath):
+            continue
+        for rec in json.load(open(tpath)).get('kernels', []):
+            if rec.get('kernel') and (rec['kernel'] in kernel_name or kernel_name in rec['kernel']):
+                return rec.get('hbm_bytes_per_launch')
     return None
 
 
