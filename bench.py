@@ -424,6 +424,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
