@@ -13,8 +13,12 @@
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing here allocates,
  *     frees, synchronises or throws, so calls are capturable in a hipGraph;
  *   - return value: HALO_OK (0) or a negative HALO_E* code; halo_strerror() names it;
- *   - thread-safe for distinct streams; dense fp32 math runs on the exact-f32 MFMA
- *     (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), i.e. k-ordered fmaf chains, no reduced precision.
+ *   - threads: every switch a halo_set_* entry changes lives in a settings record ("Contexts" below); calls from different threads are
+ *     independent when each thread has selected its own context (and its own scratch buffer) and works on its own stream; calls that
+ *     share a record -- the process-wide default one included -- must be serialised by the caller.  The persistent LSTM recurrences need
+ *     every CU of the device while they run (~0.1 ms): other work on the GPU delays them, it cannot deadlock them (every wait is bounded);
+ *   - dense fp32 math (arithmetic mode f32) runs on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), i.e. k-ordered fmaf
+ *     chains, no reduced precision; modes bf16x3 / bf16: halo_set_math_mode.
  */
 #ifndef HALO_H
 #define HALO_H
