@@ -1430,7 +1430,7 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
                                    b_hh[l], 0, 0.f, 0, 0, 0, nullptr, stream));
         }
         const float *h0l = h0 ? h0 + (size_t)l * BH : nullptr;
-        const bool persist = x3 && halo_lstm_persist_ok(B, H);
+        const bool persist = x3 && halo_lstm_persist_ok(B, H) && halo_lstm_persist_fits(T, B, H);
         unsigned *flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
         if (persist) {
             // one launch: packed W_hh, packed + row-major initial state, zeroed epoch words
@@ -1603,7 +1603,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);
-        const bool persist = !fused && x3 && halo_lstm_persist_ok(B, H);
+        const bool persist = !fused && x3 && halo_lstm_persist_ok(B, H) && halo_lstm_persist_fits(T, B, H);
         // the chain writes the gate gradients' GEMM operand images itself (three-pass images: hi and lo parts) where its tiles map onto
         // whole 16-byte chunks of them: B % 32 == 0; what the operand-image launch below then no longer reads is the 4H-wide fp32 dG
         const int in_dim_l = l == 0 ? in0 : H;

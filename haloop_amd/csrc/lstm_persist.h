@@ -61,6 +61,7 @@ struct PersistBwd {
 
 unsigned long long *halo_lstm_persist_stamp_buffer();   // NULL unless a diagnostic buffer was set (halo_lstm_persist_stamps)
 bool halo_lstm_persist_ok(int B, int H);        // shape, arithmetic mode, CU count, switch
+bool halo_lstm_persist_fits(int T, int B, int H);   // the sequence is short enough for the kernels' 32-bit image offsets
 void halo_lstm_persist_enable(int on);
 int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st);
 int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st);

@@ -449,6 +449,12 @@ extern "C" int halo_lstm_persist_stamps(void *buf) {
     return HALO_OK;
 }
 
+// image byte offsets inside the kernels are 32-bit (buffer addressing): the largest is the backward's, T images of ceil(B/16) * 4H/32 blocks
+bool halo_lstm_persist_fits(int T, int B, int H) {
+    const long nbt = (B + 15) / 16;
+    return (long)(T + 1) * nbt * (4 * H / 32) * 2048 < (1L << 31);
+}
+
 bool halo_lstm_persist_ok(int B, int H) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST") && atoi(getenv("HALO_LSTM_PERSIST")) == 0;
     if (env_off || !halo_ctx_cur().lstm_persistent) return false;

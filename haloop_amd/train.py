@@ -243,14 +243,18 @@ class LstmCtcTrainer:
         if top > 0:
             # with data parallelism this part runs beside the first bucket's all-reduce, whose kernels hold CUs: the
             # persistent recurrence needs every workgroup resident at once, so the lower layers use the launch chain there
+            # (a copy of the caller's settings with that one switch off, selected for this call only: nothing process-wide is flipped)
             if self.world > 1:
-                _lib.set_lstm_persistent(False)
-            try:
+                if getattr(self, '_ctx_steps', None) is None:
+                    self._ctx_steps = _lib.Context()
+                    with self._ctx_steps:
+                        _lib.set_lstm_persistent(False)
+                with self._ctx_steps:
+                    ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
+                                 workspace=ws, dx=dy_sub)
+            else:
                 ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
                              workspace=ws, dx=dy_sub)
-            finally:
-                if self.world > 1:
-                    _lib.set_lstm_persistent(True)
         ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
                           dbias=gv['encoder.subsample.bias'])
 
