@@ -102,6 +102,7 @@ SIGNATURES = {
     'halo_fbank_frames': (_i, [_vp, _l, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp]),
     'halo_fbank_power': (_i, [_vp, _i, _i, _vp, _i, _vp]),
     'halo_fbank_log': (_i, [_vp, _l, _f, _vp]),
+    'halo_fbank_spectrum_mel': (_i, [_vp, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'halo_star_ctc_workspace_bytes': (_sz, [_i, _i, _i]),
     'halo_star_ctc_fwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     'halo_star_ctc_bwd': (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -54,9 +54,56 @@ __global__ __launch_bounds__(256) void fbank_log_kernel(float *__restrict__ x, l
     if (idx < n) x[idx] = logf(fmaxf(x[idx], eps));
 }
 
+// The spectrum, the mel energies and their log for one frame per workgroup, in FLOAT64: X[k] = sum_n x[n] e^{-2 pi i k n / N} against a
+// table of the N twiddles (the index k n mod N is exact), |X|^2, the triangular filters, log(max(., eps)).  The fp32 product this
+// replaces put an error of ~eps_32 * |largest bin| on EVERY bin, i.e. 2e-3 on the logs of bins 6 nepers below the frame's peak; the
+// arithmetic is tiny (N / 2 + 1 bins x N terms per frame), so the double-precision vector rate is not a cost.
+__global__ __launch_bounds__(256) void fbank_spectrum_mel_kernel(const float *__restrict__ frames, int padded, const double *__restrict__ twiddle,
+                                                                 const double *__restrict__ banks, int num_bins, float eps,
+                                                                 float *__restrict__ out) {
+    extern __shared__ double sh[];                 // [x: padded][cos: padded][sin: padded][power: padded / 2 + 1]
+    double *x = sh, *c = sh + padded, *sn = sh + 2 * padded, *pw = sh + 3 * padded;
+    const int bins = padded / 2 + 1;
+    const float *f = frames + (long)blockIdx.x * padded;
+    for (int i = threadIdx.x; i < padded; i += 256) {
+        x[i] = (double)f[i];
+        c[i] = twiddle[2 * i];
+        sn[i] = twiddle[2 * i + 1];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < bins; k += 256) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;                               // k n mod N, advanced by k per term
+        for (int n = 0; n < padded; ++n) {
+            re += x[n] * c[idx];
+            im -= x[n] * sn[idx];
+            idx = (idx + k) & (padded - 1);
+        }
+        pw[k] = re * re + im * im;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < num_bins; b += 256) {
+        const double *w = banks + (long)b * bins;
+        double e = 0.0;
+        for (int k = 0; k < bins; ++k) e += pw[k] * w[k];
+        out[(long)blockIdx.x * num_bins + b] = (float)log(fmax(e, (double)eps));
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int halo_fbank_spectrum_mel(const float *frames, int n_frames, int padded, const double *twiddle, const double *banks, int num_bins,
+                            float eps, float *out, halo_stream_t stream) {
+    HALO_CHECK_ARG(frames && twiddle && banks && out && n_frames > 0 && num_bins > 0);
+    HALO_CHECK_ARG(padded >= 2 && (padded & (padded - 1)) == 0 && padded <= 2048);
+    const size_t lds = (size_t)(3 * padded + padded / 2 + 1) * sizeof(double);
+    hipLaunchKernelGGL(fbank_spectrum_mel_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, frames, padded, twiddle, banks, num_bins,
+                       eps, out);
+    return halo_launch_status();
+}
+
 
 int halo_fbank_frames(const float *wav, long n_samples, int frame_len, int shift, int padded, float preemphasis, int remove_dc,
                       const float *window, float *frames, int n_frames, halo_stream_t stream) {

@@ -381,6 +381,12 @@ int halo_fbank_frames(const float *wav, long n_samples, int frame_len, int shift
                       const float *window, float *frames, int n_frames, halo_stream_t stream);
 int halo_fbank_power(const float *spectrum, int n_frames, int bins, float *power, int ld, halo_stream_t stream);
 int halo_fbank_log(float *x, long n, float eps, halo_stream_t stream);
+/* The rest of the front-end in ONE launch and in float64: the N-point real DFT of every frame against a table of the N twiddles
+ * (twiddle[2 j] = cos(2 pi j / N), twiddle[2 j + 1] = sin(2 pi j / N), N = padded, a power of two <= 2048), |X|^2, the num_bins
+ * triangular filters (banks [num_bins][N / 2 + 1], float64) and log(max(., eps)) -> out [n_frames][num_bins] float32.  Replaces
+ * the two exact-f32 products + halo_fbank_power + halo_fbank_log where the log-mels must hold to 1e-4 far below a frame's peak. */
+int halo_fbank_spectrum_mel(const float *frames, int n_frames, int padded, const double *twiddle, const double *banks, int num_bins,
+                            float eps, float *out, halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's two further lattices, one workgroup per utterance, forward score and gradient.
