@@ -42,6 +42,7 @@ struct HaloCtx {
     unsigned long long *stamps = nullptr;
     int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)
     const float *packT_reserve = nullptr, *packT_w[3] = {nullptr, nullptr, nullptr};   // ... into this reserve, from these weights (host bookkeeping)
+    const float *emitT_reserve = nullptr;   // the two-layer forward wrote the weight-gradient products' h_prev^T / dropout(h0)^T operand images into this reserve
     int mute_block = -1;                 // test hook (halo_debug_mute_workgroup): this workgroup of a persistent forward never publishes
 };
 HaloCtx &halo_ctx_cur();

@@ -554,15 +554,26 @@ struct PackPairArgs {
     int H;
     int tile_blocks;          // workgroups that pack tiles (4 tiles each); the rest run the prologue's unit loop
     Prologue2Args rest;       // w_units = 0: states + zeroed words
+    // zcount regions of zunits 16-byte units each, zstride bytes apart, in each of the two zbase buffers: column block 0 (the zero
+    // initial state) of the two h_prev^T operand images the forward launch fills from block 1 on
+    char *zbase[2];
+    long zstride, zunits;
+    int zcount;
 };
 __global__ __launch_bounds__(256) void persist2_pack_pair_kernel(const PackPairArgs a) {
     __shared__ float tile[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= a.tile_blocks) {
         const Prologue2Args &r = a.rest;
-        const long ns = 2 * r.s_units, total = ns + r.zero_units + r.zero2_units;
+        const long ns = 2 * r.s_units, nz = 2L * a.zcount * a.zunits, total = ns + r.zero_units + r.zero2_units + nz;
         for (long u = (blockIdx.x - a.tile_blocks) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - a.tile_blocks) * 256) {
-            if (u < ns) {
+            if (u >= ns + r.zero_units + r.zero2_units) {
+                const long v = u - (ns + r.zero_units + r.zero2_units);
+                const long per = (long)a.zcount * a.zunits;
+                const int which = (int)(v / per);
+                const long w = v % per;
+                reinterpret_cast<uint4 *>(a.zbase[which] + (w / a.zunits) * a.zstride)[w % a.zunits] = make_uint4(0u, 0u, 0u, 0u);
+            } else if (u < ns) {
                 const int l = (int)(u / r.s_units);
                 pack_unit<true, 2, true>(u - l * r.s_units, r.h0[l], r.hp0[l], r.H, r.B, r.H, r.h_rm[l], r.c0[l], r.c_rm[l]);
             } else if (u < ns + r.zero_units) {
@@ -1149,6 +1160,22 @@ inline size_t bwd_flags_offset(int T, int B, int in0, int H, int L) {
     return (n + 255) & ~(size_t)255;
 }
 
+// behind the epoch words of a 2-layer reserve: what the two-layer forward leaves for the backward of the same step -- the three transposed
+// weight images, and the operand images of the weight-gradient products [h0_prev^T | in0^T slot] [h1_prev^T | dropout(h0)^T]
+inline size_t reserve_p2_bytes(int T, int B, int in0, int H) {
+    const int kin = in0 > H ? in0 : H;
+    return (size_t)3 * 4 * H * H * sizeof(float) + 3 * halo_tiled_image_bytes(H, T * B) + halo_tiled_image_bytes(kin, T * B);
+}
+inline char *reserve_p2_images(float *reserve, int T, int B, int in0, int H, int L) {
+    return (char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (size_t)3 * 4 * H * H * sizeof(float);
+}
+
+inline bool persist_emit_enabled() {
+    int &v = halo_ctx_cur().persist_emit;
+    if (v < 0) { const char *e = getenv("HALO_PERSIST_EMIT"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+
 inline bool pair_dw_enabled() {
     static const bool on = !(getenv("HALO_LSTM_PAIR_DW") && atoi(getenv("HALO_LSTM_PAIR_DW")) == 0);
     return on;
@@ -1260,6 +1287,8 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     pa.H = H; pa.B = B;
     HaloCtx &ctx = halo_ctx_cur();
     ctx.packT_reserve = nullptr;
+    ctx.emitT_reserve = nullptr;
+    char *emit_hT0 = nullptr, *emit_hT1 = nullptr, *emit_xT1 = nullptr;
     if (ctx.lstm_expect_backward && H % 32 == 0) {
         // a backward will follow (halo_set_lstm_expect_backward): its three transposed images come out of the same read of the weights
         float *wT = (float *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES);
@@ -1268,7 +1297,20 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
         pp.H = H;
         pp.tile_blocks = 3 * (4 * H / 32) * (H / 32) / 4;
         pp.rest = pa; pp.rest.w_units = 0;
-        const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units));
+        pp.zbase[0] = pp.zbase[1] = nullptr; pp.zstride = 0; pp.zunits = 0; pp.zcount = 0;
+        ctx.emitT_reserve = nullptr;
+        const bool emitT = persist_emit_enabled() && !h0 && B % 32 == 0 && H % 128 == 0 && T * B >= 32;
+        if (emitT) {
+            // the forward launch writes h_prev^T of both layers and dropout(h0)^T as GEMM operand images; their column block 0 (zero state) here
+            char *imgs = reserve_p2_images(reserve, T, B, in0, H, L);
+            const size_t hb = halo_tiled_image_bytes(H, T * B), ib = halo_tiled_image_bytes(in0 > H ? in0 : H, T * B);
+            emit_hT0 = imgs; emit_hT1 = imgs + hb + ib; emit_xT1 = emit_hT1 + hb;
+            const long KT = (T * B + 31) / 32;
+            pp.zbase[0] = emit_hT0; pp.zbase[1] = emit_hT1;
+            pp.zstride = KT * 16384; pp.zunits = (long)(B / 32) * 16384 / 16; pp.zcount = H / 128;
+            ctx.emitT_reserve = reserve;
+        }
+        const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + 2L * pp.zcount * pp.zunits));
         hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)pp.tile_blocks + rest_blocks), dim3(256), 0, st, pp);
         HALO_TRY(halo_launch_status());
         ctx.packT_reserve = reserve;
@@ -1288,6 +1330,7 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     a.ydrop = p_drop > 0.f ? l0.ydrop : nullptr;
     a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y ? (y_relu ? 2 : 1) : 0;
     a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+    a.img_hT0 = emit_hT0; a.img_hT1 = emit_hT1; a.img_xT1 = emit_xT1;
     a.flags = flags;
     a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 2][16] here
     a.T = T; a.B = B; a.H = H;
@@ -1337,7 +1380,7 @@ int halo_lstm_chain_info(int backward, int *launches, char *kernel, int kernel_l
 size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
     // L == 2: behind the epoch words, the three transposed weight images the two-layer forward leaves for the backward of the same step
-    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (L == 2 ? (size_t)3 * 4 * H * H * sizeof(float) : 0);
+    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (L == 2 ? reserve_p2_bytes(T, B, in0, H) : 0);
 }
 
 int halo_set_lstm_persistent(int on) {
@@ -1349,11 +1392,7 @@ int halo_set_lstm_persistent_images(int on) {
     halo_ctx_cur().persist_emit = on ? 1 : 0;
     return HALO_OK;
 }
-static bool persist_emit_enabled() {
-    int &v = halo_ctx_cur().persist_emit;
-    if (v < 0) { const char *e = getenv("HALO_PERSIST_EMIT"); v = e ? (atoi(e) != 0) : 1; }
-    return v != 0;
-}
+
 
 int halo_lstm_persistent_eligible(int B, int H) { return halo_lstm_persist_ok(B, H) && use_x3(H) ? 1 : 0; }
 
@@ -1593,6 +1632,27 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         chain_begin(st);
         HALO_TRY(halo_lstm_persist2_bwd(a, st));
         chain_end(st, 1, 1, "lstm_persist2_bwd_kernel");
+        if (ctx.emitT_reserve == reserve && emit0 && emit1 && pair_dw_enabled()) {
+            // the forward launch of this step left h_prev^T (both layers) and dropout(h0)^T as operand images in the reserve: ONE operand
+            // launch for what is left (the bias sums, W_ih0^T, x^T), then the two paired weight-gradient launches and the input gradient
+            char *imgs = reserve_p2_images(reserve, T, B, in0, H, L);
+            const size_t hb = halo_tiled_image_bytes(H, T * B), ib = halo_tiled_image_bytes(kin, T * B);
+            char *hT0 = imgs, *inT0 = imgs + hb, *hT1 = imgs + hb + ib;
+            HaloPrepJob jobs[4];
+            int nj = 0;
+            jobs[nj++] = {3, bias_part1, (B + 15) / 16, 4 * H, 4 * H, db_ih[1], db_hh[1]};
+            jobs[nj++] = {3, bias_part0, (B + 15) / 16, 4 * H, 4 * H, db_ih[0], db_hh[0]};
+            if (need_dx) jobs[nj++] = {1, w_ih[0], in0, 4 * H, in0, img_wT, nullptr};
+            jobs[nj++] = {1, x, in0, T * B, in0, inT0, nullptr};
+            HALO_TRY(halo_prep_jobs(jobs, nj, st));
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[1], H, H, dw_ih[1], H, st));
+            if (need_dx) {
+                const DropoutCfg nodrop = make_dropout(0.f, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+                HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in0, 4 * H, dx, in0, nullptr, nullptr, 0, &nodrop, st));
+            }
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT, hT0, 4 * H, H + in0, T * B, dw_hh[0], H, H, dw_ih[0], in0, st));
+            return HALO_OK;
+        }
         HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 1, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g, emit1 ? img_gT1 : img_gT,
                                      img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));
         HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 0, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit0, img_g, img_gT, img_hT,

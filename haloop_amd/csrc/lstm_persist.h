@@ -82,6 +82,11 @@ struct Persist2Fwd {
     long y_stride_t, y_stride_b;
     int y_mode;                    // 0 none, 1 plain, 2 relu
     DropoutCfg drop;               // layer 0's output dropout (the stream of lstm.hip's Y_DROPOUT epilogue)
+    // optional: the tiled GEMM operand images (hi parts; gemm_bf16x3.hip layout, rows = hidden unit, k = t * B + b) that the backward's
+    // weight-gradient products read: h0_{t-1}^T, h1_{t-1}^T (column block t holds the state BEFORE step t; block 0 -- the zero initial
+    // state -- is cleared by the launch ahead) and dropout(h0_t)^T.  Written off the hand-off path as each step's tile leaves the cell
+    // update, so the operand-image launch behind the backward chain need not read the fp32 states again.  Needs B % 32 == 0, H % 128 == 0.
+    char *img_hT0, *img_hT1, *img_xT1;
     unsigned *flags;
     unsigned *status;              // see PersistFwd
     int mute;                      // see PersistFwd

@@ -154,6 +154,26 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
         } else if (wave == 3 && !act0 && !act1) {
             publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
         }
+        if (p.img_hT0 && ((wave == 3 && act0) || (wave == 2 && act1))) {
+            // ---- off the hand-off path: the tile, transposed, in the operand images of the weight-gradient products.  Image row = hidden
+            //      unit j0 + (lane & 15), one 16-byte chunk = 8 consecutive batch rows.  wave 3: lanes 0-31 h0_s as the state BEFORE step
+            //      s + 1 (column block s + 1 of img_hT0), lanes 32-63 dropout(h0_s) = layer 1's input at time s (block s of img_xT1);
+            //      wave 2: lanes 0-31 h1_{s-2} as the state before step s - 1 (block s - 1 of img_hT1) ----
+            const int sel = lane >> 5, kg = (lane >> 4) & 1, row = lane & 15;
+            const float(*src)[16] = wave == 2 ? sh.hbuf[2] : (sel == 1 && p.xp ? sh.hbuf[1] : sh.hbuf[0]);
+            const int tb = wave == 2 ? s - 1 : (sel == 0 ? s + 1 : s);           // column block (time index of the image)
+            char *img = wave == 2 ? (sel == 0 ? p.img_hT1 : nullptr) : (sel == 0 ? p.img_hT0 : p.img_xT1);
+            if (img && tb < T) {
+                bf16x8 hit;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hit[e] = (__bf16)src[kg * 8 + e][row];
+                const int grow = j0 + row, kcol = tb * B + bt * 16 + kg * 8;
+                const int KT = (T * B + 31) >> 5;
+                const long blk = ((long)(grow >> 7) * KT + (kcol >> 5)) * 2;
+                const int r = grow & 127, cc = (kcol & 31) >> 3;
+                *reinterpret_cast<bf16x8 *>(img + blk * 8192 + r * 64 + ((cc ^ ((r >> 2) & 3)) << 4)) = hit;
+            }
+        }
         if (act0 && cell) {
             float *gp = p.gates0 + (s * B + b) * 4 * H + j0 + cj;
             gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
