@@ -64,6 +64,9 @@ bool halo_lstm_persist_ok(int B, int H);        // shape, arithmetic mode, CU co
 bool halo_lstm_persist_fits(int T, int B, int H);   // the sequence is short enough for the kernels' 32-bit image offsets
 void halo_lstm_persist_enable(int on);
 int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st);
+// 32 batch rows per workgroup (lstm_persist32.hip; bf16 arithmetic only): chosen by halo_lstm_persist_fwd/bwd when the 16-row grid exceeds the CU count
+int halo_lstm_persist_fwd32(const PersistFwd &a, hipStream_t st);
+int halo_lstm_persist_bwd32(const PersistBwd &a, hipStream_t st);
 int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st);
 
 // ---- both layers of a 2-layer stack in ONE persistent launch (lstm_persist2.hip; single-pass bf16 arithmetic only) ----

@@ -452,7 +452,12 @@ extern "C" int halo_lstm_persist_stamps(void *buf) {
 // image byte offsets inside the kernels are 32-bit (buffer addressing): the largest is the backward's, T images of ceil(B/16) * 4H/32 blocks
 bool halo_lstm_persist_fits(int T, int B, int H) {
     const long nbt = (B + 15) / 16;
-    return (long)(T + 1) * nbt * (4 * H / 32) * 2048 < (1L << 31);
+    return (long)(T + 1) * nbt * (4 * H / 32) * 2048 < (1L << 31) && (long)(T + 1) * B * 4 * H < (1L << 31);   // ... and 32-bit element indices
+}
+
+static bool wide_enabled() {
+    static const bool off = getenv("HALO_LSTM_PERSIST32") && atoi(getenv("HALO_LSTM_PERSIST32")) == 0;
+    return !off;
 }
 
 bool halo_lstm_persist_ok(int B, int H) {
@@ -461,12 +466,15 @@ bool halo_lstm_persist_ok(int B, int H) {
     if (halo_math_mode() == HALO_MATH_F32) return false;
     if (H % 256 != 0 || H > 1024 || B <= 0) return false;
     const int blocks = (H / 16) * ((B + 15) / 16);
-    return blocks <= cu_count();
+    if (blocks <= cu_count()) return true;
+    // 32 batch rows per workgroup (lstm_persist32.hip): single-pass bf16 only -- the split-bf16 kernels have no registers for a second sub-tile
+    return halo_math_mode() == HALO_MATH_BF16 && wide_enabled() && (H / 16) * ((B + 31) / 32) <= cu_count();
 }
 
 int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st) {
     const int blocks = (a.H / 16) * ((a.B + 15) / 16);
     const bool one = halo_math_mode() == HALO_MATH_BF16;
+    if (blocks > cu_count()) return one ? halo_lstm_persist_fwd32(a, st) : HALO_ENOTSUP;
     static bool attr = false;
     if (!attr) {
         int rc = allow_lds(lstm_persist_fwd_kernel<1, false>);
@@ -496,6 +504,7 @@ int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st) {
 int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st) {
     const int blocks = (a.H / 16) * ((a.B + 15) / 16);
     const bool one = halo_math_mode() == HALO_MATH_BF16;
+    if (blocks > cu_count()) return one ? halo_lstm_persist_bwd32(a, st) : HALO_ENOTSUP;
     static bool attr = false;
     if (!attr) {
         int rc = allow_lds(lstm_persist_bwd_kernel<1, false>);

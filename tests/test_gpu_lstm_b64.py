@@ -455,3 +455,28 @@ def test_learning_rate_changes_reach_the_captured_step(hal):
         finals.append(tr.flat.params.clone())
     hal['lib'].set_status_word(None)
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,L,p_drop,with_state', [
+    (21, 128, 128, 1024, 2, 0.2, False),    # the bench's b_sweep point: 64 hidden tiles x 4 thirty-two-row tiles = 256 workgroups
+    (6, 80, 64, 1024, 1, 0.0, True),        # five 16-row tiles: the last workgroup row has ONE sub-tile; carried state
+    (4, 100, 96, 768, 2, 0.25, False),      # ragged last sub-tile (100 = 6 * 16 + 4), 48 x 4 workgroups, dropout between the layers
+])
+def test_wide_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
+    """csrc/lstm_persist32.hip (32 batch rows per workgroup, bf16 arithmetic: batches the 16-row grid cannot hold with one workgroup
+    per CU) against the step-launch chain: same function, another summation order."""
+    lib = hal['lib']
+    cus = 256
+    assert (H // 16) * ((B + 15) // 16) > cus >= (H // 16) * ((B + 31) // 32)          # the 16-row grid does not fit, the 32-row grid does
+    assert lib.lib().halo_lstm_persistent_eligible(B, H) == 1
+    a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    assert 'persist' in lib.lstm_chain_info('bwd')['kernel']
+    lib.set_lstm_persistent(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+        assert 'step' in lib.lstm_chain_info('bwd')['kernel']
+    finally:
+        lib.set_lstm_persistent(True)
+    assert st_a == (0, 0) and st_b == (0, 0)
+    _normalised_close(a, b, rtol=3e-2, atol=3e-3)
