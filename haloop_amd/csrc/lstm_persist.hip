@@ -464,7 +464,9 @@ bool halo_lstm_persist_ok(int B, int H) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST") && atoi(getenv("HALO_LSTM_PERSIST")) == 0;
     if (env_off || !halo_ctx_cur().lstm_persistent) return false;
     if (halo_math_mode() == HALO_MATH_F32) return false;
-    if (H % 256 != 0 || H > 1024 || B <= 0) return false;
+    // split-bf16 weight slices (64 gate rows x H x 4 bytes) fill half a CU's registers at H = 1024; single-pass bf16 slices at H = 1536
+    // (the reference's wider variant, ha/init.py:171) still leave room
+    if (H % 256 != 0 || B <= 0 || H > (halo_math_mode() == HALO_MATH_BF16 ? 1536 : 1024)) return false;
     const int blocks = (H / 16) * ((B + 15) / 16);
     if (blocks <= cu_count()) return true;
     // 32 batch rows per workgroup (lstm_persist32.hip): single-pass bf16 only -- the split-bf16 kernels have no registers for a second sub-tile
@@ -485,6 +487,8 @@ int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st) {
         if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<2, true>);
         if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<3, true>);
         if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<4, true>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<5, true>);
+        if (!rc) rc = allow_lds(lstm_persist_fwd_kernel<6, true>);
         if (rc) return rc;
         attr = true;
     }
@@ -497,6 +501,8 @@ int halo_lstm_persist_fwd(const PersistFwd &a, hipStream_t st) {
         case 7: return launch_persist(lstm_persist_fwd_kernel<3, true>, a, blocks, st);
         case 8: return launch_persist(lstm_persist_fwd_kernel<4, false>, a, blocks, st);
         case 9: return launch_persist(lstm_persist_fwd_kernel<4, true>, a, blocks, st);
+        case 11: return launch_persist(lstm_persist_fwd_kernel<5, true>, a, blocks, st);
+        case 13: return launch_persist(lstm_persist_fwd_kernel<6, true>, a, blocks, st);
         default: return HALO_ENOTSUP;
     }
 }
@@ -515,6 +521,8 @@ int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st) {
         if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<2, true>);
         if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<3, true>);
         if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<4, true>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<5, true>);
+        if (!rc) rc = allow_lds(lstm_persist_bwd_kernel<6, true>);
         if (rc) return rc;
         attr = true;
     }
@@ -527,6 +535,8 @@ int halo_lstm_persist_bwd(const PersistBwd &a, hipStream_t st) {
         case 7: return launch_persist(lstm_persist_bwd_kernel<3, true>, a, blocks, st);
         case 8: return launch_persist(lstm_persist_bwd_kernel<4, false>, a, blocks, st);
         case 9: return launch_persist(lstm_persist_bwd_kernel<4, true>, a, blocks, st);
+        case 11: return launch_persist(lstm_persist_bwd_kernel<5, true>, a, blocks, st);
+        case 13: return launch_persist(lstm_persist_bwd_kernel<6, true>, a, blocks, st);
         default: return HALO_ENOTSUP;
     }
 }

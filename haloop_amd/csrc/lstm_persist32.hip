@@ -376,6 +376,8 @@ int halo_lstm_persist_fwd32(const PersistFwd &a0, hipStream_t st) {
         case 2: return launch32(lstm_persist_fwd32_kernel<2>, a, blocks, st);
         case 3: return launch32(lstm_persist_fwd32_kernel<3>, a, blocks, st);
         case 4: return launch32(lstm_persist_fwd32_kernel<4>, a, blocks, st);
+        case 5: return launch32(lstm_persist_fwd32_kernel<5>, a, blocks, st);
+        case 6: return launch32(lstm_persist_fwd32_kernel<6>, a, blocks, st);
         default: return HALO_ENOTSUP;
     }
 }
@@ -387,6 +389,8 @@ int halo_lstm_persist_bwd32(const PersistBwd &a, hipStream_t st) {
         case 2: return launch32(lstm_persist_bwd32_kernel<2>, a, blocks, st);
         case 3: return launch32(lstm_persist_bwd32_kernel<3>, a, blocks, st);
         case 4: return launch32(lstm_persist_bwd32_kernel<4>, a, blocks, st);
+        case 5: return launch32(lstm_persist_bwd32_kernel<5>, a, blocks, st);
+        case 6: return launch32(lstm_persist_bwd32_kernel<6>, a, blocks, st);
         default: return HALO_ENOTSUP;
     }
 }

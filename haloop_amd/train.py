@@ -323,6 +323,8 @@ class LstmCtcTrainer:
         return loss if self.alias_loss else loss.clone()
 
     def _step(self, x, input_lengths, targets, target_lengths):
+        if _lib._status_tensor is not self.status:          # another trainer registered its word since: this step's launches report to OURS
+            _lib.set_status_word(self.status)
         if self.accumulate > 1:
             return self._accumulating_step(x, input_lengths, targets, target_lengths)
         self.step_count += 1

@@ -462,6 +462,7 @@ def test_learning_rate_changes_reach_the_captured_step(hal):
     (21, 128, 128, 1024, 2, 0.2, False),    # the bench's b_sweep point: 64 hidden tiles x 4 thirty-two-row tiles = 256 workgroups
     (6, 80, 64, 1024, 1, 0.0, True),        # five 16-row tiles: the last workgroup row has ONE sub-tile; carried state
     (4, 100, 96, 768, 2, 0.25, False),      # ragged last sub-tile (100 = 6 * 16 + 4), 48 x 4 workgroups, dropout between the layers
+    (5, 64, 128, 1536, 1, 0.0, False),      # the reference's H = 1536 variant (ha/init.py:171): 96 hidden tiles x 2 thirty-two-row tiles
 ])
 def test_wide_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
     """csrc/lstm_persist32.hip (32 batch rows per workgroup, bf16 arithmetic: batches the 16-row grid cannot hold with one workgroup
