@@ -1256,22 +1256,26 @@ int lstm_bwd_layer_tail(const float *x, const float *const *w_ih, float *reserve
 
 // ---- both layers in one persistent launch (lstm_persist2.hip; bf16 arithmetic, L = 2) ------------------------------------------
 // layer 0's input projection (one batched GEMM), one prologue launch, ONE launch for the 2 T time steps of the stack
-int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
                       const float *const *b_hh, const float *h0, const float *c0, float *y, long y_stride_t, long y_stride_b,
                       int y_relu, float *hn, float *cn, float *reserve, float *extra, char *img_in, char *img_w, int T, int B,
-                      int in0, int H, float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev, hipStream_t st) {
-    const int L = 2;
+                      int in0, int H, int L, float p_drop, uint64_t seed, uint32_t offset, const uint32_t *offset_dev, hipStream_t st) {
+    // layers lo and lo + 1 = L - 1 (the top pair of the stack; the layers below ran one launch each): ``in`` [T*B][in_dim] is layer lo's input
+    const int hi = lo + 1;
     const size_t BH = (size_t)B * H;
-    const LayerBufs l0 = layer_bufs(reserve, 0, T, B, H), l1 = layer_bufs(reserve, 1, T, B, H);
-    if (in0 >= 64) {
-        const HaloPrepJob jobs[2] = {{0, x, T * B, in0, in0, img_in, nullptr}, {0, w_ih[0], 4 * H, in0, in0, img_w, nullptr}};
+    const LayerBufs l0 = layer_bufs(reserve, lo, T, B, H), l1 = layer_bufs(reserve, hi, T, B, H);
+    w_ih += lo; w_hh += lo; b_ih += lo; b_hh += lo;                   // index 0 / 1 below = layer lo / lo + 1
+    if (h0) h0 += (size_t)lo * BH;
+    if (c0) c0 += (size_t)lo * BH;
+    if (in_dim >= 64) {
+        const HaloPrepJob jobs[2] = {{0, in, T * B, in_dim, in_dim, img_in, nullptr}, {0, w_ih[0], 4 * H, in_dim, in_dim, img_w, nullptr}};
         HALO_TRY(halo_prep_jobs(jobs, 2, st));
-        HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in0, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
+        HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
     } else {
-        HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in0, x, in0, w_ih[0], in0, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0, 0,
+        HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[0], in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0, 0,
                                nullptr, (halo_stream_t)st));
     }
-    float *wp0 = reserve, *wp1 = fused_wpk(extra, 1, H), *wpi = wp1 + (size_t)4 * H * H;
+    float *wp0 = reserve, *wp1 = fused_wpk(extra, hi, H), *wpi = wp1 + (size_t)4 * H * H;
     unsigned *flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
     Prologue2Args pa;
     pa.w[0] = w_hh[0]; pa.wdst[0] = wp0; pa.w[1] = w_hh[1]; pa.wdst[1] = wp1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpi;
@@ -1323,13 +1327,13 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     Persist2Fwd a;
     a.wp0 = (const char *)wp0; a.wp1 = (const char *)wp1; a.wpi = (const char *)wpi;
     a.hp0 = (char *)l0.hp; a.hp1 = (char *)l1.hp;
-    a.xp = p_drop > 0.f ? (char *)fused_yp(extra, 0, T, B, H, L) : nullptr;
+    a.xp = p_drop > 0.f ? (char *)fused_yp(extra, lo, T, B, H, L) : nullptr;
     a.gates0 = l0.gates; a.h0 = l0.h; a.c0 = l0.c;
     a.gates1 = l1.gates; a.h1 = l1.h; a.c1 = l1.c;
     a.b_ih1 = b_ih[1]; a.b_hh1 = b_hh[1];
     a.ydrop = p_drop > 0.f ? l0.ydrop : nullptr;
     a.y = y; a.y_stride_t = y_stride_t; a.y_stride_b = y_stride_b; a.y_mode = y ? (y_relu ? 2 : 1) : 0;
-    a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+    a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)lo, offset, offset_dev);
     a.img_hT0 = emit_hT0; a.img_hT1 = emit_hT1; a.img_xT1 = emit_xT1;
     a.flags = flags;
     a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 2][16] here
@@ -1339,8 +1343,8 @@ int lstm_fwd_persist2(const float *x, const float *const *w_ih, const float *con
     chain_end(st, 0, 1, "lstm_persist2_fwd_kernel");
     for (int l = 0; l < 2; ++l) {
         const LayerBufs lb = l ? l1 : l0;
-        if (hn) HALO_TRY(copy_d2d(hn + (size_t)l * BH, lb.h + (size_t)T * BH, BH, st));
-        if (cn) HALO_TRY(copy_d2d(cn + (size_t)l * BH, lb.c + (size_t)T * BH, BH, st));
+        if (hn) HALO_TRY(copy_d2d(hn + (size_t)(lo + l) * BH, lb.h + (size_t)T * BH, BH, st));
+        if (cn) HALO_TRY(copy_d2d(cn + (size_t)(lo + l) * BH, lb.c + (size_t)T * BH, BH, st));
     }
     return HALO_OK;
 }
@@ -1379,8 +1383,8 @@ int halo_lstm_chain_info(int backward, int *launches, char *kernel, int kernel_l
 
 size_t halo_lstm_reserve_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
-    // L == 2: behind the epoch words, the three transposed weight images the two-layer forward leaves for the backward of the same step
-    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (L == 2 ? reserve_p2_bytes(T, B, in0, H) : 0);
+    // L >= 2: behind the epoch words, what the two-layer forward (the stack's top pair) leaves for the backward of the same step
+    return reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (L >= 2 ? reserve_p2_bytes(T, B, in0, H) : 0);
 }
 
 int halo_set_lstm_persistent(int on) {
@@ -1404,7 +1408,7 @@ int halo_set_lstm_expect_backward(int on) {
     halo_ctx_cur().lstm_expect_backward = on ? 1 : 0;
     return HALO_OK;
 }
-int halo_lstm_persistent2_eligible(int T, int B, int H, int L) { return !fused_ok(H, L) && use_x3(H) && halo_lstm_persist2_ok(T, B, H, L) ? 1 : 0; }
+int halo_lstm_persistent2_eligible(int T, int B, int H, int L) {      /* L >= 2: the stack's top two layers */ return !fused_ok(H, L) && use_x3(H) && halo_lstm_persist2_ok(T, B, H, L) ? 1 : 0; }
 
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || in0 <= 0 || H <= 0 || L <= 0) return 0;
@@ -1413,7 +1417,7 @@ size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L
 
 size_t halo_lstm_bwd_workspace_bytes(int T, int B, int in0, int H, int L) {
     if (T <= 0 || B <= 0 || H <= 0 || L <= 0) return 0;
-    if (L == 2) return bwd_p2_offset(T, B, in0, H, L) + bwd_p2_bytes(T, B, H);
+    if (L >= 2) return bwd_p2_offset(T, B, in0, H, L) + bwd_p2_bytes(T, B, H);
     // packed W_hh^T [H,4H] + dc carry [B,H] + gradient w.r.t. a layer's input [T,B,H] + packed gate-gradient images
     // [BT16, 4H] (one per time step) + tiled images for the batched gradient GEMMs + epoch words
     // ... + the batch-tile partials of a layer's bias gradient [ceil(B/16)][4H] (written by the persistent backward)
@@ -1430,17 +1434,19 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
     if (H % 16 != 0) return HALO_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PH = bt16(B) * H;
+    // what an earlier forward left for "its" backward (transposed weight images, operand images) is forgotten with every new forward,
+    // whichever path it takes: the bookkeeping then always describes the most recent forward, and a recycled reserve address cannot match
+    halo_ctx_cur().packT_reserve = nullptr;
+    halo_ctx_cur().emitT_reserve = nullptr;
     float *wp = reserve;
     const bool x3 = use_x3(H);
     const int kin = in0 > H ? in0 : H;
     char *img_in = (char *)(reserve + (size_t)4 * H * H + (size_t)L * layer_floats(T, B, H));
     char *img_w = img_in + halo_tiled_image_bytes(T * B, kin);
     for (int l = 0; l < L; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && b_ih[l] && b_hh[l]);
-    if (!fused_ok(H, L) && x3 && halo_lstm_persist2_ok(T, B, H, L)) {
-        float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
-        return lstm_fwd_persist2(x, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra, img_in,
-                                 img_w, T, B, in0, H, p_drop, seed, offset, offset_dev, st);
-    }
+    // bf16: the top two layers of the stack run as ONE persistent launch (lstm_persist2.hip); the layers below them one launch each
+    const bool pair = !fused_ok(H, L) && x3 && halo_lstm_persist2_ok(T, B, H, L);
+    const int n_single = pair ? L - 2 : L;
     if (fused_ok(H, L)) {
         float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
         return lstm_fwd_fused(x, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra,
@@ -1457,6 +1463,11 @@ int halo_lstm_fwd(const float *x, const float *const *w_ih, const float *const *
             const LayerBufs pb = layer_bufs(reserve, l - 1, T, B, H);
             in = p_drop > 0.f ? pb.ydrop : pb.h + BH;
             in_dim = H;
+        }
+        if (pair && l == n_single) {
+            float *extra = (float *)(img_w + halo_tiled_image_bytes(4 * H, kin));
+            return lstm_fwd_persist2(in, in_dim, l, w_ih, w_hh, b_ih, b_hh, h0, c0, y, y_stride_t, y_stride_b, y_relu, hn, cn, reserve, extra,
+                                     img_in, img_w, T, B, in0, H, L, p_drop, seed, offset, offset_dev, st);
         }
         // gates[T*B, 4H] = in[T*B, in_dim] * W_ih^T + b_ih + b_hh
         if (halo_math_mode() != HALO_MATH_F32 && in_dim >= 64) {
@@ -1575,12 +1586,16 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_TRY(lstm_bwd_fused_chain(w_ih, w_hh, dy, y_stride_t, y_stride_b, y_relu, dhn, dcn, reserve, extra, T, B, H, L,
                                       p_drop, seed, offset, offset_dev, st));
     }
-    if (!fused && x3 && L == 2 && layer_begin == 0 && layer_end == 2 && halo_lstm_persist2_ok(T, B, H, L)) {
-        // both layers' chains in ONE persistent launch (lstm_persist2.hip), layer 1's input gradient formed inside it
-        for (int l = 0; l < 2; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
-        const LayerBufs l0 = layer_bufs(reserve, 0, T, B, H), l1 = layer_bufs(reserve, 1, T, B, H);
+    int top_end = layer_end;          // layers [layer_begin, top_end) are left for the per-layer loop below
+    if (!fused && x3 && L >= 2 && layer_begin <= L - 2 && layer_end == L && halo_lstm_persist2_ok(T, B, H, L)) {
+        // the stack's top two layers' chains in ONE persistent launch (lstm_persist2.hip), the upper layer's input gradient formed inside it
+        const int lo = L - 2, hi = L - 1;
+        for (int l = lo; l <= hi; ++l) HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
+        const LayerBufs l0 = layer_bufs(reserve, lo, T, B, H), l1 = layer_bufs(reserve, hi, T, B, H);
+        const float *in_lo = lo == 0 ? x : (p_drop > 0.f ? layer_bufs(reserve, lo - 1, T, B, H).ydrop : layer_bufs(reserve, lo - 1, T, B, H).h + BH);
+        const int in_lo_dim = lo == 0 ? in0 : H;
         float *extra = (float *)(img_wT + halo_tiled_image_bytes(kin, 4 * H));
-        float *wpT1 = extra, *wpTi = extra + (size_t)4 * H * H, *dcarry1 = extra + (size_t)8 * H * H;      // (or the reserve's: below)
+        float *wpT0 = wpT, *wpT1 = extra, *wpTi = extra + (size_t)4 * H * H, *dcarry1 = extra + (size_t)8 * H * H;      // (or the reserve's: below)
         char *flag_base = (char *)workspace + bwd_flags_offset(T, B, in0, H, L);
         float *bias_part0 = (float *)(flag_base + PERSIST_FLAG_BYTES);
         char *p2 = (char *)workspace + bwd_p2_offset(T, B, in0, H, L);
@@ -1588,23 +1603,24 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         float *dgp1 = (float *)(p2 + (((size_t)((B + 15) / 16) * 4 * H * sizeof(float) + 255) & ~(size_t)255));
         char *img_gT1 = (char *)(dgp1 + (size_t)T * PG);
         const bool can_emit = persist_emit_enabled() && B % 32 == 0;
-        const bool emit0 = can_emit && in0 >= 64, emit1 = can_emit;
-        const bool need_dx = dx != nullptr;
+        const bool emit0 = can_emit && in_lo_dim >= 64, emit1 = can_emit;
+        const bool need_din = lo > 0 || dx != nullptr;         // the gradient w.r.t. layer lo's input: feeds layer lo - 1, or the caller
+        float *din_out = lo > 0 ? din : dx;
         // the forward of this step may have left the three transposed images in the reserve (one read of the weights for all six)
         const HaloCtx &ctx = halo_ctx_cur();
-        const bool have_T = ctx.packT_reserve == reserve && ctx.packT_w[0] == w_hh[0] && ctx.packT_w[1] == w_hh[1] && ctx.packT_w[2] == w_ih[1];
+        const bool have_T = ctx.packT_reserve == reserve && ctx.packT_w[0] == w_hh[lo] && ctx.packT_w[1] == w_hh[hi] && ctx.packT_w[2] == w_ih[hi];
         if (have_T) {
             float *wT = (float *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES);
-            wpT = wT; wpT1 = wT + (size_t)4 * H * H; wpTi = wT + (size_t)8 * H * H;
+            wpT0 = wT; wpT1 = wT + (size_t)4 * H * H; wpTi = wT + (size_t)8 * H * H;
         }
         Prologue2Args pa;
-        pa.w[0] = w_hh[0]; pa.wdst[0] = wpT; pa.w[1] = w_hh[1]; pa.wdst[1] = wpT1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpTi;
+        pa.w[0] = w_hh[lo]; pa.wdst[0] = wpT0; pa.w[1] = w_hh[hi]; pa.wdst[1] = wpT1; pa.w[2] = w_ih[hi]; pa.wdst[2] = wpTi;
         pa.w_units = have_T ? 0 : (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
         for (int l = 0; l < 2; ++l) { pa.h0[l] = nullptr; pa.hp0[l] = nullptr; pa.h_rm[l] = nullptr; pa.c0[l] = nullptr; pa.c_rm[l] = nullptr; }
         pa.s_units = 0;
         pa.zero = (unsigned *)flag_base; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
         pa.zero2 = nullptr; pa.zero2_units = 0;
-        if (emit0 && need_dx && (T * B) % 128 != 0) {   // the padded last row tile of dG0's row image
+        if (emit0 && need_din && (T * B) % 128 != 0) {   // the padded last row tile of the lower layer's dG row image
             const long tile_bytes = (long)(4 * H / 32) * 16384;
             pa.zero2 = (unsigned *)(img_g + (long)((T * B) / 128) * tile_bytes); pa.zero2_units = tile_bytes / 16;
         }
@@ -1613,17 +1629,17 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                            st, pa);
         HALO_TRY(halo_launch_status());
         Persist2Bwd a;
-        a.wpT0 = (const char *)wpT; a.wpT1 = (const char *)wpT1; a.wpTi = (const char *)wpTi;
+        a.wpT0 = (const char *)wpT0; a.wpT1 = (const char *)wpT1; a.wpTi = (const char *)wpTi;
         a.dgp0 = (char *)dgp; a.dgp1 = (char *)dgp1;
         a.gates0 = l0.gates; a.gates1 = l1.gates; a.c0 = l0.c; a.c1 = l1.c;
         a.dc0 = dcarry; a.dc1 = dcarry1;
         a.dy = dy; a.dy_stride_t = y_stride_t; a.dy_stride_b = y_stride_b; a.dy_relu = y_relu;
-        a.dhinit0 = dhn; a.dcinit0 = dcn;
-        a.dhinit1 = dhn ? dhn + BH : nullptr; a.dcinit1 = dcn ? dcn + BH : nullptr;
-        a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
+        a.dhinit0 = dhn ? dhn + (size_t)lo * BH : nullptr; a.dcinit0 = dcn ? dcn + (size_t)lo * BH : nullptr;
+        a.dhinit1 = dhn ? dhn + (size_t)hi * BH : nullptr; a.dcinit1 = dcn ? dcn + (size_t)hi * BH : nullptr;
+        a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)lo, offset, offset_dev);
         a.flags = (unsigned *)flag_base;
         a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 1][16] here
-        a.img_rows0 = emit0 && need_dx ? img_g : nullptr;
+        a.img_rows0 = emit0 && need_din ? img_g : nullptr;
         a.img_cols0 = emit0 ? img_gT : nullptr;
         a.img_cols1 = emit1 ? img_gT1 : nullptr;
         a.bias_part0 = emit0 ? bias_part0 : nullptr;
@@ -1633,33 +1649,35 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         HALO_TRY(halo_lstm_persist2_bwd(a, st));
         chain_end(st, 1, 1, "lstm_persist2_bwd_kernel");
         if (ctx.emitT_reserve == reserve && emit0 && emit1 && pair_dw_enabled()) {
-            // the forward launch of this step left h_prev^T (both layers) and dropout(h0)^T as operand images in the reserve: ONE operand
-            // launch for what is left (the bias sums, W_ih0^T, x^T), then the two paired weight-gradient launches and the input gradient
+            // the forward launch of this step left h_prev^T (both layers) and dropout(h_lo)^T as operand images in the reserve: ONE operand
+            // launch for what is left (the bias sums, W_ih_lo^T, in^T), then the two paired weight-gradient launches and the input gradient
             char *imgs = reserve_p2_images(reserve, T, B, in0, H, L);
             const size_t hb = halo_tiled_image_bytes(H, T * B), ib = halo_tiled_image_bytes(kin, T * B);
             char *hT0 = imgs, *inT0 = imgs + hb, *hT1 = imgs + hb + ib;
             HaloPrepJob jobs[4];
             int nj = 0;
-            jobs[nj++] = {3, bias_part1, (B + 15) / 16, 4 * H, 4 * H, db_ih[1], db_hh[1]};
-            jobs[nj++] = {3, bias_part0, (B + 15) / 16, 4 * H, 4 * H, db_ih[0], db_hh[0]};
-            if (need_dx) jobs[nj++] = {1, w_ih[0], in0, 4 * H, in0, img_wT, nullptr};
-            jobs[nj++] = {1, x, in0, T * B, in0, inT0, nullptr};
+            jobs[nj++] = {3, bias_part1, (B + 15) / 16, 4 * H, 4 * H, db_ih[hi], db_hh[hi]};
+            jobs[nj++] = {3, bias_part0, (B + 15) / 16, 4 * H, 4 * H, db_ih[lo], db_hh[lo]};
+            if (need_din) jobs[nj++] = {1, w_ih[lo], in_lo_dim, 4 * H, in_lo_dim, img_wT, nullptr};
+            jobs[nj++] = {1, in_lo, in_lo_dim, T * B, in_lo_dim, inT0, nullptr};
             HALO_TRY(halo_prep_jobs(jobs, nj, st));
-            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[1], H, H, dw_ih[1], H, st));
-            if (need_dx) {
-                const DropoutCfg nodrop = make_dropout(0.f, seed, HALO_STREAM_LSTM_LAYER0, offset, offset_dev);
-                HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in0, 4 * H, dx, in0, nullptr, nullptr, 0, &nodrop, st));
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H, st));
+            if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)
+                const DropoutCfg ddrop = make_dropout(lo > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(lo > 0 ? lo - 1 : 0), offset,
+                                                      offset_dev);
+                HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_lo_dim, 4 * H, din_out, in_lo_dim, nullptr, nullptr, 0, &ddrop, st));
             }
-            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT, hT0, 4 * H, H + in0, T * B, dw_hh[0], H, H, dw_ih[0], in0, st));
-            return HALO_OK;
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT, hT0, 4 * H, H + in_lo_dim, T * B, dw_hh[lo], H, H, dw_ih[lo], in_lo_dim, st));
+        } else {
+            HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, hi, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g,
+                                         emit1 ? img_gT1 : img_gT, img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));
+            HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, lo, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit0, img_g, img_gT, img_hT,
+                                         img_inT, img_wT, bias_part0, din, dx, dw_ih, dw_hh, db_ih, db_hh, need_din, st));
         }
-        HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 1, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g, emit1 ? img_gT1 : img_gT,
-                                     img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));
-        HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, 0, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit0, img_g, img_gT, img_hT,
-                                     img_inT, img_wT, bias_part0, din, dx, dw_ih, dw_hh, db_ih, db_hh, need_dx, st));
-        return HALO_OK;
+        top_end = lo;                 // the layers below (if any) follow, one launch each, fed by din
+        if (top_end <= layer_begin) return HALO_OK;
     }
-    for (int l = layer_end - 1; l >= layer_begin; --l) {
+    for (int l = top_end - 1; l >= layer_begin; --l) {
         HALO_CHECK_ARG(w_ih[l] && w_hh[l] && dw_ih[l] && dw_hh[l] && db_ih[l] && db_hh[l]);
         const LayerBufs lb = layer_bufs(reserve, l, T, B, H);
         const bool last = (l == L - 1);

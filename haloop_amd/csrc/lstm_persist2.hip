@@ -693,7 +693,7 @@ bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST2") && atoi(getenv("HALO_LSTM_PERSIST2")) == 0;
     if (env_off || !halo_ctx_cur().lstm_persistent2) return false;
     if (!halo_lstm_persist_ok(B, H) || !halo_lstm_persist_fits(T, B, H)) return false;   // the per-layer recurrence's shape / switch / CU rules
-    if (halo_math_mode() != HALO_MATH_BF16 || L != 2) return false;
+    if (halo_math_mode() != HALO_MATH_BF16 || L < 2) return false;       // the top two layers of the stack; the ones below run per layer
     if (H % 128 != 0 || H > 1024 || T < 1) return false;
     // image byte offsets are 32-bit (buffer addressing): the largest is the backward's, (T + 1) images of ceil(B/16) * 4H/32 blocks
     const long nbt = (B + 15) / 16;

@@ -263,11 +263,12 @@ int halo_set_lstm_persistent(int on);
  * (HALO_PERSIST_EMIT=0 / halo_set_lstm_persistent_images(0): off). */
 int halo_set_lstm_persistent_images(int on);
 int halo_lstm_persistent_eligible(int B, int H);
-/* Two-layer persistent recurrence (csrc/lstm_persist2.hip): for L == 2 in the single-pass bf16 arithmetic mode (HALO_MATH_BF16) and a
- * shape the persistent recurrence takes, halo_lstm_fwd runs BOTH layers' T steps in one launch of T + 1 combined steps (layer 0 at
- * time s beside layer 1 at time s - 1: one hand-off per combined step, layer 1's input projection inside its step), and halo_lstm_bwd
- * called with layer_begin = 0, layer_end = 2 likewise (layer 1's input gradient formed inside the launch).  Same reserve contents as
- * the per-layer path, so either backward follows either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
+/* Two-layer persistent recurrence (csrc/lstm_persist2.hip): for L >= 2 in the single-pass bf16 arithmetic mode (HALO_MATH_BF16) and a
+ * shape the persistent recurrence takes, halo_lstm_fwd runs the stack's TOP TWO layers' T steps in one launch of T + 2 combined steps
+ * (the lower layer at time s beside the upper at time s - 2: one hand-off per combined step, the upper layer's input projection inside
+ * its step; the layers below them one launch each), and halo_lstm_bwd called with layer_end = L and layer_begin <= L - 2 likewise (the
+ * upper layer's input gradient formed inside the launch).  Same reserve contents as the per-layer path, so either backward follows
+ * either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
 int halo_set_lstm_persistent2(int on);
 /* The two-layer forward packs its three weight images; when a backward of the same step will follow (the default) it writes the
  * backward's three transposed images from the same read of the weights, into the reserve, and halo_lstm_bwd called with that reserve

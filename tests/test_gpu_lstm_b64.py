@@ -481,3 +481,32 @@ def test_wide_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0,
         lib.set_lstm_persistent(True)
     assert st_a == (0, 0) and st_b == (0, 0)
     _normalised_close(a, b, rtol=3e-2, atol=3e-3)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,L,p_drop,with_state', [
+    (6, 16, 64, 256, 3, 0.2, False),        # the stock 3-layer encoder's shape family (ha/rnn.py:11): layer 0 alone, layers 1 + 2 in one launch
+    (5, 32, 128, 512, 3, 0.0, True),        # carried state, no dropout
+    (4, 32, 128, 256, 4, 0.25, False),      # two single layers under the pair
+])
+def test_top_pair_of_a_deeper_stack_runs_as_one_launch(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
+    """L > 2 in bf16: the stack's top two layers run as the two-layer persistent launch (its lower layer's input projection fed by the layer
+    below, its input gradient masked by that layer's dropout and handed down), the layers below one launch each -- against the per-layer
+    launches and against the step chain."""
+    lib = hal['lib']
+    assert lib.lib().halo_lstm_persistent2_eligible(T, B, H, L) == 1
+    a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    assert lib.lstm_chain_info('fwd')['kernel'] == 'lstm_persist2_fwd_kernel'
+    lib.set_lstm_persistent2(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    finally:
+        lib.set_lstm_persistent2(True)
+    lib.set_lstm_persistent(False)
+    try:
+        c, st_c = _lstm_case(hal, T, B, in0, H, L, p_drop, 5, with_state)
+    finally:
+        lib.set_lstm_persistent(True)
+    assert st_a == (0, 0) and st_b == (0, 0) and st_c == (0, 0)
+    _normalised_close(a, b, rtol=5e-3, atol=2e-3)
+    _normalised_close(a, c, rtol=3e-2, atol=3e-3)
