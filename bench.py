@@ -283,6 +283,42 @@ def read_traffic(kernel_name):
     return None
 
 
+def measure_traffic(math):
+    """HBM bytes per launch of the recurrent chains, measured IN THIS RUN: two child processes under rocprofv3, one PMC counter per
+    pass (FETCH_SIZE, then WRITE_SIZE) as MI355X_MICROARCH.md's HBM section prescribes, on tools/run_lstm2_steps.py (the benchmark's
+    LSTM stack alone: same kernels, same shapes); bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (that section's gfx950 correction
+    for 16-byte-per-lane reads).  Returns {kernel name: bytes} or None when rocprofv3 is not available or a pass fails (the
+    committed passes under profiles/ are used then)."""
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if not exe:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    work = tempfile.mkdtemp(prefix='halo_pmc_', dir='/tmp')
+    env = dict(os.environ, HALO_MATH=math, TMPDIR='/tmp')
+    found = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(work, counter)
+            proc = subprocess.run([exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable,
+                                   os.path.join(ROOT, 'tools', 'run_lstm2_steps.py')], env=env, cwd='/tmp', capture_output=True, text=True,
+                                  timeout=180)
+            csvs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
+            if proc.returncode != 0 or not csvs:
+                return None
+            found[counter] = pmc_traffic.medians(csvs[0], counter)
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    res = {}
+    for k in set(found['FETCH_SIZE']) | set(found['WRITE_SIZE']):
+        res[k] = int(round(2 * found['FETCH_SIZE'].get(k, (0.0, 0))[0] * 1024 + found['WRITE_SIZE'].get(k, (0.0, 0))[0] * 1024))
+    return res
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -388,11 +424,21 @@ def main():
             us_f, launches_f, name_f = time_chain(device, 'fwd', cl)
             kb, kf = chain_algorithmic_bytes(B_PER_GPU, 'bwd', cl), chain_algorithmic_bytes(B_PER_GPU, 'fwd', cl)
             chains = L // cl
+            live = None if args.no_extras else measure_traffic(args.math)
+
+            def traffic(name):
+                if live:
+                    for k, v in live.items():
+                        if name in k:
+                            return v
+                return read_traffic(name)
             ach = kb / launches_b / (us_b / launches_b * 1e-6) / 1e9
             out['roofline'] = {
                 'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': chains, 'layers_per_chain': cl,
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                'traffic': read_traffic(name_b),
+                'traffic': traffic(name_b),
+                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process (tools/run_lstm2_steps.py), bytes = 2 F + W'
+                                   if live else 'committed passes under profiles/ (rocprofv3 not available to this run)'),
                 'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
                 'accounting': 'SURVEY.md 8d: every weight matrix the launch multiplies by once per pass (W_hh^T per layer; the two-layer '
                               'launch also W_ih of layer 1) + per step and layer the fp32 activations entering/leaving the chain (gates in, '
@@ -401,7 +447,7 @@ def main():
                 'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
                                  'algorithmic_bytes_per_launch': kf // launches_f,
                                  'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
-                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': read_traffic(name_f),
+                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic(name_f),
                                  'share_of_step': round(chains * us_f * 1e-3 / ms_per_step, 3)}}
         if world == 1 and not args.no_extras:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
