@@ -73,6 +73,7 @@ SIGNATURES = {
     'halo_ctc_prepare': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'halo_ctc_mean_loss': (_i, [_vp, _vp, _i, _vp, _vp]),
     'halo_ctc_head_supported': (_i, [_i, _i, _i, _i]),
+    'halo_ctc_head_greedy': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'halo_ctc_head_workspace_bytes': (_sz, [_i, _i, _i]),
     'halo_ctc_head_fwd': (_i, [_vp, _vp, _vp, _f, _u64, _u32, _u32, _vp, _vp, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _i, _i, _i, _i, _vp]),

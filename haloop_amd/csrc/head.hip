@@ -48,6 +48,10 @@ struct HeadFwdArgs {
     float *lp, *alpha, *nll, *grad_out, *loss;
     int64_t *flen;
     unsigned *ticket;
+    // GREEDY instantiation (TemporalClassifier.decode, ha/recognizer.py:48-59): instead of the lattice, per frame the best class and its
+    // log-prob, the collapsed hypothesis (repeats merged, blanks dropped, zero padded) and its length
+    int64_t *ali, *hyp, *hyp_len;
+    float *scores;
     int B, T, H, V, S, ks, stride, pad;
 };
 
@@ -60,6 +64,7 @@ __device__ __forceinline__ int feature_length(long il, int ks, int stride, int p
 constexpr int KC = 256;                  // K-chunk staged through LDS per pass
 constexpr int LDK = KC + 1;              // row stride in floats: lanes (row r, k) hit bank (r + k) % 32 -> conflict-free fragment reads
 
+template <bool GREEDY>
 __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];   // [As: 32 x LDK][Ws: 32 x LDK][red: NW x 1024]
     float *As = dyn, *Ws = dyn + 32 * LDK, *red = dyn + 64 * LDK;
@@ -137,9 +142,35 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
         const float lpv = x - m - logf(s);
         __syncthreads();
         tile[i][j] = lpv;
-        if (i < T && j < V) p.lp[((long)n * T + i) * V + j] = lpv;
+        if (p.lp && i < T && j < V) p.lp[((long)n * T + i) * V + j] = lpv;
     }
     __syncthreads();
+    if (GREEDY) {
+        // one lane per frame (T <= 32): arg max over the classes (first maximum, like torch.max), then unique_consecutive + drop blanks
+        if (wave == 0) {
+            const int t = lane;
+            int best = -1;
+            float bv = -INFINITY;
+            if (t < T) {
+                best = 0; bv = tile[t][0];
+                for (int c = 1; c < V; ++c) {
+                    const float v = tile[t][c];
+                    if (v > bv) { bv = v; best = c; }
+                }
+                p.ali[(long)n * T + t] = best;
+                p.scores[(long)n * T + t] = bv;
+            }
+            int left = __shfl_up(best, 1, 64);
+            if (lane == 0) left = -1;
+            const bool keep = (t < T) && best != left && best != 0;
+            const unsigned long long mask = __ballot(keep);
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull)), count = __popcll(mask);
+            if (keep) p.hyp[(long)n * T + pos] = best;
+            if (t < T && t >= count) p.hyp[(long)n * T + t] = 0;          // the padding the separate fill launch wrote
+            if (lane == 0) p.hyp_len[n] = count;
+        }
+        return;
+    }
     // ---- CTC alpha (F.ctc_loss semantics, as ctc_alpha_wave_kernel with flags 0), wave 0: one lattice state per lane ----
     if (wave == 0) {
         const int S_ = 2 * p.S + 1;
@@ -399,7 +430,7 @@ int halo_ctc_head_fwd(const float *features, const float *weight, const float *b
     HALO_CHECK_ARG(((uintptr_t)features % 16 == 0) && ((uintptr_t)weight % 16 == 0));
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void *)ctc_head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)ctc_head_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_LDS) != hipSuccess)
             return HALO_ELAUNCH;
         attr = true;
     }
@@ -409,7 +440,28 @@ int halo_ctc_head_fwd(const float *features, const float *weight, const float *b
     a.il = input_lengths; a.targets = targets; a.tl = target_lengths; a.tg_stride = tg_stride;
     a.lp = lp; a.alpha = alpha; a.nll = nll; a.grad_out = grad_out; a.loss = loss; a.flen = feature_lengths; a.ticket = ticket;
     a.B = B; a.T = T; a.H = H; a.V = V; a.S = S; a.ks = ks; a.stride = stride; a.pad = pad;
-    hipLaunchKernelGGL(ctc_head_fwd_kernel, dim3(B), dim3(1024), HEAD_FWD_LDS, (hipStream_t)stream, a);
+    a.ali = a.hyp = a.hyp_len = nullptr; a.scores = nullptr;
+    hipLaunchKernelGGL(ctc_head_fwd_kernel<false>, dim3(B), dim3(1024), HEAD_FWD_LDS, (hipStream_t)stream, a);
+    return halo_launch_status();
+}
+
+int halo_ctc_head_greedy(const float *features, const float *weight, const float *bias, float *lp, int64_t *alignments, float *scores,
+                         int64_t *hyp, int64_t *hyp_len, int B, int T, int H, int V, halo_stream_t stream) {
+    HALO_CHECK_ARG(features && weight && bias && alignments && scores && hyp && hyp_len && B > 0);
+    if (!halo_ctc_head_supported(T, H, V, 0)) return HALO_ENOTSUP;
+    HALO_CHECK_ARG(((uintptr_t)features % 16 == 0) && ((uintptr_t)weight % 16 == 0));
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)ctc_head_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_FWD_LDS) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    HeadFwdArgs a = {};
+    a.feats = features; a.w = weight; a.bias = bias;
+    a.drop = make_dropout(0.f, 0, 0, 0, nullptr);
+    a.lp = lp; a.ali = alignments; a.scores = scores; a.hyp = hyp; a.hyp_len = hyp_len;
+    a.B = B; a.T = T; a.H = H; a.V = V;
+    hipLaunchKernelGGL(ctc_head_fwd_kernel<true>, dim3(B), dim3(1024), HEAD_FWD_LDS, (hipStream_t)stream, a);
     return halo_launch_status();
 }
 

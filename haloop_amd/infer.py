@@ -25,6 +25,9 @@ class LstmCtcRecognizer:
         Tp = y_sub.shape[0]
         feats = torch.empty(B, Tp, H, device=x.device, dtype=torch.float32)
         ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True, expect_backward=False)
+        if ops.ctc_head_supported(Tp, H, V, 0):
+            # classifier + log_softmax + greedy collapse in one launch, one workgroup per utterance (csrc/head.hip)
+            return ops.ctc_head_greedy(feats, rec.classifier.weight, rec.classifier.bias)
         logits = ops.gemm(feats.view(B * Tp, H), rec.classifier.weight, True, True, B * Tp, V, H, bias1=rec.classifier.bias)
         lp = ops.log_softmax_fwd(logits).view(B, Tp, V)
         return ops.ctc_greedy(lp)          # alignments, scores, hyp (padded), hyp_len

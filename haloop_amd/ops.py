@@ -427,6 +427,22 @@ def ctc_greedy(lp):
     return ali, scores, hyp, hyp_len
 
 
+def ctc_head_greedy(feats, weight, bias, want_lp=False):
+    """feats [B,T,H] -> (alignments, scores, hyp (zero padded), hyp_len[, log-probs]): classifier + log_softmax + greedy collapse in one launch."""
+    _f32c(feats, 'features')
+    B, T, H = feats.shape
+    V = weight.shape[0]
+    dev = feats.device
+    ali = torch.empty(B, T, device=dev, dtype=torch.int64)
+    scores = torch.empty(B, T, device=dev, dtype=torch.float32)
+    hyp = torch.empty(B, T, device=dev, dtype=torch.int64)
+    hyp_len = torch.empty(B, device=dev, dtype=torch.int64)
+    lp = torch.empty(B, T, V, device=dev, dtype=torch.float32) if want_lp else None
+    check(lib().halo_ctc_head_greedy(ptr(feats), ptr(weight), ptr(bias), ptr(lp), ptr(ali), ptr(scores), ptr(hyp), ptr(hyp_len), B, T, H, V,
+                                     _stream()), 'halo_ctc_head_greedy')
+    return (ali, scores, hyp, hyp_len, lp) if want_lp else (ali, scores, hyp, hyp_len)
+
+
 def ctc_beam(em, beam, log_domain=True):
     """em [N,T,V] -> (seqs [N,beam,T] int64, lens [N,beam] int32, scores [N,beam])."""
     _f32c(em, 'emissions')

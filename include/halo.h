@@ -339,6 +339,11 @@ int halo_ctc_prepare(const int64_t *input_lengths, const int64_t *target_lengths
 int halo_ctc_mean_loss(const float *nll, const int64_t *target_lengths, int n, float *loss,
                        halo_stream_t stream);
 
+/* TemporalClassifier.decode (ha/recognizer.py:48-59) in ONE launch, one workgroup per utterance: Linear -> log_softmax -> per frame the
+ * best class and its log-prob (alignments, scores [B][T]) -> unique_consecutive, blanks dropped (hyp [B][T] zero padded, hyp_len [B]);
+ * lp (optional) receives the log-probs [B][T][V].  Same shape limits as halo_ctc_head_fwd (T <= 32, V <= 32). */
+int halo_ctc_head_greedy(const float *features, const float *weight, const float *bias, float *lp, int64_t *alignments, float *scores,
+                         int64_t *hyp, int64_t *hyp_len, int B, int T, int H, int V, halo_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * The whole CTC head of a training step (TemporalClassifier.forward and its backward) in three launches.
  * replaces: dropout -> nn.Linear -> log_softmax -> F.ctc_loss(mean) ha/recognizer.py:43-46,61-73 plus the feature-length arithmetic of

@@ -98,3 +98,30 @@ def test_trainer_step_with_and_without_fused_head_match_oracle(fused):
         np.testing.assert_allclose(v.cpu().numpy(), ref.enc[k].detach().numpy(), atol=3e-5, err_msg=k)
     for k, v in rec.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), ref.rec[k].detach().numpy(), atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('B,T,H,V', [(64, 21, 1024, 32), (5, 32, 512, 29), (3, 1, 64, 2), (130, 7, 1536, 32)])
+def test_head_greedy_matches_the_separate_launches(B, T, H, V):
+    """classifier + log_softmax + greedy collapse in one launch (TemporalClassifier.decode, ha/recognizer.py:48-59) against the three
+    launches it replaces in the inference path (product, log-softmax, ctc_greedy) and the oracle's greedy on the same log-probs."""
+    from haloop_amd import ops
+    from oracle import lattice
+    g = torch.Generator().manual_seed(B * 7 + T)
+    feats = torch.randn(B, T, H, generator=g).cuda()
+    W = (torch.randn(V, H, generator=g) * H ** -0.5).cuda()
+    W[0] += 0.02 * feats.mean((0, 1))            # some blanks among the winners
+    b = (0.1 * torch.randn(V, generator=g)).cuda()
+    ali, scores, hyp, hyp_len, lp = ops.ctc_head_greedy(feats, W, b, want_lp=True)
+    logits = ops.gemm(feats.view(B * T, H), W, True, True, B * T, V, H, bias1=b)
+    lp2 = ops.log_softmax_fwd(logits).view(B, T, V)
+    torch.testing.assert_close(lp, lp2, rtol=0, atol=2e-5)
+    ali2, scores2, hyp2, len2 = ops.ctc_greedy(lp)            # the same log-probs: index results are exact
+    assert torch.equal(ali, ali2) and torch.equal(hyp, hyp2) and torch.equal(hyp_len, len2)
+    assert torch.equal(scores, scores2)
+    # the run without the log-prob output writes the same results
+    out = ops.ctc_head_greedy(feats, W, b)
+    assert torch.equal(out[0], ali) and torch.equal(out[2], hyp) and torch.equal(out[3], hyp_len) and torch.equal(out[1], scores)
+    hyps, lengths, alignments, best = lattice.greedy_decode(lp.cpu())
+    assert torch.equal(ali.cpu(), alignments) and torch.equal(hyp_len.cpu(), lengths) and torch.equal(scores.cpu(), best)
+    for n in range(B):
+        assert hyp[n, :lengths[n]].tolist() == hyps[n] and not hyp[n, lengths[n]:].any()
