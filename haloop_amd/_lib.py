@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 11
+HALO_ABI_VERSION = 12
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -48,6 +48,7 @@ SIGNATURES = {
     'halo_gemm_split_residual': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_image_pairs': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'halo_gemm_split_io': (_i, [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _i, _vp, _vp, _i, _vp]),
+    'halo_gemm_tn_bf16': (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _i, _i, _vp]),
     'halo_subsample_col_bytes': (_sz, [_i] * 6),
     'halo_subsample_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
     'halo_subsample_bwd': (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp]),

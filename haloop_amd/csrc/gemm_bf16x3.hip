@@ -247,6 +247,11 @@ struct TiledGemmArgs {
     // IO & 1: A is not an image but row-major bf16 [M][lda] (hi, and lo with three passes), K % 32 == 0
     const __bf16 *Arm_hi, *Arm_lo;
     long lda;
+    // IO & 8 ("TN"): BOTH operands are row-major bf16 with the contraction index as their ROW: A = Arm_hi [K][M] (lda), B = Brm [K][N]
+    // (ldb); C [M][N] = A^T B.  The weight gradient of a Linear straight from the row-major activations and output gradients: no
+    // transposed operand image is built (K % 32 == 0, M % 8 == 0, N % 8 == 0; single pass only)
+    const __bf16 *Brm;
+    long ldb;
     // IO & 2: the result also (C != NULL) or only (C == NULL) goes out as row-major bf16 [M][ldo]: hi = bf16(v), lo = bf16(v - hi)
     __bf16 *Ohi, *Olo;
     long ldo;
@@ -297,6 +302,37 @@ __device__ __forceinline__ void stage_rowmajor(const __bf16 *hi, const __bf16 *l
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
     }
+}
+
+// TN operands (IO & 8): a k-tile of a row-major bf16 matrix X [K][cols] -> 32 k-rows of 256 B (this tile's 128 columns) in the slot part.
+// Row t keeps its 16-byte chunk c (columns 8c .. 8c+7) at position (c + 4 (t & 3)) & 15: the four rows a transposed read
+// (ds_read_b64_tr_b16) gathers for one fragment then lie on disjoint banks.  As in stage_rowmajor the permutation is applied on the
+// SOURCE side (LDS-DMA writes lane l at l * 16 of its 1 KiB piece = row 4 piece + l / 16, position l % 16).  Columns past the matrix
+// read its last eight (their products are never stored).
+__device__ __forceinline__ void stage_kmajor(const __bf16 *x, long ld, int col0, int k0, int ncols, char *lds_dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = i * 4 + wave;                        // 0..7
+        const int t = piece * 4 + (lane >> 4), c = ((lane & 15) - 4 * (t & 3)) & 15;
+        const __bf16 *src = x + (long)(k0 + t) * ld + min(col0 + c * 8, ncols - 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
+    }
+}
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+// the 32x32x16 operand fragment (lane: row = lane & 31, k = 8 (lane >> 5) .. + 7) of such a part: two transposed reads of 4 k-rows x 16
+// columns per 16-lane group (lane 4q + p of a group addresses row q, columns 4p .. 4p+3 and receives column lane & 15 of the four rows)
+// Issued as inline assembly: behind the builtin the compiler drains every pending LDS-DMA (s_waitcnt vmcnt(0)) before the read, because
+// it cannot tell the ring slot being read from the one being filled, and the loop loses its pipelining (measured: 1.4x the time).  The
+// caller waits for the reads itself (tr_wait) before the first MFMA that takes them.
+__device__ __forceinline__ void tr_read2(bf16x4_t &x0, bf16x4_t &x1, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(x0), "=&v"(x1) : "v"(lds_addr) : "memory");
+}
+__device__ __forceinline__ bf16x8 join8(bf16x4_t x0, bf16x4_t x1) { return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]}; }
+// every LDS read of the wave has returned; the fragments pass through so that their MFMAs are ordered behind the wait
+__device__ __forceinline__ void tr_wait(bf16x8 &a0, bf16x8 &a1, bf16x8 &a2, bf16x8 &a3, bf16x8 &b0, bf16x8 &b1, bf16x8 &b2, bf16x8 &b3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
 }
 
 constexpr int STAGE_BYTES = 2 * BLOCK_BYTES;    // one ring slot: A block | B block = 32 KiB
@@ -368,39 +404,72 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
             boff[i][ks] = swz_byte(wn * 64 + i * 32 + lr, ks * 2 + lh);
         }
 
+    // TN: byte offset of this lane's first transposed read inside a part, k-step 0 (k-step 1: + 16 rows = 4096)
+    int aoffT[2], boffT[2];
+    if (IO & 8) {
+        static_assert(!(IO & 8) || PASSES == 1, "the TN operands are single-pass bf16");
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ca = wm * 64 + i * 32 + 16 * (g & 1) + 4 * pp, cb = wn * 64 + i * 32 + 16 * (g & 1) + 4 * pp;
+            aoffT[i] = (8 * (g >> 1) + q) * 256 + ((((ca >> 3) + 4 * q) & 15) << 4) + (ca & 7) * 2;
+            boffT[i] = (8 * (g >> 1) + q) * 256 + ((((cb >> 3) + 4 * q) & 15) << 4) + (cb & 7) * 2;
+        }
+    }
+    // one k-tile of both operands into a ring slot
+    auto stage = [&](int t, char *slot) {
+        if (IO & 8) {
+            stage_kmajor(p.Arm_hi, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, slot, wave, lane);
+            stage_kmajor(p.Brm, p.ldb, tile_n * TR, (kt0 + t) * TK, p.N, slot + OPER, wave, lane);
+        } else {
+            if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, slot, wave, lane);
+            else stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, slot, wave, lane);
+            stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, slot + OPER, wave, lane);
+        }
+    };
+
     // prologue: NSTAGE-1 k-tiles in flight.  Tiles past the end are clamped to the last one (a
     // harmless re-read into a ring slot nobody reads again) so every iteration issues exactly
     // LOADS_PER_STAGE loads and the vmcnt arithmetic stays exact.
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
-        const int t = min(s, nkt - 1);
-        if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, lds + s * SLOT, wave, lane);
-        else stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, lds + s * SLOT, wave, lane);
-        stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, lds + s * SLOT + OPER, wave, lane);
+        stage(min(s, nkt - 1), lds + s * SLOT);
     }
-    if (NSTAGE == 1) {      // single slot: filled here, refilled each iteration once every wave holds its fragments in registers
-        if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, kt0 * TK, p.M, lds, wave, lane);
-        else stage_block<PASSES>(Ablk, lds, wave, lane);
-        stage_block<PASSES>(Bblk, lds + OPER, wave, lane);
-    }
+    if (NSTAGE == 1) stage(0, lds);      // single slot: filled here, refilled each iteration once every wave holds its fragments in registers
     for (int t = 0; t < nkt; ++t) {
         // tile t is complete once all but the newest (NSTAGE-2) stages have landed
         wait_vm_and_barrier<(NSTAGE >= 2 ? NSTAGE - 2 : 0) * LOADS>();
         if (NSTAGE >= 2) {   // refill the slot consumed in iteration t-1 (every wave is past it: they all passed the barrier)
-            const int tn = min(t + NSTAGE - 1, nkt - 1);
-            char *slot = lds + ((t + NSTAGE - 1) % NSTAGE) * SLOT;
-            if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + tn) * TK, p.M, slot, wave, lane);
-            else stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, slot, wave, lane);
-            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, slot + OPER, wave, lane);
+            stage(min(t + NSTAGE - 1, nkt - 1), lds + ((t + NSTAGE - 1) % NSTAGE) * SLOT);
         }
         const char *cur = lds + (t % NSTAGE) * SLOT;
         const char *ah = cur, *al = cur + PART_BYTES, *bh = cur + OPER, *bl = cur + OPER + PART_BYTES;
         // both k-steps' fragments are requested up front: the second set lands under the first set's MFMAs
         bf16x8 fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];
+        if (IO & 8) {
+            const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)ah;
+            bf16x4_t xa[2][2][2], xb[2][2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    tr_read2(xa[ks][i][0], xa[ks][i][1], la + aoffT[i] + ks * 4096);
+                    tr_read2(xb[ks][i][0], xb[ks][i][1], la + OPER + boffT[i] + ks * 4096);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fah[ks][i] = join8(xa[ks][i][0], xa[ks][i][1]);
+                    fbh[ks][i] = join8(xb[ks][i][0], xb[ks][i][1]);
+                }
+            tr_wait(fah[0][0], fah[0][1], fah[1][0], fah[1][1], fbh[0][0], fbh[0][1], fbh[1][0], fbh[1][1]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if (IO & 8) continue;
                 fah[ks][i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
                 fbh[ks][i] = *reinterpret_cast<const bf16x8 *>(bh + boff[i][ks]);
                 if (PASSES == 3) {
@@ -411,10 +480,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         if (NSTAGE == 1) {
             // every wave has its fragments: the slot is free, the next tile streams in under this tile's MFMAs
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int tn = min(t + 1, nkt - 1);
-            if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + tn) * TK, p.M, lds, wave, lane);
-            else stage_block<PASSES>(Ablk + (long)tn * BLOCK_BYTES, lds, wave, lane);
-            stage_block<PASSES>(Bblk + (long)tn * BLOCK_BYTES, lds + OPER, wave, lane);
+            stage(min(t + 1, nkt - 1), lds);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -930,8 +996,48 @@ static int gemm_bf16x3_io(const void *Aimg, const void *a_hi, const void *a_lo, 
     return HALO_ENOTSUP;
 }
 
+// C [M][N] (+)= A^T B with A [K][M], B [K][N] row-major bf16 (IO & 8).  Split-K by the same rule as the image products.
+static int gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, int N, int K, float *C, int ldc, int flags, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<3, 1, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<3, 1, false, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<3, 1, false, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    TiledGemmArgs p = {};
+    p.Arm_hi = (const __bf16 *)a; p.lda = lda; p.Brm = (const __bf16 *)b; p.ldb = ldb;
+    p.C = C; p.R = C; p.ldr = ldc; p.ldc = ldc;
+    p.M = M; p.N = N; p.KT = K / TK; p.relu = flags;
+    p.tiles_n = (N + TR - 1) / TR;
+    p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
+    p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
+    p.ksplit = halo_pick_ksplit(p.ntiles, p.KT, (long)M * N);
+    p.ktper = (p.KT + p.ksplit - 1) / p.ksplit;
+    p.ksplit = (p.KT + p.ktper - 1) / p.ktper;
+    void *scratch; size_t bytes;
+    halo_get_scratch(&scratch, &bytes);
+    p.slab = (float *)scratch;
+    const dim3 grid((unsigned)(p.ntiles * p.ksplit));
+    if (p.ksplit > 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 2, 8>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else if (flags & HALO_GEMM_ACCUM) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 3, 8>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 8>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    const int rc = halo_launch_status();
+    if (rc != HALO_OK || p.ksplit == 1) return rc;
+    return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, nullptr, nullptr, flags, p.drop, 0, st);
+}
+
 // ---- public entry points (include/halo.h) -----------------------------------------------------
 extern "C" {
+
+int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, int N, int K, float *C, int ldc, int flags,
+                      halo_stream_t stream) {
+    HALO_CHECK_ARG(a && b && C && M > 0 && N > 0 && K > 0);
+    HALO_CHECK_ARG(K % TK == 0 && M % 8 == 0 && N % 8 == 0 && lda >= M && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0);
+    HALO_CHECK_ARG(((uintptr_t)a | (uintptr_t)b) % 16 == 0 && (flags & ~HALO_GEMM_ACCUM) == 0);
+    return gemm_tn_bf16(a, lda, b, ldb, M, N, K, C, ldc, flags, (hipStream_t)stream);
+}
 
 size_t halo_split_image_bytes(int rows, int k) {
     if (rows <= 0 || k <= 0) return 0;

@@ -171,6 +171,23 @@ def gemm_split_io(a, b_img, M, N, K, out=None, out_rowmajor=False, bias1=None, b
     return (o_hi, o_lo) if out_rowmajor else out
 
 
+def gemm_tn(a, b, out=None, accumulate=False):
+    """a [K, M]^T b [K, N] -> fp32 [M, N] for row-major bf16 a, b (the contraction index is their row): halo_gemm_tn_bf16, the weight
+    gradient of a Linear from row-major bf16 activations / output gradients without a transposed operand image."""
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError('gemm_tn: a [K, M], b [K, N] bf16')
+    if a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError('gemm_tn: row-major operands')
+    K, M = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().halo_gemm_tn_bf16(ptr(a), a.stride(0), ptr(b), b.stride(0), M, N, K, ptr(out), out.stride(0),
+                                  _lib.HALO_GEMM_ACCUM if accumulate else 0, _stream()), 'halo_gemm_tn_bf16')
+    return out
+
+
 def gemm_split_ce(a_img, b_img, M, N, K, targets, ignore_index=0, bias=None, want_logits=False, want_lse=False):
     """Per-row cross-entropy of logits = A B^T (+ bias) straight from the split GEMM's epilogue: -> (loss [M], lse [M] or None,
     logits [M, N] or None).  Without want_logits nothing of size M x N is written."""

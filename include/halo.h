@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 11
+#define HALO_ABI_VERSION 12
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -159,6 +159,15 @@ int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int 
 int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *residual,
                              int ldr, const float *bias1, const float *bias2, int flags, float p_drop, uint64_t seed,
                              uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
+
+/* C [M][N] (+)= A^T B with A [K][M] (leading dimension lda) and B [K][N] (ldb) ROW-MAJOR bf16, the contraction index as their row:
+ * the weight gradient dW = dy^T x of a Linear (ha/attention.py's nn.Linear layers under autograd) straight from the row-major bf16
+ * activations and output gradients the neighbouring launches wrote -- the operands are transposed on their way from LDS into the MFMA
+ * (ds_read_b64_tr_b16), no transposed operand image is built.  Single-pass bf16 operands, fp32 accumulation; K % 32 == 0, M % 8 == 0,
+ * N % 8 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned operands.  flags: 0 or HALO_GEMM_ACCUM (C += result).  Split-K slices go
+ * through the scratch lent by halo_set_scratch. */
+int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, int N, int K, float *C, int ldc, int flags,
+                      halo_stream_t stream);
 
 /* halo_gemm_split with row-major bf16 activations on either side, so that consecutive Linears hand their activations on without an
  * operand-image pass (ha/attention.py:136-143: c_fc -> gelu -> c_proj).  A comes either from an image (a_image) or from a row-major

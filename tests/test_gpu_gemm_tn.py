@@ -1,0 +1,52 @@
+"""halo_gemm_tn_bf16: C = A^T B from row-major bf16 operands whose row is the contraction index (the weight gradient of a Linear without
+transposed operand images), against the fp64 product of the same bf16 values and against the image path on the same operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('K,M,N', [(64, 128, 128), (8192, 768, 3072), (8192, 3072, 768), (1024, 776, 2304), (96, 8, 40), (2048, 50304, 768)])
+def test_tn_product_matches_fp64(K, M, N):
+    from haloop_amd import _lib, ops
+    _lib.lend_scratch(256 << 20)
+    g = torch.Generator().manual_seed(K + M + N)
+    a = torch.randn(K, M, generator=g).cuda().bfloat16()
+    b = torch.randn(K, N, generator=g).cuda().bfloat16()
+    got = ops.gemm_tn(a, b)
+    rows = torch.randint(0, M, (64,), generator=g).cuda()              # a sample of output rows in fp64 (the full product is large)
+    want = a.double()[:, rows].t() @ b.double()
+    err = (got[rows].double() - want).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * 16 + 1e-5, err                      # fp32 accumulation of exact bf16 products
+    # C += through the accumulate flag
+    base = torch.randn(M, N, generator=g).cuda()
+    acc = ops.gemm_tn(a, b, out=base.clone(), accumulate=True)
+    torch.testing.assert_close(acc[rows], (base[rows].double() + want).float(), rtol=0, atol=err + 1e-4)
+
+
+def test_tn_product_equals_the_image_path_in_bf16_mode():
+    """The same bf16 operand values through the transposed operand images (the path the TN product replaces): equal up to summation order."""
+    from haloop_amd import _lib, ops
+    _lib.lend_scratch(256 << 20)
+    mode = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        g = torch.Generator().manual_seed(5)
+        K, M, N = 4096, 768, 768
+        dy = torch.randn(K, M, generator=g).cuda().bfloat16()
+        x = torch.randn(K, N, generator=g).cuda().bfloat16()
+        got = ops.gemm_tn(dy, x)
+        ref = ops.gemm_split(ops.split_image(dy.float(), transposed=True), ops.split_image(x.float(), transposed=True), M, N, K)
+        torch.testing.assert_close(got, ref, rtol=0, atol=2e-3)
+    finally:
+        _lib.set_math_mode(mode)
+
+
+def test_tn_refusals():
+    from haloop_amd import _lib, ops
+    a = torch.zeros(48, 128, device='cuda', dtype=torch.bfloat16)        # K % 32 != 0
+    with pytest.raises(_lib.HaloError):
+        ops.gemm_tn(a, a)
+    a = torch.zeros(64, 12, device='cuda', dtype=torch.bfloat16)         # M % 8 != 0
+    with pytest.raises(_lib.HaloError):
+        ops.gemm_tn(a, a)
