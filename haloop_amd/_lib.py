@@ -40,6 +40,10 @@ SIGNATURES = {
     'halo_split_image_bytes': (_sz, [_i, _i]),
     'halo_split_image': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'halo_layernorm_image': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_cast_bf16': (_i, [_vp, _vp, _sz, _vp]),
+    'halo_gelu_bf16': (_i, [_vp, _vp, _sz, _i, _vp]),
+    'halo_gelu_bwd_bf16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_gemm_split_ce_workspace_bytes': (_sz, [_i, _i]),
     'halo_gemm_split_ce': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp]),
     'halo_image_pair': (_i, [_vp, _vp, _i, _i, _l, _l, _i, _vp, _vp, _vp]),
@@ -122,6 +126,7 @@ SIGNATURES = {
                                 _i, _i, _i, _i, _i, _i, _vp, _f, _u64, _u32, _u32, _vp, _vp]),
     'halo_layernorm_bwd_workspace_bytes': (_sz, [_i, _i]),
     'halo_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_layernorm_bwd_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_cross_entropy_fwd_lse': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _l, _vp]),

@@ -24,6 +24,7 @@ Not built (raises NotImplementedError): rotary (flash_attn) blocks -- the refere
 flash_attn.
 """
 import math
+import os
 from dataclasses import dataclass, asdict
 
 import torch
@@ -204,6 +205,68 @@ def block_backward(images, blk, saved, dx, B, T, cfg, put):
     return dx0
 
 
+# ---- the same block in `bf16` arithmetic with ROW-MAJOR bf16 activations between the launches (round 3) ---------------------------
+# Every Linear's input and output gradient exist once, as row-major bf16 written by the launch that produced them (the LayerNorm
+# kernels, the two GELU passes); the forward and input-gradient products stage
+# their A operand from those rows (halo_gemm_split_io), the weight-gradient products read both operands from them and transpose on the way
+# from LDS into the MFMA (halo_gemm_tn_bf16).  Gone against block_forward_train / block_backward: the four operand-image launches of the
+# activations per block and direction (gelu pair, gelu-backward pair, dy pairs, transposed LayerNorm outputs) and the fp32 round trips of
+# gelu(a)'s gradient and of the normalised rows.  Same bf16 operand values, same fp32 accumulation.
+def rowmajor_train_ok(cfg, blocks, M, training):
+    """bf16 arithmetic, no biases, no output dropout, enough rows that the products without split-K fill the chip."""
+    if os.environ.get('HALO_GPT_ROWMAJOR', '1') == '0' or _lib.get_math_mode() != 'bf16':
+        return False
+    C = cfg.n_embd
+    if cfg.bias or (training and cfg.dropout > 0.0) or M % 32 != 0 or C % 32 != 0 or not rowmajor_ok(M, 4 * C, C) or not rowmajor_ok(M, C, C):
+        return False
+    return all(blk.attn.c_attn.bias is None and blk.mlp.c_fc.bias is None for blk in blocks)
+
+
+def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
+    C, H, M = cfg.n_embd, cfg.n_head, B * T
+    w = lambda lin: images.split((lin.weight,))
+    h1b = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias)
+    qkv = ops.gemm_split_io((h1b, None), w(blk.attn.c_attn), M, 3 * C, C)
+    s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
+    y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
+                                  drop=s_att[0], stream_id=s_att[1])
+    yb = ops.cast_bf16(y)
+    x1 = ops.gemm_split_io((yb, None), w(blk.attn.c_proj), M, C, C, residual=x0)
+    h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
+    a = ops.gemm_split_io((h2b, None), w(blk.mlp.c_fc), M, 4 * C, C)
+    gb = ops.gelu_bf16(a)
+    x = ops.gemm_split_io((gb, None), w(blk.mlp.c_proj), M, C, 4 * C, residual=x1)
+    return x, (x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att)
+
+
+def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
+    """dx / dxb: the gradient w.r.t. the block's output as fp32 and as row-major bf16 -> the same pair for its input."""
+    C, H, M = cfg.n_embd, cfg.n_head, B * T
+    wt = lambda lin: images.split_t((lin.weight,))
+    x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att = saved
+    # x = x1 + c_proj(gelu(c_fc(ln_2(x1))))
+    put(blk.mlp.c_proj.weight, ops.gemm_tn(dxb, gb))
+    dab = ops.gelu_bwd_bf16(ops.gemm_split_io((dxb, None), wt(blk.mlp.c_proj), M, 4 * C, C), a)       # d a = (dx W) gelu'(a)
+    put(blk.mlp.c_fc.weight, ops.gemm_tn(dab, h2b))
+    d_ln2 = ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
+    del dab
+    dx1, dw, db, dx1b = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None, want_bf16=True)
+    put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
+    # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
+    put(blk.attn.c_proj.weight, ops.gemm_tn(dx1b, yb))
+    dy = ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
+                      B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
+    dqkvb = ops.cast_bf16(dqkv)
+    del dqkv
+    put(blk.attn.c_attn.weight, ops.gemm_tn(dqkvb, h1b))
+    d_ln1 = ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
+    dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)
+    put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
+    return dx0, dx0b
+
+
 class _GPTLoss(torch.autograd.Function):
     """Per-token NLL of GPT.forward_all with its hand-written backward (the autograd graph the reference gets from
     torch for ha/attention.py:205-232).  The parameters ride along as inputs so that loss.backward() fills their
@@ -349,8 +412,9 @@ class GPT(nn.Module):
         x = drop_rows(x, s_emb)
         blocks = []
         prefetch_block_weights(self._images, tr.h, B * T)
+        fwd = block_forward_train_rm if rowmajor_train_ok(cfg, tr.h, B * T, self.training) else block_forward_train
         for blk in tr.h:
-            x, sv = block_forward_train(self._images, blk, x, B, T, cfg, sites)
+            x, sv = fwd(self._images, blk, x, B, T, cfg, sites)
             blocks.append(sv)
         xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
@@ -387,10 +451,14 @@ class GPT(nn.Module):
             dlogits = ops.cross_entropy_bwd_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
             dw_head = linear_dw(dlogits, xf)
             dxf = linear_dx(img, dlogits, self.lm_head.weight)
-        dx, dw, db = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None)
+        rm = len(blocks) > 0 and len(blocks[0]) == 11           # block_forward_train_rm's record
+        dx, dw, db, *dxb = ops.layernorm_bwd(dxf, x_last, tr.ln_f.weight, None, tr.ln_f.bias is not None, want_bf16=rm)
         put(tr.ln_f.weight, dw); put(tr.ln_f.bias, db)
         for blk, sv in zip(reversed(tr.h), reversed(blocks)):
-            dx = block_backward(img, blk, sv, dx, B, T, cfg, put)
+            if rm:
+                dx, dxb[0] = block_backward_rm(img, blk, sv, dx, dxb[0], B, T, cfg, put)
+            else:
+                dx = block_backward(img, blk, sv, dx, B, T, cfg, put)
         dwpe = torch.zeros_like(tr.wpe.weight)
         dx = drop_rows(dx, s_emb)
         if emb_saved is not None:                                                # StableEmbedding: through the two LayerNorms first

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 template <int MAXG>
 __global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                               const float *__restrict__ b, float *__restrict__ y, char *__restrict__ img,
-                                                              int rows, int C, float eps, int with_lo) {
+                                                              int rows, int C, float eps, int with_lo, __bf16 *__restrict__ rm = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (long)row * C;
@@ -673,6 +673,8 @@ __global__ __launch_bounds__(256) void layernorm_image_kernel(const float *__res
         }
         bf16x8 hi, lo;
         split8(o, hi, lo);
+        if (rm) *reinterpret_cast<bf16x8 *>(rm + (long)row * C + 8 * g) = hi;      // row-major bf16 (halo_layernorm_bf16)
+        if (!img) return;
         char *blk = img + ((long)rt * KT + (8 * g) / TK) * BLOCK_BYTES;
         const int off = swz_byte(rin, ((8 * g) % TK) / 8);
         *reinterpret_cast<bf16x8 *>(blk + off) = hi;
@@ -1097,17 +1099,29 @@ int halo_gemm_split_ce(const void *a_image, const void *b_image, int M, int N, i
     return halo_launch_status();
 }
 
+static int layernorm_image_launch(const float *x, const float *weight, const float *bias, float *y, void *image, __bf16 *rm, int rows, int C,
+                                  float eps, hipStream_t st) {
+    const int with_lo = halo_math_mode() != HALO_MATH_BF16;
+    const bool vec = (((uintptr_t)weight | (uintptr_t)bias) % 16) == 0;       // the row-in-registers variants load w / b as float4
+    const dim3 grid((rows + 3) / 4);
+    if (vec && C <= 1024) hipLaunchKernelGGL(layernorm_image_kernel<2>, grid, dim3(256), 0, st, x, weight, bias, y, (char *)image, rows, C, eps, with_lo, rm);
+    else if (vec && C <= 2048) hipLaunchKernelGGL(layernorm_image_kernel<4>, grid, dim3(256), 0, st, x, weight, bias, y, (char *)image, rows, C, eps, with_lo, rm);
+    else hipLaunchKernelGGL(layernorm_image_kernel<0>, grid, dim3(256), 0, st, x, weight, bias, y, (char *)image, rows, C, eps, with_lo, rm);
+    return halo_launch_status();
+}
+
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C, float eps,
                          halo_stream_t stream) {
     HALO_CHECK_ARG(x && weight && image && rows > 0 && C > 0 && C % TK == 0);
     HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)image | (uintptr_t)y) % 16 == 0);
-    const int with_lo = halo_math_mode() != HALO_MATH_BF16;
-    const bool vec = (((uintptr_t)weight | (uintptr_t)bias) % 16) == 0;       // the row-in-registers variants load w / b as float4
-    const dim3 grid((rows + 3) / 4);
-    if (vec && C <= 1024) hipLaunchKernelGGL(layernorm_image_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
-    else if (vec && C <= 2048) hipLaunchKernelGGL(layernorm_image_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
-    else hipLaunchKernelGGL(layernorm_image_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, weight, bias, y, (char *)image, rows, C, eps, with_lo);
-    return halo_launch_status();
+    return layernorm_image_launch(x, weight, bias, y, image, nullptr, rows, C, eps, (hipStream_t)stream);
+}
+
+int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, int rows, int C, float eps,
+                        halo_stream_t stream) {
+    HALO_CHECK_ARG(x && weight && y_bf16 && rows > 0 && C > 0 && C % 8 == 0);
+    HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)y_bf16 | (uintptr_t)y) % 16 == 0);
+    return layernorm_image_launch(x, weight, bias, y, nullptr, (__bf16 *)y_bf16, rows, C, eps, (hipStream_t)stream);
 }
 
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *bias1,

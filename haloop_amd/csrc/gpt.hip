@@ -129,7 +129,7 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                   const float *__restrict__ w, const float *__restrict__ dres,
                                                                   float *__restrict__ dx, float *__restrict__ pw, float *__restrict__ pb,
-                                                                  int rows, int C, float eps) {
+                                                                  int rows, int C, float eps, __bf16 *__restrict__ dxb = nullptr) {
     extern __shared__ float red[];                       // [2][C]: cross-wave sums of the partials
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int C4 = C >> 2;
@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
                 for (int e = 0; e < 4; ++e) d[e] += r4[e];
             }
             *reinterpret_cast<f32x4 *>(dxr + 4 * q) = d;
+            if (dxb) {          // the same rows as row-major bf16: the operand of the next Linear's two gradient products
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<bf16x4 *>(dxb + (long)row * C + 4 * q) = bf16x4{(__bf16)d[0], (__bf16)d[1], (__bf16)d[2], (__bf16)d[3]};
+            }
         }
     }
     // the four waves' partials, added in wave order
@@ -291,6 +295,61 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const float *__restr
     *o = accumulate ? *o + s : s;
 }
 
+// fp32 -> row-major bf16 (operands of halo_gemm_split_io / halo_gemm_tn_bf16 that no producing launch wrote as bf16)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, __bf16 *__restrict__ y, long n8) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(x + 8 * i), b = *reinterpret_cast<const f32x4 *>(x + 8 * i + 4);
+        *reinterpret_cast<bf16x8 *>(y + 8 * i) =
+            bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    }
+}
+
+
+// the MLP's elementwise passes with a bf16 result: y = gelu(a), da = dy * gelu'(a)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const float *__restrict__ dy, const float *__restrict__ a, __bf16 *__restrict__ y, long n8,
+                                                        int exact) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a + 8 * i), a1 = *reinterpret_cast<const f32x4 *>(a + 8 * i + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (BWD) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dy + 8 * i), d1 = *reinterpret_cast<const f32x4 *>(dy + 8 * i + 4);
+            const float d[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = d[e] * gelu_grad(v[e], exact);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gemm_activation(v[e], exact ? 8 : 2);
+        }
+        *reinterpret_cast<bf16x8 *>(y + 8 * i) = bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5],
+                                                        (__bf16)v[6], (__bf16)v[7]};
+    }
+}
+
+int layernorm_bwd_impl(const float *dy, const float *x, const float *weight, const float *dres, float *dx, __bf16 *dxb, float *dweight,
+                              float *dbias, void *workspace, int rows, int C, float eps, hipStream_t st) {
+    float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
+    const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0;
+    if (C % 4 == 0 && C <= 2048 && aligned) {
+        const int wgs = min(HALO_LN_BWD_CHUNKS, (rows + 3) / 4);
+        const size_t lds = (size_t)2 * C * sizeof(float);
+        if (C <= 1024)
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<4>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb);
+        else
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<8>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb);
+        if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
+        return halo_colsum2(pw, wgs, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, wgs, C, C, dbias, nullptr, st) : HALO_OK);
+    }
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, weight, dres, dx, stats, rows, C, eps);
+    const int chunks = rows < HALO_LN_BWD_CHUNKS ? rows : HALO_LN_BWD_CHUNKS, rpc = (rows + chunks - 1) / chunks;
+    const int used = (rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(layernorm_bwd_dw_kernel, dim3((C + 255) / 256, used), dim3(256), 0, st, dy, x, stats, pw, pb, rows, C, rpc);
+    if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
+    return halo_colsum2(pw, used, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, used, C, C, dbias, nullptr, st) : HALO_OK);
+}
+
 }  // namespace
 
 extern "C" {
@@ -340,29 +399,43 @@ size_t halo_layernorm_bwd_workspace_bytes(int rows, int C) {
     return ((size_t)rows * 2 + (size_t)2 * HALO_LN_BWD_CHUNKS * C) * sizeof(float);
 }
 
+int halo_cast_bf16(const float *x, void *y, size_t n, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0);
+    const long n8 = (long)(n / 8);
+    const long want = (n8 + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, (hipStream_t)stream, x, (__bf16 *)y, n8);
+    return halo_launch_status();
+}
+
+int halo_gelu_bf16(const float *a, void *y_bf16, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(a && y_bf16 && n > 0 && n % 8 == 0 && (((uintptr_t)a | (uintptr_t)y_bf16) % 16) == 0);
+    const long n8 = (long)(n / 8), want = (n8 + 255) / 256;
+    hipLaunchKernelGGL(gelu_bf16_kernel<false>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream, nullptr, a,
+                       (__bf16 *)y_bf16, n8, exact);
+    return halo_launch_status();
+}
+
+int halo_gelu_bwd_bf16(const float *dy, const float *a, void *da_bf16, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && a && da_bf16 && n > 0 && n % 8 == 0 && (((uintptr_t)dy | (uintptr_t)a | (uintptr_t)da_bf16) % 16) == 0);
+    const long n8 = (long)(n / 8), want = (n8 + 255) / 256;
+    hipLaunchKernelGGL(gelu_bf16_kernel<true>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream, dy, a,
+                       (__bf16 *)da_bf16, n8, exact);
+    return halo_launch_status();
+}
+
 int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx, float *dweight,
                        float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream) {
     HALO_CHECK_ARG(dy && x && weight && dx && dweight && workspace && rows > 0 && C > 0);
-    hipStream_t st = (hipStream_t)stream;
-    float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
-    const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0;
-    if (C % 4 == 0 && C <= 2048 && aligned) {
-        const int wgs = min(HALO_LN_BWD_CHUNKS, (rows + 3) / 4);
-        const size_t lds = (size_t)2 * C * sizeof(float);
-        if (C <= 1024)
-            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<4>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps);
-        else
-            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<8>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps);
-        if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
-        return halo_colsum2(pw, wgs, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, wgs, C, C, dbias, nullptr, st) : HALO_OK);
-    }
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, x, weight, dres, dx, stats, rows, C, eps);
-    const int chunks = rows < HALO_LN_BWD_CHUNKS ? rows : HALO_LN_BWD_CHUNKS, rpc = (rows + chunks - 1) / chunks;
-    const int used = (rows + rpc - 1) / rpc;
-    hipLaunchKernelGGL(layernorm_bwd_dw_kernel, dim3((C + 255) / 256, used), dim3(256), 0, st, dy, x, stats, pw, pb, rows, C, rpc);
-    if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
-    return halo_colsum2(pw, used, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, used, C, C, dbias, nullptr, st) : HALO_OK);
+    return layernorm_bwd_impl(dy, x, weight, dres, dx, nullptr, dweight, dbias, workspace, rows, C, eps, (hipStream_t)stream);
 }
+
+int halo_layernorm_bwd_bf16(const float *dy, const float *x, const float *weight, const float *dres, float *dx, void *dx_bf16, float *dweight,
+                            float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && x && weight && dx && dx_bf16 && dweight && workspace && rows > 0 && C > 0);
+    HALO_CHECK_ARG(C % 4 == 0 && C <= 2048 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx | (uintptr_t)dx_bf16) % 16) == 0);
+    return layernorm_bwd_impl(dy, x, weight, dres, dx, (__bf16 *)dx_bf16, dweight, dbias, workspace, rows, C, eps, (hipStream_t)stream);
+}
+
 
 int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream) {
     HALO_CHECK_ARG(a && y && n > 0);

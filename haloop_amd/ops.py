@@ -119,6 +119,38 @@ def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
     return img, y
 
 
+def layernorm_bf16(x2d, weight, bias=None, eps=1e-5):
+    """LayerNorm of the rows as row-major bf16 [rows, C]: the operand form gemm_split_io (a = (hi, None)) and gemm_tn read."""
+    _f32c(x2d, 'x')
+    rows, Cn = x2d.shape
+    y = torch.empty(rows, Cn, device=x2d.device, dtype=torch.bfloat16)
+    check(lib().halo_layernorm_bf16(ptr(x2d), ptr(weight), ptr(bias), None, ptr(y), rows, Cn, eps, _stream()), 'halo_layernorm_bf16')
+    return y
+
+
+def gelu_bf16(a, exact=False):
+    """gelu(a) as bf16 (same shape)."""
+    _f32c(a, 'a')
+    y = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    check(lib().halo_gelu_bf16(ptr(a), ptr(y), a.numel(), int(exact), _stream()), 'halo_gelu_bf16')
+    return y
+
+
+def gelu_bwd_bf16(dy, a, exact=False):
+    """dy * gelu'(a) as bf16."""
+    _f32c(dy, 'dy'); _f32c(a, 'a')
+    y = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    check(lib().halo_gelu_bwd_bf16(ptr(dy), ptr(a), ptr(y), a.numel(), int(exact), _stream()), 'halo_gelu_bwd_bf16')
+    return y
+
+
+def cast_bf16(x):
+    _f32c(x, 'x')
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib().halo_cast_bf16(ptr(x), ptr(y), x.numel(), _stream()), 'halo_cast_bf16')
+    return y
+
+
 def gemm_split(a_img, b_img, M, N, K, out=None, bias1=None, bias2=None, relu=False, drop=NO_DROPOUT, stream_id=0,
                gelu=False, accumulate=False, residual=None):
     """C[M,N] = A[M,K] B[N,K]^T from split images (three bf16 MFMAs per product, fp32 accumulate).  ``residual`` [M, N]: the
@@ -165,9 +197,10 @@ def gemm_split_io(a, b_img, M, N, K, out=None, out_rowmajor=False, bias1=None, b
         out = torch.empty(M, N, device=dev, dtype=torch.float32)
     if residual is not None:
         _f32c(residual, 'residual')
+    flags = _gemm_flags(relu, gelu, accumulate or residual is not None)
     check(lib().halo_gemm_split_io(ptr(a_img), ptr(a_hi), ptr(a_lo), lda, ptr(b_img), M, N, K, ptr(out), N if out is not None else 0,
                                    ptr(o_hi), ptr(o_lo), N, ptr(residual), N if residual is not None else 0, ptr(bias1), ptr(bias2),
-                                   _gemm_flags(relu, gelu, accumulate or residual is not None), _stream()), 'halo_gemm_split_io')
+                                   flags, _stream()), 'halo_gemm_split_io')
     return (o_hi, o_lo) if out_rowmajor else out
 
 
@@ -909,8 +942,8 @@ def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, c
                                    drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_attention_bwd')
 
 
-def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5):
-    """-> (dx = dres + dLN, dweight, dbias or None)"""
+def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5, want_bf16=False):
+    """-> (dx = dres + dLN, dweight, dbias or None[, dx as row-major bf16 with ``want_bf16``])"""
     _f32c(dy, 'dy'); _f32c(x2d, 'x')
     rows, C = x2d.shape
     dev = x2d.device
@@ -918,6 +951,11 @@ def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5):
     dw = torch.empty(C, device=dev, dtype=torch.float32)
     db = torch.empty(C, device=dev, dtype=torch.float32) if has_bias else None
     ws = torch.empty(lib().halo_layernorm_bwd_workspace_bytes(rows, C), device=dev, dtype=torch.uint8)
+    if want_bf16:
+        dxb = torch.empty(rows, C, device=dev, dtype=torch.bfloat16)
+        check(lib().halo_layernorm_bwd_bf16(ptr(dy), ptr(x2d), ptr(weight), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db), ptr(ws), rows, C,
+                                            eps, _stream()), 'halo_layernorm_bwd_bf16')
+        return dx, dw, db, dxb
     check(lib().halo_layernorm_bwd(ptr(dy), ptr(x2d), ptr(weight), ptr(dres), ptr(dx), ptr(dw), ptr(db), ptr(ws), rows, C, eps,
                                    _stream()), 'halo_layernorm_bwd')
     return dx, dw, db

@@ -126,6 +126,17 @@ int halo_split_image(const float *src, int rows, int k, int ld, int src_transpos
  * optionally as fp32 rows y (NULL to skip).  C % 32 == 0. */
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C,
                          float eps, halo_stream_t stream);
+/* The same LayerNorm with the normalised rows as ROW-MAJOR bf16 [rows][C] (C % 8 == 0) -- the operand form halo_gemm_split_io (a_hi) and
+ * halo_gemm_tn_bf16 read -- instead of a tiled image; y (fp32 rows, optional) as above. */
+int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, int rows, int C, float eps,
+                        halo_stream_t stream);
+/* n fp32 values -> bf16 (n % 8 == 0, 16-byte aligned): row-major bf16 operands from fp32 tensors no launch produced as bf16 */
+int halo_cast_bf16(const float *x, void *y, size_t n, halo_stream_t stream);
+/* The GPT MLP's two elementwise passes with a bf16 result (n % 8 == 0, 16-byte aligned): y = gelu(a) -- the c_proj input, never needed in
+ * fp32 -- and da = dy * gelu'(a) (exact: 0 tanh form new_gelu ha/attention.py:12-17, 1 erf form).  Measured against the same math in the
+ * producing GEMM's epilogue (GPT training direction): the separate pass is hidden under its HBM stream, the epilogue is not. */
+int halo_gelu_bf16(const float *a, void *y_bf16, size_t n, int exact, halo_stream_t stream);
+int halo_gelu_bwd_bf16(const float *dy, const float *a, void *da_bf16, size_t n, int exact, halo_stream_t stream);
 /* One read of an fp32 matrix src [rows][cols] (leading dimension ld), optionally through an elementwise operator, written as
  * BOTH split images a Linear's backward consumes: image_rows = halo_split_image(value [rows][cols]) (the A operand of
  * dx = dy W, ha/attention.py:117-129,141) and image_cols = halo_split_image(value^T [cols][rows]) (the operand of dW = dy^T x);
@@ -175,7 +186,7 @@ int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, i
  * LDS staging fetches each 16-byte chunk from where the swizzled image would hold it.  The result goes to fp32 C (may be NULL when
  * out_hi is given) and / or to row-major bf16 out_hi [M][ldo] = bf16(v) (and out_lo = bf16(v - out_hi) in bf16x3 mode).
  * flags: HALO_GEMM_RELU / GELU* / ACCUM (adds residual [M][ldr], or C itself when residual is NULL).  No dropout, no split-K.
- * Combinations built: image -> bf16 (with or without activation), bf16 -> fp32 (with or without ACCUM); others HALO_ENOTSUP. */
+ * Combinations built: image -> bf16 (with or without activation), bf16 -> fp32 (with or without ACCUM); others HALO_ENOTSUP.  */
 int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, long lda, const void *b_image, int M, int N, int K, float *C,
                        int ldc, void *out_hi, void *out_lo, long ldo, const float *residual, int ldr, const float *bias1,
                        const float *bias2, int flags, halo_stream_t stream);
@@ -588,6 +599,10 @@ size_t halo_layernorm_bwd_workspace_bytes(int rows, int C);
 int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx,
                        float *dweight, float *dbias, void *workspace, int rows, int C, float eps,
                        halo_stream_t stream);
+/* halo_layernorm_bwd that also writes dx as row-major bf16 (dx_bf16 [rows][C]; C % 4 == 0, C <= 2048, 16-byte aligned operands): dx is the
+ * output gradient of the Linear below, whose two gradient products read it as bf16 */
+int halo_layernorm_bwd_bf16(const float *dy, const float *x, const float *weight, const float *dres, float *dx, void *dx_bf16,
+                            float *dweight, float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream);
 int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream);
 int halo_gelu_bwd(const float *dy, const float *a, float *da, size_t n, int exact, halo_stream_t stream);
 int halo_cross_entropy_fwd_lse(const float *logits, const int64_t *targets, float *loss, float *lse, int rows, int V,
