@@ -219,6 +219,8 @@ def rowmajor_train_ok(cfg, blocks, M, training):
     C = cfg.n_embd
     if cfg.bias or (training and cfg.dropout > 0.0) or M % 32 != 0 or C % 32 != 0 or not rowmajor_ok(M, 4 * C, C) or not rowmajor_ok(M, C, C):
         return False
+    if C // cfg.n_head not in (32, 64):               # the matrix-core attention kernels write the bf16 outputs
+        return False
     return all(blk.attn.c_attn.bias is None and blk.mlp.c_fc.bias is None for blk in blocks)
 
 
@@ -228,9 +230,8 @@ def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
     h1b = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias)
     qkv = ops.gemm_split_io((h1b, None), w(blk.attn.c_attn), M, 3 * C, C)
     s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
-    y, lse, _ = ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True,
-                                  drop=s_att[0], stream_id=s_att[1])
-    yb = ops.cast_bf16(y)
+    y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
+                                        drop=s_att[0], stream_id=s_att[1])
     x1 = ops.gemm_split_io((yb, None), w(blk.attn.c_proj), M, C, C, residual=x0)
     h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
     a = ops.gemm_split_io((h2b, None), w(blk.mlp.c_fc), M, 4 * C, C)
@@ -255,11 +256,9 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
     put(blk.attn.c_proj.weight, ops.gemm_tn(dx1b, yb))
     dy = ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
-    dqkv = torch.empty_like(qkv)
-    ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:],
-                      B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
-    dqkvb = ops.cast_bf16(dqkv)
-    del dqkv
+    dqkvb = torch.empty(M, 3 * C, device=dx.device, dtype=torch.bfloat16)
+    ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
+                           B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
     put(blk.attn.c_attn.weight, ops.gemm_tn(dqkvb, h1b))
     d_ln1 = ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
     dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)

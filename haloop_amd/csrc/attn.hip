@@ -698,6 +698,54 @@ int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_s
     }
 }
 
+// the training forward on the matrix-core kernel with the output ALSO as row-major bf16 (the c_proj operand); packed rows (head stride = head_dim)
+int halo_attention_fwd_bf16(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
+                            long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, void *y_bf16, long ybf_row_stride,
+                            long ybf_batch_stride, float *lse, int N, int heads, int head_dim, int Tq, int Tk, int causal,
+                            const int *key_lengths, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                            const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k && v && y && y_bf16 && N > 0 && heads > 0 && Tq > 0 && Tk > 0 && N <= 65535 && heads <= 65535);
+    HALO_CHECK_ARG(((uintptr_t)k | (uintptr_t)v) % 16 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0);
+    HALO_CHECK_ARG((uintptr_t)y_bf16 % 8 == 0 && ybf_row_stride % 4 == 0 && ybf_batch_stride % 4 == 0);
+    if (halo_math_mode() == HALO_MATH_F32 || !(head_dim == 64 || head_dim == 32)) return HALO_ENOTSUP;
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.y = y; a.lse = lse; a.ent = nullptr;
+    a.q_hs = head_dim; a.kv_hs = head_dim;
+    a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
+    a.y_rs = y_row_stride; a.y_bs = y_batch_stride; a.key_len = key_lengths;
+    a.y_bf = (__bf16 *)y_bf16; a.ybf_rs = ybf_row_stride; a.ybf_bs = ybf_batch_stride;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    a.use_drop = p_drop > 0.f;
+    return halo_attention_fwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, (hipStream_t)stream);
+}
+
+// the matrix-core backward with dq, dk, dv as row-major bf16 (one row / batch stride) instead of fp32
+int halo_attention_bwd_bf16(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
+                            long kv_batch_stride, const float *y, const float *dy, long y_row_stride, long y_batch_stride, const float *lse,
+                            float *delta, void *dq_bf16, void *dk_bf16, void *dv_bf16, long d_row_stride, long d_batch_stride, int N,
+                            int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths, float p_drop, uint64_t seed,
+                            uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k && v && y && dy && lse && delta && dq_bf16 && dk_bf16 && dv_bf16 && N > 0 && heads > 0 && Tq > 0 && Tk > 0);
+    HALO_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dy | (uintptr_t)y) % 16 == 0);
+    HALO_CHECK_ARG(q_row_stride % 4 == 0 && q_batch_stride % 4 == 0 && kv_row_stride % 4 == 0 && kv_batch_stride % 4 == 0 &&
+                   y_row_stride % 4 == 0 && y_batch_stride % 4 == 0);
+    HALO_CHECK_ARG(N <= 65535 && heads <= 65535 && y_batch_stride == y_row_stride * Tq);
+    if (halo_math_mode() == HALO_MATH_F32 || !(head_dim == 64 || head_dim == 32)) return HALO_ENOTSUP;
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.dy = dy; a.lse = lse; a.delta = delta; a.dq = nullptr; a.dk = nullptr; a.dv = nullptr;
+    a.y = y; a.delta_w = delta;
+    a.q_rs = q_row_stride; a.q_bs = q_batch_stride; a.kv_rs = kv_row_stride; a.kv_bs = kv_batch_stride;
+    a.dy_rs = y_row_stride; a.dy_bs = y_batch_stride; a.dq_rs = 0; a.dq_bs = 0; a.dkv_rs = 0; a.dkv_bs = 0; a.key_len = key_lengths;
+    a.dq_bf = (__bf16 *)dq_bf16; a.dk_bf = (__bf16 *)dk_bf16; a.dv_bf = (__bf16 *)dv_bf16; a.dqb_rs = d_row_stride; a.dqb_bs = d_batch_stride;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    a.use_drop = p_drop > 0.f;
+    return halo_attention_bwd_mx(a, N, head_dim, halo_math_mode() == HALO_MATH_BF16 ? 1 : 3, (hipStream_t)stream);
+}
+
 int halo_attention_fwd(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v,
                        long kv_row_stride, long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, float *lse,
                        float *entropy, int N, int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths,

@@ -13,6 +13,9 @@ struct AttnArgs {
     float scale;
     DropoutCfg drop;                             // dropout on the attention probabilities (training), see attn_drop_index
     int use_drop;
+    // attn_mx.hip: the output also as row-major bf16 (the operand of the Linear behind the attention: halo_attention_fwd_bf16)
+    __bf16 *y_bf = nullptr;
+    long ybf_rs = 0, ybf_bs = 0;
 };
 
 // Philox element index of attention probability (n, h, i, j): the four 16-key sub-tiles (j%64)/16 = 0..3 that one lane holds
@@ -36,6 +39,10 @@ struct AttnBwdArgs {
     float scale;
     DropoutCfg drop;
     int use_drop;
+    // attn_mx.hip: the three gradients as row-major bf16 INSTEAD of fp32 (they are only ever operands of the c_attn Linear's two
+    // gradient products: halo_attention_bwd_bf16); one row / batch stride for all three
+    __bf16 *dq_bf = nullptr, *dk_bf = nullptr, *dv_bf = nullptr;
+    long dqb_rs = 0, dqb_bs = 0;
 };
 
 // attn_mx.hip: the same products on v_mfma_f32_16x16x32_bf16 with operands split hi + lo (passes = 3) or rounded to bf16 (passes = 1)

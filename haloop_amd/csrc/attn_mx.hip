@@ -290,6 +290,13 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_fwd_mx_kernel(
     #pragma unroll
                 for (int m = 0; m < HD / 16; ++m)
                     *reinterpret_cast<f32x4 *>(yp + 16 * m) = f32x4{o[g][m][0] * inv, o[g][m][1] * inv, o[g][m][2] * inv, o[g][m][3] * inv};
+                if (a.y_bf) {
+                    __bf16 *yb = a.y_bf + (long)b * a.ybf_bs + (long)qrow[g] * a.ybf_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
+                    for (int m = 0; m < HD / 16; ++m)
+                        *reinterpret_cast<bf16x4 *>(yb + 16 * m) =
+                            bf16x4{(__bf16)(o[g][m][0] * inv), (__bf16)(o[g][m][1] * inv), (__bf16)(o[g][m][2] * inv), (__bf16)(o[g][m][3] * inv)};
+                }
                 if (a.lse && lq == 0) a.lse[((long)b * a.heads + h) * Tq + qrow[g]] = mref[g] * LN2 + logf(lrow);
             }
         }
@@ -404,7 +411,13 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
                 }
             }
         }
-        if (qrow < Tq) {
+        if (qrow < Tq && a.dq_bf) {
+            __bf16 *dp = a.dq_bf + (long)b * a.dqb_bs + (long)qrow * a.dqb_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+                *reinterpret_cast<bf16x4 *>(dp + 16 * m) =
+                    bf16x4{(__bf16)(dq[m][0] * a.scale), (__bf16)(dq[m][1] * a.scale), (__bf16)(dq[m][2] * a.scale), (__bf16)(dq[m][3] * a.scale)};
+        } else if (qrow < Tq) {
             float *dp = a.dq + (long)b * a.dq_bs + (long)qrow * a.dq_rs + (long)h * HD + 4 * lq;
     #pragma unroll
             for (int m = 0; m < HD / 16; ++m)
@@ -528,7 +541,16 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_mx_kernel(AttnBwdArg
                 }
             }
         }
-        if (key < Tk) {
+        if (key < Tk && a.dk_bf) {
+            __bf16 *kp = a.dk_bf + (long)b * a.dqb_bs + (long)key * a.dqb_rs + (long)h * HD + 4 * lq;
+            __bf16 *vp = a.dv_bf + (long)b * a.dqb_bs + (long)key * a.dqb_rs + (long)h * HD + 4 * lq;
+    #pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                *reinterpret_cast<bf16x4 *>(kp + 16 * m) =
+                    bf16x4{(__bf16)(dk[m][0] * a.scale), (__bf16)(dk[m][1] * a.scale), (__bf16)(dk[m][2] * a.scale), (__bf16)(dk[m][3] * a.scale)};
+                *reinterpret_cast<bf16x4 *>(vp + 16 * m) = bf16x4{(__bf16)dv[m][0], (__bf16)dv[m][1], (__bf16)dv[m][2], (__bf16)dv[m][3]};
+            }
+        } else if (key < Tk) {
             float *kp = a.dk + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
             float *vp = a.dv + (long)b * a.dkv_bs + (long)key * a.dkv_rs + (long)h * HD + 4 * lq;
     #pragma unroll
@@ -587,6 +609,9 @@ int halo_attention_fwd_mx(const AttnArgs &a, int N, int head_dim, int passes, hi
 
 int halo_attention_bwd_mx(const AttnBwdArgs &a, int N, int head_dim, int passes, hipStream_t st) {
     // gradients go out as 16-byte stores
+    if (a.dq_bf) {
+        if (!a.dk_bf || !a.dv_bf || ((uintptr_t)a.dq_bf | (uintptr_t)a.dk_bf | (uintptr_t)a.dv_bf) % 8 || a.dqb_rs % 4 || a.dqb_bs % 4) return HALO_EINVAL;
+    } else
     if (!aligned16(a.dq) || !aligned16(a.dk) || !aligned16(a.dv) || a.dq_rs % 4 || a.dq_bs % 4 || a.dkv_rs % 4 || a.dkv_bs % 4) return HALO_ENOTSUP;
     if (head_dim == 64) return passes == 1 ? launch_bwd<64, 1>(a, N, st) : launch_bwd<64, 3>(a, N, st);
     if (head_dim == 32) return passes == 1 ? launch_bwd<32, 1>(a, N, st) : launch_bwd<32, 3>(a, N, st);

@@ -942,6 +942,35 @@ def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, c
                                    drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_attention_bwd')
 
 
+def attention_fwd_bf16(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT, stream_id=0):
+    """attention_fwd (training: with lse) that also returns y as row-major bf16 -> (y, lse, y_bf16)."""
+    C = heads * head_dim
+    dev = q.device
+    y = torch.empty(N * Tq, C, device=dev, dtype=torch.float32)
+    yb = torch.empty(N * Tq, C, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(N, heads, Tq, device=dev, dtype=torch.float32)
+    if key_lengths is not None:
+        key_lengths = key_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    check(lib().halo_attention_fwd_bf16(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), C,
+                                        C * Tq, ptr(yb), C, C * Tq, ptr(lse), N, heads, head_dim, Tq, Tk, int(causal), ptr(key_lengths),
+                                        drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_attention_fwd_bf16')
+    return y, lse, yb
+
+
+def attention_bwd_bf16(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT,
+                       stream_id=0):
+    """attention_bwd with dq / dk / dv bf16 views of one row stride (the column blocks of a packed [rows, 3C] bf16 buffer)."""
+    C = heads * head_dim
+    _f32c(y, 'y'); _f32c(dy, 'dy')
+    if not (dq.dtype == dk.dtype == dv.dtype == torch.bfloat16) or not (dq.stride(0) == dk.stride(0) == dv.stride(0)) or Tq != Tk:
+        raise ValueError('attention_bwd_bf16: bf16 dq / dk / dv with one row stride (self-attention)')
+    delta = torch.empty(N, heads, Tq, device=q.device, dtype=torch.float32)
+    check(lib().halo_attention_bwd_bf16(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), ptr(dy),
+                                        C, C * Tq, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dq.stride(0), dq.stride(0) * Tq, N, heads,
+                                        head_dim, Tq, Tk, int(causal), ptr(key_lengths), drop.p, drop.seed, stream_id, drop.offset,
+                                        drop.counter_ptr, _stream()), 'halo_attention_bwd_bf16')
+
+
 def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5, want_bf16=False):
     """-> (dx = dres + dLN, dweight, dbias or None[, dx as row-major bf16 with ``want_bf16``])"""
     _f32c(dy, 'dy'); _f32c(x2d, 'x')

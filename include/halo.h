@@ -595,6 +595,20 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
                        int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths, float p_drop,
                        uint64_t seed, uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev,
                        halo_stream_t stream);
+/* halo_attention_fwd_strided (packed rows) / halo_attention_bwd on the matrix-core kernels with row-major bf16 outputs for the Linear
+ * layers around the attention (bf16 / bf16x3 modes, head_dim 32 or 64; HALO_ENOTSUP otherwise): the forward writes y in fp32 (the
+ * backward's delta needs it) AND as bf16 [rows][ybf_row_stride]; the backward writes dq, dk, dv as bf16 ONLY (one row / batch stride,
+ * e.g. the three column blocks of a packed [rows][3C] buffer) -- they are operands of c_attn's two gradient products and nothing else. */
+int halo_attention_fwd_bf16(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
+                            long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, void *y_bf16, long ybf_row_stride,
+                            long ybf_batch_stride, float *lse, int N, int heads, int head_dim, int Tq, int Tk, int causal,
+                            const int *key_lengths, float p_drop, uint64_t seed, uint32_t stream_id, uint32_t offset,
+                            const uint32_t *offset_dev, halo_stream_t stream);
+int halo_attention_bwd_bf16(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
+                            long kv_batch_stride, const float *y, const float *dy, long y_row_stride, long y_batch_stride, const float *lse,
+                            float *delta, void *dq_bf16, void *dk_bf16, void *dv_bf16, long d_row_stride, long d_batch_stride, int N,
+                            int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths, float p_drop, uint64_t seed,
+                            uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, halo_stream_t stream);
 size_t halo_layernorm_bwd_workspace_bytes(int rows, int C);
 int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, const float *dres, float *dx,
                        float *dweight, float *dbias, void *workspace, int rows, int C, float eps,

@@ -95,3 +95,27 @@ def test_bf16_producers_match_the_fp32_operators():
         assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dxb, dx.bfloat16())
     finally:
         _lib.set_math_mode(prev)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_attention_bf16_outputs_are_the_rounded_fp32_outputs(mode):
+    from haloop_amd import _lib, ops
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        N, heads, hd, T = 3, 4, 64, 320
+        C = heads * hd
+        g = torch.Generator().manual_seed(21)
+        qkv = torch.randn(N * T, 3 * C, generator=g).to(DEV)
+        dy = torch.randn(N * T, C, generator=g).to(DEV)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        y, lse, _ = ops.attention_fwd(q, k, v, N, heads, hd, T, T, causal=True, want_lse=True)
+        y2, lse2, yb = ops.attention_fwd_bf16(q, k, v, N, heads, hd, T, T, causal=True)
+        assert torch.equal(y, y2) and torch.equal(lse, lse2) and torch.equal(yb, y.bfloat16())
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(q, k, v, y, dy, lse, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], N, heads, hd, T, T, causal=True)
+        dqkvb = torch.zeros(N * T, 3 * C, device=DEV, dtype=torch.bfloat16)
+        ops.attention_bwd_bf16(q, k, v, y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:], N, heads, hd, T, T, causal=True)
+        assert torch.equal(dqkvb, dqkv.bfloat16())
+    finally:
+        _lib.set_math_mode(prev)
