@@ -65,6 +65,7 @@ SIGNATURES = {
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
     'halo_set_lstm_expect_backward': (_i, [_i]),
+    'halo_set_lstm_weights_stamp': (_i, [_u64]),
     'halo_lstm_persistent2_eligible': (_i, [_i, _i, _i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),
     'halo_lstm_persist_stamps': (_i, [_vp]),
@@ -218,6 +219,20 @@ def set_lstm_persistent(on):
 def set_lstm_persistent2(on):
     """Both layers of a 2-layer LSTM in one persistent launch per direction (bf16 mode; include/halo.h) on / off."""
     check(lib().halo_set_lstm_persistent2(int(bool(on))), 'halo_set_lstm_persistent2')
+
+
+# The optimizer kernels write parameters through raw pointers: torch's per-tensor version counters do not see it.  Every Python-side
+# path that lets such a kernel run (ops.adamw*, a replay of a captured training step) bumps this counter, and caches of data derived
+# from weights that outlive a call (infer.LstmCtcRecognizer's packed LSTM weights) carry it in their stamp.
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
 
 
 def set_lstm_expect_backward(on):

@@ -43,6 +43,11 @@ struct HaloCtx {
     int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)
     const float *packT_reserve = nullptr, *packT_w[3] = {nullptr, nullptr, nullptr};   // ... into this reserve, from these weights (host bookkeeping)
     const float *emitT_reserve = nullptr;   // the two-layer forward wrote the weight-gradient products' h_prev^T / dropout(h0)^T operand images into this reserve
+    // halo_set_lstm_weights_stamp: a non-zero stamp is the caller's promise that the LSTM weights only change when the stamp does; the
+    // forward-only two-layer launch then keeps the packed weight images a previous call with the same reserve, weights, shape and stamp left
+    uint64_t lstm_weights_stamp = 0, packF_stamp = 0;
+    const float *packF_reserve = nullptr, *packF_w[3] = {nullptr, nullptr, nullptr};
+    int packF_dims[5] = {0, 0, 0, 0, 0};
     int mute_block = -1;                 // test hook (halo_debug_mute_workgroup): this workgroup of a persistent forward never publishes
 };
 HaloCtx &halo_ctx_cur();

@@ -13,7 +13,15 @@ class LstmCtcRecognizer:
         self._graph = None
         self._static = None
         self._out = None
+        self._reserve = None          # owned between calls: the packed weight images stay in it while the weights do (see _stamp)
+        self._graph_stamp = None
         _lib.lend_scratch(device=next(encoder.parameters()).device)
+
+    def _stamp(self):
+        """Changes whenever an LSTM weight may have changed: (storage address, torch version counter) of every parameter, and the
+        process-wide count of optimizer launches, which write parameters behind torch's back (_lib.bump_weights_epoch)."""
+        key = (_lib.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in lstm_param_list(self.encoder.lstm))
+        return (hash(key) & 0x7fffffffffffffff) | 1
 
     def _run(self, x):
         enc, rec = self.encoder, self.recognizer
@@ -24,7 +32,11 @@ class LstmCtcRecognizer:
         y_sub, _ = ops.subsample_fwd(x, enc.subsample.weight, enc.subsample.bias, NO_DROPOUT)
         Tp = y_sub.shape[0]
         feats = torch.empty(B, Tp, H, device=x.device, dtype=torch.float32)
-        ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True, expect_backward=False)
+        need = (_lib.lib().halo_lstm_reserve_bytes(Tp, B, y_sub.shape[2], H, len(w_hh)) + 3) // 4
+        if self._reserve is None or self._reserve.numel() != need or self._reserve.device != x.device:
+            self._reserve = ops.lstm_reserve(Tp, B, y_sub.shape[2], H, len(w_hh), x.device)
+        ops.lstm_fwd(y_sub, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, Tp * H), y_relu=True, expect_backward=False,
+                     reserve=self._reserve, weights_stamp=self._stamp())
         if ops.ctc_head_supported(Tp, H, V, 0):
             # classifier + log_softmax + greedy collapse in one launch, one workgroup per utterance (csrc/head.hip)
             return ops.ctc_head_greedy(feats, rec.classifier.weight, rec.classifier.bias)
@@ -43,7 +55,10 @@ class LstmCtcRecognizer:
         call overwrites (for loops that consume each result before asking for the next one)."""
         if not self.use_graph:
             return self._run(x.contiguous())
-        if self._graph is None or self._static.shape != x.shape:
+        stamp = self._stamp()
+        if self._graph is None or self._static.shape != x.shape or self._graph_stamp != stamp:
+            # (a changed weight: the graph replays launches that skip the weight packing, so it is captured again)
+            self._graph_stamp = stamp
             self._static = x.contiguous().clone()        # private: refilling it must not write into the caller's tensor
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

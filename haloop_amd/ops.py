@@ -269,9 +269,11 @@ def subsample_bwd(dy, y, col, B, T, F, Cc, p_drop, dw=None, dbias=None, ks=5, st
 
 
 def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=None, y_relu=False,
-             want_state=False, drop=NO_DROPOUT, expect_backward=True):
+             want_state=False, drop=NO_DROPOUT, expect_backward=True, reserve=None, weights_stamp=0):
     """x_tm [T,B,in] time-major.  Returns (y, hn, cn, reserve).
-    expect_backward=False (inference): the two-layer launch packs only the forward's weight images (include/halo.h).
+    expect_backward=False (inference): the two-layer launch packs only the forward's weight images (include/halo.h); with a
+    caller-owned ``reserve`` (ops.lstm_reserve) and a non-zero ``weights_stamp`` that changes whenever the weights do, it keeps the
+    images the previous call left there (halo_set_lstm_weights_stamp).
 
     y defaults to a time-major [T,B,H] tensor; pass a preallocated ``y`` with ``y_strides`` =
     (stride_t, stride_b) in elements to have the last layer write e.g. batch-first."""
@@ -285,7 +287,11 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     if y is None:
         y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
         y_strides = (B * H, H)
-    reserve = torch.empty((lib().halo_lstm_reserve_bytes(T, B, in0, H, L) + 3) // 4, device=dev, dtype=torch.float32)
+    need = (lib().halo_lstm_reserve_bytes(T, B, in0, H, L) + 3) // 4
+    if reserve is None:
+        reserve = torch.empty(need, device=dev, dtype=torch.float32)
+    elif reserve.dtype != torch.float32 or reserve.numel() < need or not reserve.is_contiguous():
+        raise ValueError('lstm_fwd: the reserve is too small for this shape (ops.lstm_reserve)')
     hn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
     cn = torch.empty(L, B, H, device=dev, dtype=torch.float32) if want_state else None
     if h0 is not None:
@@ -293,6 +299,7 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     a_ih, a_hh, a_bi, a_bh = ptr_array(w_ih), ptr_array(w_hh), ptr_array(b_ih), ptr_array(b_hh)
     if not expect_backward:
         lib().halo_set_lstm_expect_backward(0)
+        lib().halo_set_lstm_weights_stamp(int(weights_stamp))
     try:
         check(lib().halo_lstm_fwd(ptr(x_tm), a_ih, a_hh, a_bi, a_bh, ptr(h0), ptr(c0), ptr(y), y_strides[0], y_strides[1],
                                   int(y_relu), ptr(hn), ptr(cn), ptr(reserve), T, B, in0, H, L, drop.p, drop.seed,
@@ -300,7 +307,13 @@ def lstm_fwd(x_tm, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, y=None, y_strides=N
     finally:
         if not expect_backward:
             lib().halo_set_lstm_expect_backward(1)
+            lib().halo_set_lstm_weights_stamp(0)
     return y, hn, cn, reserve
+
+
+def lstm_reserve(T, B, in0, H, L, device):
+    """A reserve buffer the caller owns (lstm_fwd(reserve=...))."""
+    return torch.empty((lib().halo_lstm_reserve_bytes(T, B, in0, H, L) + 3) // 4, device=device, dtype=torch.float32)
 
 
 def lstm_bwd_workspace(x_tm, w_hh):
@@ -543,6 +556,7 @@ def clip_coef(partials, count, max_norm, coef, norm, applied_steps=None):
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
     """In-place AdamW on flat views.  Pass views that share the parameter's version counter (``param.detach().view(-1)``,
     not ``param.data``): the update bumps it so that cached operand images of the weight (haloop_amd/_linear.py) are rebuilt."""
+    _lib.bump_weights_epoch()
     check(lib().halo_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            ptr(grad_scale), _stream()), 'halo_adamw')
     torch.autograd.graph.increment_version(p)
@@ -552,6 +566,7 @@ def adamw_ranges(p, g, m, v, ranges, lr, beta1, beta2, eps, step, counter=None):
     """One-launch AdamW over ``ranges`` = [(begin, end, weight_decay, grad_scale tensor or None), ...] of flat buffers.
     ``step``: the 1-based update count as a python int, or a device int32 tensor holding it (no host scalar: graph-capturable).
     ``lr``: a python float, or (with a device ``step``) a one-element float32 device tensor the launch reads it from."""
+    _lib.bump_weights_epoch()
     n = len(ranges)
     begin = (C.c_size_t * n)(*[r[0] for r in ranges])
     end = (C.c_size_t * n)(*[r[1] for r in ranges])
@@ -608,6 +623,7 @@ class AdamWMulti:
         self.param_groups[0]['lr'] = float(value)
 
     def step(self, grad_scale=None):
+        _lib.bump_weights_epoch()
         self.t += 1
         for first, count, table, chunks, n_chunks in self.groups:
             ptrs = (C.c_void_p * count)()

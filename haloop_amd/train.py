@@ -366,6 +366,7 @@ class LstmCtcTrainer:
                 torch.cuda.synchronize()
                 self._tail_graph = None
         if getattr(self, '_tail_graph', None) is not None:
+            _lib.bump_weights_epoch()
             self._tail_graph.replay()
         else:
             self._sharded_tail()
@@ -409,6 +410,7 @@ class LstmCtcTrainer:
         for dst, src in zip(self._static, (x, il, tg, tl)):
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
+        _lib.bump_weights_epoch()
         self._graphs[0].replay()
 
     def _graph_step(self, x, il, tg, tl):
@@ -450,14 +452,18 @@ class LstmCtcTrainer:
             if src.data_ptr() != dst.data_ptr():       # a new batch: refill the captured input buffers
                 dst.copy_(src)
         if len(self._graphs) == 1:
+            _lib.bump_weights_epoch()
             self._graphs[0].replay()
         else:
+            _lib.bump_weights_epoch()
             self._graphs[0].replay()
             w1 = self.avg_early.start()
+            _lib.bump_weights_epoch()
             self._graphs[1].replay()
             w2 = self.avg_late.start()
             self.avg_early.finish(w1)
             self.avg_late.finish(w2)
+            _lib.bump_weights_epoch()
             self._graphs[2].replay()
         return self.loss
 
@@ -527,5 +533,6 @@ class GraphedTrainStep:
             self._graph = graph
         for dst, src in zip(self._static, inputs):
             dst.copy_(src)
+        _lib.bump_weights_epoch()
         self._graph.replay()
         return self._loss.detach().clone()

@@ -290,6 +290,11 @@ int halo_lstm_persistent_eligible(int B, int H);
  * upper layer's input gradient formed inside the launch).  Same reserve contents as the per-layer path, so either backward follows
  * either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
 int halo_set_lstm_persistent2(int on);
+/* Inference with static weights.  stamp != 0 is the caller's promise that the LSTM weights change only when the stamp does: a forward-only
+ * call (halo_set_lstm_expect_backward(0)) of the two-layer launch then KEEPS the packed weight images that the previous call with the same
+ * reserve buffer, weight pointers, shape and stamp left in that reserve (24 MB read + 12 MB written per call at H = 1024 otherwise), so the
+ * caller must own the reserve between the calls.  0 (default): every call packs.  Per context. */
+int halo_set_lstm_weights_stamp(uint64_t stamp);
 /* The two-layer forward packs its three weight images; when a backward of the same step will follow (the default) it writes the
  * backward's three transposed images from the same read of the weights, into the reserve, and halo_lstm_bwd called with that reserve
  * and those weight pointers packs nothing.  Inference callers switch it off (0): the forward then packs its own three only. */

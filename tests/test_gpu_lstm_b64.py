@@ -510,3 +510,43 @@ def test_top_pair_of_a_deeper_stack_runs_as_one_launch(hal, math_mode, T, B, in0
     assert st_a == (0, 0) and st_b == (0, 0) and st_c == (0, 0)
     _normalised_close(a, b, rtol=5e-3, atol=2e-3)
     _normalised_close(a, c, rtol=3e-2, atol=3e-3)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_recognizer_keeps_packed_weights_only_while_the_weights_stand(hal, math_mode, use_graph):
+    """infer.LstmCtcRecognizer at the two-layer launch's shape: the packed weight images stay in the recognizer's reserve between calls
+    (halo_set_lstm_weights_stamp) -- and are rebuilt after training steps, whose optimizer launches write the parameters behind torch's
+    version counters, and after an in-place torch update: every result equals that of a recognizer built fresh on the same weights."""
+    from oracle import cpu_ref
+    from haloop_amd.infer import LstmCtcRecognizer
+    from haloop_amd.train import LstmCtcTrainer
+    F_, C, H, L, V, B, T, S = 40, 64, 256, 2, 16, 32, 40, 4
+    enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 4)
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV).eval(); rec.to(DEV).eval()
+    assert hal['lib'].lib().halo_lstm_persistent2_eligible(10, B, H, L) == 1
+    x = cpu_ref.synthetic_batch(B, T, F_, V, S, 77)[0].to(DEV)
+    reco = LstmCtcRecognizer(enc, rec, use_graph=use_graph)
+
+    def same_as_fresh():
+        got = [o.clone() for o in reco.recognize(x)]
+        again = [o.clone() for o in reco.recognize(x)]                      # (second call: the images are kept)
+        want = LstmCtcRecognizer(enc, rec, use_graph=False).recognize(x)
+        for a, b, c in zip(got, again, want):
+            assert torch.equal(a, c) and torch.equal(b, c)
+        return got
+
+    first = same_as_fresh()
+    tr = LstmCtcTrainer(enc, rec, lr=3e-2, use_graph=True)
+    for step in range(3):                                                    # (the third replays the captured step)
+        xb, il, tg, tl = (t.to(DEV) for t in cpu_ref.synthetic_batch(B, T, F_, V, S, 30 + step))
+        tr.step(xb, il, tg, tl)
+    hal['lib'].set_status_word(None)
+    after = same_as_fresh()
+    assert not torch.equal(first[1], after[1])                               # the scores moved with the weights
+    with torch.no_grad():
+        enc.lstm.weight_hh_l1.mul_(0.5)
+    moved = same_as_fresh()
+    assert not torch.equal(after[1], moved[1])
