@@ -156,6 +156,7 @@ SIGNATURES = {
     'halo_ctx_use': (_i, [_vp]),
     'halo_set_status_word': (_i, [_vp]),
     'halo_debug_mute_workgroup': (_i, [_i]),
+    'halo_debug_mfma_clock': (_i, [_vp, _vp, _i, _i, _i, _u32, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw_multi_tensor_bytes': (_sz, []),

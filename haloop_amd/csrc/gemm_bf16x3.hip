@@ -1030,8 +1030,56 @@ static int gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M,
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, nullptr, nullptr, flags, p.drop, 0, st);
 }
 
+// Diagnostic (halo_debug_mfma_clock): the clock the chip holds under a bare bf16 MFMA loop on random operands -- fragments in
+// registers, no memory traffic, four independent accumulators per wave, one wave per SIMD -- as delta s_memtime / delta s_memrealtime
+// x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6), and with it the matrix pipes' sustained rate.  SHAPE 0: 32x32x16, 1: 16x16x32.
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_clock_kernel(unsigned long long *out, int iters, unsigned seed, float *sink) {
+    unsigned h = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f)); };
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[i][e] = rnd(); b[i][e] = rnd(); }
+    f32x16 acc32[4];
+    f32x4 acc16[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if (SHAPE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc32[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[(j + 1) & 3], acc32[j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc16[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j & 3], b[(j + 1) & 3], acc16[j], 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc32[i][0] + acc32[i][7];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc16[i][0];
+    if (s == 123456.789f) *sink = s;                 // keeps the accumulators alive; never true in practice
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 // ---- public entry points (include/halo.h) -----------------------------------------------------
 extern "C" {
+
+int halo_debug_mfma_clock(unsigned long long *ticks, float *sink, int blocks, int iters, int shape, unsigned seed, halo_stream_t stream) {
+    HALO_CHECK_ARG(ticks && sink && blocks > 0 && iters > 0 && (shape == 0 || shape == 1));
+    if (shape == 0) hipLaunchKernelGGL(mfma_clock_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ticks, iters, seed, sink);
+    else hipLaunchKernelGGL(mfma_clock_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ticks, iters, seed, sink);
+    return halo_launch_status();
+}
 
 int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, int N, int K, float *C, int ldc, int flags,
                       halo_stream_t stream) {

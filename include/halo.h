@@ -268,6 +268,11 @@ int halo_set_status_word(uint32_t *device_word);
 /* Test hook: the workgroup with this blockIdx of every persistent LSTM forward launched afterwards never publishes its epoch, so its
  * peers run into their bounded waits (0.2 s), raise the abort and status words and leave; -1 (default): none. */
 int halo_debug_mute_workgroup(int block);
+/* Diagnostic: `blocks` workgroups of 4 waves run `iters` rounds of a bare bf16 MFMA loop on random register operands (shape 0: four
+ * 32x32x16 per round and wave, 1: eight 16x16x32 -- 131072 FLOP per wave and round either way) and report per workgroup
+ * ticks[2 b] = shader clocks (s_memtime), ticks[2 b + 1] = 100 MHz ticks (s_memrealtime): the clock the chip holds under matrix load
+ * (tools/mfma_clock.py).  sink: one float of device memory, never written in practice. */
+int halo_debug_mfma_clock(unsigned long long *ticks, float *sink, int blocks, int iters, int shape, unsigned seed, halo_stream_t stream);
 
 /* Weight-resident persistent recurrence (csrc/lstm_persist.hip): when the shape is eligible (split-bf16 arithmetic modes,
  * H in {256, 512, 768, 1024}, (H/16) * ceil(B/16) <= number of CUs) a layer's T dependent step launches become ONE launch
