@@ -266,11 +266,17 @@ int halo_splitk_reduce(const float *slab, int ksplit, int M, int N, float *C, in
 // how many K slices make an under-filled grid cover the chip, given the caller-provided scratch
 int halo_pick_ksplit(long tiles, int k_steps, long out_elems) {
     { static int force = -1; if (force < 0) { const char *e = getenv("HALO_KSPLIT"); force = e ? atoi(e) : 0; } if (force > 0 && tiles < 256 && k_steps >= 8) return force; }
-    if (tiles >= 256 || k_steps < 8) return 1;
+    if (tiles >= 512 || k_steps < 8) return 1;
     if (tiles >= 128 && k_steps < 64) return 1;
     void *scratch; size_t bytes;
     halo_get_scratch(&scratch, &bytes);
     if (!scratch) return 1;
+    if (tiles >= 256) {
+        // 256 .. 511 tiles are 1-2 workgroups per CU with three resident: a very long contraction gains from two slices, which fill the
+        // third slot (the lm_head's input gradient [8192 x 768 x 50304], 384 tiles: 843 -> 780 us with the reduce; at K = 3072 two slices
+        // LOSE, 59 -> 67 us)
+        return k_steps >= 1024 && bytes >= 2 * sizeof(float) * (size_t)out_elems ? 2 : 1;
+    }
     // as many slices as still fit ONE round of the 256 CUs (tiles * s <= 256): [1280 x 1024 x 4096], 80 tiles: 3 slices 45.0 us, 4 slices
     // (320 workgroups: 64 CUs hold two) 53.6 us, 6 slices 46.1 us, GEMM + reduce (tools/ksplit_probe.py)
     long s = 256 / tiles;

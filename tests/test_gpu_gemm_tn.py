@@ -50,3 +50,23 @@ def test_tn_refusals():
     a = torch.zeros(64, 12, device='cuda', dtype=torch.bfloat16)         # M % 8 != 0
     with pytest.raises(_lib.HaloError):
         ops.gemm_tn(a, a)
+
+
+def test_two_slices_of_a_very_long_contraction():
+    """256 .. 511 output tiles with K >= 32768 run as two K slices + a reduce (halo_pick_ksplit; the lm_head's input gradient): same result
+    as the fp64 product of the same bf16 operand values."""
+    from haloop_amd import _lib, ops
+    _lib.lend_scratch(256 << 20)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        g = torch.Generator().manual_seed(2)
+        M, N, K = 4096, 1024, 32768                                   # 32 x 8 = 256 tiles, 1024 k-steps
+        a = (torch.randn(M, K, generator=g) * 0.1).cuda()
+        b = (torch.randn(N, K, generator=g) * 0.1).cuda()
+        got = ops.gemm_split(ops.split_image(a), ops.split_image(b), M, N, K)
+        rows = torch.randint(0, M, (32,), generator=g).cuda()
+        want = a[rows].bfloat16().double() @ b.bfloat16().double().t()
+        assert (got[rows].double() - want).abs().max().item() <= 5e-3
+    finally:
+        _lib.set_math_mode(prev)
