@@ -62,6 +62,8 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
     const int BH = B * H;                            // element counts of a layer fit 31 bits (halo_lstm_persist2_ok)
     const int e0 = b * H + j0 + cj;
     float cst = 0.f, gin[4] = {0.f, 0.f, 0.f, 0.f};  // c_{t-1}; the step's pre-activations x W_ih0^T + biases
+    // this step's dropout multiplier of h0 (one Philox block per element): drawn in the PREVIOUS step's hand-off window, off the chain
+    float dmul = (cell && p.xp) ? dropout_mult(p.drop, (uint64_t)e0) : 1.f;
     if (cell) {
         cst = p.c0[e0];
 #pragma unroll
@@ -119,7 +121,7 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
                 ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
                 cst = fg * cst + ig * gg;
                 h = og * fast_tanh(cst);
-                if (p.xp) xv = h * dropout_mult(p.drop, (uint64_t)((long)s * BH + e0));
+                if (p.xp) xv = h * dmul;
             }
             sh.hbuf[0][ci][cj] = h;                      // rows >= B: zeros
             if (p.xp) sh.hbuf[1][ci][cj] = xv;
@@ -180,6 +182,7 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
             p.c0[(s + 1) * BH + e0] = cst;
             p.h0[(s + 1) * BH + e0] = h;
             if (p.ydrop) p.ydrop[s * BH + e0] = xv;
+            if (p.xp && s + 1 < T) dmul = dropout_mult(p.drop, (uint64_t)((long)(s + 1) * BH + e0));
             if (s + 1 < T) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) gin[g] = p.gates0[((s + 1) * B + b) * 4 * H + g * H + j0 + cj];
@@ -379,6 +382,8 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
     Bwd2Cell c;
     c.cc = c.cprev = c.dcarry = 0.f;
     float dh0 = 0.f, bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // layer 0's output mask at the step's time (one Philox block per element): drawn in the previous step's hand-off window
+    float dmul = cell ? dropout_mult(p.drop, (uint64_t)((long)(T - 1) * BH + e0)) : 1.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) c.gv[g] = 0.f;
     if (cell) {
@@ -437,7 +442,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
                 float rec = 0.f, above = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { rec += sh.red[0][k][u]; above += sh.red[2][k][u]; }
-                above *= dropout_mult(p.drop, (uint64_t)((long)t * BH + e0));       // layer 0's own output mask
+                above *= dmul;                                                      // layer 0's own output mask
                 c.update((s == 1 ? dh0 : rec) + above, dg);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
@@ -493,6 +498,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
             float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
             gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
             if (t > 0) {
+                dmul = dropout_mult(p.drop, (uint64_t)((long)(t - 1) * BH + e0));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) c.gv[g] = p.gates0[((t - 1) * B + b) * K + g * H + j0 + cj];
                 c.cc = c.cprev;
