@@ -217,7 +217,7 @@ __device__ __forceinline__ void fwd2_layer1_waves(const Persist2Fwd &p, const Fw
             const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p.wpi + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
             if (i * 4 + g < NWREG) wir[i * 4 + g < NWREG ? i * 4 + g : 0] = v;
             else *reinterpret_cast<bf16x8 *>(my_wi + (i * 4 + g - NWREG) * 1024) = v;           // read back by this lane only
-            if (g == 3 && (i & 1)) __builtin_amdgcn_sched_barrier(0);      // eight fragments in flight at a time: the registers are half full already
+            if (g == 3 && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // sixteen fragments in flight at a time: the registers are half full already
         }
     const int ci = u >> 4, cj = u & 15;
     const int b = bt * 16 + ci;
@@ -535,7 +535,7 @@ __device__ __forceinline__ void bwd2_layer1_waves(const Persist2Bwd &p, const Bw
     for (int i = 0; i < KBW; ++i) {
         *reinterpret_cast<bf16x8 *>(my_wi + i * 1024) =
             *reinterpret_cast<const bf16x8 *>(p.wpTi + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
-        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // eight fragments in flight at a time: W_hh1^T already fills half the registers
+        if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);     // sixteen fragments in flight at a time: W_hh1^T already fills half the registers
     }
     const int ci = u >> 4, cj = u & 15;
     const int b = bt * 16 + ci;
