@@ -125,6 +125,7 @@ SIGNATURES = {
     'halo_decode_token': (_i, [_vp, _l, _i, _i, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'halo_attention_bwd': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _l, _l, _vp, _vp, _l, _l,
                                 _i, _i, _i, _i, _i, _i, _vp, _f, _u64, _u32, _u32, _vp, _vp]),
+    'halo_attention_masked': (_i, [_vp, _vp, _vp, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'halo_attention_fwd_bf16': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _u64, _u32, _u32,
                                      _vp, _vp]),
     'halo_attention_bwd_bf16': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp,

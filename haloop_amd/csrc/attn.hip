@@ -698,6 +698,78 @@ int halo_attention_fwd_strided(const float *q, long q_row_stride, long q_batch_s
     }
 }
 
+// Any boolean mask, any head dimension: ha/transformer.py:413-430 `attend(q, k, v, mask)` as the reference states it -- a mask of shape
+// (N, ..., T, S) broadcast over what it lacks, True = the key is hidden from the query -- for call sites outside the models' shapes (the
+// reference's own tests/test_attention.py calls it with head_dim 7 and a (T, S) triangle).  One wave per query row, exact fp32, no tiling:
+// a slow path, kept off every model's forward (those run the tiled kernels through key lengths / the causal flag).
+// q, k, v: [N, H, T|S, hd] contiguous; mask: bytes with element strides (0 = broadcast); y like q; ent [N, H, T] (may be NULL).
+namespace {
+__global__ __launch_bounds__(256) void attention_generic_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                                const float *__restrict__ v, const unsigned char *__restrict__ mask,
+                                                                long m_sn, long m_sh, long m_st, float *__restrict__ y,
+                                                                float *__restrict__ ent, int rows, int H, int T, int S, int hd, float scale) {
+    extern __shared__ float dyn[];                       // per wave: [q: hd][p: S]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;               // (n * H + h) * T + t
+    if (row >= rows) return;
+    float *qs = dyn + (long)wave * (hd + S), *ps = qs + hd;
+    const int t = row % T, nh = row / T, h = nh % H, n = nh / H;
+    const float *qr = q + (long)row * hd, *kb = k + (long)nh * S * hd, *vb = v + (long)nh * S * hd;
+    for (int d = lane; d < hd; d += 64) qs[d] = qr[d] * scale;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned char *mr = mask ? mask + n * m_sn + h * m_sh + t * m_st : nullptr;
+    float m = -INFINITY;
+    for (int j = lane; j < S; j += 64) {
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s += qs[d] * kb[(long)j * hd + d];
+        if (mr && mr[j]) s = -INFINITY;
+        ps[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < S; j += 64) {
+        const float p = expf(ps[j] - m);                 // a row with every key hidden: exp(nan) -> nan, as softmax gives
+        ps[j] = p;
+        l += p;
+    }
+    l = wave_sum(l);
+    float e = 0.f;
+    for (int j = lane; j < S; j += 64) {
+        const float att = ps[j] / l;
+        ps[j] = att;
+        e -= att * logf(att + 1e-8f);
+    }
+    e = wave_sum(e);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < S; ++j) acc += ps[j] * vb[(long)j * hd + d];
+        y[(long)row * hd + d] = acc;
+    }
+    if (ent && lane == 0) ent[row] = e;
+}
+}  // namespace
+
+int halo_attention_masked(const float *q, const float *k, const float *v, const unsigned char *mask, long mask_stride_n, long mask_stride_h,
+                          long mask_stride_t, float *y, float *entropy, int N, int heads, int T, int S, int head_dim, halo_stream_t stream) {
+    HALO_CHECK_ARG(q && k && v && y && N > 0 && heads > 0 && T > 0 && S > 0 && head_dim > 0);
+    const size_t lds = (size_t)4 * (head_dim + S) * sizeof(float);
+    if (lds > 160 * 1024 - 256 || (long)N * heads * T >= (1L << 31)) return HALO_ENOTSUP;
+    static size_t opted = 0;
+    if (lds > opted) {
+        if (hipFuncSetAttribute((const void *)attention_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return HALO_ELAUNCH;
+        opted = lds;
+    }
+    const int rows = N * heads * T;
+    hipLaunchKernelGGL(attention_generic_kernel, dim3((rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, q, k, v, mask, mask_stride_n,
+                       mask_stride_h, mask_stride_t, y, entropy, rows, heads, T, S, head_dim, 1.0f / sqrtf((float)head_dim));
+    return halo_launch_status();
+}
+
 // the training forward on the matrix-core kernel with the output ALSO as row-major bf16 (the c_proj operand); packed rows (head stride = head_dim)
 int halo_attention_fwd_bf16(const float *q, long q_row_stride, long q_batch_stride, const float *k, const float *v, long kv_row_stride,
                             long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, void *y_bf16, long ybf_row_stride,

@@ -958,6 +958,25 @@ def attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, c
                                    drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, _stream()), 'halo_attention_bwd')
 
 
+def attention_masked(q, k, v, mask):
+    """ha/transformer.py:413-430 attend for any boolean mask (True = hidden; broadcastable to (N, heads, T, S)) and any head dimension:
+    q (N, heads, T, hd), k / v (N, heads, S, hd) -> (y like q, entropy [N, heads, T]).  The slow general path (halo_attention_masked)."""
+    N, H, T, hd = q.shape
+    S = k.shape[-2]
+    qc, kc, vc = (t.float().contiguous() for t in (q, k, v))
+    y = torch.empty_like(qc)
+    ent = torch.empty(N, H, T, device=q.device, dtype=torch.float32)
+    m8, sn, sh, st = None, 0, 0, 0
+    if mask is not None:
+        m8 = torch.broadcast_to(mask.to(torch.uint8), (N, H, T, S))
+        if m8.stride(3) not in (1, 0) or (m8.stride(3) == 0 and S > 1):
+            m8 = m8.contiguous()
+        sn, sh, st = m8.stride(0), m8.stride(1), m8.stride(2)
+    check(lib().halo_attention_masked(ptr(qc), ptr(kc), ptr(vc), ptr(m8), sn, sh, st, ptr(y), ptr(ent), N, H, T, S, hd, _stream()),
+          'halo_attention_masked')
+    return y, ent
+
+
 def attention_fwd_bf16(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT, stream_id=0):
     """attention_fwd (training: with lse) that also returns y as row-major bf16 -> (y, lse, y_bf16)."""
     C = heads * head_dim

@@ -146,10 +146,14 @@ def rotate_interleaved(x, *, t0=0, base=10000):
 
 def attend(q, k, v, mask):
     """(N, heads, T, hd) x (N, heads, S, hd) -> (N, heads, T, hd), entropy (ha/transformer.py:413-430).
-    ``mask`` None or a key-padding mask (N, 1, 1, S) whose True entries form a suffix."""
+    ``mask`` None, a key-padding mask (N, 1, 1, S) whose True entries form a suffix (the models' case: the tiled kernel), or any
+    boolean mask broadcastable to (N, heads, T, S) -- and any head dimension -- through the general one-wave-per-row kernel."""
     N, H, T, hd = q.shape
     S = k.shape[-2]
     lens = None
+    if hd not in (16, 32, 64) or (mask is not None and not _is_suffix_padding_mask(mask, N, S)):
+        y, ent = ops.attention_masked(q, k, v, mask)
+        return y.to(q.dtype), ent.mean()
     if mask is not None:
         lens = _suffix_mask_lengths(mask, N, S)
     q2, k2, v2 = (t.transpose(1, 2).reshape(N * t.shape[2], H * hd).float().contiguous() for t in (q, k, v))
@@ -161,6 +165,14 @@ def attend_chunked(q, k, v, mask, chunk_size=32):
     "same result as attend without the monitor (ha/transformer.py:374-410); the kernel is already tiled"
     x, _ = attend(q, k, v, mask)
     return x, torch.tensor(float('-inf'))
+
+
+def _is_suffix_padding_mask(mask, N, S):
+    if mask.numel() != N * S or mask.shape[0] != N or mask.shape[-1] != S:
+        return False
+    m = mask.reshape(N, S)
+    lens = (~m).sum(-1)
+    return bool((m == (torch.arange(S, device=m.device)[None, :] >= lens[:, None])).all())
 
 
 def _suffix_mask_lengths(mask, N, S):

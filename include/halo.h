@@ -605,6 +605,13 @@ int halo_attention_bwd(const float *q, long q_row_stride, long q_batch_stride, c
                        int heads, int head_dim, int Tq, int Tk, int causal, const int *key_lengths, float p_drop,
                        uint64_t seed, uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev,
                        halo_stream_t stream);
+/* ha/transformer.py:413-430 `attend(q, k, v, mask)` for ANY boolean mask and head dimension (the reference's tests/test_attention.py: head
+ * dimension 7, a (T, S) triangle): q [N][heads][T][hd], k / v [N][heads][S][hd] contiguous fp32; mask bytes (non-zero = the key is hidden
+ * from the query) addressed as mask[n * stride_n + h * stride_h + t * stride_t + s] (stride 0 = broadcast), NULL = none; y like q;
+ * entropy [N][heads][T] = -sum att log(att + 1e-8) (optional).  One wave per query row, exact fp32: the slow, general path; the models run
+ * the tiled kernels above through key lengths and the causal flag.  HALO_ENOTSUP when 4 (hd + S) floats exceed the LDS. */
+int halo_attention_masked(const float *q, const float *k, const float *v, const unsigned char *mask, long mask_stride_n, long mask_stride_h,
+                          long mask_stride_t, float *y, float *entropy, int N, int heads, int T, int S, int head_dim, halo_stream_t stream);
 /* halo_attention_fwd_strided (packed rows) / halo_attention_bwd on the matrix-core kernels with row-major bf16 outputs for the Linear
  * layers around the attention (bf16 / bf16x3 modes, head_dim 32 or 64; HALO_ENOTSUP otherwise): the forward writes y in fp32 (the
  * backward's delta needs it) AND as bf16 [rows][ybf_row_stride]; the backward writes dq, dk, dv as bf16 ONLY (one row / batch stride,
