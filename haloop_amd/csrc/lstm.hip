@@ -1162,9 +1162,15 @@ inline size_t bwd_flags_offset(int T, int B, int in0, int H, int L) {
 
 // behind the epoch words of a 2-layer reserve: what the two-layer forward leaves for the backward of the same step -- the three transposed
 // weight images, and the operand images of the weight-gradient products [h0_prev^T | in0^T slot] [h1_prev^T | dropout(h0)^T]
-inline size_t reserve_p2_bytes(int T, int B, int in0, int H) {
+// ... and, last, the epoch words of the two-layer BACKWARD launch, zeroed by the forward's packing launch so that the backward of the same
+// step starts without a prologue launch of its own
+inline size_t reserve_p2_images_bytes(int T, int B, int in0, int H) {
     const int kin = in0 > H ? in0 : H;
     return (size_t)3 * 4 * H * H * sizeof(float) + 3 * halo_tiled_image_bytes(H, T * B) + halo_tiled_image_bytes(kin, T * B);
+}
+inline size_t reserve_p2_bytes(int T, int B, int in0, int H) { return reserve_p2_images_bytes(T, B, in0, H) + PERSIST_FLAG_BYTES; }
+inline unsigned *reserve_bwd_flags(float *reserve, int T, int B, int in0, int H, int L) {
+    return (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + reserve_p2_images_bytes(T, B, in0, H));
 }
 inline char *reserve_p2_images(float *reserve, int T, int B, int in0, int H, int L) {
     return (char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (size_t)3 * 4 * H * H * sizeof(float);
@@ -1301,6 +1307,7 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
         pp.H = H;
         pp.tile_blocks = 3 * (4 * H / 32) * (H / 32) / 4;
         pp.rest = pa; pp.rest.w_units = 0;
+        pp.rest.zero2 = reserve_bwd_flags(reserve, T, B, in0, H, L); pp.rest.zero2_units = (long)(PERSIST_FLAG_BYTES / 16);
         pp.zbase[0] = pp.zbase[1] = nullptr; pp.zstride = 0; pp.zunits = 0; pp.zcount = 0;
         ctx.emitT_reserve = nullptr;
         const bool emitT = persist_emit_enabled() && !h0 && B % 32 == 0 && H % 128 == 0 && T * B >= 32;
@@ -1314,10 +1321,11 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
             pp.zstride = KT * 16384; pp.zunits = (long)(B / 32) * 16384 / 16; pp.zcount = H / 128;
             ctx.emitT_reserve = reserve;
         }
-        const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + 2L * pp.zcount * pp.zunits));
+        const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + pp.rest.zero2_units + 2L * pp.zcount * pp.zunits));
         hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)pp.tile_blocks + rest_blocks), dim3(256), 0, st, pp);
         HALO_TRY(halo_launch_status());
         ctx.packT_reserve = reserve;
+        ctx.bwdflags_reserve = reserve;
         for (int m = 0; m < 3; ++m) ctx.packT_w[m] = pa.w[m];
     } else {
         // forward only.  Weights the caller declared unchanged (halo_set_lstm_weights_stamp) keep the images the previous call packed into
@@ -1623,8 +1631,13 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         const bool need_din = lo > 0 || dx != nullptr;         // the gradient w.r.t. layer lo's input: feeds layer lo - 1, or the caller
         float *din_out = lo > 0 ? din : dx;
         // the forward of this step may have left the three transposed images in the reserve (one read of the weights for all six)
-        const HaloCtx &ctx = halo_ctx_cur();
+        HaloCtx &ctx = halo_ctx_cur();
         const bool have_T = ctx.packT_reserve == reserve && ctx.packT_w[0] == w_hh[lo] && ctx.packT_w[1] == w_hh[hi] && ctx.packT_w[2] == w_ih[hi];
+        // ... and have zeroed this launch's epoch words there: nothing is left for a prologue launch (the padding rows of the gate-gradient
+        // row image need no zeroing: they only reach output rows past T*B, which no product stores)
+        const bool clean = have_T && ctx.bwdflags_reserve == reserve;
+        ctx.bwdflags_reserve = nullptr;                        // one backward per forward finds them clean
+        if (clean) flag_base = (char *)reserve_bwd_flags(reserve, T, B, in0, H, L);
         if (have_T) {
             float *wT = (float *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES);
             wpT0 = wT; wpT1 = wT + (size_t)4 * H * H; wpTi = wT + (size_t)8 * H * H;
@@ -1641,9 +1654,11 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             pa.zero2 = (unsigned *)(img_g + (long)((T * B) / 128) * tile_bytes); pa.zero2_units = tile_bytes / 16;
         }
         pa.H = H; pa.B = B;
-        hipLaunchKernelGGL(persist2_prologue_kernel<1>, dim3(pack_grid((size_t)(3 * pa.w_units + pa.zero_units + pa.zero2_units))), dim3(256), 0,
-                           st, pa);
-        HALO_TRY(halo_launch_status());
+        if (!clean) {
+            hipLaunchKernelGGL(persist2_prologue_kernel<1>, dim3(pack_grid((size_t)(3 * pa.w_units + pa.zero_units + pa.zero2_units))), dim3(256), 0,
+                               st, pa);
+            HALO_TRY(halo_launch_status());
+        }
         Persist2Bwd a;
         a.wpT0 = (const char *)wpT0; a.wpT1 = (const char *)wpT1; a.wpTi = (const char *)wpTi;
         a.dgp0 = (char *)dgp; a.dgp1 = (char *)dgp1;
@@ -1654,6 +1669,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         a.dhinit1 = dhn ? dhn + (size_t)hi * BH : nullptr; a.dcinit1 = dcn ? dcn + (size_t)hi * BH : nullptr;
         a.drop = make_dropout(p_drop, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)lo, offset, offset_dev);
         a.flags = (unsigned *)flag_base;
+        a.abort_word = (unsigned *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L));      // (== flags unless the words live in the reserve)
         a.stamps = halo_lstm_persist_stamp_buffer();       // diagnostic: [blocks][T + 1][16] here
         a.img_rows0 = emit0 && need_din ? img_g : nullptr;
         a.img_cols0 = emit0 ? img_gT : nullptr;

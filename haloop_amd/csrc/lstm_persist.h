@@ -113,6 +113,8 @@ struct Persist2Bwd {
     const float *dhinit0, *dcinit0, *dhinit1, *dcinit1;   // [B][H], may be NULL
     DropoutCfg drop;                  // layer 0's output dropout mask (applied to the gradient arriving from layer 1)
     unsigned *flags;
+    unsigned *abort_word;   // the call's own abort word (halo_lstm_status_offset of the backward workspace): zeroed by workgroup 0 at the start of the launch
+   
     unsigned *status;                 // see PersistFwd
     unsigned long long *stamps;
     // optional GEMM operand images of the gate gradients (see PersistBwd): rows image of layer 0 only (layer 1's input gradient

@@ -406,7 +406,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
         if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
             *sh.s_abort = 1;
-            raise_abort(p.flags, p.status);
+            raise_abort(p.abort_word, p.status);
         }
         lds_barrier();                                                             // (A)
         if (*sh.s_abort) return;
@@ -655,6 +655,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
     int jt, bt;
     map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
     if (tid == 0) { s_abort = 0; s_published = 0; }
+    // the call's abort word is only ever raised after a 0.2 s wait: clearing it here, at the start of the launch, cannot lose one
+    if (blockIdx.x == 0 && tid == 0 && p.abort_word != p.flags) __hip_atomic_store(p.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const Bwd2Shared sh = {red, dgbuf, &s_abort, &s_published};
     if (wave < 4) bwd2_layer0_waves<KC>(p, sh, jt, bt, wave, lane, tid & 255);
     else bwd2_layer1_waves<KC>(p, sh, wi_lds, jt, bt, wave, lane, tid & 255);
