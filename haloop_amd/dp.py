@@ -141,9 +141,14 @@ class ShardedUpdate:
     reduce_scatter_tensor / all_gather_into_tensor in place on the flat buffers; ``gloo`` (the CPU tests) has no reduce-scatter:
     there the mean is an all-reduce of which each rank keeps its span -- the same values."""
 
-    def __init__(self, flat_params, flat_grads, group=None, always=False):
+    def __init__(self, flat_params, flat_grads, group=None, always=False, wire_dtype='f32'):
         """always: issue the collectives on a one-rank group too (where each is the identity) -- how a single GPU rehearses the
-        sharded step on the real backend, captured graphs included."""
+        sharded step on the real backend, captured graphs included.
+        wire_dtype: 'f32' reduce-scatters the fp32 gradients in place; 'bf16' rounds them to bf16 for the reduce-scatter (half of
+        the step's gradient bytes on the links; the sums are formed in bf16 by the collective) and writes the fp32 mean of this
+        rank's span back -- the all-gather of the parameters stays fp32 either way."""
+        if wire_dtype not in ('f32', 'bf16'):
+            raise ValueError(f"wire_dtype must be 'f32' or 'bf16', got {wire_dtype!r}")
         self.params, self.grads, self.group = flat_params, flat_grads, group
         self.always = bool(always) and dist.is_available() and dist.is_initialized()
         self.world = world_size(group)
@@ -155,6 +160,8 @@ class ShardedUpdate:
         self.span = (self.rank * self.shard, (self.rank + 1) * self.shard)
         self._native = (self.world > 1 or self.always) and dist.get_backend(group) == 'nccl'
         self._avg_op = self._native and _avg_supported(flat_grads, group)
+        self._wire = (torch.empty(n, dtype=torch.bfloat16, device=flat_grads.device)
+                      if wire_dtype == 'bf16' and (self.world > 1 or self.always) else None)
 
     @staticmethod
     def padded_numel(n, world):
@@ -165,6 +172,22 @@ class ShardedUpdate:
         if self.world == 1 and not self.always:
             return
         lo, hi = self.span
+        if self._wire is not None:
+            w = self._wire
+            if self.grads.is_cuda:
+                from . import ops
+                ops.cast_f32_to_bf16_(w, self.grads)
+            else:
+                w.copy_(self.grads)
+            if self._native:
+                dist.reduce_scatter_tensor(w[lo:hi], w, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+            if self.grads.is_cuda:
+                ops.cast_bf16_to_f32_(self.grads[lo:hi], w[lo:hi], 1.0 / self.world)
+            else:
+                self.grads[lo:hi].copy_(w[lo:hi].float().mul_(1.0 / self.world))
+            return
         if self._native:
             op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
             dist.reduce_scatter_tensor(self.grads[lo:hi], self.grads, op=op, group=self.group)     # in place: out = in + rank * count

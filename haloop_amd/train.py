@@ -97,7 +97,8 @@ class LstmCtcTrainer:
         A micro-batch whose loss is NaN/Inf contributes nothing (the reference skips it, loop.py:167-174; here it still counts
         towards the cycle, because nothing synchronises with the host); an update whose gradient norm is not finite is
         skipped on the device and does not advance the Adam step count (loop.py:185-189).
-        grad_dtype: wire format of the data-parallel all-reduce ('f32' = DistributedDataParallel's; 'bf16' halves the bytes).
+        grad_dtype: wire format of the data-parallel gradient exchange -- the all-reduce, or the reduce-scatter of ``rs_ag`` --
+            ('f32' = DistributedDataParallel's; 'bf16' halves its bytes on the links).
         alias_loss: step() returns ``self.loss`` itself -- ONE device scalar that every later step overwrites -- instead of a
         copy the caller owns (for loops that read each loss before the next step, or never).
         dp_algo (more than one rank): 'rs_ag' -- the gradients are reduce-scattered, every rank clips and updates ITS 1/world span of
@@ -117,7 +118,7 @@ class LstmCtcTrainer:
             raise ValueError(f"dp_algo must be 'rs_ag' or 'allreduce', got {dp_algo!r}")
         self.world = dp.world_size(process_group)
         # gradient accumulation and the bf16 wire format live on the all-reduce path
-        self.dp_algo = dp_algo if ((self.world > 1 or rehearse_dp) and self.accumulate == 1 and grad_dtype == 'f32') else 'allreduce'
+        self.dp_algo = dp_algo if ((self.world > 1 or rehearse_dp) and self.accumulate == 1) else 'allreduce'
         self._rehearse_dp = bool(rehearse_dp)
         self.flat = FlatParams(encoder, recognizer, pad_to=4 * self.world if self.dp_algo == 'rs_ag' else 4)
         dev = self.flat.params.device
@@ -143,7 +144,7 @@ class LstmCtcTrainer:
         self.use_graph = use_graph
         self.pg = process_group
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
-        self.sharded = (dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp)
+        self.sharded = (dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp, wire_dtype=grad_dtype)
                         if self.dp_algo == 'rs_ag' else None)
         # two buckets in readiness order: [top layer + recognizer] then [the rest]
         self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range, wire_dtype=grad_dtype)

@@ -65,8 +65,17 @@ def _worker(rank, world, port, out):
         other = (lo - 1) % npad if lo else hi            # an element of another rank's span: untouched until the all-gather
         before = float(P[other])
         sh.all_gather()
+        # the same reduce-scatter with bf16 on the wire: this rank's span of the mean, through bf16 sums
+        G16 = torch.zeros(npad)
+        G16[:n] = torch.cat([(pe[k] if w == 'e' else pr[k]).grad.reshape(-1) for w, k in names])
+        sh16 = dp.ShardedUpdate(P.clone(), G16, wire_dtype='bf16')
+        sh16.reduce_scatter()
+        span16 = torch.zeros(npad)
+        span16[lo:hi] = G16[lo:hi]
+        dist.all_reduce(span16)                               # (test plumbing: collect every rank's span on rank 0)
         if rank == 0:
-            out.put((flat.numpy(), grads.numpy(), float(loss), g16.numpy(), P[:n].numpy(), float(part.sqrt()), before != float(P[other])))
+            out.put((flat.numpy(), grads.numpy(), float(loss), g16.numpy(), P[:n].numpy(), float(part.sqrt()), before != float(P[other]),
+                     span16[:n].numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -80,7 +89,7 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    flat, grads, _, g16, p_sharded, norm_sharded, moved = out.get()
+    flat, grads, _, g16, p_sharded, norm_sharded, moved, rs16 = out.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -103,6 +112,9 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     np.testing.assert_allclose(norm_sharded, norm, rtol=1e-4)
     np.testing.assert_allclose(p_sharded, want_flat - 0.1 * min(1.0, 0.05 / (norm + 1e-6)) * want, rtol=1e-4, atol=1e-7)
     assert moved                                                          # the other rank's span arrived through the all-gather
+    # the sharded reduce-scatter with bf16 on the wire: the mean to bf16 accuracy, and not the fp32 one
+    np.testing.assert_allclose(rs16, want, rtol=2e-2, atol=1e-2 * np.abs(want).max())
+    assert np.abs(rs16 - want).max() > 0
 
 
 def test_shard_slice_and_buckets():

@@ -297,6 +297,14 @@ def _rccl_sharded_worker(port, out, math_mode):
             torch.cuda.synchronize()
             tr.check_status()
             res[rehearse] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None)
+        # the same with bf16 on the wire of the reduce-scatter (cast, reduce_scatter_tensor on the bf16 buffer, cast back: captured too)
+        enc, rec = _build(100, c)
+        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=True, grad_dtype='bf16')
+        assert tr.sharded is not None and tr.sharded._wire is not None
+        losses = [float(tr.step(x, il, tg, tl).item()) for _ in range(4)]
+        torch.cuda.synchronize()
+        tr.check_status()
+        res['bf16'] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None)
         out.put(('ok', res))
     except Exception:
         out.put(('error', traceback.format_exc()))
@@ -325,3 +333,8 @@ def test_rccl_backend_runs_the_sharded_step(math_mode):
     assert sharded[1] == plain[1]
     assert np.array_equal(sharded[0], plain[0])
     assert sharded[2], 'the collectives were not captured (they ran eagerly): see the warning in the log'
+    # bf16 on the wire: the first step's loss is the same (same weights), the trajectory follows within the gradients' bf16 rounding
+    wire = msg[1]['bf16']
+    assert wire[2] and wire[1][0] == plain[1][0]
+    np.testing.assert_allclose(wire[1], plain[1], rtol=2e-2)
+    assert not np.array_equal(wire[0], plain[0])
