@@ -40,7 +40,7 @@ SIGNATURES = {
     'halo_split_image_bytes': (_sz, [_i, _i]),
     'halo_split_image': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'halo_layernorm_image': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    'halo_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_cast_bf16': (_i, [_vp, _vp, _sz, _vp]),
     'halo_gelu_bf16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_bf16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

@@ -227,14 +227,18 @@ def rowmajor_train_ok(cfg, blocks, M, training):
 def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
     C, H, M = cfg.n_embd, cfg.n_head, B * T
     w = lambda lin: images.split((lin.weight,))
-    h1b = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias)
-    qkv = ops.gemm_split_io((h1b, None), w(blk.attn.c_attn), M, 3 * C, C)
+    # (the normalised rows twice from one launch: the tiled image for the forward product, which stages an image 10-15 % faster than
+    # rows from cold caches, and the row-major rows for the weight-gradient product)
+    h1b, h1i = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias, want_image=True)
+    qkv = ops.gemm_split(h1i, w(blk.attn.c_attn), M, 3 * C, C)
+    del h1i
     s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
     y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
                                         drop=s_att[0], stream_id=s_att[1])
     x1 = ops.gemm_split_io((yb, None), w(blk.attn.c_proj), M, C, C, residual=x0)
-    h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
-    a = ops.gemm_split_io((h2b, None), w(blk.mlp.c_fc), M, 4 * C, C)
+    h2b, h2i = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias, want_image=True)
+    a = ops.gemm_split(h2i, w(blk.mlp.c_fc), M, 4 * C, C)
+    del h2i
     gb = ops.gelu_bf16(a)
     x = ops.gemm_split_io((gb, None), w(blk.mlp.c_proj), M, C, 4 * C, residual=x1)
     return x, (x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att)

@@ -1165,11 +1165,11 @@ int halo_layernorm_image(const float *x, const float *weight, const float *bias,
     return layernorm_image_launch(x, weight, bias, y, image, nullptr, rows, C, eps, (hipStream_t)stream);
 }
 
-int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, int rows, int C, float eps,
-                        halo_stream_t stream) {
-    HALO_CHECK_ARG(x && weight && y_bf16 && rows > 0 && C > 0 && C % 8 == 0);
-    HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)y_bf16 | (uintptr_t)y) % 16 == 0);
-    return layernorm_image_launch(x, weight, bias, y, nullptr, (__bf16 *)y_bf16, rows, C, eps, (hipStream_t)stream);
+int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, void *image, int rows, int C,
+                        float eps, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && weight && y_bf16 && rows > 0 && C > 0 && C % 8 == 0 && (!image || C % TK == 0));
+    HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)y_bf16 | (uintptr_t)y | (uintptr_t)image) % 16 == 0);
+    return layernorm_image_launch(x, weight, bias, y, image, (__bf16 *)y_bf16, rows, C, eps, (hipStream_t)stream);
 }
 
 int halo_gemm_split(const void *a_image, const void *b_image, int M, int N, int K, float *C, int ldc, const float *bias1,

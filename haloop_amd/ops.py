@@ -119,13 +119,15 @@ def layernorm_image(x2d, weight, bias=None, eps=1e-5, want_y=False):
     return img, y
 
 
-def layernorm_bf16(x2d, weight, bias=None, eps=1e-5):
-    """LayerNorm of the rows as row-major bf16 [rows, C]: the operand form gemm_split_io (a = (hi, None)) and gemm_tn read."""
+def layernorm_bf16(x2d, weight, bias=None, eps=1e-5, want_image=False):
+    """LayerNorm of the rows as row-major bf16 [rows, C]: the operand form gemm_split_io (a = (hi, None)) and gemm_tn read.
+    ``want_image``: -> (rows, tiled operand image of the same values) from the one launch."""
     _f32c(x2d, 'x')
     rows, Cn = x2d.shape
     y = torch.empty(rows, Cn, device=x2d.device, dtype=torch.bfloat16)
-    check(lib().halo_layernorm_bf16(ptr(x2d), ptr(weight), ptr(bias), None, ptr(y), rows, Cn, eps, _stream()), 'halo_layernorm_bf16')
-    return y
+    img = torch.empty(lib().halo_split_image_bytes(rows, Cn), device=x2d.device, dtype=torch.uint8) if want_image else None
+    check(lib().halo_layernorm_bf16(ptr(x2d), ptr(weight), ptr(bias), None, ptr(y), ptr(img), rows, Cn, eps, _stream()), 'halo_layernorm_bf16')
+    return (y, img) if want_image else y
 
 
 def gelu_bf16(a, exact=False):

@@ -127,9 +127,11 @@ int halo_split_image(const float *src, int rows, int k, int ld, int src_transpos
 int halo_layernorm_image(const float *x, const float *weight, const float *bias, float *y, void *image, int rows, int C,
                          float eps, halo_stream_t stream);
 /* The same LayerNorm with the normalised rows as ROW-MAJOR bf16 [rows][C] (C % 8 == 0) -- the operand form halo_gemm_split_io (a_hi) and
- * halo_gemm_tn_bf16 read -- instead of a tiled image; y (fp32 rows, optional) as above. */
-int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, int rows, int C, float eps,
-                        halo_stream_t stream);
+ * halo_gemm_tn_bf16 read; y (fp32 rows) and image (the tiled image as well, C % 32 == 0) are optional: a product that stages its A operand
+ * from row-major rows fetches half cache lines and runs 10-15 % slower from cold caches than from the image, so the forward
+ * product of a training step takes the image and the weight-gradient product the rows, both from this one launch. */
+int halo_layernorm_bf16(const float *x, const float *weight, const float *bias, float *y, void *y_bf16, void *image, int rows, int C,
+                        float eps, halo_stream_t stream);
 /* n fp32 values -> bf16 (n % 8 == 0, 16-byte aligned): row-major bf16 operands from fp32 tensors no launch produced as bf16 */
 int halo_cast_bf16(const float *x, void *y, size_t n, halo_stream_t stream);
 /* The GPT MLP's two elementwise passes with a bf16 result (n % 8 == 0, 16-byte aligned): y = gelu(a) -- the c_proj input, never needed in

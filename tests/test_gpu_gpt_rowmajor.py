@@ -89,7 +89,12 @@ def test_bf16_producers_match_the_fp32_operators():
             assert torch.equal(ops.gelu_bwd_bf16(dg, a, exact), ops.gelu_bwd(dg, a, exact).bfloat16())
         # LayerNorm as row-major bf16, and its backward's bf16 copy
         lw, lb = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
-        assert torch.equal(ops.layernorm_bf16(x, lw, lb), ops.layernorm_image(x, lw, lb, want_y=True)[1].bfloat16())
+        img_ref, y_ref = ops.layernorm_image(x, lw, lb, want_y=True)
+        assert torch.equal(ops.layernorm_bf16(x, lw, lb), y_ref.bfloat16())
+        rows, img = ops.layernorm_bf16(x, lw, lb, want_image=True)              # rows and tiled image from one launch
+        wimg = ops.split_image(w)
+        assert torch.equal(rows, y_ref.bfloat16())
+        assert torch.equal(ops.gemm_split(img, wimg, M, 4 * C, C), ops.gemm_split(img_ref, wimg, M, 4 * C, C))
         dx, dw, db, dxb = ops.layernorm_bwd(dy, x, lw, dy, has_bias=True, want_bf16=True)
         dx2, dw2, db2 = ops.layernorm_bwd(dy, x, lw, dy, has_bias=True)
         assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dxb, dx.bfloat16())
