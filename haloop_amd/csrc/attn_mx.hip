@@ -426,6 +426,146 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
     }
 }
 
+// The dQ sweep with QB 16-query blocks per wave (a workgroup covers 64 QB queries) and one query tile per workgroup dispatched longest
+// first when causal -- what the forward gained from (every K / V / K^T fragment read from LDS feeds QB MFMAs; a staged key tile and its
+// two barriers serve QB times the queries).  grid (heads * N, n_tiles).
+template <int HD, int PASSES, bool DROP, int QB>
+__global__ __launch_bounds__(256, 2) void attention_bwd_dq_mx_qb_kernel(AttnBwdArgs a) {
+    using I = Img<HD, PASSES>;
+    constexpr int WQ = 16 * QB, TQ = 64 * QB;
+    __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
+    __shared__ __attribute__((aligned(16))) char Vimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
+    const int n_tiles_x = (a.Tq + TQ - 1) / TQ;
+    const int rank = blockIdx.y, h = (int)blockIdx.x % a.heads, b = (int)blockIdx.x / a.heads;
+    const int qt = a.causal ? n_tiles_x - 1 - rank : rank;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
+    const float *dyb = a.dy + (long)b * a.dy_bs + (long)h * HD;
+    const float *kb = a.k + (long)b * a.kv_bs + (long)h * HD;
+    const float *vb = a.v + (long)b * a.kv_bs + (long)h * HD;
+    const int q0 = qt * TQ + wave * WQ;
+    const int klim = a.key_len ? max(0, min(Tk, a.key_len[b])) : Tk;
+    const int coff = Tk - Tq;
+    int qrow[QB], qsafe[QB];
+    bf16x8 qh[QB][I::KSTEPS], ql[QB][I::KSTEPS], doh[QB][I::KSTEPS], dol[QB][I::KSTEPS];
+    float delta[QB], lse[QB];
+    f32x4 dq[QB][HD / 16];
+#pragma unroll
+    for (int g = 0; g < QB; ++g) {
+        qrow[g] = q0 + 16 * g + lr;
+        qsafe[g] = min(qrow[g], Tq - 1);
+#pragma unroll
+        for (int ks = 0; ks < I::KSTEPS; ++ks) {
+            load_split8(qb + (long)qsafe[g] * a.q_rs + 32 * ks + 8 * lq, a.scale * LOG2E, qh[g][ks], ql[g][ks]);
+            load_split8(dyb + (long)qsafe[g] * a.dy_rs + 32 * ks + 8 * lq, 1.0f, doh[g][ks], dol[g][ks]);
+        }
+        const long stat = ((long)b * a.heads + h) * Tq + qsafe[g];
+        if (a.y) {
+            const float *yb = a.y + (long)b * a.dy_bs + (long)h * HD + (long)qsafe[g] * a.dy_rs;
+            const float *db = dyb + (long)qsafe[g] * a.dy_rs;
+            float part = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const int d0 = 32 * ks + 8 * lq;
+                const f32x4 y0 = *reinterpret_cast<const f32x4 *>(yb + d0), y1 = *reinterpret_cast<const f32x4 *>(yb + d0 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(db + d0), g1 = *reinterpret_cast<const f32x4 *>(db + d0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += g0[e] * y0[e] + g1[e] * y1[e];
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            delta[g] = part;
+            if (lq == 0 && qrow[g] < Tq) a.delta_w[stat] = part;
+        } else {
+            delta[g] = a.delta[stat];
+        }
+        lse[g] = a.lse[stat] * LOG2E;
+#pragma unroll
+        for (int m = 0; m < HD / 16; ++m) dq[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int n_ktiles = (klim + 63) / 64;
+    if (a.causal) n_ktiles = min(n_ktiles, max(0, (min(qt * TQ + TQ - 1, Tq - 1) + coff) / 64 + 1));
+    f32x4 kreg[I::UNITS], vreg[I::UNITS];
+    if (n_ktiles > 0) { fetch_tile<HD>(kreg, kb, a.kv_rs, 0, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, 0, Tk); }
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+        __syncthreads();
+        stage_tile<HD, PASSES>(Kimg, kreg);
+        stage_tile<HD, PASSES>(Vimg, vreg);
+        __syncthreads();
+        if (kt + 1 < n_ktiles) { fetch_tile<HD>(kreg, kb, a.kv_rs, (kt + 1) * 64, Tk); fetch_tile<HD>(vreg, vb, a.kv_rs, (kt + 1) * 64, Tk); }
+        f32x4 sacc[QB][4], pacc[QB][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+            for (int g = 0; g < QB; ++g) { sacc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < I::KSTEPS; ++ks) {
+                const bf16x8 kh = row_frag<HD, PASSES>(Kimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 kl = PASSES == 3 ? row_frag<HD, PASSES>(Kimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : kh;
+                const bf16x8 vh = row_frag<HD, PASSES>(Vimg, 16 * n + lr, 32 * ks + 8 * lq);
+                const bf16x8 vl = PASSES == 3 ? row_frag<HD, PASSES>(Vimg + I::BYTES, 16 * n + lr, 32 * ks + 8 * lq) : vh;
+#pragma unroll
+                for (int g = 0; g < QB; ++g) {
+                    sacc[g][n] = mma<PASSES>(sacc[g][n], kh, kl, qh[g][ks], ql[g][ks]);
+                    pacc[g][n] = mma<PASSES>(pacc[g][n], vh, vl, doh[g][ks], dol[g][ks]);
+                }
+            }
+        }
+        // dS^T = P^T (dP^T . dropout - delta), in place in sacc
+        const bool edge = kt * 64 + 63 >= klim || (a.causal && kt * 64 + 63 > q0 + coff);      // wave-uniform (q0: the wave's first query)
+#pragma unroll
+        for (int g = 0; g < QB; ++g) {
+            const int kmax = a.causal ? min(klim - 1, qrow[g] + coff) : klim - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (DROP && a.use_drop)
+                    dm = dropout_mult4(a.drop, attn_drop_tile_base(b, a.heads, h, Tq, qsafe[g], (Tk + 63) / 64, kt) + 4 * (4 * lq + r));
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    float p = __builtin_amdgcn_exp2f(sacc[g][n][r] - lse[g]);
+                    if (edge && kt * 64 + 16 * n + 4 * lq + r > kmax) p = 0.f;
+                    sacc[g][n][r] = p * (pacc[g][n][r] * dm[n] - delta[g]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 dh[QB], dl[QB];
+#pragma unroll
+            for (int g = 0; g < QB; ++g) {
+                const float df[8] = {sacc[g][2 * kk][0], sacc[g][2 * kk][1], sacc[g][2 * kk][2], sacc[g][2 * kk][3],
+                                     sacc[g][2 * kk + 1][0], sacc[g][2 * kk + 1][1], sacc[g][2 * kk + 1][2], sacc[g][2 * kk + 1][3]};
+                split8(df, dh[g], dl[g]);
+            }
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m) {
+                const bf16x8 kh = tr_frag2<HD, PASSES>(Kimg, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr);
+                const bf16x8 kl = PASSES == 3 ? tr_frag2<HD, PASSES>(Kimg + I::BYTES, 32 * kk + 4 * lq, 32 * kk + 16 + 4 * lq, 16 * m, lr) : kh;
+#pragma unroll
+                for (int g = 0; g < QB; ++g) dq[g][m] = mma<PASSES>(dq[g][m], kh, kl, dh[g], dl[g]);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < QB; ++g) {
+        if (qrow[g] >= Tq) continue;
+        if (a.dq_bf) {
+            __bf16 *dp = a.dq_bf + (long)b * a.dqb_bs + (long)qrow[g] * a.dqb_rs + (long)h * HD + 4 * lq;
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+                *reinterpret_cast<bf16x4 *>(dp + 16 * m) = bf16x4{(__bf16)(dq[g][m][0] * a.scale), (__bf16)(dq[g][m][1] * a.scale),
+                                                                 (__bf16)(dq[g][m][2] * a.scale), (__bf16)(dq[g][m][3] * a.scale)};
+        } else {
+            float *dp = a.dq + (long)b * a.dq_bs + (long)qrow[g] * a.dq_rs + (long)h * HD + 4 * lq;
+#pragma unroll
+            for (int m = 0; m < HD / 16; ++m)
+                *reinterpret_cast<f32x4 *>(dp + 16 * m) = f32x4{dq[g][m][0] * a.scale, dq[g][m][1] * a.scale, dq[g][m][2] * a.scale, dq[g][m][3] * a.scale};
+        }
+    }
+}
+
 // ---- backward, dK/dV sweep: one workgroup = 64 keys, walks the query tiles -----------------------------------
 // Here the lane-fixed index is the KEY: S = Q K^T and dP = dO V^T (this wave's 16 keys as the B operand, from registers)
 // leave a lane with 16 queries of one key, and P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
@@ -584,11 +724,20 @@ template <int HD, int PASSES>
 int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
     const int nq = (a.Tq + 63) / 64, nk = (a.Tk + 63) / 64;
     const dim3 gq(a.causal ? (nq + 1) / 2 : nq, a.heads, N), gk(a.causal ? (nk + 1) / 2 : nk, a.heads, N);
+    // dQ sweep: 128-query workgroups (two query blocks per wave, longest tile first) in the single-pass mode once they fill the chip, as in
+    // the forward; HALO_ATTN_BWD_QB=1|2 forces either
+    static int qb = -1;
+    if (qb < 0) { const char *e = getenv("HALO_ATTN_BWD_QB"); qb = e ? atoi(e) : 0; }
+    const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
+    const bool two = PASSES == 1 && (qb == 2 || (qb == 0 && a.Tq >= 256 && wg128 >= 512));      // (three passes: 248-256 registers, spills)
+    const dim3 gq2(a.heads * N, (a.Tq + 127) / 128);
     if (a.use_drop) {
-        hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, true>), gq, dim3(256), 0, st, a);
+        if (two) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, true, 2>), gq2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, true>), gq, dim3(256), 0, st, a);
         hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, true>), gk, dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, false>), gq, dim3(256), 0, st, a);
+        if (two) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, false, 2>), gq2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, false>), gq, dim3(256), 0, st, a);
         hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, false>), gk, dim3(256), 0, st, a);
     }
     return halo_launch_status();
