@@ -43,6 +43,7 @@ struct AttnBwdArgs {
     // gradient products: halo_attention_bwd_bf16); one row / batch stride for all three
     __bf16 *dq_bf = nullptr, *dk_bf = nullptr, *dv_bf = nullptr;
     long dqb_rs = 0, dqb_bs = 0;
+    int dkv_longest_first = 0;                   // attn_mx.hip, set by its launcher: grid (heads * N, key tiles), one tile per workgroup
 };
 
 // attn_mx.hip: the same products on v_mfma_f32_16x16x32_bf16 with operands split hi + lo (passes = 3) or rounded to bf16 (passes = 1)

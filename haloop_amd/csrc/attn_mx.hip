@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 3) void attention_bwd_dq_mx_kernel(AttnBwdArgs
 // first when causal -- what the forward gained from (every K / V / K^T fragment read from LDS feeds QB MFMAs; a staged key tile and its
 // two barriers serve QB times the queries).  grid (heads * N, n_tiles).
 template <int HD, int PASSES, bool DROP, int QB>
-__global__ __launch_bounds__(256, 2) void attention_bwd_dq_mx_qb_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attention_bwd_dq_mx_qb_kernel(AttnBwdArgs a) {
     using I = Img<HD, PASSES>;
     constexpr int WQ = 16 * QB, TQ = 64 * QB;
     __shared__ __attribute__((aligned(16))) char Kimg[(PASSES == 3 ? 2 : 1) * I::BYTES];
@@ -577,10 +577,16 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_mx_kernel(AttnBwdArg
     __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
     // Causal work per key tile falls from n (tile 0 sees every query tile) to 1: a workgroup takes tile x and then tile n-1-x, so every
     // workgroup walks n + 1 query tiles and the grid (ceil(n/2) wide) drains evenly instead of leaving the chip to a few long tails.
-    const int n_tiles_x = (a.Tk + 63) / 64, h = blockIdx.y, b = blockIdx.z;
+    // (dkv_longest_first, the single-pass launches: one key tile per workgroup, grid (heads * N, tiles) with the tile in blockIdx.y -- under
+    // the causal mask tile 0 is the longest job and is dispatched first, and the 512 resident workgroups are topped up with ever
+    // shorter ones, as in the forward: at B = 8, T = 1024, 12 heads the pairs were 768 equal jobs of 17 tile-steps on 512 slots, 34 on
+    // the CUs that drew two against a mean of 25.5)
+    const int n_tiles_x = (a.Tk + 63) / 64;
+    const int h = a.dkv_longest_first ? (int)blockIdx.x % a.heads : (int)blockIdx.y, b = a.dkv_longest_first ? (int)blockIdx.x / a.heads : (int)blockIdx.z;
     for (int pass = 0; pass < 2; ++pass) {
-        const int kt = a.causal ? (pass == 0 ? (int)blockIdx.x : n_tiles_x - 1 - (int)blockIdx.x) : (int)blockIdx.x;
-        if (pass == 1 && (!a.causal || kt == (int)blockIdx.x)) break;
+        const int px = a.dkv_longest_first ? (int)blockIdx.y : (int)blockIdx.x;
+        const int kt = (a.causal && !a.dkv_longest_first) ? (pass == 0 ? px : n_tiles_x - 1 - px) : px;
+        if (pass == 1 && (!a.causal || a.dkv_longest_first || kt == px)) break;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
         const int Tq = a.Tq, Tk = a.Tk;
         const float *qb = a.q + (long)b * a.q_bs + (long)h * HD;
@@ -731,14 +737,26 @@ int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
     const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
     const bool two = PASSES == 1 && (qb == 2 || (qb == 0 && a.Tq >= 256 && wg128 >= 512));      // (three passes: 248-256 registers, spills)
     const dim3 gq2(a.heads * N, (a.Tq + 127) / 128);
+    // dK/dV sweep: one key tile per workgroup, longest first, where the paired jobs would not fill the resident slots evenly
+    static int lf = -1;
+    if (lf < 0) { const char *e = getenv("HALO_ATTN_DKV_LF"); lf = e ? atoi(e) : 2; }
+    AttnBwdArgs ak = a;
+    ak.dkv_longest_first = (lf == 1 || (lf == 2 && a.causal && (long)nk * a.heads * N >= 1024)) ? 1 : 0;
+    const dim3 gkl(a.heads * N, nk);
+    const dim3 gkk = ak.dkv_longest_first ? gkl : gk;
+    // (the dQ sweep with ONE block per wave, same rule: longest first instead of pairs)
+    const bool one_lf = !two && ak.dkv_longest_first;
+    const dim3 gq1(a.heads * N, nq);
     if (a.use_drop) {
         if (two) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, true, 2>), gq2, dim3(256), 0, st, a);
+        else if (one_lf) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, true, 1>), gq1, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, true>), gq, dim3(256), 0, st, a);
-        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, true>), gk, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, true>), gkk, dim3(256), 0, st, ak);
     } else {
         if (two) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, false, 2>), gq2, dim3(256), 0, st, a);
+        else if (one_lf) hipLaunchKernelGGL((attention_bwd_dq_mx_qb_kernel<HD, PASSES, false, 1>), gq1, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_bwd_dq_mx_kernel<HD, PASSES, false>), gq, dim3(256), 0, st, a);
-        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, false>), gk, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_bwd_dkv_mx_kernel<HD, PASSES, false>), gkk, dim3(256), 0, st, ak);
     }
     return halo_launch_status();
 }
