@@ -732,14 +732,14 @@ int launch_bwd(const AttnBwdArgs &a, int N, hipStream_t st) {
     const dim3 gq(a.causal ? (nq + 1) / 2 : nq, a.heads, N), gk(a.causal ? (nk + 1) / 2 : nk, a.heads, N);
     // dQ sweep: 128-query workgroups (two query blocks per wave, longest tile first) in the single-pass mode once they fill the chip, as in
     // the forward; HALO_ATTN_BWD_QB=1|2 forces either
-    static int qb = -1;
-    if (qb < 0) { const char *e = getenv("HALO_ATTN_BWD_QB"); qb = e ? atoi(e) : 0; }
+    const char *eq = getenv("HALO_ATTN_BWD_QB");               // (read per call: the tests switch it)
+    const int qb = eq ? atoi(eq) : 0;
     const long wg128 = (long)((a.Tq + 127) / 128) * a.heads * N;
     const bool two = PASSES == 1 && (qb == 2 || (qb == 0 && a.Tq >= 256 && wg128 >= 512));      // (three passes: 248-256 registers, spills)
     const dim3 gq2(a.heads * N, (a.Tq + 127) / 128);
     // dK/dV sweep: one key tile per workgroup, longest first, where the paired jobs would not fill the resident slots evenly
-    static int lf = -1;
-    if (lf < 0) { const char *e = getenv("HALO_ATTN_DKV_LF"); lf = e ? atoi(e) : 2; }
+    const char *el = getenv("HALO_ATTN_DKV_LF");
+    const int lf = el ? atoi(el) : 2;
     AttnBwdArgs ak = a;
     ak.dkv_longest_first = (lf == 1 || (lf == 2 && a.causal && (long)nk * a.heads * N >= 1024)) ? 1 : 0;
     const dim3 gkl(a.heads * N, nk);

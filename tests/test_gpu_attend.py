@@ -56,3 +56,36 @@ def test_attend_with_general_masks(shape):
         assert abs(ent.item() - want_ent.item()) <= (1e-5 if hd not in (16, 32, 64) or mask is not None else 5e-2)
     y, e = ops.attention_masked(q, k, v, None)
     assert y.shape == q.shape and e.shape == (N, H, T)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('N,heads,hd,T,causal,ragged,p', [(2, 3, 64, 300, True, False, 0.0), (2, 2, 64, 333, True, True, 0.1),
+                                                         (1, 4, 32, 257, True, False, 0.0), (2, 2, 64, 200, False, True, 0.0)])
+def test_attention_backward_dispatch_forms_agree(monkeypatch, mode, N, heads, hd, T, causal, ragged, p):
+    """The backward sweeps' two dispatch forms -- two query blocks per wave + one tile per workgroup, longest first, against one block per
+    wave + long/short tile pairs -- walk the same tiles in the same order per output element: bitwise equal gradients, on ragged sizes
+    (T not a multiple of the 128-query tile), key lengths and dropout too.  (The defaults pick per shape; the environment forces either.)"""
+    from haloop_amd import _lib, ops
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        C = heads * hd
+        g = torch.Generator().manual_seed(T)
+        qkv = torch.randn(N * T, 3 * C, generator=g).cuda()
+        dy = torch.randn(N * T, C, generator=g).cuda()
+        lens = torch.tensor([T - (41 * n) % T for n in range(N)], dtype=torch.int32).cuda() if ragged else None
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        drop = ops.Dropout(p, 5, 0) if p > 0 else ops.NO_DROPOUT
+        y, lse, _ = ops.attention_fwd(q, k, v, N, heads, hd, T, T, causal=causal, key_lengths=lens, want_lse=True, drop=drop, stream_id=3)
+        out = {}
+        for name, qb, lf in (('new', '2', '1'), ('old', '1', '0')):
+            monkeypatch.setenv('HALO_ATTN_BWD_QB', qb)
+            monkeypatch.setenv('HALO_ATTN_DKV_LF', lf)
+            d = torch.full_like(qkv, float('nan'))
+            ops.attention_bwd(q, k, v, y, dy, lse, d[:, :C], d[:, C:2 * C], d[:, 2 * C:], N, heads, hd, T, T, causal=causal, key_lengths=lens,
+                              drop=drop, stream_id=3)
+            out[name] = d
+        assert torch.isfinite(out['new']).all()
+        assert torch.equal(out['new'], out['old'])
+    finally:
+        _lib.set_math_mode(prev)
