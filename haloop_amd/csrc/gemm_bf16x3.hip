@@ -276,11 +276,12 @@ struct TiledGemmArgs {
     int n_split, ldc2;
 };
 
-template <int PASSES>
+template <int PASSES, int ITERS = (PASSES == 3 ? 4 : 2)>
 __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int wave, int lane) {
-    // 16 KiB block = 16 wave-instructions of 1 KiB; each of the 4 waves issues 4 (PASSES == 1: only the hi part, 2 each)
+    // 16 KiB block = 16 wave-instructions of 1 KiB; each of the 4 waves issues 4 (PASSES == 1: only the hi part, 2 each; ITERS = 1: the
+    // 64 rows of a half block)
 #pragma unroll
-    for (int i = 0; i < (PASSES == 3 ? 4 : 2); ++i) {
+    for (int i = 0; i < ITERS; ++i) {
         const int piece = i * 4 + wave;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gblk + piece * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
@@ -291,11 +292,11 @@ __device__ __forceinline__ void stage_block(const char *gblk, char *lds_dst, int
 // piece, i.e. at (row = 16 piece + l / 4, position l % 4) of the slot's 64-byte rows; the swizzled image holds logical chunk
 // pos ^ ((row >> 2) & 3) there -- so the lane simply FETCHES that chunk: the swizzle is applied on the source side and no operand-image
 // pass over the activations is needed.  Rows past M read row M - 1 (their products are never stored).
-template <int PASSES>
+template <int PASSES, int ITERS = (PASSES == 3 ? 4 : 2)>
 __device__ __forceinline__ void stage_rowmajor(const __bf16 *hi, const __bf16 *lo, long lda, int row0, int k0, int M, char *lds_dst, int wave,
                                                int lane) {
 #pragma unroll
-    for (int i = 0; i < (PASSES == 3 ? 4 : 2); ++i) {
+    for (int i = 0; i < ITERS; ++i) {
         const int piece = i * 4 + wave;                        // 0..7: hi part, 8..15: lo part (as stage_block)
         const int row = (piece & 7) * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
         const __bf16 *src = (piece < 8 ? hi : lo) + (long)min(row0 + row, M - 1) * lda + k0 + chunk * 8;
@@ -360,12 +361,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // EPI: 0 the full epilogue; 1 bias only; 3 bias + residual add (neither: no activation, no dropout, no split-K); 2 a split-K slice (raw sums to its slab).
 // The plain products run on 1 / 2: the code they do not need costs them 3-6 % when it is compiled in.
 // IO: bit 0 = A staged from row-major bf16 (stage_rowmajor), bit 1 = bf16 row-major output; both only in their own instantiations
-template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0, int IO = 0>
+// TI: 32-row blocks per wave = 2 (a 128 x 128 workgroup tile) or 1 (64 x 128: the single-pass, whole-K products whose 128-row tiles would
+// number 257 .. 511 -- one or two workgroups on a CU that holds three -- run on twice as many half-height tiles, three per CU)
+template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0, int IO = 0, int TI = 2>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
-    constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : LOADS_PER_STAGE / 2;
+    static_assert(TI == 2 || (TI == 1 && PASSES == 1 && !CE && !(IO & 8)), "64-row tiles: single pass, plain epilogues");
+    constexpr int TRM = 64 * TI;
+    constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : (TI == 2 ? LOADS_PER_STAGE / 2 : 3);
     // ring slot: [A block | B block]; with one pass only the hi parts are staged, so a slot is half the size and the
     // same LDS holds a ring twice as deep (the single-pass loop is bound by LDS-DMA latency, not by the MFMAs)
-    constexpr int OPER = PASSES == 3 ? BLOCK_BYTES : PART_BYTES, SLOT = 2 * OPER;
+    constexpr int OPERB = PASSES == 3 ? BLOCK_BYTES : PART_BYTES, OPER = OPERB * TI / 2, SLOT = OPER + OPERB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int kslice = blockIdx.x / p.ntiles;
     // within an XCD's contiguous run, walk the tiles in groups of 8 tile rows, column by column: the
@@ -383,12 +388,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const char *Ablk = p.A + ((long)tile_m * p.KT + kt0) * BLOCK_BYTES;
+    const char *Ablk = TI == 2 ? p.A + ((long)tile_m * p.KT + kt0) * BLOCK_BYTES
+                               : p.A + ((long)(tile_m >> 1) * p.KT + kt0) * BLOCK_BYTES + (tile_m & 1) * (PART_BYTES / 2);
     const char *Bblk = p.B + ((long)tile_n * p.KT + kt0) * BLOCK_BYTES;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            aoff[i][ks] = swz_byte(wm * 64 + i * 32 + lr, ks * 2 + lh);
+            aoff[i][ks] = swz_byte(wm * 32 * TI + (i < TI ? i : 0) * 32 + lr, ks * 2 + lh);
             boff[i][ks] = swz_byte(wn * 64 + i * 32 + lr, ks * 2 + lh);
         }
 
@@ -421,6 +427,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         if (IO & 8) {
             stage_kmajor(p.Arm_hi, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, slot, wave, lane);
             stage_kmajor(p.Brm, p.ldb, tile_n * TR, (kt0 + t) * TK, p.N, slot + OPER, wave, lane);
+        } else if (TI == 1) {
+            if (IO & 1) stage_rowmajor<PASSES, 1>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TRM, (kt0 + t) * TK, p.M, slot, wave, lane);
+            else stage_block<PASSES, 1>(Ablk + (long)t * BLOCK_BYTES, slot, wave, lane);
+            stage_block<PASSES>(Bblk + (long)t * BLOCK_BYTES, slot + OPER, wave, lane);
         } else {
             if (IO & 1) stage_rowmajor<PASSES>(p.Arm_hi, p.Arm_lo, p.lda, tile_m * TR, (kt0 + t) * TK, p.M, slot, wave, lane);
             else stage_block<PASSES>(Ablk + (long)t * BLOCK_BYTES, slot, wave, lane);
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (IO & 8) continue;
-                fah[ks][i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
+                if (i < TI) fah[ks][i] = *reinterpret_cast<const bf16x8 *>(ah + aoff[i][ks]);
                 fbh[ks][i] = *reinterpret_cast<const bf16x8 *>(bh + boff[i][ks]);
                 if (PASSES == 3) {
                     fal[ks][i] = *reinterpret_cast<const bf16x8 *>(al + aoff[i][ks]);
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (PASSES == 3) {
@@ -498,17 +508,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail loads before the workgroup retires
 
     // epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    const int m0 = tile_m * TR, n0 = tile_n * TR;
+    const int m0 = tile_m * TRM, n0 = tile_n * TR;
     if (CE) {               // softmax statistics of this wave's 64 x 64 block, row by row (a row = 32 lanes x 2)
         const int c0 = n0 + wn * 64 + lr, c1 = c0 + 32;
         const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
         float b0 = 0.f, b1 = 0.f;
         if (p.bias1) { if (ok0) b0 = p.bias1[c0]; if (ok1) b1 = p.bias1[c1]; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float v0 = ok0 ? acc[i][0][r] + b0 : -INFINITY, v1 = ok1 ? acc[i][1][r] + b1 : -INFINITY;
                 float mx = row16_max(fmaxf(v0, v1)), other = mx;
                 swap_rows16(mx, other);                      // the two 16-lane rows of each 32-lane half
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         // written in the store loop each wait for the store before them ([8192 x 768 x 768] bf16: 21 us plain, 39 us with the add); here the 16 addends of a 32 x 32
         // block are requested together (30 us).  Element (i, j, r) of this lane: row = m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 lh,
         // col = n0 + 64 wn + 32 j + lr -- everything but 4 lh and lr is wave-uniform
-        const int urow0 = m0 + wm * 64, ucol0 = n0 + wn * 64;
+        const int urow0 = m0 + wm * 32 * TI, ucol0 = n0 + wn * 64;
         float bias[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)lr;
         const unsigned lane_off_r = (unsigned)(4 * lh) * (unsigned)p.ldr + (unsigned)lr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2 * TI; ++q) {
             const int i = q >> 1, j = q & 1;
             const bool col_ok = ucol0 + j * 32 + lr < p.N;
             float *cb = p.C + (long)(urow0 + i * 32) * p.ldc + ucol0 + j * 32;       // wave-uniform
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + lr;
@@ -589,7 +599,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 float *slab = p.slab + (long)kslice * p.M * p.N;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < p.M) slab[(long)row * p.N + col] = acc[i][j][r];
                 }
                 continue;
@@ -602,14 +612,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 const int ldq = n0 >= p.n_split ? p.ldc2 : p.ldc, colq = n0 >= p.n_split ? col - p.n_split : col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < p.M) cq[(long)row * ldq + colq] = acc[i][j][r];
                 }
                 continue;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (EPI == 0) v = gemm_activation(v, p.relu);
@@ -817,6 +827,15 @@ static int launch_image_pair(PairArgs &p, int op, hipStream_t st) {
     return halo_launch_status();
 }
 
+// 64 x 128 workgroup tiles (TI = 1) for single-pass, whole-K products whose 128-row tiles would number 257 .. 511: a CU holds three
+// workgroups, so such a launch leaves half the CUs with two and half with one; twice as many half-height tiles are three per CU.
+// HALO_GEMM_HALF_TILES=0 keeps the 128-row tiles.
+static bool half_tiles_wanted(int M, int ntiles128, int ksplit) {
+    const char *e = getenv("HALO_GEMM_HALF_TILES");
+    if (e && atoi(e) == 0) return false;
+    return ksplit == 1 && ntiles128 > 256 && ntiles128 < 512 && M >= 128;
+}
+
 struct CeEpilogue {
     const int64_t *target;
     float *part, *tlogit;
@@ -891,6 +910,13 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     const bool slice = p.ksplit > 1;                                                     // raw sums: the reduce kernel applies the epilogue
     const bool lean_any = p.ksplit == 1 && !p.use_drop && (relu & ~HALO_GEMM_ACCUM) == 0;
     const bool lean = lean_any && !(relu & HALO_GEMM_ACCUM), lean_add = lean_any && (relu & HALO_GEMM_ACCUM);   // bias only / bias + C += result
+    if (one_pass && nstage1 == 3 && !ce && (lean || lean_add) && half_tiles_wanted(M, p.ntiles, p.ksplit)) {
+        p.ntiles = ((M + 63) / 64) * p.tiles_n;
+        const dim3 gh((unsigned)p.ntiles);
+        if (lean) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 0, 1>), gh, dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 3, 0, 1>), gh, dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);
+        return halo_launch_status();
+    }
     if (ce) {                       // the epilogue instantiations (kept apart: compiled into the common kernel the extra registers and
                                     // epilogue code cost every product 6-17 % and the LSTM-CTC step 2.6 %, same-box A/B)
         if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, true>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
@@ -949,6 +975,10 @@ int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int
     p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
     p.ksplit = 1; p.ktper = p.KT;
     const dim3 grid((unsigned)p.ntiles);
+    if (halo_math_mode() == HALO_MATH_BF16 && half_tiles_wanted(M, p.ntiles, 1)) {
+        p.ntiles = ((M + 63) / 64) * p.tiles_n;
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4, 1>), dim3((unsigned)p.ntiles), dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);
+    } else
     if (halo_math_mode() == HALO_MATH_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (p.ntiles >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 1, 4>), grid, dim3(256), STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 1, 4>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
@@ -958,7 +988,15 @@ int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int
 // The tiled product with row-major bf16 on either side (IO instantiations of the kernel): A from a row-major bf16 matrix (a_hi [, a_lo])
 // instead of an image, and / or the result as row-major bf16 (o_hi [, o_lo]) beside or instead of fp32 C.  No split-K, no dropout.
 template <int EPI, int IO>
-static int launch_io(const TiledGemmArgs &p, bool one_pass, hipStream_t st) {
+static int launch_io(const TiledGemmArgs &p0, bool one_pass, hipStream_t st) {
+    TiledGemmArgs p = p0;
+    if constexpr (IO == 1 && (EPI == 1 || EPI == 3)) {
+        if (one_pass && half_tiles_wanted(p.M, p.ntiles, 1)) {
+            p.ntiles = ((p.M + 63) / 64) * p.tiles_n;
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, EPI, IO, 1>), dim3((unsigned)p.ntiles), dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);
+            return halo_launch_status();
+        }
+    }
     const dim3 grid((unsigned)p.ntiles);
     if (one_pass) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, EPI, IO>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (p.ntiles >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, EPI, IO>), grid, dim3(256), STAGE_BYTES, st, p);

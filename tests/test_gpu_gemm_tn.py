@@ -70,3 +70,33 @@ def test_two_slices_of_a_very_long_contraction():
         assert (got[rows].double() - want).abs().max().item() <= 5e-3
     finally:
         _lib.set_math_mode(prev)
+
+
+@pytest.mark.parametrize('M,N,K', [(8192, 768, 768), (8192, 768, 3072), (8200, 640, 96), (4096, 1152, 1344)])
+def test_half_height_tiles_equal_the_full_tiles(monkeypatch, M, N, K):
+    """Single-pass products with 257 .. 511 full tiles run on 64 x 128 tiles (three workgroups per CU instead of one or two): the same
+    k order per output element, so the same bits -- plain, with a residual addend, and with the A operand staged from row-major rows."""
+    from haloop_amd import _lib, ops
+    _lib.lend_scratch(256 << 20)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        a = torch.randn(M, K, generator=g).cuda()
+        b = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        r = torch.randn(M, N, generator=g).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        ai, bi, ab = ops.split_image(a), ops.split_image(b), ops.cast_bf16(a)
+        rows_ok = K % 32 == 0
+        out = {}
+        for name, v in (('half', '1'), ('full', '0')):
+            monkeypatch.setenv('HALO_GEMM_HALF_TILES', v)
+            out[name] = (ops.gemm_split(ai, bi, M, N, K, bias1=bias), ops.gemm_split(ai, bi, M, N, K, residual=r),
+                         ops.gemm_split_io((ab, None), bi, M, N, K, bias1=bias) if rows_ok else None,
+                         ops.gemm_split_io((ab, None), bi, M, N, K, residual=r) if rows_ok else None)
+        for x, y in zip(out['half'], out['full']):
+            assert (x is None and y is None) or torch.equal(x, y)
+        want = a[:64].bfloat16().double() @ b.bfloat16().double().t() + bias.double()
+        assert (out['half'][0][:64].double() - want).abs().max().item() <= 2e-3
+    finally:
+        _lib.set_math_mode(prev)
