@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 12
+HALO_ABI_VERSION = 13
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -56,6 +56,7 @@ SIGNATURES = {
     'halo_subsample_col_bytes': (_sz, [_i] * 6),
     'halo_subsample_fwd': (_i, [_vp] * 5 + [_i] * 7 + [_f, _u64, _u32, _vp, _vp]),
     'halo_subsample_bwd': (_i, [_vp] * 6 + [_i] * 7 + [_f, _vp]),
+    'halo_subsample_bwd_slabs': (_i, [_vp, _i] + [_vp] * 5 + [_i] * 7 + [_f, _vp]),
     'halo_lstm_reserve_bytes': (_sz, [_i] * 5),
     'halo_lstm_bwd_workspace_bytes': (_sz, [_i] * 5),
     'halo_lstm_fwd': (_i, [_vp] * 8 + [_l, _l, _i, _vp, _vp, _vp] + [_i] * 5 + [_f, _u64, _u32, _vp, _vp]),
@@ -65,6 +66,8 @@ SIGNATURES = {
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
     'halo_set_lstm_expect_backward': (_i, [_i]),
+    'halo_set_lstm_dx_slabs': (_i, [_i]),
+    'halo_lstm_dx_slabs_left': (_i, []),
     'halo_set_lstm_weights_stamp': (_i, [_u64]),
     'halo_lstm_persistent2_eligible': (_i, [_i, _i, _i, _i]),
     'halo_lstm_status_offset': (_sz, [_i] * 6),

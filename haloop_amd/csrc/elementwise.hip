@@ -118,15 +118,26 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__re
         dpre[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
+// dy slices summed in place into slice 0 (the unfused fallback of halo_subsample_bwd_slabs)
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float *__restrict__ dy, size_t n, int slabs, long slab_stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float g = dy[i];
+        for (int q = 1; q < slabs; ++q) g += dy[i + q * slab_stride];
+        dy[i] = g;
+    }
+}
+
 // The front-end convolution's backward in two launches (relu/dropout mask + weight-gradient product + bias column sums, then the
 // reduction of the row chunks) instead of four (mask, exact-f32 GEMM, split-K reduce, column sum).  Workgroup (chunk, c-tile, n-half):
 // rows [chunk * CH, +CH) of dy / y / col, 16 output channels, half of the K = F * ks columns.  dpre = dy * (y > 0 ? scale : 0) of its
 // rows x 16 channels goes to LDS (it is the A operand, read transposed: A[m = channel][k = row]); the B fragments B[k = row][n] are
 // read straight from col (4 rows x 16 columns = 4 x 64 contiguous bytes per wave instruction); fp32 MFMA 16x16x4, rows in order.
 // part[chunk][c][k] and bias_part[chunk][c] are summed over the chunks, in order, by subsample_bwd_reduce_kernel.
+// slabs > 1: dy is the sum of that many [rows][C] matrices slab_stride floats apart (halo_subsample_bwd_slabs).
 __global__ __launch_bounds__(256) void subsample_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                                     const float *__restrict__ col, float *__restrict__ part,
-                                                                    float *__restrict__ bias_part, int rows, int C, int K, int CH, float scale) {
+                                                                    float *__restrict__ bias_part, int rows, int C, int K, int CH, float scale,
+                                                                    int slabs, long slab_stride) {
     extern __shared__ float dp[];                      // [CH rounded up to 32][17], zero beyond the chunk's rows
     const int chunk = blockIdx.x, c0 = blockIdx.y * 16, nh = blockIdx.z;
     const int row0 = chunk * CH, nrows = min(CH, rows - row0), CHP = (CH + 31) / 32 * 32;
@@ -136,7 +147,16 @@ __global__ __launch_bounds__(256) void subsample_bwd_partial_kernel(const float 
         float v = 0.f;
         if (r < nrows) {
             const long o = (long)(row0 + r) * C + c0 + c;
-            v = y[o] > 0.f ? dy[o] * scale : 0.f;
+            // dy left as K-slices by its producer: added in order, eight independent loads at a time
+            float g = dy[o];
+            for (int q0 = 1; q0 < slabs; q0 += 8) {
+                float gq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gq[q] = dy[o + min(q0 + q, slabs - 1) * slab_stride];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) g += q0 + q < slabs ? gq[q] : 0.f;
+            }
+            v = y[o] > 0.f ? g * scale : 0.f;
         }
         dp[r * 17 + c] = v;
     }
@@ -391,7 +411,12 @@ int halo_subsample_fwd(const float *x, const float *w, const float *bias, float 
 
 int halo_subsample_bwd(const float *dy, const float *y, const float *col, float *dpre, float *dw, float *dbias, int B,
                        int T, int F, int C, int ks, int stride, int pad, float p_drop, halo_stream_t stream) {
-    HALO_CHECK_ARG(dy && y && col && dpre && dw && dbias);
+    return halo_subsample_bwd_slabs((float *)dy, 1, y, col, dpre, dw, dbias, B, T, F, C, ks, stride, pad, p_drop, stream);
+}
+
+int halo_subsample_bwd_slabs(float *dy, int slabs, const float *y, const float *col, float *dpre, float *dw, float *dbias, int B,
+                             int T, int F, int C, int ks, int stride, int pad, float p_drop, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy && y && col && dpre && dw && dbias && slabs >= 1);
     HALO_CHECK_ARG(B > 0 && T > 0 && F > 0 && C > 0 && ks > 0 && stride > 0 && pad >= 0 && T + 2 * pad >= ks);
     const int Tp = subsampled_len(T, ks, stride, pad);
     const size_t n = (size_t)Tp * B * C;
@@ -409,7 +434,7 @@ int halo_subsample_bwd(const float *dy, const float *y, const float *col, float 
         if (fused && scratch && bytes >= need && K % 16 == 0 && K / 16 <= 32 && C % 16 == 0 && rows >= 64 && CH <= 512) {
             float *part = (float *)scratch, *bias_part = part + (size_t)chunks * C * K;
             hipLaunchKernelGGL(subsample_bwd_partial_kernel, dim3(chunks, C / 16, 2), dim3(256), (size_t)((CH + 31) / 32 * 32) * 17 * sizeof(float), st, dy, y,
-                               col, part, bias_part, rows, C, K, CH, scale);
+                               col, part, bias_part, rows, C, K, CH, scale, slabs, (long)n);
             int rc = halo_launch_status();
             if (rc) return rc;
             const long CK = (long)C * K;
@@ -417,6 +442,11 @@ int halo_subsample_bwd(const float *dy, const float *y, const float *col, float 
                                dbias, chunks, CK, C);
             return halo_launch_status();
         }
+    }
+    if (slabs > 1) {
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, n, slabs, (long)n);
+        int rc = halo_launch_status();
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, y, dpre, n, scale);
     int rc = halo_launch_status();

@@ -13,56 +13,11 @@
 #include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
+#include "tiled_image.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int TR = 128;          // rows per tile
-constexpr int TK = 32;           // k per tile
-constexpr int PART_BYTES = TR * TK * 2;      // 8192
-constexpr int BLOCK_BYTES = 2 * PART_BYTES;  // hi + lo
-
-__device__ __forceinline__ int swz_byte(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
-
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        hi[j] = h;
-        lo[j] = (__bf16)(x[j] - (float)h);
-    }
-}
-
-// src row-major [R][K] (leading dimension ld): one workgroup writes one (rt, kt) block
-__device__ __forceinline__ void prep_rowmajor_block(const float *__restrict__ src, int R, int K, int ld, char *__restrict__ img,
-                                                    int KT, int with_lo, int kt, int rt) {
-    char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
-    const bool vec = (ld % 4 == 0) && ((uintptr_t)src % 16 == 0);
-#pragma unroll
-    for (int u = threadIdx.x; u < TR * 4; u += 256) {
-        const int row = u >> 2, c = u & 3;
-        const int gr = rt * TR + row, gk = kt * TK + c * 8;
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = 0.f;
-        if (gr < R) {
-            const float *p = src + (long)gr * ld + gk;
-            if (vec && gk + 7 < K) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
-                x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (gk + j < K) x[j] = p[j];
-            }
-        }
-        bf16x8 hi, lo;
-        split8(x, hi, lo);
-        const int off = swz_byte(row, c);
-        *reinterpret_cast<bf16x8 *>(blk + off) = hi;
-        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;   // HALO_MATH_BF16 never reads the lo part
-    }
-}
+using namespace halo_img;
 
 __global__ __launch_bounds__(256) void prep_rowmajor_kernel(const float *__restrict__ src, int R, int K, int ld,
                                                             char *__restrict__ img, int KT, int with_lo) {
@@ -952,6 +907,33 @@ static int gemm_bf16x3_tiled_impl(const void *Aimg, const void *Bimg, int M, int
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, bias1, bias2, relu, p.drop, p.use_drop, st);
 }
 
+
+// K-slices of A [M][K] x B [N][K]^T left UNREDUCED: slice s (k-tiles [s ktper, (s + 1) ktper)) goes to slab + s M N as plain [M][N] sums, for a
+// consumer that adds the slices while it reads them (the front-end convolution's backward reads the LSTM's input gradient exactly once:
+// the reduce launch between them, 8 us for 2.7 MB, is pure latency).  *slices = how many were written (<= want).
+int halo_gemm_bf16x3_tiled_slices(const void *Aimg, const void *Bimg, int M, int N, int K, float *slab, int want, int *slices, hipStream_t st) {
+    if (!Aimg || !Bimg || !slab || !slices || M <= 0 || N <= 0 || K <= 0 || want < 1) return HALO_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gemm_bf16x3_kernel<2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    TiledGemmArgs p = {};
+    p.A = (const char *)Aimg; p.B = (const char *)Bimg;
+    p.M = M; p.N = N; p.KT = (K + TK - 1) / TK; p.ldc = N;
+    p.tiles_n = (N + TR - 1) / TR;
+    p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
+    p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
+    p.ktper = (p.KT + want - 1) / want;
+    p.ksplit = (p.KT + p.ktper - 1) / p.ktper;
+    p.slab = slab;
+    *slices = p.ksplit;
+    const dim3 grid((unsigned)(p.ntiles * p.ksplit));
+    if (halo_math_mode() == HALO_MATH_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 2>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 2>), grid, dim3(256), 2 * STAGE_BYTES, st, p);
+    return halo_launch_status();
+}
 
 // C [M][n_split] | C2 [M][N - n_split] = A [M][K] x (B [n_split][K] stacked on B2 [N - n_split][K])^T in ONE launch: the image of the
 // stacked operand is the two images one after the other when n_split is a multiple of the 128-row tile.  The LSTM's two weight-gradient

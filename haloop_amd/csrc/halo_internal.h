@@ -26,6 +26,7 @@ int halo_prep_jobs(const HaloPrepJob *jobs, int n, hipStream_t st);
 // C[M,N] = A[M,K] * B[N,K]^T from images, epilogue as halo_gemm_f32
 int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc,
                            const float *bias1, const float *bias2, int relu, const DropoutCfg *drop, hipStream_t st);
+int halo_gemm_bf16x3_tiled_slices(const void *Aimg, const void *Bimg, int M, int N, int K, float *slab, int want, int *slices, hipStream_t st);
 // ---- settings record (include/halo.h, "Contexts"): every switch the halo_set_* entries change lives here.  A thread that has selected
 // a caller-owned context with halo_ctx_use() reads and writes THAT record; every other thread the process-wide default one.
 struct HaloCtx {
@@ -40,6 +41,8 @@ struct HaloCtx {
     unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
     hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
     unsigned long long *stamps = nullptr;
+    int lstm_dx_slabs = 1;               // halo_set_lstm_dx_slabs: K-slices the caller's dx buffer has room for
+    int lstm_dx_slabs_left = 1;          // how many the last halo_lstm_bwd left unreduced there (1: dx itself)
     int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)
     const float *packT_reserve = nullptr, *packT_w[3] = {nullptr, nullptr, nullptr};   // ... into this reserve, from these weights (host bookkeeping)
     const float *bwdflags_reserve = nullptr;   // ... and zeroed the backward launch's epoch words in this reserve (the backward then needs no prologue launch)

@@ -24,6 +24,7 @@
 #include <string.h>
 #include "halo_common.h"
 #include "halo_internal.h"
+#include "tiled_image.h"
 #include "lstm_persist.h"
 
 namespace {
@@ -559,14 +560,25 @@ struct PackPairArgs {
     char *zbase[2];
     long zstride, zunits;
     int zcount;
+    // rm_blocks workgroups behind the tile blocks write GEMM operand images (tiled_image.h) of up to two row-major fp32 matrices: layer
+    // lo's input and W_ih of layer lo, the operands of its input projection -- that product's own operand launch is gone
+    struct { const float *src; int R, K, ld, KT; char *img; } rm[2];
+    int rm_first1, rm_blocks, rm_with_lo;
 };
 __global__ __launch_bounds__(256) void persist2_pack_pair_kernel(const PackPairArgs a) {
     __shared__ float tile[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= a.tile_blocks && (int)blockIdx.x < a.tile_blocks + a.rm_blocks) {
+        const int b = blockIdx.x - a.tile_blocks, j = b >= a.rm_first1 ? 1 : 0, local = b - (j ? a.rm_first1 : 0);
+        halo_img::prep_rowmajor_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, local % a.rm[j].KT,
+                                      local / a.rm[j].KT);
+        return;
+    }
     if ((int)blockIdx.x >= a.tile_blocks) {
         const Prologue2Args &r = a.rest;
         const long ns = 2 * r.s_units, nz = 2L * a.zcount * a.zunits, total = ns + r.zero_units + r.zero2_units + nz;
-        for (long u = (blockIdx.x - a.tile_blocks) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - a.tile_blocks) * 256) {
+        const int first = a.tile_blocks + a.rm_blocks;
+        for (long u = (blockIdx.x - first) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - first) * 256) {
             if (u >= ns + r.zero_units + r.zero2_units) {
                 const long v = u - (ns + r.zero_units + r.zero2_units);
                 const long per = (long)a.zcount * a.zunits;
@@ -1273,11 +1285,14 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
     w_ih += lo; w_hh += lo; b_ih += lo; b_hh += lo;                   // index 0 / 1 below = layer lo / lo + 1
     if (h0) h0 += (size_t)lo * BH;
     if (c0) c0 += (size_t)lo * BH;
-    if (in_dim >= 64) {
+    HaloCtx &ctx = halo_ctx_cur();
+    // with a backward to follow, the weight-packing launch below also writes this product's two operand images: it then runs first
+    const bool images_by_pack = in_dim >= 64 && ctx.lstm_expect_backward && H % 32 == 0;
+    if (in_dim >= 64 && !images_by_pack) {
         const HaloPrepJob jobs[2] = {{0, in, T * B, in_dim, in_dim, img_in, nullptr}, {0, w_ih[0], 4 * H, in_dim, in_dim, img_w, nullptr}};
         HALO_TRY(halo_prep_jobs(jobs, 2, st));
         HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
-    } else {
+    } else if (in_dim < 64) {
         HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[0], in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0, 0,
                                nullptr, (halo_stream_t)st));
     }
@@ -1295,7 +1310,6 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
     pa.zero = flags; pa.zero_units = (long)(PERSIST_FLAG_BYTES / 16);
     pa.zero2 = nullptr; pa.zero2_units = 0;
     pa.H = H; pa.B = B;
-    HaloCtx &ctx = halo_ctx_cur();
     ctx.packT_reserve = nullptr;
     ctx.emitT_reserve = nullptr;
     char *emit_hT0 = nullptr, *emit_hT1 = nullptr, *emit_xT1 = nullptr;
@@ -1321,9 +1335,19 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
             pp.zstride = KT * 16384; pp.zunits = (long)(B / 32) * 16384 / 16; pp.zcount = H / 128;
             ctx.emitT_reserve = reserve;
         }
+        pp.rm_first1 = 0; pp.rm_blocks = 0; pp.rm_with_lo = halo_math_mode() != HALO_MATH_BF16;
+        if (images_by_pack) {
+            const int KT = (in_dim + 31) / 32;
+            pp.rm[0] = {in, T * B, in_dim, in_dim, KT, img_in};
+            pp.rm[1] = {w_ih[0], 4 * H, in_dim, in_dim, KT, img_w};
+            pp.rm_first1 = ((T * B + 127) / 128) * KT;
+            pp.rm_blocks = pp.rm_first1 + ((4 * H + 127) / 128) * KT;
+        }
         const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + pp.rest.zero2_units + 2L * pp.zcount * pp.zunits));
-        hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)pp.tile_blocks + rest_blocks), dim3(256), 0, st, pp);
+        hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)(pp.tile_blocks + pp.rm_blocks) + rest_blocks), dim3(256), 0, st, pp);
         HALO_TRY(halo_launch_status());
+        if (images_by_pack)
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
         ctx.packT_reserve = reserve;
         ctx.bwdflags_reserve = reserve;
         for (int m = 0; m < 3; ++m) ctx.packT_w[m] = pa.w[m];
@@ -1428,6 +1452,12 @@ int halo_set_lstm_weights_stamp(uint64_t stamp) {
     return HALO_OK;
 }
 
+int halo_set_lstm_dx_slabs(int n) {
+    if (n < 1 || n > 64) return HALO_EINVAL;
+    halo_ctx_cur().lstm_dx_slabs = n;
+    return HALO_OK;
+}
+int halo_lstm_dx_slabs_left(void) { return halo_ctx_cur().lstm_dx_slabs_left; }
 int halo_set_lstm_expect_backward(int on) {
     halo_ctx_cur().lstm_expect_backward = on ? 1 : 0;
     return HALO_OK;
@@ -1586,6 +1616,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
     HALO_CHECK_ARG(layer_end < L || dy || dhn || dcn);
     HALO_CHECK_ARG(T > 0 && B > 0 && in0 > 0 && H > 0 && L > 0);
     if (H % 16 != 0) return HALO_ENOTSUP;
+    halo_ctx_cur().lstm_dx_slabs_left = 1;
     hipStream_t st = (hipStream_t)stream;
     const size_t BH = (size_t)B * H, PG = bt16(B) * 4 * H;
     const bool x3 = use_x3(H);
@@ -1697,6 +1728,10 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)
                 const DropoutCfg ddrop = make_dropout(lo > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(lo > 0 ? lo - 1 : 0), offset,
                                                       offset_dev);
+                if (lo == 0 && ctx.lstm_dx_slabs > 1) {
+                    // the caller's buffer has room for K-slices and its consumer adds them as it reads (halo_set_lstm_dx_slabs): no reduce launch
+                    HALO_TRY(halo_gemm_bf16x3_tiled_slices(img_g, img_wT, T * B, in_lo_dim, 4 * H, din_out, ctx.lstm_dx_slabs, &ctx.lstm_dx_slabs_left, st));
+                } else
                 HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_lo_dim, 4 * H, din_out, in_lo_dim, nullptr, nullptr, 0, &ddrop, st));
             }
             HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT, hT0, 4 * H, H + in_lo_dim, T * B, dw_hh[lo], H, H, dw_ih[lo], in_lo_dim, st));

@@ -258,15 +258,19 @@ def subsample_fwd(x, w, bias, drop, ks=5, stride=4, pad=3):
     return y, col
 
 
-def subsample_bwd(dy, y, col, B, T, F, Cc, p_drop, dw=None, dbias=None, ks=5, stride=4, pad=3):
+def subsample_bwd(dy, y, col, B, T, F, Cc, p_drop, dw=None, dbias=None, ks=5, stride=4, pad=3, slabs=1):
+    """``slabs`` > 1: ``dy`` is [slabs, T', B, C], the gradient left as that many K-slices by ``lstm_bwd(..., dx_slabs=)``; they are added
+    while they are read."""
     _f32c(dy, 'dy')
+    if slabs > 1 and dy.numel() < slabs * y.numel():
+        raise ValueError('haloop_amd.ops.subsample_bwd: dy holds fewer than `slabs` matrices')
     dpre = torch.empty_like(y)
     if dw is None:
         dw = torch.empty(Cc, F, ks, device=y.device, dtype=torch.float32)
     if dbias is None:
         dbias = torch.empty(Cc, device=y.device, dtype=torch.float32)
-    check(lib().halo_subsample_bwd(ptr(dy), ptr(y), ptr(col), ptr(dpre), ptr(dw), ptr(dbias), B, T, F, Cc, ks, stride,
-                                   pad, p_drop, _stream()), 'halo_subsample_bwd')
+    check(lib().halo_subsample_bwd_slabs(ptr(dy), int(slabs), ptr(y), ptr(col), ptr(dpre), ptr(dw), ptr(dbias), B, T, F, Cc, ks, stride,
+                                         pad, p_drop, _stream()), 'halo_subsample_bwd_slabs')
     return dw, dbias
 
 
@@ -325,10 +329,12 @@ def lstm_bwd_workspace(x_tm, w_hh):
 
 
 def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=None, want_dx=False,
-             grads=None, drop=NO_DROPOUT, layers=None, workspace=None, dx=None):
+             grads=None, drop=NO_DROPOUT, layers=None, workspace=None, dx=None, dx_slabs=1):
     """Returns (dx or None, grads dict of lists dw_ih/dw_hh/db_ih/db_hh).  ``grads`` may carry
     preallocated outputs.  ``layers=(lo, hi)`` runs only that range (top down); a split backward
-    passes the same ``workspace`` (ops.lstm_bwd_workspace) to both calls."""
+    passes the same ``workspace`` (ops.lstm_bwd_workspace) to both calls.
+    ``dx_slabs`` > 1: ``dx`` has room for that many [T, B, in] matrices and the call may leave the input gradient there as unreduced
+    K-slices; ``lstm_dx_slabs_left()`` right after the call says how many (1: dx[0] is the gradient), for ``subsample_bwd(slabs=)``."""
     T, B, in0 = x_tm.shape
     L = len(w_hh)
     H = w_hh[0].shape[1]
@@ -347,10 +353,23 @@ def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=Non
     a_ih, a_hh = ptr_array(w_ih), ptr_array(w_hh)
     g_ih, g_hh = ptr_array(grads['dw_ih']), ptr_array(grads['dw_hh'])
     g_bi, g_bh = ptr_array(grads['db_ih']), ptr_array(grads['db_hh'])
-    check(lib().halo_lstm_bwd(ptr(x_tm), a_ih, a_hh, ptr(dy), y_strides[0], y_strides[1], int(y_relu), ptr(dhn),
-                              ptr(dcn), ptr(reserve), ptr(ws), ptr(dx), g_ih, g_hh, g_bi, g_bh, T, B, in0, H, L, lo, hi,
-                              drop.p, drop.seed, drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_bwd')
+    if dx_slabs > 1:
+        if dx is None or dx.numel() < dx_slabs * T * B * in0:
+            raise ValueError('haloop_amd.ops.lstm_bwd: dx_slabs needs a dx buffer of that many [T, B, in] matrices')
+        check(lib().halo_set_lstm_dx_slabs(int(dx_slabs)), 'halo_set_lstm_dx_slabs')
+    try:
+        check(lib().halo_lstm_bwd(ptr(x_tm), a_ih, a_hh, ptr(dy), y_strides[0], y_strides[1], int(y_relu), ptr(dhn),
+                                  ptr(dcn), ptr(reserve), ptr(ws), ptr(dx), g_ih, g_hh, g_bi, g_bh, T, B, in0, H, L, lo, hi,
+                                  drop.p, drop.seed, drop.offset, drop.counter_ptr, _stream()), 'halo_lstm_bwd')
+    finally:
+        if dx_slabs > 1:
+            lib().halo_set_lstm_dx_slabs(1)
     return dx, grads
+
+
+def lstm_dx_slabs_left():
+    """How many K-slices the last ``lstm_bwd`` of this thread's context left in its dx buffer (1: the gradient itself)."""
+    return int(lib().halo_lstm_dx_slabs_left())
 
 
 def log_softmax_fwd(x2d):

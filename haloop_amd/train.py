@@ -89,6 +89,8 @@ class FlatParams:
 
 
 class LstmCtcTrainer:
+    DX_SLABS = int(os.environ.get('HALO_DX_SLABS', '16'))        # K-slices of the LSTM's input-gradient product that the conv backward adds while reading (ops.lstm_bwd dx_slabs)
+
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
                  alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False):
@@ -229,12 +231,14 @@ class LstmCtcTrainer:
     def _lstm_backward_top(self, x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats, dims):
         B, T, F, Cc, H, Tp, L = dims
         ws = ops.lstm_bwd_workspace(y_sub, w_hh)
-        dy_sub = torch.empty_like(y_sub)
+        # room for the K-slices of the input-gradient product: the conv backward adds them as it reads, no reduce launch between
+        dy_sub = torch.empty((self.DX_SLABS,) + tuple(y_sub.shape), device=y_sub.device, dtype=torch.float32)
         # one process: the whole stack in one call (a 2-layer stack in bf16 mode then runs as ONE two-layer persistent launch,
         # csrc/lstm_persist2.hip); data parallel: the top layer first, so that the first gradient bucket is final early
         top = (L - 1 if L > 1 else 0) if (self.world > 1 and self.dp_algo == 'allreduce') else 0
         ops.lstm_bwd(y_sub, w_ih, w_hh, dfeats, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(top, L),
-                     workspace=ws, dx=dy_sub)
+                     workspace=ws, dx=dy_sub, dx_slabs=self.DX_SLABS)
+        self._dx_slabs = ops.lstm_dx_slabs_left() if top == 0 else 1
         return (y_sub, col, w_ih, w_hh, reserve, grads, drop, ws, dy_sub, top, (B, T, F, Cc, H, Tp, L))
 
     def _backward_rest(self, st):
@@ -257,7 +261,7 @@ class LstmCtcTrainer:
                 ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
                              workspace=ws, dx=dy_sub)
         ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
-                          dbias=gv['encoder.subsample.bias'])
+                          dbias=gv['encoder.subsample.bias'], slabs=self._dx_slabs)
 
     def _all_reduce(self):
         self.avg_early.average()

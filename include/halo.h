@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 12
+#define HALO_ABI_VERSION 13
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -219,6 +219,12 @@ int halo_subsample_fwd(const float *x, const float *w, const float *bias, float 
 int halo_subsample_bwd(const float *dy, const float *y, const float *col, float *dpre, float *dw,
                        float *dbias, int B, int T, int F, int C, int ks, int stride, int pad, float p_drop,
                        halo_stream_t stream);
+/* The same with dy handed over as `slabs` K-slices of the product that formed it -- [slabs][T'*B][C] floats, dy = their sum in order --
+ * which the kernel adds while it reads them (halo_set_lstm_dx_slabs below: the LSTM backward's input-gradient product then runs without
+ * its split-K reduce launch).  slabs = 1 is halo_subsample_bwd.  The unfused fallback sums the slices into slice 0 first. */
+int halo_subsample_bwd_slabs(float *dy, int slabs, const float *y, const float *col, float *dpre, float *dw,
+                             float *dbias, int B, int T, int F, int C, int ks, int stride, int pad, float p_drop,
+                             halo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-layer LSTM, gate order i,f,g,o, two bias vectors per layer.
@@ -306,6 +312,12 @@ int halo_set_lstm_weights_stamp(uint64_t stamp);
  * backward's three transposed images from the same read of the weights, into the reserve, and halo_lstm_bwd called with that reserve
  * and those weight pointers packs nothing.  Inference callers switch it off (0): the forward then packs its own three only. */
 int halo_set_lstm_expect_backward(int on);
+/* n > 1: the caller's dx buffer of the NEXT halo_lstm_bwd calls has room for n matrices [T*B][in0] and its consumer can add K-slices
+ * (halo_subsample_bwd_slabs): the two-layer launch's input-gradient product (layer_begin = 0) may then leave up to n unreduced slices there
+ * instead of running a reduce launch.  halo_lstm_dx_slabs_left() after the call says how many it left (1: dx is the gradient itself, as
+ * always on every other path).  1 <= n <= 64; default 1.  Per context. */
+int halo_set_lstm_dx_slabs(int n);
+int halo_lstm_dx_slabs_left(void);
 int halo_lstm_persistent2_eligible(int T, int B, int H, int L);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 

@@ -347,6 +347,50 @@ def test_split_backward_follows_the_two_layer_forward(hal, math_mode):
 
 
 @pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,C,H', [(20, 64, 128, 1024), (7, 32, 128, 256)])
+def test_input_gradient_left_as_k_slices_for_the_conv_backward(hal, math_mode, T, B, C, H):
+    """ops.lstm_bwd(dx_slabs=n) leaves the two-layer launch's input gradient as unreduced K-slices (no split-K reduce launch) and
+    ops.subsample_bwd(slabs=) adds them while reading: the slices sum to the plain call's dx (another summation order of the same
+    products), and the conv's weight / bias gradients from the slices equal those from the summed matrix."""
+    ops, lib = hal['ops'], hal['lib']
+    L, F_, ks = 2, 16, 5
+    g = torch.Generator().manual_seed(5)
+    k = 1.0 / H ** 0.5
+    x = torch.relu(torch.randn(T, B, C, generator=g)).to(DEV)            # the conv's relu output: its sign pattern is the mask
+    col = torch.randn(T * B, F_ * ks, generator=g).to(DEV)
+    w_ih = [((torch.rand(4 * H, C if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_ih = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b_hh = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    dy = torch.randn(T, B, H, generator=g).to(DEV)
+    _, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh)
+    ws = ops.lstm_bwd_workspace(x, w_hh)
+    dx_plain, grads_plain = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, workspace=ws, want_dx=True)
+    assert ops.lstm_dx_slabs_left() == 1
+    _, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh)
+    n = 16
+    slabs = torch.full((n, T, B, C), float('nan'), device=DEV)
+    _, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, workspace=ws, dx=slabs, dx_slabs=n)
+    left = ops.lstm_dx_slabs_left()
+    two_layer = bool(lib.lib().halo_lstm_persistent2_eligible(T, B, H, L)) and math_mode == 'bf16'
+    assert (left > 1) == two_layer and left <= n
+    summed = slabs[:left].sum(0)
+    assert torch.isfinite(summed).all()
+    scale = dx_plain.abs().max().item()
+    assert (summed - dx_plain).abs().max().item() <= 2e-5 * scale + 1e-7
+    for name in grads:
+        for a, b in zip(grads[name], grads_plain[name]):
+            assert torch.equal(a, b)
+    Tin = 4 * (T - 1) + ks - 6          # a frame count whose subsampled length is T
+    dw_a, db_a = ops.subsample_bwd(slabs, x, col, B, Tin, F_, C, 0.0, slabs=left)
+    dw_b, db_b = ops.subsample_bwd(summed.contiguous(), x, col, B, Tin, F_, C, 0.0)
+    assert torch.allclose(dw_a, dw_b, rtol=1e-5, atol=1e-5 * dw_b.abs().max().item())
+    assert torch.allclose(db_a, db_b, rtol=1e-5, atol=1e-5 * db_b.abs().max().item())
+    assert ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh)[3], workspace=ws, want_dx=True)[0] is not None
+    assert ops.lstm_dx_slabs_left() == 1                # the setting does not outlive the call that asked for it
+
+
+@pytest.mark.parametrize('math_mode', ['bf16x3', 'bf16'], indirect=True)
 def test_two_train_mode_steps_at_config2_match_the_oracle_with_the_same_masks(hal, math_mode):
     """The benchmarked configuration itself -- LC-2x1024, B=64, dropout 0.2 in all three places (ha/rnn.py:8,11, ha/recognizer.py:41),
     the whole step replayed from one HIP graph with the device-side dropout counter, the persistent recurrences (bf16: the two-layer
