@@ -67,6 +67,8 @@ SIGNATURES = {
     'halo_set_lstm_persistent2': (_i, [_i]),
     'halo_set_lstm_expect_backward': (_i, [_i]),
     'halo_set_lstm_dx_slabs': (_i, [_i]),
+    'halo_set_defer_small_jobs': (_i, [_i]),
+    'halo_flush_small_jobs': (_i, [_vp]),
     'halo_lstm_dx_slabs_left': (_i, []),
     'halo_set_lstm_weights_stamp': (_i, [_u64]),
     'halo_lstm_persistent2_eligible': (_i, [_i, _i, _i, _i]),

@@ -203,8 +203,15 @@ __global__ __launch_bounds__(256) void subsample_bwd_partial_kernel(const float 
     }
 }
 
+// ... and, from the blocks behind its own (own_blocks of them), the small reductions queued on the context (small_jobs.h)
 __global__ __launch_bounds__(256) void subsample_bwd_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part,
-                                                                   float *__restrict__ dw, float *__restrict__ dbias, int chunks, long CK, int C) {
+                                                                   float *__restrict__ dw, float *__restrict__ dbias, int chunks, long CK, int C,
+                                                                   int own_blocks, const HaloSmallJobs jobs) {
+    if ((int)blockIdx.x >= own_blocks) {
+        __shared__ float red[4][64];
+        halo_small_jobs_block(jobs, blockIdx.x - own_blocks, red);
+        return;
+    }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < CK) {
         float sum = 0.f;
@@ -215,6 +222,11 @@ __global__ __launch_bounds__(256) void subsample_bwd_reduce_kernel(const float *
         for (int q = 0; q < chunks; ++q) sum += bias_part[(long)q * C + (i - CK)];
         dbias[i - CK] = sum;
     }
+}
+
+__global__ __launch_bounds__(256) void small_jobs_kernel(const HaloSmallJobs jobs) {
+    __shared__ float red[4][64];
+    halo_small_jobs_block(jobs, blockIdx.x, red);
 }
 
 // one wave per row
@@ -346,6 +358,16 @@ int halo_fill(float *p, size_t n, float v, hipStream_t st) {
 
 static inline int subsampled_len(int T, int ks, int stride, int pad) { return (T + 2 * pad - ks) / stride + 1; }
 
+bool halo_defer_small_job(const HaloSmallJob &job) {
+    HaloCtx &ctx = halo_ctx_cur();
+    if (!ctx.defer_small_jobs || ctx.small_jobs.n >= HALO_SMALL_JOBS_MAX) return false;
+    HaloSmallJob &j = ctx.small_jobs.job[ctx.small_jobs.n++];
+    j = job;
+    j.blocks = halo_small_job_blocks(job);
+    ctx.small_jobs.blocks += j.blocks;
+    return true;
+}
+
 extern "C" {
 
 int halo_dropout_fwd(const float *x, float *y, size_t n, float p, uint64_t seed, uint32_t stream_id, uint32_t offset,
@@ -438,8 +460,11 @@ int halo_subsample_bwd_slabs(float *dy, int slabs, const float *y, const float *
             int rc = halo_launch_status();
             if (rc) return rc;
             const long CK = (long)C * K;
-            hipLaunchKernelGGL(subsample_bwd_reduce_kernel, dim3((unsigned)((CK + C + 255) / 256)), dim3(256), 0, st, part, bias_part, dw,
-                               dbias, chunks, CK, C);
+            const int own = (int)((CK + C + 255) / 256);
+            HaloSmallJobs &q = halo_ctx_cur().small_jobs;            // queued small reductions ride in this launch's tail blocks
+            hipLaunchKernelGGL(subsample_bwd_reduce_kernel, dim3((unsigned)(own + q.blocks)), dim3(256), 0, st, part, bias_part, dw,
+                               dbias, chunks, CK, C, own, q);
+            q.n = 0; q.blocks = 0;
             return halo_launch_status();
         }
     }
@@ -455,7 +480,24 @@ int halo_subsample_bwd_slabs(float *dy, int slabs, const float *y, const float *
     rc = halo_gemm_f32(0, 0, C, F * ks, Tp * B, dpre, C, col, F * ks, dw, F * ks, nullptr, nullptr, 0, 0.f, 0, 0, 0,
                        nullptr, stream);
     if (rc) return rc;
-    return halo_colsum(dpre, Tp * B, C, C, dbias, stream);
+    rc = halo_colsum(dpre, Tp * B, C, C, dbias, stream);
+    if (rc) return rc;
+    return halo_flush_small_jobs(stream);
+}
+
+int halo_set_defer_small_jobs(int on) {
+    HaloCtx &ctx = halo_ctx_cur();
+    ctx.defer_small_jobs = on ? 1 : 0;
+    if (on) { ctx.small_jobs.n = 0; ctx.small_jobs.blocks = 0; }
+    return HALO_OK;
+}
+
+int halo_flush_small_jobs(halo_stream_t stream) {
+    HaloSmallJobs &q = halo_ctx_cur().small_jobs;
+    if (q.n == 0) return HALO_OK;
+    hipLaunchKernelGGL(small_jobs_kernel, dim3((unsigned)q.blocks), dim3(256), 0, (hipStream_t)stream, q);
+    q.n = 0; q.blocks = 0;
+    return halo_launch_status();
 }
 
 int halo_log_softmax_fwd(const float *x, float *y, int rows, int cols, halo_stream_t stream) {

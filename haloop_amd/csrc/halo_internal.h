@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "halo_common.h"
+#include "small_jobs.h"
 
 int halo_transpose(const float *in, float *out, int rows, int cols, hipStream_t st);
 int halo_fill(float *p, size_t n, float v, hipStream_t st);
@@ -29,6 +30,8 @@ int halo_gemm_bf16x3_tiled(const void *Aimg, const void *Bimg, int M, int N, int
 int halo_gemm_bf16x3_tiled_slices(const void *Aimg, const void *Bimg, int M, int N, int K, float *slab, int want, int *slices, hipStream_t st);
 // ---- settings record (include/halo.h, "Contexts"): every switch the halo_set_* entries change lives here.  A thread that has selected
 // a caller-owned context with halo_ctx_use() reads and writes THAT record; every other thread the process-wide default one.
+// queue a small reduction on the context (true) or tell the caller to launch it itself (false: deferral off or the queue is full)
+bool halo_defer_small_job(const HaloSmallJob &job);
 struct HaloCtx {
     int math_mode = 0;
     int lstm_fusion = 0;
@@ -41,6 +44,8 @@ struct HaloCtx {
     unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
     hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
     unsigned long long *stamps = nullptr;
+    int defer_small_jobs = 0;            // halo_set_defer_small_jobs: small reductions wait in `small_jobs` for a launch that carries them
+    HaloSmallJobs small_jobs = {};
     int lstm_dx_slabs = 1;               // halo_set_lstm_dx_slabs: K-slices the caller's dx buffer has room for
     int lstm_dx_slabs_left = 1;          // how many the last halo_lstm_bwd left unreduced there (1: dx itself)
     int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)

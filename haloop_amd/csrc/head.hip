@@ -12,6 +12,7 @@
 // path needs T' <= 32, V <= 32, 2S+1 <= 64 and H % 64 == 0 (the caller falls back to the separate operators otherwise).
 #include <float.h>
 #include "halo_common.h"
+#include "halo_internal.h"
 
 namespace {
 
@@ -386,26 +387,11 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
     }
 }
 
-// dW[v][k] = sum_n dw_part[n][v][k], db[v] = sum_n db_part[n][v]: a block takes 64 consecutive elements, its four waves a quarter of the
-// utterances each (fixed order inside a quarter, then quarter 0 + 1 + 2 + 3)
-__global__ __launch_bounds__(256) void ctc_head_reduce_kernel(const float *__restrict__ dw_part, const float *__restrict__ db_part,
-                                                              float *__restrict__ dw, float *__restrict__ db, int B, long VH, int V) {
+// dW[v][k] = sum_n dw_part[n][v][k], db[v] = sum_n db_part[n][v]: small_jobs.h kind 1 (a block takes 64 consecutive elements, its four
+// waves a quarter of the utterances each); this launch when the caller does not defer small reductions
+__global__ __launch_bounds__(256) void ctc_head_reduce_kernel(const HaloSmallJobs q) {
     __shared__ float part[4][64];
-    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + e;
-    const int n0 = q * ((B + 3) / 4), n1 = min(B, n0 + (B + 3) / 4);
-    const bool is_db = i >= VH;                       // the blocks behind the weight elements sum the bias partials
-    const long j = is_db ? i - VH : i;
-    const float *src = is_db ? db_part : dw_part;
-    const long stride = is_db ? V : VH;
-    float s = 0.f;
-    if (j < (is_db ? (long)V : VH)) {
-#pragma unroll 8
-        for (int n = n0; n < n1; ++n) s += src[(long)n * stride + j];
-    }
-    part[q][e] = s;
-    __syncthreads();
-    if (q == 0 && j < (is_db ? (long)V : VH)) (is_db ? db : dw)[j] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    halo_small_jobs_block(q, blockIdx.x, part);
 }
 
 }  // namespace
@@ -495,9 +481,13 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
     int rc = halo_launch_status();
     if (rc != HALO_OK) return rc;
     const long VH = (long)V * H;
-    // VH is a multiple of 64 (H % 64 == 0): weight elements fill whole blocks, one more block for the bias
-    hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)(VH / 64 + (V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a.dw_part,
-                       a.db_part, dweight, dbias, B, VH, V);
+    // the fixed-order sum of the partials: queued for a later launch's tail blocks when the caller defers small reductions (small_jobs.h)
+    HaloSmallJob j = {};
+    j.kind = 1; j.n = B; j.m = V; j.len = VH; j.a = a.dw_part; j.b = a.db_part; j.o1 = dweight; j.o2 = dbias;
+    if (halo_defer_small_job(j)) return HALO_OK;
+    HaloSmallJobs q = {};
+    q.n = 1; q.job[0] = j; q.job[0].blocks = q.blocks = halo_small_job_blocks(j);
+    hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)q.blocks), dim3(256), 0, (hipStream_t)stream, q);
     return halo_launch_status();
 }
 

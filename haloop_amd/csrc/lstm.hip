@@ -1719,8 +1719,12 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             char *hT0 = imgs, *inT0 = imgs + hb, *hT1 = imgs + hb + ib;
             HaloPrepJob jobs[4];
             int nj = 0;
-            jobs[nj++] = {3, bias_part1, (B + 15) / 16, 4 * H, 4 * H, db_ih[hi], db_hh[hi]};
-            jobs[nj++] = {3, bias_part0, (B + 15) / 16, 4 * H, 4 * H, db_ih[lo], db_hh[lo]};
+            // the bias gradients' batch-tile partials: summed here, or queued for a later launch's tail blocks (small_jobs.h)
+            for (int l = 1; l >= 0; --l) {
+                HaloSmallJob j = {};
+                j.kind = 2; j.n = (B + 15) / 16; j.len = 4 * H; j.a = l ? bias_part1 : bias_part0; j.o1 = db_ih[l ? hi : lo]; j.o2 = db_hh[l ? hi : lo];
+                if (!halo_defer_small_job(j)) jobs[nj++] = {3, j.a, (B + 15) / 16, 4 * H, 4 * H, j.o1, j.o2};
+            }
             if (need_din) jobs[nj++] = {1, w_ih[lo], in_lo_dim, 4 * H, in_lo_dim, img_wT, nullptr};
             jobs[nj++] = {1, in_lo, in_lo_dim, T * B, in_lo_dim, inT0, nullptr};
             HALO_TRY(halo_prep_jobs(jobs, nj, st));

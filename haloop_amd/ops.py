@@ -367,6 +367,32 @@ def lstm_bwd(x_tm, w_ih, w_hh, dy, y_strides, y_relu, reserve, dhn=None, dcn=Non
     return dx, grads
 
 
+class defer_small_jobs:
+    """``with ops.defer_small_jobs():`` -- the small fixed-order reductions at the end of a backward pass (the CTC head's partial sums, the
+    two-layer LSTM launch's bias-gradient partials) are queued on the context instead of launched, and ride in the tail blocks of the conv
+    backward's reduce launch (``subsample_bwd``); whatever is still queued at the end of the block runs in one launch of its own.  The
+    buffers those reductions read must live until then (``ctc_head_bwd(workspace=)``, the LSTM backward's workspace)."""
+
+    def __enter__(self):
+        self.begin()
+        return self
+
+    def __exit__(self, *exc):
+        self.end()
+        return False
+
+    @staticmethod
+    def begin():
+        check(lib().halo_set_defer_small_jobs(1), 'halo_set_defer_small_jobs')
+
+    @staticmethod
+    def end():
+        try:
+            check(lib().halo_flush_small_jobs(_stream()), 'halo_flush_small_jobs')
+        finally:
+            lib().halo_set_defer_small_jobs(0)
+
+
 def lstm_dx_slabs_left():
     """How many K-slices the last ``lstm_bwd`` of this thread's context left in its dx buffer (1: the gradient itself)."""
     return int(lib().halo_lstm_dx_slabs_left())
@@ -486,12 +512,18 @@ def ctc_head_fwd(feats, weight, bias, drop, stream_id, input_lengths, targets, t
     return lp, alpha, nll, flen, grad_out, (tg, tl)
 
 
-def ctc_head_bwd(feats, weight, drop, stream_id, flen, tg, tl, lp, alpha, nll, grad_out, dweight, dbias):
-    """The CTC head's backward (two launches): returns d features [B,T,H]; the classifier's gradients go to dweight / dbias."""
+def ctc_head_workspace(B, H, V, device):
+    return torch.empty(lib().halo_ctc_head_workspace_bytes(B, H, V), device=device, dtype=torch.uint8)
+
+
+def ctc_head_bwd(feats, weight, drop, stream_id, flen, tg, tl, lp, alpha, nll, grad_out, dweight, dbias, workspace=None):
+    """The CTC head's backward (two launches): returns d features [B,T,H]; the classifier's gradients go to dweight / dbias.
+    Inside ``defer_small_jobs()`` the second launch (the fixed-order sum of the per-utterance partials) is queued instead and dweight /
+    dbias are complete after the block's flush; the caller then passes a ``workspace`` (``ctc_head_workspace``) that lives that long."""
     B, T, H = feats.shape
     V = weight.shape[0]
     dfeats = torch.empty_like(feats)
-    ws = torch.empty(lib().halo_ctc_head_workspace_bytes(B, H, V), device=feats.device, dtype=torch.uint8)
+    ws = workspace if workspace is not None else ctc_head_workspace(B, H, V, feats.device)
     check(lib().halo_ctc_head_bwd(ptr(feats), ptr(weight), drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr, ptr(flen), ptr(tg),
                                   tg.stride(0), tg.shape[1], ptr(tl), ptr(lp), ptr(alpha), ptr(nll), ptr(grad_out), ptr(dfeats),
                                   ptr(dweight), ptr(dbias), ptr(ws), B, T, H, V, _stream()), 'halo_ctc_head_bwd')

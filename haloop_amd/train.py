@@ -184,6 +184,20 @@ class LstmCtcTrainer:
     def _forward_backward_top(self, x, il, tg, tl):
         """Forward, loss, and backward down to (and including) the top LSTM layer: every gradient of
         FlatParams.early_range is final when this returns."""
+        # the small fixed-order sums (the head's partials, the LSTM bias partials) ride in the conv backward's reduce launch at the end of
+        # _backward_rest -- unless the first gradient bucket is all-reduced in between, which needs the head's gradients final here
+        self._defer = not (self.world > 1 and self.dp_algo == 'allreduce')
+        if self._defer:
+            ops.defer_small_jobs.begin()
+        try:
+            return self._forward_backward_top_body(x, il, tg, tl)
+        except BaseException:
+            if self._defer:
+                self._defer = False
+                _lib.lib().halo_set_defer_small_jobs(0)
+            raise
+
+    def _forward_backward_top_body(self, x, il, tg, tl):
         enc, rec, gv = self.encoder, self.recognizer, self.flat.grad_views
         drop = self._dropout()
         B, T, F = x.shape
@@ -209,8 +223,11 @@ class LstmCtcTrainer:
             sid = _lib.HALO_STREAM_CLASSIFIER
             lp, alpha, nll, flen, grad_out, (tg64, tl64) = ops.ctc_head_fwd(feats, rec.classifier.weight, rec.classifier.bias, cdrop, sid,
                                                                            il, tg, tl, self.loss, self._ticket)
+            if getattr(self, '_head_ws', None) is None or self._head_ws_dims != (B, H, V):
+                self._head_ws, self._head_ws_dims = ops.ctc_head_workspace(B, H, V, x.device), (B, H, V)      # outlives the deferred sum
             dfeats = ops.ctc_head_bwd(feats, rec.classifier.weight, cdrop, sid, flen, tg64, tl64, lp, alpha, nll, grad_out,
-                                      gv['recognizer.classifier.weight'], gv['recognizer.classifier.bias']).view(B * Tp, H)
+                                      gv['recognizer.classifier.weight'], gv['recognizer.classifier.bias'],
+                                      workspace=self._head_ws).view(B * Tp, H)
             return self._lstm_backward_top(x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats, (B, T, F, Cc, H, Tp, L))
         fdrop = ops.dropout_fwd(feats, cdrop, _lib.HALO_STREAM_CLASSIFIER) if p_cls > 0 else feats
         f2d = fdrop.view(B * Tp, H)
@@ -260,8 +277,13 @@ class LstmCtcTrainer:
             else:
                 ops.lstm_bwd(y_sub, w_ih, w_hh, None, (H, Tp * H), True, reserve, grads=grads, drop=drop, layers=(0, top),
                              workspace=ws, dx=dy_sub)
-        ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
-                          dbias=gv['encoder.subsample.bias'], slabs=self._dx_slabs)
+        try:
+            ops.subsample_bwd(dy_sub, y_sub, col, B, T, F, Cc, drop.p, dw=gv['encoder.subsample.weight'],
+                              dbias=gv['encoder.subsample.bias'], slabs=self._dx_slabs)
+        finally:
+            if self._defer:
+                self._defer = False
+                ops.defer_small_jobs.end()
 
     def _all_reduce(self):
         self.avg_early.average()

@@ -318,6 +318,14 @@ int halo_set_lstm_expect_backward(int on);
  * always on every other path).  1 <= n <= 64; default 1.  Per context. */
 int halo_set_lstm_dx_slabs(int n);
 int halo_lstm_dx_slabs_left(void);
+/* Small reductions that ride in another launch.  on = 1: halo_ctc_head_bwd's second launch (the fixed-order sum of its per-utterance
+ * partials) and the two-layer halo_lstm_bwd's bias-gradient sums are QUEUED on the context (at most 4; a full queue launches as before)
+ * instead of launched, and the next halo_subsample_bwd[_slabs] runs them from the tail blocks of its reduce launch -- same arithmetic and
+ * order, one ~5 us launch each less.  halo_flush_small_jobs launches whatever is queued (nothing: no launch).  The caller keeps the
+ * workspaces those reductions read alive until then, calls everything on one stream, and reads the results (dweight / dbias, db_ih /
+ * db_hh) only after the carrying launch.  Switching on clears the queue.  Default 0.  Per context. */
+int halo_set_defer_small_jobs(int on);
+int halo_flush_small_jobs(halo_stream_t stream);
 int halo_lstm_persistent2_eligible(int T, int B, int H, int L);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 

@@ -191,7 +191,8 @@ def test_gpt_under_torch_ddp_averages_gradients():
     inputs, targets = gpt_ref.synthetic_tokens(4, 24, 61, 9, pad_tail=False)
     model.forward_all(inputs.cuda(), targets.cuda()).backward()
     for k, p in model.named_parameters():
-        np.testing.assert_allclose(grads2[k], p.grad.cpu().numpy(), rtol=2e-4, atol=2e-7, err_msg=k)
+        # two half-batch sums averaged against one whole-batch sum: fp32 regrouping, ~1e-4 of the gradients' 1e-2 scale on their small elements
+        np.testing.assert_allclose(grads2[k], p.grad.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
 def _rccl_worker(port, out, grad_dtype):

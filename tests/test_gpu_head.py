@@ -125,3 +125,69 @@ def test_head_greedy_matches_the_separate_launches(B, T, H, V):
     assert torch.equal(ali.cpu(), alignments) and torch.equal(hyp_len.cpu(), lengths) and torch.equal(scores.cpu(), best)
     for n in range(B):
         assert hyp[n, :lengths[n]].tolist() == hyps[n] and not hyp[n, lengths[n]:].any()
+
+
+def test_deferred_small_reductions_ride_in_the_conv_backward_launch():
+    """ops.defer_small_jobs(): the head's partial sums and the two-layer LSTM launch's bias-gradient sums are queued and run from the tail
+    blocks of the conv backward's reduce launch (csrc/small_jobs.h) -- bitwise what their own launches give; a block that ends with jobs
+    still queued flushes them in one launch; nothing stays queued or switched on afterwards."""
+    from haloop_amd import _lib, ops
+    _lib.lib(); _lib.lend_scratch()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        B, T, C, H, V, S, L, F_, ks = 64, 20, 128, 256, 32, 8, 2, 16, 5
+        g = torch.Generator().manual_seed(3)
+        k = 1.0 / H ** 0.5
+        x = torch.relu(torch.randn(T, B, C, generator=g)).to(DEV)
+        col = torch.randn(T * B, F_ * ks, generator=g).to(DEV)
+        w_ih = [((torch.rand(4 * H, C if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+        w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+        b_ih = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+        b_hh = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+        W = (torch.randn(V, H, generator=g) / H ** 0.5).to(DEV)
+        b = (torch.randn(V, generator=g) * 0.1).to(DEV)
+        T_in = 4 * (T - 1) + ks - 6
+        il = torch.tensor([T_in - 3 * (i % 5) for i in range(B)], dtype=torch.int64).to(DEV)
+        tg = torch.randint(1, V, (B, S), generator=g).to(DEV)
+        tl = torch.randint(S // 2, S + 1, (B,), generator=g).to(DEV)
+        assert _lib.lib().halo_lstm_persistent2_eligible(T, B, H, L)
+
+        def run(defer, flush_by_conv=True):
+            loss = torch.zeros((), device=DEV)
+            ticket = torch.zeros(1, device=DEV, dtype=torch.int32)
+            feats = torch.empty(B, T, H, device=DEV)
+            _, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, y=feats, y_strides=(H, T * H), y_relu=True)
+            dW, db = torch.full_like(W, float('nan')), torch.full_like(b, float('nan'))
+            hws = ops.ctc_head_workspace(B, H, V, DEV)
+            ws = ops.lstm_bwd_workspace(x, w_hh)
+            if defer:
+                ops.defer_small_jobs.begin()
+            lp, alpha, nll, flen, grad_out, (tg64, tl64) = ops.ctc_head_fwd(feats, W, b, ops.NO_DROPOUT, _lib.HALO_STREAM_CLASSIFIER, il, tg, tl, loss, ticket)
+            dfeats = ops.ctc_head_bwd(feats, W, ops.NO_DROPOUT, _lib.HALO_STREAM_CLASSIFIER, flen, tg64, tl64, lp, alpha, nll, grad_out, dW, db, workspace=hws)
+            dx, grads = ops.lstm_bwd(x, w_ih, w_hh, dfeats.view(B * T, H), (H, T * H), True, reserve, workspace=ws, want_dx=True)
+            if defer:
+                torch.cuda.synchronize()
+                assert torch.isnan(dW).all()                 # still queued: nothing has written the sums
+            out = {}
+            if flush_by_conv:
+                out['cw'], out['cb'] = ops.subsample_bwd(dx, x, col, B, T_in, F_, C, 0.0)
+            if defer:
+                ops.defer_small_jobs.end()
+            out.update(dW=dW, db=db, dfeats=dfeats, dx=dx)
+            for name, lst in grads.items():
+                for l, t in enumerate(lst):
+                    out[f'{name}{l}'] = t
+            torch.cuda.synchronize()
+            return {k_: v.clone() for k_, v in out.items()}
+
+        plain = run(False)
+        for flush_by_conv in (True, False):
+            got = run(True, flush_by_conv)
+            for name, v in got.items():
+                assert torch.equal(v, plain[name]), name
+        assert _lib.lib().halo_flush_small_jobs(None) == 0
+        again = run(False)                                   # the switch is off again: the head's own launch runs
+        assert torch.equal(again['dW'], plain['dW'])
+    finally:
+        _lib.set_math_mode(prev)
