@@ -51,6 +51,8 @@ struct HaloCtx {
     int lstm_expect_backward = 1;        // the two-layer forward also packs the backward's transposed weight images (halo_set_lstm_expect_backward)
     const float *packT_reserve = nullptr, *packT_w[3] = {nullptr, nullptr, nullptr};   // ... into this reserve, from these weights (host bookkeeping)
     const float *bwdflags_reserve = nullptr;   // ... and zeroed the backward launch's epoch words in this reserve (the backward then needs no prologue launch)
+    const float *fwdT_src[2] = {nullptr, nullptr};
+    const float *fwdT_reserve = nullptr;    // ... and in^T / W_ih^T of the pair's lower layer (the backward's operand launch then has nothing left to write)
     const float *emitT_reserve = nullptr;   // the two-layer forward wrote the weight-gradient products' h_prev^T / dropout(h0)^T operand images into this reserve
     // halo_set_lstm_weights_stamp: a non-zero stamp is the caller's promise that the LSTM weights only change when the stamp does; the
     // forward-only two-layer launch then keeps the packed weight images a previous call with the same reserve, weights, shape and stamp left

@@ -560,18 +560,27 @@ struct PackPairArgs {
     char *zbase[2];
     long zstride, zunits;
     int zcount;
-    // rm_blocks workgroups behind the tile blocks write GEMM operand images (tiled_image.h) of up to two row-major fp32 matrices: layer
-    // lo's input and W_ih of layer lo, the operands of its input projection -- that product's own operand launch is gone
-    struct { const float *src; int R, K, ld, KT; char *img; } rm[2];
-    int rm_first1, rm_blocks, rm_with_lo;
+    // rm_blocks workgroups behind the tile blocks write GEMM operand images (tiled_image.h) of up to four fp32 matrices: layer lo's input
+    // and its W_ih, the operands of the input projection (that product's own operand launch is gone), and the transposes of both, which
+    // the backward's weight-gradient and input-gradient products want (its operand launch is gone too).  tr: the source is [K][R].
+    struct { const float *src; int R, K, ld, KT, tr, first; char *img; } rm[4];
+    int rm_n, rm_blocks, rm_with_lo;
 };
 __global__ __launch_bounds__(256) void persist2_pack_pair_kernel(const PackPairArgs a) {
     __shared__ float tile[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= a.tile_blocks && (int)blockIdx.x < a.tile_blocks + a.rm_blocks) {
-        const int b = blockIdx.x - a.tile_blocks, j = b >= a.rm_first1 ? 1 : 0, local = b - (j ? a.rm_first1 : 0);
-        halo_img::prep_rowmajor_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, local % a.rm[j].KT,
-                                      local / a.rm[j].KT);
+        const int b = blockIdx.x - a.tile_blocks;
+        int j = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < a.rm_n && b >= a.rm[i].first) j = i;
+        const int local = b - a.rm[j].first, kt = local % a.rm[j].KT, rt = local / a.rm[j].KT;
+        if (a.rm[j].tr)
+            halo_img::prep_transposed_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, kt, rt,
+                                            reinterpret_cast<float (*)[halo_img::TR + 1]>(&tile[0][0][0]));
+        else
+            halo_img::prep_rowmajor_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, kt, rt);
         return;
     }
     if ((int)blockIdx.x >= a.tile_blocks) {
@@ -1180,9 +1189,15 @@ inline size_t reserve_p2_images_bytes(int T, int B, int in0, int H) {
     const int kin = in0 > H ? in0 : H;
     return (size_t)3 * 4 * H * H * sizeof(float) + 3 * halo_tiled_image_bytes(H, T * B) + halo_tiled_image_bytes(kin, T * B);
 }
-inline size_t reserve_p2_bytes(int T, int B, int in0, int H) { return reserve_p2_images_bytes(T, B, in0, H) + PERSIST_FLAG_BYTES; }
+inline size_t reserve_p2_bytes(int T, int B, int in0, int H) {
+    return reserve_p2_images_bytes(T, B, in0, H) + PERSIST_FLAG_BYTES + halo_tiled_image_bytes(in0 > H ? in0 : H, 4 * H);
+}
 inline unsigned *reserve_bwd_flags(float *reserve, int T, int B, int in0, int H, int L) {
     return (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + reserve_p2_images_bytes(T, B, in0, H));
+}
+// ... and behind them the image of W_ih^T of the pair's lower layer (rows: its input width), written by the forward's packing launch
+inline char *reserve_p2_wT(float *reserve, int T, int B, int in0, int H, int L) {
+    return (char *)reserve_bwd_flags(reserve, T, B, in0, H, L) + PERSIST_FLAG_BYTES;
 }
 inline char *reserve_p2_images(float *reserve, int T, int B, int in0, int H, int L) {
     return (char *)reserve + reserve_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES + (size_t)3 * 4 * H * H * sizeof(float);
@@ -1335,13 +1350,21 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
             pp.zstride = KT * 16384; pp.zunits = (long)(B / 32) * 16384 / 16; pp.zcount = H / 128;
             ctx.emitT_reserve = reserve;
         }
-        pp.rm_first1 = 0; pp.rm_blocks = 0; pp.rm_with_lo = halo_math_mode() != HALO_MATH_BF16;
+        pp.rm_n = 0; pp.rm_blocks = 0; pp.rm_with_lo = halo_math_mode() != HALO_MATH_BF16;
+        ctx.fwdT_reserve = nullptr;
+        auto add_image = [&](const float *src, int R, int K, int tr, char *img) {
+            const int KT = (K + 31) / 32;
+            pp.rm[pp.rm_n++] = {src, R, K, in_dim, KT, tr, pp.rm_blocks, img};
+            pp.rm_blocks += ((R + 127) / 128) * KT;
+        };
         if (images_by_pack) {
-            const int KT = (in_dim + 31) / 32;
-            pp.rm[0] = {in, T * B, in_dim, in_dim, KT, img_in};
-            pp.rm[1] = {w_ih[0], 4 * H, in_dim, in_dim, KT, img_w};
-            pp.rm_first1 = ((T * B + 127) / 128) * KT;
-            pp.rm_blocks = pp.rm_first1 + ((4 * H + 127) / 128) * KT;
+            add_image(in, T * B, in_dim, 0, img_in);
+            add_image(w_ih[0], 4 * H, in_dim, 0, img_w);
+            if (emitT) {        // ... and their transposes for the backward: in^T beside the h_prev^T images, W_ih^T behind the backward's words
+                add_image(in, in_dim, T * B, 1, emit_hT0 + halo_tiled_image_bytes(H, T * B));
+                add_image(w_ih[0], in_dim, 4 * H, 1, reserve_p2_wT(reserve, T, B, in0, H, L));
+                ctx.fwdT_reserve = reserve; ctx.fwdT_src[0] = in; ctx.fwdT_src[1] = w_ih[0];
+            }
         }
         const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + pp.rest.zero2_units + 2L * pp.zcount * pp.zunits));
         hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)(pp.tile_blocks + pp.rm_blocks) + rest_blocks), dim3(256), 0, st, pp);
@@ -1725,8 +1748,13 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                 j.kind = 2; j.n = (B + 15) / 16; j.len = 4 * H; j.a = l ? bias_part1 : bias_part0; j.o1 = db_ih[l ? hi : lo]; j.o2 = db_hh[l ? hi : lo];
                 if (!halo_defer_small_job(j)) jobs[nj++] = {3, j.a, (B + 15) / 16, 4 * H, 4 * H, j.o1, j.o2};
             }
-            if (need_din) jobs[nj++] = {1, w_ih[lo], in_lo_dim, 4 * H, in_lo_dim, img_wT, nullptr};
-            jobs[nj++] = {1, in_lo, in_lo_dim, T * B, in_lo_dim, inT0, nullptr};
+            // W_ih_lo^T and in^T: the forward's packing launch of this step may have written them (same reserve, same weights: have_T)
+            const bool have_fwdT = have_T && ctx.fwdT_reserve == reserve && ctx.fwdT_src[0] == in_lo && ctx.fwdT_src[1] == w_ih[lo];
+            if (have_fwdT) img_wT = reserve_p2_wT(reserve, T, B, in0, H, L);
+            else {
+                if (need_din) jobs[nj++] = {1, w_ih[lo], in_lo_dim, 4 * H, in_lo_dim, img_wT, nullptr};
+                jobs[nj++] = {1, in_lo, in_lo_dim, T * B, in_lo_dim, inT0, nullptr};
+            }
             HALO_TRY(halo_prep_jobs(jobs, nj, st));
             HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H, st));
             if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)

@@ -53,4 +53,37 @@ __device__ __forceinline__ void prep_rowmajor_block(const float *__restrict__ sr
     }
 }
 
+// src stored transposed: memory [K][R] (leading dimension ld, R contiguous); logical X[r][k] = src[k*ld + r]
+__device__ __forceinline__ void prep_transposed_block(const float *__restrict__ src, int R, int K, int ld, char *__restrict__ img,
+                                                      int KT, int with_lo, int kt, int rt, float (*tile)[TR + 1]) {
+    char *blk = img + ((long)rt * KT + kt) * BLOCK_BYTES;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)src % 16 == 0);
+    for (int u = threadIdx.x; u < TK * (TR / 4); u += 256) {
+        const int kk = u / (TR / 4), r4 = (u % (TR / 4)) * 4;
+        const int gk = kt * TK + kk, gr = rt * TR + r4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < K) {
+            const float *p = src + (long)gk * ld + gr;
+            if (vec && gr + 3 < R) v = *reinterpret_cast<const f32x4 *>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gr + e < R) v[e] = p[e];
+            }
+        }
+        tile[kk][r4] = v[0]; tile[kk][r4 + 1] = v[1]; tile[kk][r4 + 2] = v[2]; tile[kk][r4 + 3] = v[3];
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < TR * 4; u += 256) {
+        const int row = u >> 2, c = u & 3;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = tile[c * 8 + j][row];
+        bf16x8 hi, lo;
+        split8(x, hi, lo);
+        const int off = swz_byte(row, c);
+        *reinterpret_cast<bf16x8 *>(blk + off) = hi;
+        if (with_lo) *reinterpret_cast<bf16x8 *>(blk + PART_BYTES + off) = lo;   // HALO_MATH_BF16 never reads the lo part
+    }
+}
+
 }  // namespace halo_img

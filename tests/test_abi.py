@@ -38,7 +38,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     flags = 8 * 4096                                                  # epoch words of the persistent recurrence (8 replicas, 4 KiB apart), 256-byte aligned
     # what the two-layer forward leaves for the backward: three transposed weight images; h_prev^T of both layers, an x^T slot, dropout(h0)^T
     # ... and the epoch words of the two-layer backward launch, zeroed by the forward's packing launch
-    packs_t = 3 * 4 * H * H * 4 + 4 * (8 * 42 * 16384) + flags
+    # ... and the image of the lower layer's W_ih^T (sized for an H-wide input: 8 row tiles x 128 k-tiles), also written by that launch
+    packs_t = 3 * 4 * H * H * 4 + 4 * (8 * 42 * 16384) + flags + 8 * 128 * 16384
     assert handle.halo_lstm_reserve_bytes(21, 64, 128, H, 2) == (body + 255) // 256 * 256 + flags + packs_t
     assert handle.halo_lstm_status_offset(0, 21, 64, 128, H, 2) == (body + 255) // 256 * 256
     assert handle.halo_subsample_col_bytes(64, 80, 80, 5, 4, 3) == 21 * 64 * 400 * 4
