@@ -196,6 +196,12 @@ struct TiledGemmArgs {
     // multiple of the 128-column tile.  Two products that share their A operand run as ONE launch over the stacked B operands.
     float *C2;
     int n_split, ldc2;
+    // ... and such a launch can CARRY a second, independent product in the workgroups behind its own (block index >= rider_first > 0):
+    // K-slices of rA [rM][K'] x rB [rN][K']^T, slice s to rslab + s rM rN as plain sums (halo_gemm_bf16x3_tiled_slices' product).  A
+    // 512-tile product leaves every CU's third workgroup slot free; 100-200 more workgroups of a latency-bound product ride there.
+    const char *rA, *rB;
+    float *rslab;
+    int rM, rN, rKT, r_ntiles, r_tiles_n, r_ktper, rider_first;
 };
 
 template <int PASSES, int ITERS = (PASSES == 3 ? 4 : 2)>
@@ -294,25 +300,31 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     // same LDS holds a ring twice as deep (the single-pass loop is bound by LDS-DMA latency, not by the MFMAs)
     constexpr int OPERB = PASSES == 3 ? BLOCK_BYTES : PART_BYTES, OPER = OPERB * TI / 2, SLOT = OPER + OPERB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int kslice = blockIdx.x / p.ntiles;
+    // a carried product's workgroup (IO & 4, TI == 2 launches only) works on the rider's operands and tile grid
+    const bool rider = (IO & 4) && TI == 2 && p.rider_first > 0 && (int)blockIdx.x >= p.rider_first;
+    const int bid = rider ? blockIdx.x - p.rider_first : blockIdx.x;
+    const int ntiles = rider ? p.r_ntiles : p.ntiles, tiles_n = rider ? p.r_tiles_n : p.tiles_n, KT = rider ? p.rKT : p.KT;
+    const int ktper = rider ? p.r_ktper : p.ktper;
+    const char *Aimg = rider ? p.rA : p.A, *Bimg = rider ? p.rB : p.B;
+    const int kslice = bid / ntiles;
     // within an XCD's contiguous run, walk the tiles in groups of 8 tile rows, column by column: the
     // ~64 workgroups resident on one XCD then cover an 8x8 block (8 A panels + 8 B panels, in k
     // lockstep) instead of 2 x 32, so each staged k-tile is fetched from beyond L2 once, not 4 times
-    const int tile = xcd_remap(blockIdx.x % p.ntiles, p.ntiles);
-    const int tiles_m = p.ntiles / p.tiles_n;
+    const int tile = xcd_remap(bid % ntiles, ntiles);
+    const int tiles_m = ntiles / tiles_n;
     const int GM = 8;
-    const int group = tile / (GM * p.tiles_n), first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m), in_group = tile % (GM * p.tiles_n);
+    const int group = tile / (GM * tiles_n), first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m), in_group = tile % (GM * tiles_n);
     const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
-    const int kt0 = kslice * p.ktper, kt1 = min(p.KT, kt0 + p.ktper);
+    const int kt0 = kslice * ktper, kt1 = min(KT, kt0 + ktper);
     const int nkt = kt1 - kt0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const char *Ablk = TI == 2 ? p.A + ((long)tile_m * p.KT + kt0) * BLOCK_BYTES
-                               : p.A + ((long)(tile_m >> 1) * p.KT + kt0) * BLOCK_BYTES + (tile_m & 1) * (PART_BYTES / 2);
-    const char *Bblk = p.B + ((long)tile_n * p.KT + kt0) * BLOCK_BYTES;
+    const char *Ablk = TI == 2 ? Aimg + ((long)tile_m * KT + kt0) * BLOCK_BYTES
+                               : Aimg + ((long)(tile_m >> 1) * KT + kt0) * BLOCK_BYTES + (tile_m & 1) * (PART_BYTES / 2);
+    const char *Bblk = Bimg + ((long)tile_n * KT + kt0) * BLOCK_BYTES;
 
     f32x16 acc[TI][2];
 #pragma unroll
@@ -431,6 +443,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 
     // epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     const int m0 = tile_m * TRM, n0 = tile_n * TR;
+    if (rider) {            // the carried product's slice: raw sums to its slab
+        float *slab = p.rslab + (long)kslice * p.rM * p.rN;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+                if (col >= p.rN) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < p.rM) slab[(long)row * p.rN + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     if (CE) {               // softmax statistics of this wave's 64 x 64 block, row by row (a row = 32 lanes x 2)
         const int c0 = n0 + wn * 64 + lr, c1 = c0 + 32;
         const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
@@ -907,6 +935,15 @@ int halo_gemm_bf16x3_tiled_slices(const void *Aimg, const void *Bimg, int M, int
 // products of a layer share dG^T this way (lstm.hip).  Plain sums: no bias, activation, dropout or split-K.
 int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                   hipStream_t st) {
+    return halo_gemm_bf16x3_tiled_nsplit_carry(Aimg, Bimg, M, N, K, C, ldc, n_split, C2, ldc2, nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, st);
+}
+
+// ... carrying halo_gemm_bf16x3_tiled_slices(rA, rB, rM, rN, rK, rslab, want, slices) in the same launch when the main product runs on
+// whole 128-row tiles in single-pass mode and leaves room beside them (*slices > 0 on return: carried; 0: the caller launches it itself)
+int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
+                                        const void *rA, const void *rB, int rM, int rN, int rK, float *rslab, int want, int *slices,
+                                        hipStream_t st) {
+    if (slices) *slices = 0;
     if (n_split % TR != 0 || n_split <= 0 || n_split >= N) return HALO_EINVAL;
     static bool attr = false;
     if (!attr) {
@@ -923,7 +960,19 @@ int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int
     p.drop = make_dropout(0.f, 0, 0, 0, nullptr);
     p.ntiles = ((M + TR - 1) / TR) * p.tiles_n;
     p.ksplit = 1; p.ktper = p.KT;
-    const dim3 grid((unsigned)p.ntiles);
+    dim3 grid((unsigned)p.ntiles);
+    if (rA && rB && rslab && slices && want >= 1 && rM > 0 && rN > 0 && rK > 0 && halo_math_mode() == HALO_MATH_BF16 &&
+        !half_tiles_wanted(M, p.ntiles, 1)) {
+        p.rA = (const char *)rA; p.rB = (const char *)rB; p.rslab = rslab; p.rM = rM; p.rN = rN;
+        p.rKT = (rK + TK - 1) / TK;
+        p.r_tiles_n = (rN + TR - 1) / TR;
+        p.r_ntiles = ((rM + TR - 1) / TR) * p.r_tiles_n;
+        p.r_ktper = (p.rKT + want - 1) / want;
+        const int rs = (p.rKT + p.r_ktper - 1) / p.r_ktper;
+        p.rider_first = p.ntiles;
+        grid = dim3((unsigned)(p.ntiles + p.r_ntiles * rs));
+        *slices = rs;
+    }
     if (halo_math_mode() == HALO_MATH_BF16 && half_tiles_wanted(M, p.ntiles, 1)) {
         p.ntiles = ((M + 63) / 64) * p.tiles_n;
         hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4, 1>), dim3((unsigned)p.ntiles), dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);

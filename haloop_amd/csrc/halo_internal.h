@@ -65,6 +65,9 @@ HaloCtx &halo_ctx_cur();
 // C | C2 = A x (B stacked on B2)^T in one launch (columns [n_split, N) of the result go to C2); plain sums
 int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                   hipStream_t st);
+int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
+                                        const void *rA, const void *rB, int rM, int rN, int rK, float *rslab, int want, int *slices,
+                                        hipStream_t st);
 int halo_math_mode();
 int halo_lstm_fusion();   // 1: run multi-layer LSTMs as layer-diagonal fused launches (halo_set_lstm_fusion)   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
 

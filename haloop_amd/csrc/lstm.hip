@@ -1756,7 +1756,14 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                 jobs[nj++] = {1, in_lo, in_lo_dim, T * B, in_lo_dim, inT0, nullptr};
             }
             HALO_TRY(halo_prep_jobs(jobs, nj, st));
-            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H, st));
+            // the upper layer's two weight gradients; the K-slices of the caller's input gradient ride in the same launch where it has room
+            int carried = 0;
+            const bool dx_slices = need_din && lo == 0 && ctx.lstm_dx_slabs > 1;
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit_carry(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H,
+                                                         dx_slices ? img_g : nullptr, img_wT, T * B, in_lo_dim, 4 * H, din_out, ctx.lstm_dx_slabs,
+                                                         &carried, st));
+            if (carried) ctx.lstm_dx_slabs_left = carried;
+            else
             if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)
                 const DropoutCfg ddrop = make_dropout(lo > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(lo > 0 ? lo - 1 : 0), offset,
                                                       offset_dev);
