@@ -68,6 +68,8 @@ SIGNATURES = {
     'halo_set_lstm_expect_backward': (_i, [_i]),
     'halo_set_lstm_dx_slabs': (_i, [_i]),
     'halo_set_defer_small_jobs': (_i, [_i]),
+    'halo_set_grad_sumsq': (_i, [_vp, _i]),
+    'halo_grad_sumsq_state': (_i, [_vp, _vp]),
     'halo_flush_small_jobs': (_i, [_vp]),
     'halo_lstm_dx_slabs_left': (_i, []),
     'halo_set_lstm_weights_stamp': (_i, [_u64]),

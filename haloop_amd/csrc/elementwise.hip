@@ -206,21 +206,26 @@ __global__ __launch_bounds__(256) void subsample_bwd_partial_kernel(const float 
 // ... and, from the blocks behind its own (own_blocks of them), the small reductions queued on the context (small_jobs.h)
 __global__ __launch_bounds__(256) void subsample_bwd_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias_part,
                                                                    float *__restrict__ dw, float *__restrict__ dbias, int chunks, long CK, int C,
-                                                                   int own_blocks, const HaloSmallJobs jobs) {
+                                                                   int own_blocks, const HaloSmallJobs jobs, float *__restrict__ ss) {
+    __shared__ float red[4][64];
     if ((int)blockIdx.x >= own_blocks) {
-        __shared__ float red[4][64];
         halo_small_jobs_block(jobs, blockIdx.x - own_blocks, red);
         return;
     }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float sum = 0.f;
     if (i < CK) {
-        float sum = 0.f;
         for (int q = 0; q < chunks; ++q) sum += part[(long)q * CK + i];
         dw[i] = sum;
     } else if (i - CK < C) {
-        float sum = 0.f;
         for (int q = 0; q < chunks; ++q) sum += bias_part[(long)q * C + (i - CK)];
         dbias[i - CK] = sum;
+    }
+    if (ss) {           // the squared-norm partial of this block's 256 gradient elements (halo_set_grad_sumsq)
+        const float q = wave_sum(sum * sum);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) ss[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     }
 }
 
@@ -461,9 +466,12 @@ int halo_subsample_bwd_slabs(float *dy, int slabs, const float *y, const float *
             if (rc) return rc;
             const long CK = (long)C * K;
             const int own = (int)((CK + C + 255) / 256);
-            HaloSmallJobs &q = halo_ctx_cur().small_jobs;            // queued small reductions ride in this launch's tail blocks
+            HaloCtx &ctx = halo_ctx_cur();
+            HaloSmallJobs &q = ctx.small_jobs;                       // queued small reductions ride in this launch's tail blocks
+            float *ss = ctx.grad_sumsq && ctx.grad_sumsq_n + own <= ctx.grad_sumsq_cap ? ctx.grad_sumsq + ctx.grad_sumsq_n : nullptr;
             hipLaunchKernelGGL(subsample_bwd_reduce_kernel, dim3((unsigned)(own + q.blocks)), dim3(256), 0, st, part, bias_part, dw,
-                               dbias, chunks, CK, C, own, q);
+                               dbias, chunks, CK, C, own, q, ss);
+            if (ss) { ctx.grad_sumsq_n += own; ctx.grad_sumsq_cover |= 16u; }
             q.n = 0; q.blocks = 0;
             return halo_launch_status();
         }

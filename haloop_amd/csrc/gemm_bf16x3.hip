@@ -202,6 +202,10 @@ struct TiledGemmArgs {
     const char *rA, *rB;
     float *rslab;
     int rM, rN, rKT, r_ntiles, r_tiles_n, r_ktper, rider_first;
+    // IO & 4: sumsq_part != NULL -> workgroup b of the main product also writes the sum of the squares of the elements it stored to
+    // sumsq_part[b] (fixed order inside the workgroup): the squared gradient norm's partials from the registers that hold the gradient,
+    // instead of a pass that re-reads it
+    float *sumsq_part;
 };
 
 template <int PASSES, int ITERS = (PASSES == 3 ? 4 : 2)>
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         }
         return;
     }
+    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < p.M) cq[(long)row * ldq + colq] = acc[i][j][r];
+                    if (row < p.M) { cq[(long)row * ldq + colq] = acc[i][j][r]; ss += acc[i][j][r] * acc[i][j][r]; }
                 }
                 continue;
             }
@@ -585,6 +590,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
                 if (!(IO & 2) || p.C) p.C[e] = v;
             }
         }
+    }
+    if ((IO & 4) && p.sumsq_part) {         // (workgroup-uniform; the ring's LDS is free: every wave is past its last k-tile after the barrier)
+        ss = wave_sum(ss);
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) p.sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -935,14 +948,14 @@ int halo_gemm_bf16x3_tiled_slices(const void *Aimg, const void *Bimg, int M, int
 // products of a layer share dG^T this way (lstm.hip).  Plain sums: no bias, activation, dropout or split-K.
 int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                   hipStream_t st) {
-    return halo_gemm_bf16x3_tiled_nsplit_carry(Aimg, Bimg, M, N, K, C, ldc, n_split, C2, ldc2, nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, st);
+    return halo_gemm_bf16x3_tiled_nsplit_carry(Aimg, Bimg, M, N, K, C, ldc, n_split, C2, ldc2, nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, st);
 }
 
 // ... carrying halo_gemm_bf16x3_tiled_slices(rA, rB, rM, rN, rK, rslab, want, slices) in the same launch when the main product runs on
 // whole 128-row tiles in single-pass mode and leaves room beside them (*slices > 0 on return: carried; 0: the caller launches it itself)
 int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                         const void *rA, const void *rB, int rM, int rN, int rK, float *rslab, int want, int *slices,
-                                        hipStream_t st) {
+                                        float *sumsq_part, int *sumsq_parts, hipStream_t st) {
     if (slices) *slices = 0;
     if (n_split % TR != 0 || n_split <= 0 || n_split >= N) return HALO_EINVAL;
     static bool attr = false;
@@ -973,10 +986,14 @@ int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int 
         grid = dim3((unsigned)(p.ntiles + p.r_ntiles * rs));
         *slices = rs;
     }
+    p.sumsq_part = sumsq_parts ? sumsq_part : nullptr;
     if (halo_math_mode() == HALO_MATH_BF16 && half_tiles_wanted(M, p.ntiles, 1)) {
         p.ntiles = ((M + 63) / 64) * p.tiles_n;
+        if (sumsq_parts) *sumsq_parts = p.ntiles;
         hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4, 1>), dim3((unsigned)p.ntiles), dim3(256), 3 * (PART_BYTES / 2 + PART_BYTES), st, p);
-    } else
+        return halo_launch_status();
+    }
+    if (sumsq_parts) *sumsq_parts = p.ntiles;       // (the carried product's workgroups write none)
     if (halo_math_mode() == HALO_MATH_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, 1, false, 1, 4>), grid, dim3(256), 3 * STAGE_BYTES / 2, st, p);
     else if (p.ntiles >= 768) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 3, false, 1, 4>), grid, dim3(256), STAGE_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 3, false, 1, 4>), grid, dim3(256), 2 * STAGE_BYTES, st, p);

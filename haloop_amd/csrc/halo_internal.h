@@ -44,6 +44,11 @@ struct HaloCtx {
     unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
     hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
     unsigned long long *stamps = nullptr;
+    // halo_set_grad_sumsq: the squared-norm partials of a training step's clipped gradients, written by the launches that produce those
+    // gradients (host bookkeeping: destination, capacity, how many slots are taken, which producers have contributed)
+    float *grad_sumsq = nullptr;
+    int grad_sumsq_cap = 0, grad_sumsq_n = 0;
+    unsigned grad_sumsq_cover = 0;       // bit 0 / 1: the two-layer launch's upper / lower weight gradients; 2 / 3: their bias gradients; 4: the conv front end
     int defer_small_jobs = 0;            // halo_set_defer_small_jobs: small reductions wait in `small_jobs` for a launch that carries them
     HaloSmallJobs small_jobs = {};
     int lstm_dx_slabs = 1;               // halo_set_lstm_dx_slabs: K-slices the caller's dx buffer has room for
@@ -67,7 +72,7 @@ int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int
                                   hipStream_t st);
 int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                         const void *rA, const void *rB, int rM, int rN, int rK, float *rslab, int want, int *slices,
-                                        hipStream_t st);
+                                        float *sumsq_part, int *sumsq_parts, hipStream_t st);
 int halo_math_mode();
 int halo_lstm_fusion();   // 1: run multi-layer LSTMs as layer-diagonal fused launches (halo_set_lstm_fusion)   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
 

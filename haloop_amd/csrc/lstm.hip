@@ -1475,6 +1475,18 @@ int halo_set_lstm_weights_stamp(uint64_t stamp) {
     return HALO_OK;
 }
 
+int halo_set_grad_sumsq(float *partials, int capacity) {
+    HaloCtx &ctx = halo_ctx_cur();
+    if (partials && capacity <= 0) return HALO_EINVAL;
+    ctx.grad_sumsq = partials; ctx.grad_sumsq_cap = partials ? capacity : 0; ctx.grad_sumsq_n = 0; ctx.grad_sumsq_cover = 0;
+    return HALO_OK;
+}
+int halo_grad_sumsq_state(int *count, unsigned *covered) {
+    const HaloCtx &ctx = halo_ctx_cur();
+    if (count) *count = ctx.grad_sumsq_n;
+    if (covered) *covered = ctx.grad_sumsq_cover;
+    return HALO_OK;
+}
 int halo_set_lstm_dx_slabs(int n) {
     if (n < 1 || n > 64) return HALO_EINVAL;
     halo_ctx_cur().lstm_dx_slabs = n;
@@ -1743,10 +1755,16 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             HaloPrepJob jobs[4];
             int nj = 0;
             // the bias gradients' batch-tile partials: summed here, or queued for a later launch's tail blocks (small_jobs.h)
+            // (queued, they also leave the squared-norm partials of what they write when the caller collects those: halo_set_grad_sumsq)
             for (int l = 1; l >= 0; --l) {
                 HaloSmallJob j = {};
                 j.kind = 2; j.n = (B + 15) / 16; j.len = 4 * H; j.a = l ? bias_part1 : bias_part0; j.o1 = db_ih[l ? hi : lo]; j.o2 = db_hh[l ? hi : lo];
-                if (!halo_defer_small_job(j)) jobs[nj++] = {3, j.a, (B + 15) / 16, 4 * H, 4 * H, j.o1, j.o2};
+                const int jb = halo_small_job_blocks(j);
+                const bool collect = ctx.grad_sumsq && ctx.defer_small_jobs && ctx.grad_sumsq_n + jb <= ctx.grad_sumsq_cap;
+                if (collect) j.ss = ctx.grad_sumsq + ctx.grad_sumsq_n;
+                if (halo_defer_small_job(j)) {
+                    if (collect) { ctx.grad_sumsq_n += jb; ctx.grad_sumsq_cover |= l ? 4u : 8u; }
+                } else jobs[nj++] = {3, j.a, (B + 15) / 16, 4 * H, 4 * H, j.o1, j.o2};
             }
             // W_ih_lo^T and in^T: the forward's packing launch of this step may have written them (same reserve, same weights: have_T)
             const bool have_fwdT = have_T && ctx.fwdT_reserve == reserve && ctx.fwdT_src[0] == in_lo && ctx.fwdT_src[1] == w_ih[lo];
@@ -1759,9 +1777,14 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             // the upper layer's two weight gradients; the K-slices of the caller's input gradient ride in the same launch where it has room
             int carried = 0;
             const bool dx_slices = need_din && lo == 0 && ctx.lstm_dx_slabs > 1;
+            // (and each launch leaves the squared-norm partials of the gradients it stores when the caller collects them)
+            auto sumsq_slot = [&](int tiles) { return ctx.grad_sumsq && ctx.grad_sumsq_n + tiles <= ctx.grad_sumsq_cap ? ctx.grad_sumsq + ctx.grad_sumsq_n : nullptr; };
+            int parts = 0;
+            float *slot = sumsq_slot(((4 * H + 63) / 64) * ((2 * H + 127) / 128));       // (room for the most workgroups the launch may use: half-height tiles)
             HALO_TRY(halo_gemm_bf16x3_tiled_nsplit_carry(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H,
                                                          dx_slices ? img_g : nullptr, img_wT, T * B, in_lo_dim, 4 * H, din_out, ctx.lstm_dx_slabs,
-                                                         &carried, st));
+                                                         &carried, slot, slot ? &parts : nullptr, st));
+            if (slot) { ctx.grad_sumsq_n += parts; ctx.grad_sumsq_cover |= 1u; }
             if (carried) ctx.lstm_dx_slabs_left = carried;
             else
             if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)
@@ -1773,7 +1796,11 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                 } else
                 HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_lo_dim, 4 * H, din_out, in_lo_dim, nullptr, nullptr, 0, &ddrop, st));
             }
-            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit(img_gT, hT0, 4 * H, H + in_lo_dim, T * B, dw_hh[lo], H, H, dw_ih[lo], in_lo_dim, st));
+            slot = sumsq_slot(((4 * H + 63) / 64) * ((H + in_lo_dim + 127) / 128));
+            parts = 0;
+            HALO_TRY(halo_gemm_bf16x3_tiled_nsplit_carry(img_gT, hT0, 4 * H, H + in_lo_dim, T * B, dw_hh[lo], H, H, dw_ih[lo], in_lo_dim, nullptr,
+                                                         nullptr, 0, 0, 0, nullptr, 0, nullptr, slot, slot ? &parts : nullptr, st));
+            if (slot) { ctx.grad_sumsq_n += parts; ctx.grad_sumsq_cover |= 2u; }
         } else {
             HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, hi, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g,
                                          emit1 ? img_gT1 : img_gT, img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));

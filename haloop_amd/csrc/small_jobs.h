@@ -15,6 +15,7 @@ struct HaloSmallJob {
     long len;
     const float *a, *b;
     float *o1, *o2;
+    float *ss;       // kind 2, optional: block i also writes the sum of the squares of what it stored (both outputs) to ss[i]
 };
 struct HaloSmallJobs {
     HaloSmallJob job[HALO_SMALL_JOBS_MAX];
@@ -47,11 +48,17 @@ __device__ __forceinline__ void halo_small_jobs_block(const HaloSmallJobs &q, in
         if (w == 0 && k < count) (is_b ? j.o2 : j.o1)[k] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
     } else {
         const long c = (long)local * 256 + threadIdx.x;
+        float s = 0.f;
         if (c < j.len) {
-            float s = 0.f;
             for (int r = 0; r < j.n; ++r) s += j.a[(long)r * j.len + c];
             j.o1[c] = s;
             if (j.o2) j.o2[c] = s;
+        }
+        if (j.ss) {      // (uniform over the block)
+            float q = wave_sum(s * s);
+            if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = q;
+            __syncthreads();
+            if (threadIdx.x == 0) j.ss[local] = ((part[0][0] + part[0][1]) + (part[0][2] + part[0][3])) * (j.o2 ? 2.f : 1.f);
         }
     }
 }

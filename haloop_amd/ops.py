@@ -600,6 +600,23 @@ def sumsq_partials(flat, partials=None):
     return partials
 
 
+GRAD_SUMSQ_ALL = 31        # halo_grad_sumsq_state: both layers' matrices and biases and the conv front end have contributed
+
+
+def collect_grad_sumsq(partials):
+    """The backward launches that follow write the squared-norm partials of the clipped gradients they store into ``partials`` (float32;
+    None: off) -- see ``grad_sumsq_state``."""
+    check(lib().halo_set_grad_sumsq(ptr(partials), 0 if partials is None else partials.numel()), 'halo_set_grad_sumsq')
+
+
+def grad_sumsq_state():
+    """(slots written, producer bits) since ``collect_grad_sumsq``: the partials are the whole clipped norm when bits == GRAD_SUMSQ_ALL
+    and the clipped parameters are the conv front end + a 2-layer LSTM."""
+    n, bits = C.c_int(0), C.c_uint(0)
+    check(lib().halo_grad_sumsq_state(C.byref(n), C.byref(bits)), 'halo_grad_sumsq_state')
+    return int(n.value), int(bits.value)
+
+
 def clip_coef(partials, count, max_norm, coef, norm, applied_steps=None):
     """applied_steps: optional device int32 counter advanced when the norm is finite (the Adam step count of applied updates)."""
     check(lib().halo_clip_coef_step(ptr(partials), count, float(max_norm), ptr(coef), ptr(norm), ptr(applied_steps), _stream()),

@@ -137,6 +137,7 @@ class LstmCtcTrainer:
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.counter = torch.zeros(1, device=dev, dtype=torch.int32)     # device-side step counter (dropout offset)
         self.partials = torch.zeros(_lib.HALO_SUMSQ_PARTS, device=dev, dtype=torch.float32)
+        self.partials_p = torch.zeros(4 * _lib.HALO_SUMSQ_PARTS, device=dev, dtype=torch.float32)     # the producers' partials (ops.collect_grad_sumsq)
         self.coef = torch.ones(2, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.loss = torch.zeros((), device=dev, dtype=torch.float32)
@@ -189,6 +190,11 @@ class LstmCtcTrainer:
         self._defer = not (self.world > 1 and self.dp_algo == 'allreduce')
         if self._defer:
             ops.defer_small_jobs.begin()
+        # one process, no accumulation: the clipped gradients' squared-norm partials come from the launches that store those gradients
+        self._norm_count = 0
+        self._collect = self._defer and self.world == 1 and self.sharded is None and self.accumulate == 1 and self.encoder.lstm.num_layers == 2
+        if self._collect:
+            ops.collect_grad_sumsq(self.partials_p)
         try:
             return self._forward_backward_top_body(x, il, tg, tl)
         except BaseException:
@@ -284,6 +290,11 @@ class LstmCtcTrainer:
             if self._defer:
                 self._defer = False
                 ops.defer_small_jobs.end()
+            if self._collect:
+                self._collect = False
+                n, bits = ops.grad_sumsq_state()
+                ops.collect_grad_sumsq(None)
+                self._norm_count = n if bits == ops.GRAD_SUMSQ_ALL else 0      # 0: a path that did not contribute -- the plain pass runs
 
     def _all_reduce(self):
         self.avg_early.average()
@@ -304,6 +315,9 @@ class LstmCtcTrainer:
     def _optimizer(self):
         """clip + AdamW; the update count lives on the device, so these three launches have no host scalar and are captured
         in the step graph."""
+        if getattr(self, '_norm_count', 0) > 0 and self.sharded is None:
+            self._apply_update(count=self._norm_count)       # the partials are already there (ops.collect_grad_sumsq)
+            return
         self._norm_partials()
         self._apply_update()
 
@@ -320,10 +334,11 @@ class LstmCtcTrainer:
         else:
             self.partials.zero_()
 
-    def _apply_update(self):
+    def _apply_update(self, count=None):
         f = self.flat
         lo, hi = self._span()
-        ops.clip_coef(self.partials, _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm, applied_steps=self.adam_step)
+        ops.clip_coef(self.partials_p if count else self.partials, count or _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm,
+                      applied_steps=self.adam_step)
         # all (decay, clip) ranges (cut to this rank's span) and the dropout step counter in one launch
         ranges = [(max(a, lo), min(b, hi), self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
                   for a, b, decays, clipped in f.ranges if min(b, hi) > max(a, lo)]

@@ -326,6 +326,16 @@ int halo_lstm_dx_slabs_left(void);
  * db_hh) only after the carrying launch.  Switching on clears the queue.  Default 0.  Per context. */
 int halo_set_defer_small_jobs(int on);
 int halo_flush_small_jobs(halo_stream_t stream);
+/* The squared gradient norm without a pass over the gradients.  partials != NULL: the launches of the NEXT backward calls that store
+ * clipped gradients also write the sums of their squares, one float per workgroup, into partials[0 .. count) -- the two-layer
+ * halo_lstm_bwd's two weight-gradient launches (from the accumulators they store), its bias sums (when deferred: small jobs above), and
+ * halo_subsample_bwd[_slabs]'s reduce launch.  halo_grad_sumsq_state reports how many slots were written and which producers
+ * contributed: bit 0 / 1 the upper / lower layer's W_ih + W_hh, bit 2 / 3 their b_ih + b_hh, bit 4 the conv's weight + bias.  A caller whose
+ * clipped parameters are exactly those (a 2-layer stack behind the conv front end) passes the partials to halo_clip_coef[_step] with that
+ * count when all five bits are set, and runs halo_sumsq otherwise.  capacity: floats available (a producer without room does not
+ * contribute).  NULL: off (default).  Setting it (to anything) resets count and bits.  Host bookkeeping, per context. */
+int halo_set_grad_sumsq(float *partials, int capacity);
+int halo_grad_sumsq_state(int *count, unsigned *covered);
 int halo_lstm_persistent2_eligible(int T, int B, int H, int L);
 size_t halo_lstm_status_offset(int backward, int T, int B, int in0, int H, int L);
 

@@ -191,3 +191,45 @@ def test_deferred_small_reductions_ride_in_the_conv_backward_launch():
         assert torch.equal(again['dW'], plain['dW'])
     finally:
         _lib.set_math_mode(prev)
+
+
+def test_squared_gradient_norm_from_the_producing_launches():
+    """ops.collect_grad_sumsq: the two-layer LSTM backward's weight-gradient launches, its (deferred) bias sums and the conv backward's
+    reduce launch leave the squared-norm partials of what they store; their sum is the squared norm of exactly those gradients."""
+    from haloop_amd import _lib, ops
+    _lib.lib(); _lib.lend_scratch()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        for (T, B, C, H) in ((20, 64, 128, 1024), (7, 32, 128, 256)):
+            L, F_, ks = 2, 16, 5
+            g = torch.Generator().manual_seed(T)
+            k = 1.0 / H ** 0.5
+            x = torch.relu(torch.randn(T, B, C, generator=g)).to(DEV)
+            col = torch.randn(T * B, F_ * ks, generator=g).to(DEV)
+            w_ih = [((torch.rand(4 * H, C if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+            w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+            b_ih = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+            b_hh = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+            dy = torch.randn(T, B, H, generator=g).to(DEV)
+            T_in = 4 * (T - 1) + ks - 6
+            _, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh)
+            ws = ops.lstm_bwd_workspace(x, w_hh)
+            parts = torch.full((4096,), float('nan'), device=DEV)
+            ops.defer_small_jobs.begin()
+            ops.collect_grad_sumsq(parts)
+            dx, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, workspace=ws, want_dx=True)
+            n1, bits1 = ops.grad_sumsq_state()
+            assert bits1 == 15 and n1 > 0
+            cw, cb = ops.subsample_bwd(dx, x, col, B, T_in, F_, C, 0.0)
+            n, bits = ops.grad_sumsq_state()
+            ops.collect_grad_sumsq(None)
+            ops.defer_small_jobs.end()
+            assert bits == ops.GRAD_SUMSQ_ALL and n1 < n <= parts.numel()
+            assert ops.grad_sumsq_state() == (0, 0)
+            got = parts[:n].double().sum().item()
+            assert torch.isnan(parts[n:]).all()
+            want = sum(t.double().pow(2).sum().item() for lst in grads.values() for t in lst) + cw.double().pow(2).sum().item() + cb.double().pow(2).sum().item()
+            assert abs(got - want) <= 1e-5 * want, (got, want)
+    finally:
+        _lib.set_math_mode(prev)
