@@ -518,18 +518,50 @@ __global__ __launch_bounds__(256) void persist_prologue_kernel(const PrologueArg
 // The same for the two-layer persistent launch (lstm_persist2.hip): three weight images (W_hh0, W_hh1, W_ih1; transposed for the
 // backward), both layers' initial states, the epoch words.  That launch runs in single-pass bf16 and reads the hi halves only: the lo
 // halves of the packed blocks are not written (a third of the prologue's bytes).
+// GEMM operand images (tiled_image.h) of up to four fp32 matrices, written by `blocks` workgroups of a packing launch: layer lo's input
+// and its W_ih, the operands of the input projection (that product's own operand launch is gone), and the transposes of both, which the
+// backward's weight-gradient and input-gradient products want (its operand launch is gone too).  tr: the source is [K][R].
+struct ImageJobs {
+    struct { const float *src; int R, K, ld, KT, tr, first; char *img; } job[4];
+    int n, blocks, with_lo;
+};
+// block b of the jobs; tile: 32 x 129 floats of LDS (transposed sources only)
+__device__ __forceinline__ void image_jobs_block(const ImageJobs &a, int b, float *tile) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < a.n && b >= a.job[i].first) j = i;
+    const int local = b - a.job[j].first, kt = local % a.job[j].KT, rt = local / a.job[j].KT;
+    if (a.job[j].tr)
+        halo_img::prep_transposed_block(a.job[j].src, a.job[j].R, a.job[j].K, a.job[j].ld, a.job[j].img, a.job[j].KT, a.with_lo, kt, rt,
+                                        reinterpret_cast<float (*)[halo_img::TR + 1]>(tile));
+    else
+        halo_img::prep_rowmajor_block(a.job[j].src, a.job[j].R, a.job[j].K, a.job[j].ld, a.job[j].img, a.job[j].KT, a.with_lo, kt, rt);
+}
+inline void image_jobs_add(ImageJobs &a, const float *src, int R, int K, int ld, int tr, char *img) {
+    const int KT = (K + 31) / 32;
+    a.job[a.n++] = {src, R, K, ld, KT, tr, a.blocks, img};
+    a.blocks += ((R + 127) / 128) * KT;
+}
+
 struct Prologue2Args {
     const float *w[3]; void *wdst[3]; long w_units; int wK;         // w_units per matrix
     const float *h0[2]; void *hp0[2]; float *h_rm[2]; const float *c0[2]; float *c_rm[2]; long s_units;   // per layer (forward only)
     unsigned *zero; long zero_units;
     unsigned *zero2; long zero2_units;
     int H, B;
+    ImageJobs img;          // the first img.blocks workgroups of persist2_prologue_kernel (pack_pair: behind its tile blocks)
 };
 template <int WMODE>
 __global__ __launch_bounds__(256) void persist2_prologue_kernel(const Prologue2Args a) {
+    if ((int)blockIdx.x < a.img.blocks) {
+        __shared__ float tile[32 * (halo_img::TR + 1)];
+        image_jobs_block(a.img, blockIdx.x, tile);
+        return;
+    }
     const long nw = 3 * a.w_units, ns = 2 * a.s_units;
     const long total = nw + ns + a.zero_units + a.zero2_units;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    for (long u = (blockIdx.x - a.img.blocks) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - a.img.blocks) * 256) {
         if (u < nw) {
             const int m = (int)(u / a.w_units);
             pack_unit<true, WMODE, true>(u - m * a.w_units, a.w[m], a.wdst[m], a.H, a.B, a.wK, nullptr, nullptr, nullptr);
@@ -560,33 +592,18 @@ struct PackPairArgs {
     char *zbase[2];
     long zstride, zunits;
     int zcount;
-    // rm_blocks workgroups behind the tile blocks write GEMM operand images (tiled_image.h) of up to four fp32 matrices: layer lo's input
-    // and its W_ih, the operands of the input projection (that product's own operand launch is gone), and the transposes of both, which
-    // the backward's weight-gradient and input-gradient products want (its operand launch is gone too).  tr: the source is [K][R].
-    struct { const float *src; int R, K, ld, KT, tr, first; char *img; } rm[4];
-    int rm_n, rm_blocks, rm_with_lo;
 };
 __global__ __launch_bounds__(256) void persist2_pack_pair_kernel(const PackPairArgs a) {
     __shared__ float tile[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)blockIdx.x >= a.tile_blocks && (int)blockIdx.x < a.tile_blocks + a.rm_blocks) {
-        const int b = blockIdx.x - a.tile_blocks;
-        int j = 0;
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-            if (i < a.rm_n && b >= a.rm[i].first) j = i;
-        const int local = b - a.rm[j].first, kt = local % a.rm[j].KT, rt = local / a.rm[j].KT;
-        if (a.rm[j].tr)
-            halo_img::prep_transposed_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, kt, rt,
-                                            reinterpret_cast<float (*)[halo_img::TR + 1]>(&tile[0][0][0]));
-        else
-            halo_img::prep_rowmajor_block(a.rm[j].src, a.rm[j].R, a.rm[j].K, a.rm[j].ld, a.rm[j].img, a.rm[j].KT, a.rm_with_lo, kt, rt);
+    if ((int)blockIdx.x >= a.tile_blocks && (int)blockIdx.x < a.tile_blocks + a.rest.img.blocks) {
+        image_jobs_block(a.rest.img, blockIdx.x - a.tile_blocks, &tile[0][0][0]);
         return;
     }
     if ((int)blockIdx.x >= a.tile_blocks) {
         const Prologue2Args &r = a.rest;
         const long ns = 2 * r.s_units, nz = 2L * a.zcount * a.zunits, total = ns + r.zero_units + r.zero2_units + nz;
-        const int first = a.tile_blocks + a.rm_blocks;
+        const int first = a.tile_blocks + a.rest.img.blocks;
         for (long u = (blockIdx.x - first) * 256L + threadIdx.x; u < total; u += (long)(gridDim.x - first) * 256) {
             if (u >= ns + r.zero_units + r.zero2_units) {
                 const long v = u - (ns + r.zero_units + r.zero2_units);
@@ -1301,19 +1318,16 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
     if (h0) h0 += (size_t)lo * BH;
     if (c0) c0 += (size_t)lo * BH;
     HaloCtx &ctx = halo_ctx_cur();
-    // with a backward to follow, the weight-packing launch below also writes this product's two operand images: it then runs first
-    const bool images_by_pack = in_dim >= 64 && ctx.lstm_expect_backward && H % 32 == 0;
-    if (in_dim >= 64 && !images_by_pack) {
-        const HaloPrepJob jobs[2] = {{0, in, T * B, in_dim, in_dim, img_in, nullptr}, {0, w_ih[0], 4 * H, in_dim, in_dim, img_w, nullptr}};
-        HALO_TRY(halo_prep_jobs(jobs, 2, st));
-        HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
-    } else if (in_dim < 64) {
+    // the packing / prologue launch below also writes this product's two operand images: it runs first, the product behind it
+    const bool images_by_pack = in_dim >= 64;
+    if (in_dim < 64) {
         HALO_TRY(halo_gemm_f32(1, 1, T * B, 4 * H, in_dim, in, in_dim, w_ih[0], in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, 0.f, 0, 0, 0,
                                nullptr, (halo_stream_t)st));
     }
     float *wp0 = reserve, *wp1 = fused_wpk(extra, hi, H), *wpi = wp1 + (size_t)4 * H * H;
     unsigned *flags = (unsigned *)((char *)reserve + reserve_flags_offset(T, B, in0, H, L));
     Prologue2Args pa;
+    pa.img.n = 0; pa.img.blocks = 0; pa.img.with_lo = halo_math_mode() != HALO_MATH_BF16;
     pa.w[0] = w_hh[0]; pa.wdst[0] = wp0; pa.w[1] = w_hh[1]; pa.wdst[1] = wp1; pa.w[2] = w_ih[1]; pa.wdst[2] = wpi;
     pa.w_units = (long)(H / 16) * 4 * (H / 32) * 64; pa.wK = H;
     for (int l = 0; l < 2; ++l) {
@@ -1350,24 +1364,19 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
             pp.zstride = KT * 16384; pp.zunits = (long)(B / 32) * 16384 / 16; pp.zcount = H / 128;
             ctx.emitT_reserve = reserve;
         }
-        pp.rm_n = 0; pp.rm_blocks = 0; pp.rm_with_lo = halo_math_mode() != HALO_MATH_BF16;
         ctx.fwdT_reserve = nullptr;
-        auto add_image = [&](const float *src, int R, int K, int tr, char *img) {
-            const int KT = (K + 31) / 32;
-            pp.rm[pp.rm_n++] = {src, R, K, in_dim, KT, tr, pp.rm_blocks, img};
-            pp.rm_blocks += ((R + 127) / 128) * KT;
-        };
         if (images_by_pack) {
-            add_image(in, T * B, in_dim, 0, img_in);
-            add_image(w_ih[0], 4 * H, in_dim, 0, img_w);
+            ImageJobs &ij = pp.rest.img;
+            image_jobs_add(ij, in, T * B, in_dim, in_dim, 0, img_in);
+            image_jobs_add(ij, w_ih[0], 4 * H, in_dim, in_dim, 0, img_w);
             if (emitT) {        // ... and their transposes for the backward: in^T beside the h_prev^T images, W_ih^T behind the backward's words
-                add_image(in, in_dim, T * B, 1, emit_hT0 + halo_tiled_image_bytes(H, T * B));
-                add_image(w_ih[0], in_dim, 4 * H, 1, reserve_p2_wT(reserve, T, B, in0, H, L));
+                image_jobs_add(ij, in, in_dim, T * B, in_dim, 1, emit_hT0 + halo_tiled_image_bytes(H, T * B));
+                image_jobs_add(ij, w_ih[0], in_dim, 4 * H, in_dim, 1, reserve_p2_wT(reserve, T, B, in0, H, L));
                 ctx.fwdT_reserve = reserve; ctx.fwdT_src[0] = in; ctx.fwdT_src[1] = w_ih[0];
             }
         }
         const unsigned rest_blocks = pack_grid((size_t)(2 * pa.s_units + pa.zero_units + pp.rest.zero2_units + 2L * pp.zcount * pp.zunits));
-        hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)(pp.tile_blocks + pp.rm_blocks) + rest_blocks), dim3(256), 0, st, pp);
+        hipLaunchKernelGGL(persist2_pack_pair_kernel, dim3((unsigned)(pp.tile_blocks + pp.rest.img.blocks) + rest_blocks), dim3(256), 0, st, pp);
         HALO_TRY(halo_launch_status());
         if (images_by_pack)
             HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
@@ -1382,9 +1391,15 @@ int lstm_fwd_persist2(const float *in, int in_dim, int lo, const float *const *w
                           ctx.packF_w[0] == pa.w[0] && ctx.packF_w[1] == pa.w[1] && ctx.packF_w[2] == pa.w[2] &&
                           !memcmp(ctx.packF_dims, dims, sizeof(dims));
         if (keep) pa.w_units = 0;
-        hipLaunchKernelGGL(persist2_prologue_kernel<0>, dim3(pack_grid((size_t)(3 * pa.w_units + 2 * pa.s_units + pa.zero_units))), dim3(256),
-                           0, st, pa);
+        if (images_by_pack) {
+            image_jobs_add(pa.img, in, T * B, in_dim, in_dim, 0, img_in);
+            image_jobs_add(pa.img, w_ih[0], 4 * H, in_dim, in_dim, 0, img_w);
+        }
+        hipLaunchKernelGGL(persist2_prologue_kernel<0>, dim3((unsigned)pa.img.blocks + pack_grid((size_t)(3 * pa.w_units + 2 * pa.s_units + pa.zero_units))),
+                           dim3(256), 0, st, pa);
         HALO_TRY(halo_launch_status());
+        if (images_by_pack)
+            HALO_TRY(halo_gemm_bf16x3_tiled(img_in, img_w, T * B, 4 * H, in_dim, l0.gates, 4 * H, b_ih[0], b_hh[0], 0, nullptr, st));
         ctx.packF_stamp = lo == 0 ? ctx.lstm_weights_stamp : 0;
         ctx.packF_reserve = reserve;
         for (int m = 0; m < 3; ++m) ctx.packF_w[m] = pa.w[m];
@@ -1709,6 +1724,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             wpT0 = wT; wpT1 = wT + (size_t)4 * H * H; wpTi = wT + (size_t)8 * H * H;
         }
         Prologue2Args pa;
+        pa.img.n = 0; pa.img.blocks = 0; pa.img.with_lo = 0;
         pa.w[0] = w_hh[lo]; pa.wdst[0] = wpT0; pa.w[1] = w_hh[hi]; pa.wdst[1] = wpT1; pa.w[2] = w_ih[hi]; pa.wdst[2] = wpTi;
         pa.w_units = have_T ? 0 : (long)(H / 16) * (4 * H / 32) * 64; pa.wK = 4 * H;
         for (int l = 0; l < 2; ++l) { pa.h0[l] = nullptr; pa.hp0[l] = nullptr; pa.h_rm[l] = nullptr; pa.c0[l] = nullptr; pa.c_rm[l] = nullptr; }
