@@ -89,7 +89,7 @@ class FlatParams:
 
 
 class LstmCtcTrainer:
-    DX_SLABS = int(os.environ.get('HALO_DX_SLABS', '16'))        # K-slices of the LSTM's input-gradient product that the conv backward adds while reading (ops.lstm_bwd dx_slabs)
+    DX_SLABS = int(os.environ.get('HALO_DX_SLABS', '8'))        # K-slices of the LSTM's input-gradient product that the conv backward adds while reading (ops.lstm_bwd dx_slabs)
 
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
