@@ -325,10 +325,12 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
     int jt, bt;
     map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
     if (tid == 0) { s_abort = 0; s_published = 0; }
+    if (wave == 0) stamp(p.stamps, p.T + 2, 0, 14, lane);            // (diagnostic: launch entry / exit of this workgroup)
     const Fwd2Shared sh = {red, hbuf, &s_abort, &s_published};
     // (the first barrier of either loop orders the two initialisations above before any use)
     if (wave < 4) fwd2_layer0_waves<KBQ>(p, sh, jt, bt, wave, lane, tid & 255);
     else fwd2_layer1_waves<KBQ>(p, sh, wi_lds, jt, bt, wave, lane, tid & 255);
+    if (wave == 0) stamp(p.stamps, p.T + 2, 0, 15, lane);
 }
 
 // ================================================================================================================
@@ -657,9 +659,11 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
     if (tid == 0) { s_abort = 0; s_published = 0; }
     // the call's abort word is only ever raised after a 0.2 s wait: clearing it here, at the start of the launch, cannot lose one
     if (blockIdx.x == 0 && tid == 0 && p.abort_word != p.flags) __hip_atomic_store(p.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) stamp(p.stamps, p.T + 1, 0, 14, lane);            // (diagnostic: launch entry / exit of this workgroup)
     const Bwd2Shared sh = {red, dgbuf, &s_abort, &s_published};
     if (wave < 4) bwd2_layer0_waves<KC>(p, sh, jt, bt, wave, lane, tid & 255);
     else bwd2_layer1_waves<KC>(p, sh, wi_lds, jt, bt, wave, lane, tid & 255);
+    if (wave == 0) stamp(p.stamps, p.T + 1, 0, 15, lane);
 }
 
 int g_cu_count2 = 0;

@@ -36,6 +36,8 @@ steps = slice(3, T - 1)
 base = s[:, steps, 0]
 print(f'kernel span (first loop top to last): {(s[:, -1, 0].max() - s[:, 0, 0].min()):.1f} us')
 print(f'per combined step (loop top to loop top), mean over workgroups: {np.diff(s[:, 2:T, 0], axis=1).mean():.3f} us')
+print(f'workgroup entry -> first loop top (weights into registers / LDS): mean {(s[:, 0, 0] - s[:, 0, 14]).mean():.2f} us, max {(s[:, 0, 0] - s[:, 0, 14]).max():.2f};'
+      f' entry skew {s[:, 0, 14].max() - s[:, 0, 14].min():.2f}; last loop top -> exit: mean {(s[:, 0, 15] - s[:, -1, 0]).mean():.2f}; first entry -> last exit {s[:, 0, 15].max() - s[:, 0, 14].min():.1f} us')
 for k in (0, 8, 1, 2, 3, 4, 5, 7, 6):
     d = s[:, steps, k] - base
     print(f'  {names[k]:52s} +{d.mean():7.3f} us  (min {d.min():6.2f}  max {d.max():6.2f})')
@@ -59,6 +61,8 @@ steps = slice(3, T - 1)
 base = s[:, steps, 0]
 print(f'BACKWARD kernel span (first loop top to last): {(s[:, -1, 0].max() - s[:, 0, 0].min()):.1f} us')
 print(f'per combined step (loop top to loop top), mean over workgroups: {np.diff(s[:, 2:T, 0], axis=1).mean():.3f} us')
+print(f'workgroup entry -> first loop top (weights into registers / LDS): mean {(s[:, 0, 0] - s[:, 0, 14]).mean():.2f} us, max {(s[:, 0, 0] - s[:, 0, 14]).max():.2f};'
+      f' entry skew {s[:, 0, 14].max() - s[:, 0, 14].min():.2f}; last loop top -> exit: mean {(s[:, 0, 15] - s[:, -1, 0]).mean():.2f}; first entry -> last exit {s[:, 0, 15].max() - s[:, 0, 14].min():.1f} us')
 for k in (0, 1, 2, 3, 4):
     d = s[:, steps, k] - base
     print(f'  {names[k]:52s} +{d.mean():7.3f} us  (min {d.min():6.2f}  max {d.max():6.2f})')
