@@ -96,6 +96,11 @@ struct Persist2Fwd {
     unsigned long long *stamps;
     int poll_mode, replica_shift, nap;
     int T, B, H;
+    // the launch works on batch tiles [bt0, bt0 + nbt) of the ceil(B/16) (a batch larger than the chip holds workgroups for runs as several
+    // launches over the same buffers); its epoch words are those of the tiles' LOCAL index and count from epoch0, so a later launch never
+    // mistakes an earlier one's epochs for its own (set by halo_lstm_persist2_fwd / _bwd)
+    int bt0, nbt;
+    unsigned epoch0;
 };
 
 // Combined step s = 0 .. T of the backward runs layer 1's time step T-1-s and layer 0's time step T-s: the gate gradients of
@@ -123,6 +128,11 @@ struct Persist2Bwd {
     float *bias_part0, *bias_part1;   // [ceil(B/16)][4H] per layer, may be NULL
     int poll_mode, replica_shift, nap;
     int T, B, H;
+    // the launch works on batch tiles [bt0, bt0 + nbt) of the ceil(B/16) (a batch larger than the chip holds workgroups for runs as several
+    // launches over the same buffers); its epoch words are those of the tiles' LOCAL index and count from epoch0, so a later launch never
+    // mistakes an earlier one's epochs for its own (set by halo_lstm_persist2_fwd / _bwd)
+    int bt0, nbt;
+    unsigned epoch0;
 };
 
 bool halo_lstm_persist2_ok(int T, int B, int H, int L);   // shape, arithmetic mode (bf16), CU count, switch

@@ -72,13 +72,14 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
     const __amdgpu_buffer_rsrc_t hp0_rsrc = make_rsrc(p.hp0), hp1_rsrc = make_rsrc(p.hp1);
     const __amdgpu_buffer_rsrc_t x_rsrc = p.xp ? make_rsrc(p.xp) : hp0_rsrc;
     const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
-    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
+    const int btl = bt - p.bt0;                      // the epoch words are indexed by the tile's place in this launch
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + btl * NJ;
     for (int s = 0; s <= T + 1; ++s) {
         if (wave == 0) stamp(p.stamps, T + 2, s, 0, lane);
         const bool act0 = s < T, act1 = s >= 2;
         // ---- epoch s: every workgroup of the batch group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-3} ----
         bool ok = true;
-        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
             *sh.s_abort = 1;
             raise_abort(p.flags, p.status);
@@ -151,10 +152,10 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
             if (lane == 0) old = atomicAdd(sh.s_published, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
             const unsigned target = (unsigned)((s + 1 < T ? s + 1 : T) + (s >= 2 ? s - 1 : 0));
-            if (old + 1u == target && (int)blockIdx.x != p.mute) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            if (old + 1u == target && (int)blockIdx.x != p.mute) publish_epoch(p.flags, btl * NJ + jt, p.epoch0 + (unsigned)(s + 1), lane);
             stamp(p.stamps, T + 2, s, wave == 3 ? 4 : 5, lane);
         } else if (wave == 3 && !act0 && !act1) {
-            publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
+            publish_epoch(p.flags, btl * NJ + jt, p.epoch0 + (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
         }
         if (p.img_hT0 && ((wave == 3 && act0) || (wave == 2 && act1))) {
             // ---- off the hand-off path: the tile, transposed, in the operand images of the weight-gradient products.  Image row = hidden
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_fwd_kernel(const Persist
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int jt, bt;
-    map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
+    map_block(blockIdx.x, gridDim.x, p.H / 16, p.nbt, jt, bt);
+    bt += p.bt0;
     if (tid == 0) { s_abort = 0; s_published = 0; }
     if (wave == 0) stamp(p.stamps, p.T + 2, 0, 14, lane);            // (diagnostic: launch entry / exit of this workgroup)
     const Fwd2Shared sh = {red, hbuf, &s_abort, &s_published};
@@ -399,13 +401,14 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
     }
     const __amdgpu_buffer_rsrc_t dg0_rsrc = make_rsrc(p.dgp0), dg1_rsrc = make_rsrc(p.dgp1);
     const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
-    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + bt * NJ;
+    const int btl = bt - p.bt0;                      // the epoch words are indexed by the tile's place in this launch
+    const unsigned *grp_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER + btl * NJ;
     for (int s = 0; s <= T; ++s) {
         if (wave == 0) stamp(p.stamps, T + 1, s, 0, lane);
         const bool act = s >= 1;                     // layer 0 has a cell update in combined step s ...
         const int t = T - s;                          // ... at this time
         bool ok = true;
-        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, (unsigned)s, lane, p.nap);
+        if (s > 0 && wave == 1) ok = poll_group(grp_flags, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
         if (!ok && lane == 0) {
             *sh.s_abort = 1;
             raise_abort(p.abort_word, p.status);
@@ -472,7 +475,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
             unsigned old = 0;
             if (lane == 0) old = atomicAdd(sh.s_published, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
-            if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, bt * NJ + jt, (unsigned)(s + 1), lane);
+            if (old == 4u * (unsigned)s + 3u) publish_epoch(p.flags, btl * NJ + jt, p.epoch0 + (unsigned)(s + 1), lane);
             if (wave == 3) stamp(p.stamps, T + 1, s, 4, lane);
             // ---- off the hand-off path: the tile in the GEMM operand images (hi parts; gemm_bf16x3.hip layout) ----
             if (on) {
@@ -655,7 +658,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2_bwd_kernel(const Persist
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int jt, bt;
-    map_block(blockIdx.x, gridDim.x, p.H / 16, (p.B + 15) / 16, jt, bt);
+    map_block(blockIdx.x, gridDim.x, p.H / 16, p.nbt, jt, bt);
+    bt += p.bt0;
     if (tid == 0) { s_abort = 0; s_published = 0; }
     // the call's abort word is only ever raised after a 0.2 s wait: clearing it here, at the start of the launch, cannot lose one
     if (blockIdx.x == 0 && tid == 0 && p.abort_word != p.flags) __hip_atomic_store(p.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -676,6 +680,9 @@ inline int cu_count2() {
     }
     return g_cu_count2;
 }
+
+// batch tiles a launch can hold: every workgroup of a launch must be resident (one per CU)
+inline int tiles_per_launch(int H) { return max(1, cu_count2() / (H / 16)); }
 
 constexpr size_t MIN_DYN_LDS = 64 * 1024;             // with the static arrays: more than half a CU's LDS -> one workgroup per CU
 
@@ -704,38 +711,57 @@ void halo_lstm_persist2_enable(int on) { halo_ctx_cur().lstm_persistent2 = on ? 
 bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST2") && atoi(getenv("HALO_LSTM_PERSIST2")) == 0;
     if (env_off || !halo_ctx_cur().lstm_persistent2) return false;
-    if (!halo_lstm_persist_ok(B, H) || !halo_lstm_persist_fits(T, B, H)) return false;   // the per-layer recurrence's shape / switch / CU rules
+    // the per-layer recurrence's switch and shape rules, but not its limit on the batch: a large batch runs as several launches
+    if (!halo_lstm_persist_ok(16, H) || B <= 0 || !halo_lstm_persist_fits(T, B, H)) return false;
     if (halo_math_mode() != HALO_MATH_BF16 || L < 2) return false;       // the top two layers of the stack; the ones below run per layer
     if (H % 128 != 0 || H > 1024 || T < 1) return false;
     // image byte offsets are 32-bit (buffer addressing): the largest is the backward's, (T + 1) images of ceil(B/16) * 4H/32 blocks
     const long nbt = (B + 15) / 16;
     if ((long)(T + 2) * nbt * (4 * H / 32) * 2048 >= (1L << 31)) return false;
     if ((long)(T + 1) * B * 4 * H >= (1L << 31)) return false;             // 32-bit element indices inside the kernels
-    return (H / 16) * nbt <= cu_count2();
+    // the epoch words of a launch's tiles (local index) fit a replica
+    return H / 16 <= cu_count2() && PERSIST_FLAG_HEADER + (long)tiles_per_launch(H) * (H / 16) <= PERSIST_REPLICA_WORDS;
 }
 
-int halo_lstm_persist2_fwd(const Persist2Fwd &a, hipStream_t st) {
-    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
-    const int kbq = a.H / 128;
+// The batch rows are independent chains: a batch of more 16-row tiles than the chip holds workgroups for runs as consecutive launches over
+// the same buffers, each on its own tiles (B = 128 at H = 1024: two launches of 256 workgroups).  The epochs of launch g start behind
+// those of launch g - 1, so the (once zeroed) epoch words need no clearing between them.
+template <typename A, typename F>
+int launch_groups(const A &a0, int steps, F launch_one) {
+    const int nbt = (a0.B + 15) / 16, per = tiles_per_launch(a0.H);
+    for (int bt0 = 0, g = 0; bt0 < nbt; bt0 += per, ++g) {
+        A a = a0;
+        a.bt0 = bt0; a.nbt = min(per, nbt - bt0); a.epoch0 = (unsigned)g * (unsigned)(steps + 2);
+        const int rc = launch_one(a, (a.H / 16) * a.nbt);
+        if (rc != HALO_OK) return rc;
+    }
+    return HALO_OK;
+}
+
+int halo_lstm_persist2_fwd(const Persist2Fwd &a0, hipStream_t st) {
+    const int kbq = a0.H / 128;
     const size_t dyn = (size_t)4 * 1024 * (4 * kbq - (kbq >= 8 ? 2 : 0));      // 4 quarters x NWLDS fragments of 1 KiB
-    switch (kbq) {
-        case 2: return launch2(lstm_persist2_fwd_kernel<2>, a, blocks, dyn, st);
-        case 4: return launch2(lstm_persist2_fwd_kernel<4>, a, blocks, dyn, st);
-        case 6: return launch2(lstm_persist2_fwd_kernel<6>, a, blocks, dyn, st);
-        case 8: return launch2(lstm_persist2_fwd_kernel<8>, a, blocks, dyn, st);
-        default: return HALO_ENOTSUP;
-    }
+    return launch_groups(a0, a0.T + 2, [&](const Persist2Fwd &a, int blocks) {
+        switch (kbq) {
+            case 2: return launch2(lstm_persist2_fwd_kernel<2>, a, blocks, dyn, st);
+            case 4: return launch2(lstm_persist2_fwd_kernel<4>, a, blocks, dyn, st);
+            case 6: return launch2(lstm_persist2_fwd_kernel<6>, a, blocks, dyn, st);
+            case 8: return launch2(lstm_persist2_fwd_kernel<8>, a, blocks, dyn, st);
+            default: return (int)HALO_ENOTSUP;
+        }
+    });
 }
 
-int halo_lstm_persist2_bwd(const Persist2Bwd &a, hipStream_t st) {
-    const int blocks = (a.H / 16) * ((a.B + 15) / 16);
-    const int kc = a.H / 128;
+int halo_lstm_persist2_bwd(const Persist2Bwd &a0, hipStream_t st) {
+    const int kc = a0.H / 128;
     const size_t dyn = (size_t)4 * 4 * kc * 1024;     // 4 quarters x KBW fragments of 1 KiB
-    switch (kc) {
-        case 2: return launch2(lstm_persist2_bwd_kernel<2>, a, blocks, dyn, st);
-        case 4: return launch2(lstm_persist2_bwd_kernel<4>, a, blocks, dyn, st);
-        case 6: return launch2(lstm_persist2_bwd_kernel<6>, a, blocks, dyn, st);
-        case 8: return launch2(lstm_persist2_bwd_kernel<8>, a, blocks, dyn, st);
-        default: return HALO_ENOTSUP;
-    }
+    return launch_groups(a0, a0.T + 1, [&](const Persist2Bwd &a, int blocks) {
+        switch (kc) {
+            case 2: return launch2(lstm_persist2_bwd_kernel<2>, a, blocks, dyn, st);
+            case 4: return launch2(lstm_persist2_bwd_kernel<4>, a, blocks, dyn, st);
+            case 6: return launch2(lstm_persist2_bwd_kernel<6>, a, blocks, dyn, st);
+            case 8: return launch2(lstm_persist2_bwd_kernel<8>, a, blocks, dyn, st);
+            default: return (int)HALO_ENOTSUP;
+        }
+    });
 }

@@ -295,6 +295,9 @@ def _normalised_close(a, b, rtol, atol):
     (9, 33, 64, 512, 0.0, False),           # 3 batch tiles (plain block map), no dropout: layer 1 reads layer 0's own images
     (21, 64, 128, 1024, 0.2, False),        # the benchmark's grid: 256 workgroups, W_ih1 split between registers and LDS
     (1, 32, 128, 1024, 0.2, True),          # a single time step: combined steps 0 and 1 only
+    (8, 128, 128, 1024, 0.2, False),        # 8 batch tiles on 256 CUs: two launches of 256 workgroups over the same buffers
+    (5, 88, 64, 1024, 0.0, True),           # 6 tiles (the last ragged): launches of 4 and 2 tiles, carried state
+    (4, 160, 128, 512, 0.1, False),         # H = 512: 8 tiles per launch, 10 tiles
 ])
 def test_two_layer_launch_equals_layer_launches(hal, math_mode, T, B, in0, H, p_drop, with_state):
     """csrc/lstm_persist2.hip (both layers in one persistent launch per direction, bf16 mode) computes what the two per-layer
