@@ -124,3 +124,34 @@ def test_a_batch_of_two_launches_is_the_two_batches(model):
         np.testing.assert_allclose(n_ab[:B].cpu().numpy(), n_a.cpu().numpy(), rtol=2e-5)
     finally:
         lib.set_math_mode(prev)
+
+
+def test_beam_search_properties_at_full_size(model):
+    """CTC beam search (beam 16) on the model's own log-probs, all 64 utterances: scores come out sorted (descending) for every utterance;
+    the batched entry gives what one call per utterance gives, and a permuted batch the permuted result -- bit for bit; hypotheses of an
+    utterance are distinct; the best hypothesis scores at least the greedy path's own probability."""
+    lib, enc, rec, (x, il, tg, tl) = model
+    from haloop_amd import beam
+    prev = lib.get_math_mode()
+    lib.set_math_mode('bf16')
+    try:
+        with torch.no_grad():
+            feats, flen, _ = enc(x, il)
+            lp = rec.log_probs(feats).contiguous()
+        hyps, scores = beam.decode_batch(lp, 16, True)
+        sc = scores.cpu().numpy()
+        assert np.isfinite(sc).all() and (np.diff(sc, axis=1) <= 0).all()
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(2))
+        hyps_p, scores_p = beam.decode_batch(lp[perm.to(DEV)].contiguous(), 16, True)
+        assert torch.equal(scores[perm.to(DEV)], scores_p)
+        for i, j in enumerate(perm.tolist()):
+            assert hyps[j] == hyps_p[i]
+        greedy = lp.max(-1).values.sum(-1).cpu().numpy()           # log-probability of the single best alignment
+        for n in (0, 17, 63):
+            one, s_one = beam.ctc_beam_search_decode_logits(lp[n], 16)
+            assert one == hyps[n] and torch.equal(s_one, scores[n])
+        for n in range(B):
+            assert len({tuple(h) for h in hyps[n]}) == 16
+            assert sc[n, 0] >= greedy[n] - 1e-4
+    finally:
+        lib.set_math_mode(prev)
