@@ -155,3 +155,34 @@ def test_beam_search_properties_at_full_size(model):
             assert sc[n, 0] >= greedy[n] - 1e-4
     finally:
         lib.set_math_mode(prev)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_gpt2_small_is_causal_and_row_independent(mode):
+    """BASELINE config 3 (GPT-2 small, 12 layers x 12 heads x 768, T = 1024, vocab 50304; random weights): the per-token losses of a
+    sequence do not depend on the other sequences of the batch (each row scored alone gives the same numbers up to fp32 regrouping of the
+    lm_head product), nor on any token after the position -- replacing the inputs from position 600 on leaves the first 600 per-token
+    losses of every row bit-identical and changes later ones."""
+    from haloop_amd import _lib, attention, synth
+    _lib.lib(); _lib.lend_scratch()
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        torch.manual_seed(0)
+        cfg = attention.GPTConfig(block_size=1024, vocab_size=50304, n_layer=12, n_head=12, n_embd=768, dropout=0.0, bias=False)
+        model = attention.GPT(cfg).to(DEV).eval()
+        N, T, cut = 4, 1024, 600
+        inputs, targets = synth.synthetic_tokens(N, T, 50304, 5, pad_tail=False)
+        inputs, targets = inputs.to(DEV), targets.to(DEV)
+        with torch.no_grad():
+            base = model.forward_all(inputs, targets, reduction='none').view(N, T)
+            changed = inputs.clone()
+            changed[:, cut:] = torch.randint(1, 50304, (N, T - cut), generator=torch.Generator().manual_seed(6)).to(DEV)
+            other = model.forward_all(changed, targets, reduction='none').view(N, T)
+            assert torch.isfinite(base).all()
+            assert torch.equal(base[:, :cut], other[:, :cut])
+            assert not torch.equal(base[:, cut:], other[:, cut:])
+            alone = model.forward_all(inputs[2:3].contiguous(), targets[2:3].contiguous(), reduction='none').view(1, T)
+        np.testing.assert_allclose(alone[0].cpu().numpy(), base[2].cpu().numpy(), rtol=3e-5 if mode == 'bf16x3' else 2e-3, atol=1e-5 if mode == 'bf16x3' else 2e-3)
+    finally:
+        _lib.set_math_mode(prev)
