@@ -54,7 +54,11 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step from its HIP graph.  Neither flag (one process): both ways are timed over 40 steps after the warm-up and the '
+                         'faster one runs the timed region -- at 13 launches per step the host keeps ahead of the GPU and eager launches save the '
+                         '~15 us a graph replay costs on ROCm 7.2; a slow or busy host reverses that')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / bf16_mode / f32_mode legs')
     ap.add_argument('--dp-rehearsal', action='store_true',
                     help='N=1 only, a measurement aid: run the data-parallel code path (three graphs, RCCL all-reduces between them, '
@@ -199,8 +203,7 @@ def time_other_mode(mode, device, batch, warmup, steps, use_graph):
 
 def batch_sweep(mode, device, warmup, steps, use_graph):
     """'larger B raises the achieved fraction.  Report both.'  The same step at B = 128 and 256 per GPU
-    (bytes(B) = 10*4*P + 2.12e6*B); the persistent recurrences take (H/16) * ceil(B/16) <= 256 workgroups, larger batches
-    run the step-launch chain."""
+    (bytes(B) = 10*4*P + 2.12e6*B); in bf16 arithmetic the two-layer persistent launches run once per 64 batch rows."""
     from haloop_amd import _lib, synth
     out = {}
     for B in (128, 256):
@@ -369,7 +372,25 @@ def main():
         trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=False, grad_dtype=args.grad_dtype, alias_loss=True, **dp_kw)
         for _ in range(args.warmup):
             trainer.step(x, il, tg, tl)
-    if trainer.static_inputs() is not None:                 # inputs resident in the step graph's own buffers (no per-step copy)
+    mode_probe = None
+    if world == 1 and not args.dp_rehearsal and use_graph and not args.graph and not args.no_graph:
+        # graph replay or eager launches: whichever is faster on this box (both are the same launches on the same stream)
+        def probe(n):
+            for _ in range(5):
+                trainer.step(x, il, tg, tl)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                trainer.step(x, il, tg, tl)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t) / n
+        graph_ms = probe(40)
+        trainer.use_graph = False
+        eager_ms = probe(40)
+        use_graph = graph_ms <= eager_ms
+        trainer.use_graph = use_graph
+        mode_probe = {'graph_replay_ms': round(graph_ms, 4), 'eager_launches_ms': round(eager_ms, 4), 'steps_each': 40}
+    if use_graph and trainer.static_inputs() is not None:   # inputs resident in the step graph's own buffers (no per-step copy)
         x, il, tg, tl = trainer.static_inputs()
     if world > 1:
         dist.barrier()
@@ -404,12 +425,12 @@ def main():
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'math': args.math,
+                       'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'launch_mode_probe': mode_probe, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None,
                        'dp_algo': trainer.dp_algo if (world > 1 or args.dp_rehearsal) else None,
                        'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None},
             'n_ranks_seen': n_ranks_seen,
-            'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps,
+            'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps + (90 if mode_probe else 0),
             'step_roofline': {'algorithmic_bytes_per_step': step_bytes,
                               'achieved_GBs': round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               'frac_of_hbm_peak': round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -455,7 +476,7 @@ def main():
             for mode in ('bf16', 'bf16x3', 'f32'):
                 if mode != args.math:
                     out[mode + '_mode'] = time_other_mode(mode, device, (x, il, tg, tl), args.warmup, n2, not args.no_graph)
-            out['b_sweep'] = batch_sweep(args.math, device, args.warmup, max(20, args.steps // 4), not args.no_graph)
+            out['b_sweep'] = batch_sweep(args.math, device, args.warmup, max(20, args.steps // 4), use_graph)       # (the launch mode the headline chose)
             out['b_sweep'][f'B{B_PER_GPU}'] = {'value': out['value'], 'unit': 'utterances/s', 'ms_per_step': out['ms_per_step'], 'batch': B_PER_GPU,
                                                'step_frac_of_hbm_peak': out['step_roofline']['frac_of_hbm_peak'],
                                                'recurrence': out.get('roofline', {}).get('kernel')}
