@@ -161,19 +161,26 @@ def time_inference(enc, rec, x, steps):
     import torch
     from haloop_amd.infer import LstmCtcRecognizer
     was_training = enc.training
-    reco = LstmCtcRecognizer(enc, rec)
-    for _ in range(5):
-        reco.recognize(x)
-    x = reco.static_input() if reco.static_input() is not None else x      # resident in the graph's own buffer
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        reco.recognize(x, clone=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def run(use_graph, n):
+        reco = LstmCtcRecognizer(enc, rec, use_graph=use_graph)
+        for _ in range(5):
+            reco.recognize(x)
+        xs = reco.static_input() if reco.static_input() is not None else x      # resident in the graph's own buffer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            reco.recognize(xs, clone=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    # six launches per batch: replayed from a HIP graph or launched eagerly, whichever is faster on this box (as the training step)
+    probe = {True: run(True, 60), False: run(False, 60)}
+    use_graph = probe[True] <= probe[False]
+    dt = run(use_graph, steps)
     enc.train(was_training); rec.train(was_training)
-    return {'metric': 'utterances/sec, forward + greedy CTC decode (eval)', 'value': round(steps * x.shape[0] / dt, 1),
-            'unit': 'utterances/s', 'ms_per_batch': round(1e3 * dt / steps, 4), 'batch': x.shape[0]}
+    return {'metric': 'utterances/sec, forward + greedy CTC decode (eval)', 'value': round(x.shape[0] / dt, 1),
+            'unit': 'utterances/s', 'ms_per_batch': round(1e3 * dt, 4), 'batch': x.shape[0], 'hip_graph': use_graph,
+            'launch_mode_probe': {'graph_replay_ms': round(1e3 * probe[True], 4), 'eager_launches_ms': round(1e3 * probe[False], 4)}}
 
 
 def time_other_mode(mode, device, batch, warmup, steps, use_graph):
