@@ -145,6 +145,8 @@ class LstmCtcTrainer:
         self.adam_step = torch.zeros(1, device=dev, dtype=torch.int32)    # APPLIED updates: advanced on the device (clip_coef)
         self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)      # last-workgroup ticket of the fused CTC head
         self.use_graph = use_graph
+        # sharded data-parallel step in graph mode: forward + backward launched eagerly, only the tail (the collectives) replayed
+        self.eager_forward_backward = os.environ.get('HALO_DP_EAGER_FB', '1') != '0'
         self.pg = process_group
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
         self.sharded = (dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp, wire_dtype=grad_dtype)
@@ -391,7 +393,11 @@ class LstmCtcTrainer:
             self._forward_backward(x, il, tg, tl)
             self._sharded_tail()
             return self.loss
-        self._replay_forward_backward(x, il, tg, tl)
+        if self.eager_forward_backward:
+            # 13-16 launches: the host keeps ahead of the GPU, and eager launches save what a graph replay costs
+            self._forward_backward(x, il, tg, tl)
+        else:
+            self._replay_forward_backward(x, il, tg, tl)
         self._tail_calls = getattr(self, '_tail_calls', 0) + 1
         if self._tail_calls == 2 and self.sharded._native and os.environ.get('HALO_DP_CAPTURE', '1') != '0':
             # the first tail ran eagerly (communicator and kernels warm); record the second
