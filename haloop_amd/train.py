@@ -12,6 +12,7 @@ gradients averaged with one RCCL all-reduce per step over the flat gradient buff
 semantics of DistributedDataParallel in ha/attention_loop.py:154.
 """
 import os
+import time
 
 import torch
 
@@ -94,7 +95,10 @@ class LstmCtcTrainer:
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
                  alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False):
-        """accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
+        """use_graph: True -- the step replays from HIP graphs (default); False -- the same launches issued eagerly; 'auto' (one process,
+        accumulate == 1) -- both are timed over the first 53 steps and the faster way stays (``auto_choice``): with the two-layer launches a
+        step is 13 launches, the host enqueues them in ~0.2 ms against ~0.47 ms on the GPU, and a replay costs ~15 us more than it saves.
+        accumulate: micro-batches per optimizer step (--accumulate, ha/loop.py:176-181): every step() call runs one
         forward/backward on loss / accumulate; the all-reduce, clip and AdamW run on every accumulate-th call.
         A micro-batch whose loss is NaN/Inf contributes nothing (the reference skips it, loop.py:167-174; here it still counts
         towards the cycle, because nothing synchronises with the host); an update whose gradient norm is not finite is
@@ -144,7 +148,14 @@ class LstmCtcTrainer:
         self.step_count = 0                                                # step() calls that reached the optimizer
         self.adam_step = torch.zeros(1, device=dev, dtype=torch.int32)    # APPLIED updates: advanced on the device (clip_coef)
         self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)      # last-workgroup ticket of the fused CTC head
+        # use_graph: True -- the step replays from HIP graphs; False -- eager launches; 'auto' (one process, no accumulation) -- both are
+        # timed over the first steps and the faster one stays (_auto_step; at 13 launches per step eager launches win by 2-4 % on an idle host)
+        auto = use_graph == 'auto'
+        if auto:
+            use_graph = True
         self.use_graph = use_graph
+        self._auto = {'n': 0} if (auto and self.world == 1 and not rehearse_dp and self.accumulate == 1) else None
+        self.auto_choice = None
         # sharded data-parallel step in graph mode: forward + backward launched eagerly, only the tail (the collectives) replayed
         self.eager_forward_backward = os.environ.get('HALO_DP_EAGER_FB', '1') != '0'
         self.pg = process_group
@@ -363,8 +374,34 @@ class LstmCtcTrainer:
     def step(self, x, input_lengths, targets, target_lengths):
         """One optimizer step (one micro-step of it when accumulate > 1).  Returns the (device) loss of this batch: a copy the
         caller owns, or ``self.loss`` itself under ``alias_loss``; nothing here synchronises."""
-        loss = self._step(x, input_lengths, targets, target_lengths)
+        if self._auto is not None:
+            loss = self._auto_step(x, input_lengths, targets, target_lengths)
+        else:
+            loss = self._step(x, input_lengths, targets, target_lengths)
         return loss if self.alias_loss else loss.clone()
+
+    # use_graph='auto' (one process): steps 1-8 replay the graph (warm-up and capture), 9-28 are timed replayed, 29-33 and 34-53 run
+    # as eager launches (warm-up, timed); from step 54 on the faster way runs.  Three host synchronisations in all.
+    _AUTO = (8, 28, 33, 53)
+
+    def _auto_step(self, x, il, tg, tl):
+        a, (w0, g1, w1, e1) = self._auto, self._AUTO
+        a['n'] += 1
+        n = a['n']
+        if n == w0 + 1 or n == w1 + 1:
+            torch.cuda.synchronize()
+            a['t0'] = time.perf_counter()
+        self.use_graph = n <= g1
+        loss = self._step(x, il, tg, tl)
+        if n == g1 or n == e1:
+            torch.cuda.synchronize()
+            a['graph' if n == g1 else 'eager'] = time.perf_counter() - a['t0']
+        if n == e1:
+            self.use_graph = a['graph'] <= a['eager']
+            self.auto_choice = {'graph_replay_ms': 1e3 * a['graph'] / (g1 - w0), 'eager_launches_ms': 1e3 * a['eager'] / (e1 - w1),
+                                'use_graph': self.use_graph}
+            self._auto = None
+        return loss
 
     def _step(self, x, input_lengths, targets, target_lengths):
         if _lib._status_tensor is not self.status:          # another trainer registered its word since: this step's launches report to OURS

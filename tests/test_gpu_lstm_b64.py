@@ -597,3 +597,26 @@ def test_recognizer_keeps_packed_weights_only_while_the_weights_stand(hal, math_
         enc.lstm.weight_hh_l1.mul_(0.5)
     moved = same_as_fresh()
     assert not torch.equal(after[1], moved[1])
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_trainer_auto_launch_mode_settles_and_keeps_the_trajectory(hal, math_mode):
+    """LstmCtcTrainer(use_graph='auto') times graph replays and eager launches over its first 53 steps and keeps the faster way: the
+    losses are those of the graph-mode trainer step for step (the same launches either way), and a choice has been recorded."""
+    from haloop_amd.train import LstmCtcTrainer
+    from haloop_amd import synth
+    F_, C, H, L, V, B, T, S = 80, 128, 512, 2, 32, 32, 80, 8
+    x, il, tg, tl = [t.to(DEV) for t in synth.synthetic_batch(B, T, F_, V, S, 3)]
+    losses = {}
+    for mode in (True, 'auto'):
+        enc_p, rec_p = synth.make_params(F_, C, H, L, V, 42)
+        enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+        enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+        enc.to(DEV).train(); rec.to(DEV).train()
+        tr = LstmCtcTrainer(enc, rec, lr=3e-4, seed=5, use_graph=mode)
+        losses[mode] = torch.stack([tr.step(x, il, tg, tl) for _ in range(60)]).cpu()
+        tr.check_status()
+        if mode == 'auto':
+            assert tr._auto is None and tr.auto_choice is not None and isinstance(tr.use_graph, bool)
+            assert tr.auto_choice['graph_replay_ms'] > 0 and tr.auto_choice['eager_launches_ms'] > 0
+    assert torch.equal(losses[True], losses['auto'])
