@@ -301,7 +301,8 @@ int halo_lstm_persistent_eligible(int B, int H);
  * (the lower layer at time s beside the upper at time s - 2: one hand-off per combined step, the upper layer's input projection inside
  * its step; the layers below them one launch each), and halo_lstm_bwd called with layer_end = L and layer_begin <= L - 2 likewise (the
  * upper layer's input gradient formed inside the launch).  Same reserve contents as the per-layer path, so either backward follows
- * either forward.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
+ * either forward.  Any batch: the batch rows are independent chains, so more 16-row tiles than the chip has CUs for (H/16 workgroups per
+ * tile) run as consecutive launches over the same buffers.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
 int halo_set_lstm_persistent2(int on);
 /* Inference with static weights.  stamp != 0 is the caller's promise that the LSTM weights change only when the stamp does: a forward-only
  * call (halo_set_lstm_expect_backward(0)) of the two-layer launch then KEEPS the packed weight images that the previous call with the same
