@@ -214,6 +214,9 @@ class LstmCtcTrainer:
             if self._defer:
                 self._defer = False
                 _lib.lib().halo_set_defer_small_jobs(0)
+            if self._collect:
+                self._collect = False
+                _lib.lib().halo_set_grad_sumsq(None, 0)
             raise
 
     def _forward_backward_top_body(self, x, il, tg, tl):
