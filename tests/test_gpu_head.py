@@ -41,6 +41,7 @@ def test_fused_head_equals_separate_operators(B, T_in, H, V, S, p):
     tl = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
     if B >= 3:
         il[1] = 9; tg[1] = 1; tl[1] = min(S, 4)          # infeasible when S >= 4 (equal labels need 2S-1 frames): nll = inf
+        tl[2] = 0                                        # an empty target: only blanks
     il, tg, tl = il.to(DEV), tg.to(DEV), tl.to(DEV)
     drop = ops.Dropout(p, 0x1234ABCD5678, 5) if p > 0 else ops.NO_DROPOUT
     want = _separate(ops, _lib, feats, W, b, drop, il, tg, tl)

@@ -112,6 +112,38 @@ def test_ctc_gradient_vs_torch_cpu(hal):
     np.testing.assert_allclose(lg.grad.cpu().numpy(), lc.grad.numpy(), atol=1e-5)   # stated logits-grad tolerance
 
 
+def test_ctc_edge_cases_vs_torch_cpu(hal):
+    """The lattice's corners against stock torch CPU ``F.ctc_loss`` (what the reference runs, ha/recognizer.py:71): an EMPTY target (only
+    blanks may be emitted), a single frame, exactly as many frames as labels, repeated labels that need separating blanks (one frame
+    short: infeasible, inf and a zero gradient row... torch gives nan there: compared as 'not finite'), the longest target the batch
+    holds, and a batch of one -- per-utterance losses (reduction='none') and the gradient at the logits of the feasible utterances."""
+    gen = torch.Generator().manual_seed(12)
+    T, C, S = 12, 7, 6
+    tg = torch.tensor([[1, 2, 3, 4, 5, 6],      # tl = 0: empty target
+                       [3, 0, 0, 0, 0, 0],      # one label, one frame
+                       [1, 2, 3, 4, 0, 0],      # il == tl: every frame a label
+                       [2, 2, 2, 0, 0, 0],      # repeats: needs 2 tl - 1 = 5 frames, has 5
+                       [2, 2, 2, 0, 0, 0],      # ... has 4: infeasible
+                       [6, 5, 6, 5, 6, 5]])     # the full width S, all frames
+    il = torch.tensor([7, 1, 4, 5, 4, 12])
+    tl = torch.tensor([0, 1, 4, 3, 3, 6])
+    for N in (6, 1):
+        logits = torch.randn(T, N, C, generator=gen)
+        lc = logits.clone().requires_grad_(True)
+        want = torch.nn.functional.ctc_loss(lc.log_softmax(-1), tg[:N], il[:N], tl[:N], reduction='none')
+        fin = torch.isfinite(want)
+        want[fin].sum().backward()
+        lg = logits.to(DEV).requires_grad_(True)
+        got = hal['F'].ctc_loss(hal['F'].log_softmax(lg), tg[:N].to(DEV), il[:N].to(DEV), tl[:N].to(DEV), reduction='none')
+        assert torch.equal(torch.isfinite(got).cpu(), fin), (got, want)
+        np.testing.assert_allclose(got.detach().cpu().numpy()[fin.numpy()], want.detach().numpy()[fin.numpy()], rtol=2e-6, atol=2e-6)
+        got[fin.to(DEV)].sum().backward()
+        np.testing.assert_allclose(lg.grad.cpu().numpy()[:, fin.numpy()], lc.grad.numpy()[:, fin.numpy()], atol=1e-5)
+        if N == 6:
+            assert not fin[4] and fin[[0, 1, 2, 3, 5]].all()
+            assert abs(want[0].item() + lc.log_softmax(-1)[:7, 0, 0].sum().item()) < 1e-5      # empty target: -sum of the blank log-probs
+
+
 # ----------------------------------------------------------------------------------- greedy / beam
 def test_greedy_matches_reference(hal):
     g = load_golden('g1_tiny_l2')
