@@ -620,3 +620,23 @@ def test_trainer_auto_launch_mode_settles_and_keeps_the_trajectory(hal, math_mod
             assert tr._auto is None and tr.auto_choice is not None and isinstance(tr.use_graph, bool)
             assert tr.auto_choice['graph_replay_ms'] > 0 and tr.auto_choice['eager_launches_ms'] > 0
     assert torch.equal(losses[True], losses['auto'])
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_recognizer_auto_launch_mode(hal, math_mode):
+    """LstmCtcRecognizer(use_graph='auto'): 46 calls settle the launch mode; every call's result equals the graph-mode recognizer's."""
+    from haloop_amd.infer import LstmCtcRecognizer
+    from haloop_amd import synth
+    F_, C, H, L, V, B, T = 80, 128, 512, 2, 32, 32, 80
+    enc_p, rec_p = synth.make_params(F_, C, H, L, V, 42)
+    enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+    enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+    enc.to(DEV); rec.to(DEV)
+    ref = LstmCtcRecognizer(enc, rec, use_graph=True)
+    auto = LstmCtcRecognizer(enc, rec, use_graph='auto')
+    for i in range(50):
+        x = synth.synthetic_batch(B, T, F_, V, 8, 100 + i % 3)[0].to(DEV)
+        want, got = ref.recognize(x), auto.recognize(x)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b), i
+    assert auto._auto is None and auto.auto_choice is not None and isinstance(auto.use_graph, bool)
