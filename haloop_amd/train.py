@@ -400,7 +400,7 @@ class LstmCtcTrainer:
             torch.cuda.synchronize()
             a['graph' if n == g1 else 'eager'] = time.perf_counter() - a['t0']
         if n == e1:
-            self.use_graph = a['graph'] <= a['eager']
+            self.use_graph = not (a['eager'] / (e1 - w1) < 0.99 * a['graph'] / (g1 - w0))      # eager must win by 1 % to be kept
             self.auto_choice = {'graph_replay_ms': 1e3 * a['graph'] / (g1 - w0), 'eager_launches_ms': 1e3 * a['eager'] / (e1 - w1),
                                 'use_graph': self.use_graph}
             self._auto = None
