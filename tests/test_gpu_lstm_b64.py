@@ -298,6 +298,7 @@ def _normalised_close(a, b, rtol, atol):
     (8, 128, 128, 1024, 0.2, False),        # 8 batch tiles on 256 CUs: two launches of 256 workgroups over the same buffers
     (5, 88, 64, 1024, 0.0, True),           # 6 tiles (the last ragged): launches of 4 and 2 tiles, carried state
     (4, 160, 128, 512, 0.1, False),         # H = 512: 8 tiles per launch, 10 tiles
+    (251, 64, 128, 1024, 0.2, False),       # a 1000-frame utterance batch: 253 combined steps per launch, epochs and image offsets far from the benchmark's
 ])
 def test_two_layer_launch_equals_layer_launches(hal, math_mode, T, B, in0, H, p_drop, with_state):
     """csrc/lstm_persist2.hip (both layers in one persistent launch per direction, bf16 mode) computes what the two per-layer
