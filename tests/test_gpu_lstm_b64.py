@@ -641,3 +641,24 @@ def test_recognizer_auto_launch_mode(hal, math_mode):
         for a, b in zip(want, got):
             assert torch.equal(a, b), i
     assert auto._auto is None and auto.auto_choice is not None and isinstance(auto.use_graph, bool)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16', 'bf16x3'], indirect=True)
+def test_trainer_on_long_utterances(hal, math_mode):
+    """400-frame utterances (T' = 101: the head runs as separate operators, the LSTM's small sums still ride in the conv backward's launch):
+    three trainer steps replayed from the graph and launched eagerly give the same losses bit for bit, finite and decreasing on a repeated batch."""
+    from haloop_amd.train import LstmCtcTrainer
+    from haloop_amd import synth
+    F_, C, H, L, V, B, T, S = 40, 64, 256, 2, 32, 16, 400, 12
+    x, il, tg, tl = [t.to(DEV) for t in synth.synthetic_batch(B, T, F_, V, S, 4)]
+    out = {}
+    for graph in (True, False):
+        enc_p, rec_p = synth.make_params(F_, C, H, L, V, 42)
+        enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+        enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+        enc.to(DEV).train(); rec.to(DEV).train()
+        tr = LstmCtcTrainer(enc, rec, lr=1e-3, seed=9, use_graph=graph)
+        out[graph] = torch.stack([tr.step(x, il, tg, tl) for _ in range(6)]).cpu()
+        tr.check_status()
+    assert torch.equal(out[True], out[False])
+    assert torch.isfinite(out[True]).all() and out[True][-1] < out[True][0]

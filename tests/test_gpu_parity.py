@@ -614,6 +614,7 @@ def test_gpt_refuses_what_is_not_built(hal):
     (20, 24, 48, 1, 11, 17, 37, 5),        # single layer, H % 32 != 0 (f32-packed fallback), B not a multiple of 16
     (20, 32, 64, 3, 11, 20, 45, 5),        # smallest shape of the layer-diagonal fused path (H % 64 == 0, L = 3)
     (40, 64, 128, 2, 32, 64, 80, 10),      # fused path, B = 64
+    (40, 64, 256, 2, 32, 8, 400, 12),      # 400-frame utterances: T' = 101 feature frames (beyond the fused head's 32-frame tile)
 ])
 def test_other_shapes_match_oracle(hal, math_mode, fusion, F_, C, H, L, V, B, T, S):
     """Sizes outside the goldens are checked against the CPU oracle (itself pinned to the reference)."""
