@@ -90,13 +90,21 @@ def self_launch(args):
     raise SystemExit(proc.returncode)
 
 
-def algorithmic_step_bytes(B):
-    """10 * 4 * P parameter-side bytes + 2.12 MB of activations per utterance."""
-    P = 13_207_712
-    return 10 * 4 * P + 2_120_000 * B
+def param_count(hidden=H, layers=L):
+    """Parameters of Encoder(80, 128, hidden) with `layers` LSTM layers + TemporalClassifier(hidden, 32): 13,207,712 for LC-2x1024."""
+    lstm = sum(4 * hidden * ((C_SUB if l == 0 else hidden) + hidden) + 8 * hidden for l in range(layers))
+    return C_SUB * F * 5 + C_SUB + lstm + V * hidden + V
 
 
-def chain_algorithmic_bytes(B, direction, layers=1):
+def algorithmic_step_bytes(B, hidden=H, layers=L):
+    """10 * 4 * P parameter-side bytes + per utterance the activations: x read (25,600), conv out written + read
+    (2 x 10,752), the LSTM's saved gates / c / h (6H x 4 B x T' x L) written forward and read backward, logits / log-probs (3 x 2,688):
+    2.12 MB per utterance for LC-2x1024."""
+    per_utt = 2 * 6 * hidden * 4 * T_SUB * layers + 55_616
+    return 10 * 4 * param_count(hidden, layers) + per_utt * B
+
+
+def chain_algorithmic_bytes(B, direction, layers=1, strict=False):
     """Bytes ONE launch of the recurrent chain must move over its T' steps, SURVEY.md 8d accounting: every weight matrix the launch
     multiplies by once per pass (4 bytes per parameter), plus per step, utterance and layer the fp32 activations that enter or leave.
     forward : W_hh [4H,H]; per step: gate pre-activations in [4H], activated gates out [4H], c_t out [H], h_t out [H]
@@ -105,15 +113,17 @@ def chain_algorithmic_bytes(B, direction, layers=1):
     layers = 2 (the two-layer launch, csrc/lstm_persist2.hip): both layers' terms plus W_ih of layer 1 [4H,H], which that launch
     multiplies by as well (forward: the input projection; backward: the input gradient)"""
     per_step = (4 * H + 4 * H + H + H) if direction == 'fwd' else (4 * H + H + H + 4 * H)
+    if strict:
+        per_step = 6 * H             # SURVEY.md 8d's own activation term: the saved gates / c / h, 6H per step, written forward, read backward
     weights = 1 if layers == 1 else 3
     return 4 * weights * (4 * H * H) + 4 * T_SUB * B * per_step * layers
 
 
-def build_model(device, seed=42):
+def build_model(device, seed=42, hidden=H, layers=L):
     from haloop_amd import rnn, recognizer, synth
-    enc_p, rec_p = synth.make_params(F, C_SUB, H, L, V, seed)
-    enc = rnn.Encoder(F, C_SUB, H, num_layers=L)
-    rec = recognizer.TemporalClassifier(H, V)
+    enc_p, rec_p = synth.make_params(F, C_SUB, hidden, layers, V, seed)
+    enc = rnn.Encoder(F, C_SUB, hidden, num_layers=layers)
+    rec = recognizer.TemporalClassifier(hidden, V)
     enc.load_state_dict(enc_p)
     rec.load_state_dict(rec_p)
     return enc.to(device).train(), rec.to(device).train(), (enc_p, rec_p)
@@ -186,13 +196,14 @@ def time_inference(enc, rec, x, steps):
             'launch_mode_probe': {'graph_replay_ms': [round(1e3 * t, 4) for t in probe[True]], 'eager_launches_ms': [round(1e3 * t, 4) for t in probe[False]]}}
 
 
-def time_other_mode(mode, device, batch, warmup, steps, use_graph):
-    """The same training step in another arithmetic mode, or at another batch size (own model + trainer, same seeds)."""
+def time_other_mode(mode, device, batch, warmup, steps, use_graph, hidden=H, layers=L):
+    """The same training step in another arithmetic mode, at another batch size, or on another of the reference's model shapes
+    (own model + trainer, same seeds)."""
     import torch
     from haloop_amd import _lib
     from haloop_amd.train import LstmCtcTrainer
     _lib.set_math_mode(mode)
-    enc, rec, _ = build_model(device)
+    enc, rec, _ = build_model(device, hidden=hidden, layers=layers)
     tr = LstmCtcTrainer(enc, rec, seed=1337, use_graph=True, alias_loss=True)
     for _ in range(warmup):
         tr.step(*batch)
@@ -226,7 +237,7 @@ def time_other_mode(mode, device, batch, warmup, steps, use_graph):
     dt = time.perf_counter() - t1
     tr.check_status()
     B = batch[0].shape[0]
-    nbytes = algorithmic_step_bytes(B)
+    nbytes = algorithmic_step_bytes(B, hidden, layers)
     return {'value': round(B * steps / dt, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt / steps, 4), 'batch': B,
             'dtype': MATH_DTYPE[mode], 'final_loss': round(tr.loss.item(), 5), 'hip_graph': tr.use_graph,
             'step_frac_of_hbm_peak': round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -491,9 +502,14 @@ def main():
                             return v
                 return read_traffic(name)
             ach = kb / launches_b / (us_b / launches_b * 1e-6) / 1e9
+            kb_s, kf_s = chain_algorithmic_bytes(B_PER_GPU, 'bwd', cl, strict=True), chain_algorithmic_bytes(B_PER_GPU, 'fwd', cl, strict=True)
             out['roofline'] = {
                 'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': chains, 'layers_per_chain': cl,
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                # the same launch under SURVEY.md 8d's own activation term (the 6H saved values per step and layer instead of the 10H
+                # this launch reads and writes): the stricter reading of the two
+                'frac_8d_strict': round(kb_s / (us_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                'algorithmic_bytes_per_launch_8d_strict': kb_s // launches_b,
                 'traffic': traffic(name_b),
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process (tools/run_lstm2_steps.py), bytes = 2 F + W'
                                    if live else 'committed passes under profiles/ (rocprofv3 not available to this run)'),
@@ -505,14 +521,35 @@ def main():
                 'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
                                  'algorithmic_bytes_per_launch': kf // launches_f,
                                  'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
-                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic(name_f),
+                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 'frac_8d_strict': round(kf_s / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic(name_f),
                                  'share_of_step': round(chains * us_f * 1e-3 / ms_per_step, 3)}}
         if world == 1 and not args.no_extras:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
+            out['inference']['dtype'] = MATH_DTYPE[args.math]
+            if args.math != 'bf16x3':
+                # the same leg in the fp32-grade arithmetic, the mode whose greedy alignments are exact on the reference's random-init
+                # fixtures (bf16's are exact on peaked posteriors: tests/test_gpu_bf16_contract.py)
+                _lib.set_math_mode('bf16x3')
+                out['inference_bf16x3'] = time_inference(enc, rec, x, max(20, args.steps // 2))
+                out['inference_bf16x3']['dtype'] = MATH_DTYPE['bf16x3']
+                _lib.set_math_mode(args.math)
             n2 = max(20, args.steps // 2)
+            launch_mode = False if args.no_graph else (True if args.graph else None)
             for mode in ('bf16', 'bf16x3', 'f32'):
                 if mode != args.math:
-                    out[mode + '_mode'] = time_other_mode(mode, device, (x, il, tg, tl), args.warmup, n2, False if args.no_graph else (True if args.graph else None))
+                    out[mode + '_mode'] = time_other_mode(mode, device, (x, il, tg, tl), args.warmup, n2, launch_mode)
+            # the fp32-grade step in the parsed headline's config, not only in an extra key
+            out['config']['bf16x3_ms_per_step'] = out.get('bf16x3_mode', out)['ms_per_step']
+            out['config']['bf16x3_utterances_per_s'] = out.get('bf16x3_mode', out)['value']
+            # the reference's own model shapes: the stock 3-layer encoder (ha/rnn.py:6-11; layer 0 one persistent
+            # launch, the top pair one two-layer launch) and the H = 1536 variant (ha/init.py:171; per-layer 32-row launches)
+            out['stock3'] = time_other_mode(args.math, device, (x, il, tg, tl), args.warmup, n2, launch_mode, hidden=1024, layers=3)
+            out['stock3'].update(model='Encoder(80,128,1024), stock 3-layer nn.LSTM (ha/rnn.py:6-11) + TemporalClassifier(1024,32)',
+                                 params=param_count(1024, 3), recurrence=_lib.lstm_chain_info('bwd')['kernel'])
+            out['H1536'] = time_other_mode(args.math, device, (x, il, tg, tl), args.warmup, n2, launch_mode, hidden=1536, layers=2)
+            out['H1536'].update(model='Encoder(80,128,1536), 2-layer LSTM (ha/init.py:171 width) + TemporalClassifier(1536,32)',
+                                params=param_count(1536, 2), recurrence=_lib.lstm_chain_info('bwd')['kernel'])
             out['b_sweep'] = batch_sweep(args.math, device, args.warmup, max(20, args.steps // 4), use_graph)       # (the launch mode the headline chose)
             out['b_sweep'][f'B{B_PER_GPU}'] = {'value': out['value'], 'unit': 'utterances/s', 'ms_per_step': out['ms_per_step'], 'batch': B_PER_GPU,
                                                'step_frac_of_hbm_peak': out['step_roofline']['frac_of_hbm_peak'],
