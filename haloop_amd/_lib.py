@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 13
+HALO_ABI_VERSION = 14
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -65,6 +65,7 @@ SIGNATURES = {
     'halo_set_lstm_persistent_images': (_i, [_i]),
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
+    'halo_set_lstm_interleave': (_i, [_i]),
     'halo_set_lstm_expect_backward': (_i, [_i]),
     'halo_set_lstm_dx_slabs': (_i, [_i]),
     'halo_set_defer_small_jobs': (_i, [_i]),
@@ -223,6 +224,11 @@ def set_lstm_fusion(on):
 def set_lstm_persistent(on):
     """Weight-resident persistent LSTM recurrence (one launch per layer and direction) on / off (include/halo.h)."""
     check(lib().halo_set_lstm_persistent(int(bool(on))), 'halo_set_lstm_persistent')
+
+
+def set_lstm_interleave(on):
+    """Two batch tiles per workgroup, interleaved, in the two-layer launches of a batch larger than one launch holds (include/halo.h)."""
+    check(lib().halo_set_lstm_interleave(int(bool(on))), 'halo_set_lstm_interleave')
 
 
 def set_lstm_persistent2(on):

@@ -36,6 +36,7 @@ struct HaloCtx {
     int math_mode = 0;
     int lstm_fusion = 0;
     int lstm_persistent = 1, lstm_persistent2 = 1;
+    int lstm_interleave = 1;             // two batch tiles per workgroup in the two-layer launches when the batch has more tiles than one launch holds (lstm_persist2x.hip)
     int persist_emit = -1;               // -1: HALO_PERSIST_EMIT from the environment (default on)
     int beam_vec_chunk = 32;
     void *scratch = nullptr;

@@ -1485,6 +1485,10 @@ int halo_set_lstm_persistent2(int on) {
     halo_lstm_persist2_enable(on);
     return HALO_OK;
 }
+int halo_set_lstm_interleave(int on) {
+    halo_lstm_interleave_enable(on);
+    return HALO_OK;
+}
 int halo_set_lstm_weights_stamp(uint64_t stamp) {
     halo_ctx_cur().lstm_weights_stamp = stamp;
     return HALO_OK;

@@ -137,5 +137,9 @@ struct Persist2Bwd {
 
 bool halo_lstm_persist2_ok(int T, int B, int H, int L);   // shape, arithmetic mode (bf16), CU count, switch
 void halo_lstm_persist2_enable(int on);
+void halo_lstm_interleave_enable(int on);
 int halo_lstm_persist2_fwd(const Persist2Fwd &a, hipStream_t st);
 int halo_lstm_persist2_bwd(const Persist2Bwd &a, hipStream_t st);
+// the same launches with TWO batch tiles per workgroup, interleaved (lstm_persist2x.hip): tiles [a.bt0, a.bt0 + a.nbt), a.epoch0 set by the caller
+int halo_lstm_persist2x_fwd(const Persist2Fwd &a, hipStream_t st);
+int halo_lstm_persist2x_bwd(const Persist2Bwd &a, hipStream_t st);

@@ -119,9 +119,7 @@ __device__ __forceinline__ void fwd2_layer0_waves(const Persist2Fwd &p, const Fw
                     for (int k = 0; k < 4; ++k) sum += sh.red[0][k][g][u];
                     pre[g] = sum + gin[g];
                 }
-                ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
-                cst = fg * cst + ig * gg;
-                h = og * fast_tanh(cst);
+                h = persist2_fwd_cell(pre, cst, ig, fg, gg, og);
                 if (p.xp) xv = h * dmul;
             }
             sh.hbuf[0][ci][cj] = h;                      // rows >= B: zeros
@@ -279,9 +277,7 @@ __device__ __forceinline__ void fwd2_layer1_waves(const Persist2Fwd &p, const Fw
                     for (int k = 0; k < 4; ++k) sum += sh.red[1][k][g][u];
                     pre[g] = sum + bias[g];
                 }
-                ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
-                cst = fg * cst + ig * gg;
-                h = og * fast_tanh(cst);
+                h = persist2_fwd_cell(pre, cst, ig, fg, gg, og);
             }
             sh.hbuf[2][ci][cj] = h;
         }
@@ -352,21 +348,10 @@ struct Bwd2Shared {
     unsigned *s_published;
 };
 
-// one layer's cell update of the backward: dh -> gate gradients (and the carried cell gradient)
+// one layer's cell update of the backward: dh -> gate gradients (and the carried cell gradient); arithmetic in lstm_persist_dev.h
 struct Bwd2Cell {
     float gv[4], cc, cprev, dcarry;
-    __device__ __forceinline__ void update(float dh, float (&dg)[4]) {
-        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-        const float tc = fast_tanh(cc);
-        const float dcc = dcarry + dh * og * (1.f - tc * tc);
-        const float d_o = dh * tc;
-        const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
-        dcarry = dcc * fg;
-        dg[0] = d_i * ig * (1.f - ig);
-        dg[1] = d_f * fg * (1.f - fg);
-        dg[2] = d_g * (1.f - gg * gg);
-        dg[3] = d_o * og * (1.f - og);
-    }
+    __device__ __forceinline__ void update(float dh, float (&dg)[4]) { dcarry = persist2_bwd_cell(gv, cc, cprev, dcarry, dh, dg); }
 };
 
 template <int KC>
@@ -447,8 +432,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
                 float rec = 0.f, above = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { rec += sh.red[0][k][u]; above += sh.red[2][k][u]; }
-                above *= dmul;                                                      // layer 0's own output mask
-                c.update((s == 1 ? dh0 : rec) + above, dg);
+                c.update(persist2_add_masked(s == 1 ? dh0 : rec, above, dmul), dg);      // (dmul: layer 0's own output mask)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
             }
@@ -609,7 +593,7 @@ __device__ __forceinline__ void bwd2_layer1_waves(const Persist2Bwd &p, const Bw
                     for (int k = 0; k < 4; ++k) dh += sh.red[1][k][u];
                 }
                 if (p.dy) {
-                    const float tc = fast_tanh(c.cc);
+                    const float tc = persist2_tanh(c.cc);
                     float d = dyv;
                     if (p.dy_relu && !(c.gv[3] * tc > 0.f)) d = 0.f;
                     dh += d;
@@ -707,6 +691,7 @@ int launch2(K kernel, const A &a0, int blocks, size_t dyn, hipStream_t st) {
 }  // namespace
 
 void halo_lstm_persist2_enable(int on) { halo_ctx_cur().lstm_persistent2 = on ? 1 : 0; }
+void halo_lstm_interleave_enable(int on) { halo_ctx_cur().lstm_interleave = on ? 1 : 0; }
 
 bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     static const bool env_off = getenv("HALO_LSTM_PERSIST2") && atoi(getenv("HALO_LSTM_PERSIST2")) == 0;
@@ -720,20 +705,37 @@ bool halo_lstm_persist2_ok(int T, int B, int H, int L) {
     if ((long)(T + 2) * nbt * (4 * H / 32) * 2048 >= (1L << 31)) return false;
     if ((long)(T + 1) * B * 4 * H >= (1L << 31)) return false;             // 32-bit element indices inside the kernels
     // the epoch words of a launch's tiles (local index) fit a replica
-    return H / 16 <= cu_count2() && PERSIST_FLAG_HEADER + (long)tiles_per_launch(H) * (H / 16) <= PERSIST_REPLICA_WORDS;
+    return H / 16 <= cu_count2() && PERSIST_FLAG_HEADER + 2L * tiles_per_launch(H) * (H / 16) <= PERSIST_REPLICA_WORDS;      // (two tiles per workgroup: lstm_persist2x.hip)
 }
 
 // The batch rows are independent chains: a batch of more 16-row tiles than the chip holds workgroups for runs as consecutive launches over
 // the same buffers, each on its own tiles (B = 128 at H = 1024: two launches of 256 workgroups).  The epochs of launch g start behind
 // those of launch g - 1, so the (once zeroed) epoch words need no clearing between them.
-template <typename A, typename F>
-int launch_groups(const A &a0, int steps, F launch_one) {
+// With halo_set_lstm_interleave (default on) a batch of more tiles than one launch holds runs TWO tiles per workgroup, interleaved
+// (lstm_persist2x.hip): B = 128 at H = 1024 is one launch of 256 workgroups, each hiding one tile's hand-off behind the other tile's step.
+inline bool interleave_on() {
+    static const bool env_off = getenv("HALO_LSTM_INTERLEAVE") && atoi(getenv("HALO_LSTM_INTERLEAVE")) == 0;
+    return !env_off && halo_ctx_cur().lstm_interleave != 0;
+}
+
+template <typename A, typename F, typename FX>
+int launch_groups(const A &a0, int steps, F launch_one, FX launch_pairs) {
     const int nbt = (a0.B + 15) / 16, per = tiles_per_launch(a0.H);
-    for (int bt0 = 0, g = 0; bt0 < nbt; bt0 += per, ++g) {
+    const bool pairs = nbt > per && interleave_on();
+    for (int bt0 = 0, g = 0; bt0 < nbt; ++g) {
         A a = a0;
-        a.bt0 = bt0; a.nbt = min(per, nbt - bt0); a.epoch0 = (unsigned)g * (unsigned)(steps + 2);
-        const int rc = launch_one(a, (a.H / 16) * a.nbt);
+        const int left = nbt - bt0;
+        a.bt0 = bt0; a.epoch0 = (unsigned)g * (unsigned)(steps + 2);
+        int rc;
+        if (pairs && left > per) {                   // (a remainder that fits one plain launch runs as one: a workgroup per tile is faster)
+            a.nbt = min(2 * per, left);
+            rc = launch_pairs(a);
+        } else {
+            a.nbt = min(per, left);
+            rc = launch_one(a, (a.H / 16) * a.nbt);
+        }
         if (rc != HALO_OK) return rc;
+        bt0 += a.nbt;
     }
     return HALO_OK;
 }
@@ -749,7 +751,7 @@ int halo_lstm_persist2_fwd(const Persist2Fwd &a0, hipStream_t st) {
             case 8: return launch2(lstm_persist2_fwd_kernel<8>, a, blocks, dyn, st);
             default: return (int)HALO_ENOTSUP;
         }
-    });
+    }, [&](const Persist2Fwd &a) { return halo_lstm_persist2x_fwd(a, st); });
 }
 
 int halo_lstm_persist2_bwd(const Persist2Bwd &a0, hipStream_t st) {
@@ -763,5 +765,5 @@ int halo_lstm_persist2_bwd(const Persist2Bwd &a0, hipStream_t st) {
             case 8: return launch2(lstm_persist2_bwd_kernel<8>, a, blocks, dyn, st);
             default: return (int)HALO_ENOTSUP;
         }
-    });
+    }, [&](const Persist2Bwd &a) { return halo_lstm_persist2x_bwd(a, st); });
 }

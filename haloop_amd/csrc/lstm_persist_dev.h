@@ -90,6 +90,43 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// ---- the cell updates of the two-layer launches (lstm_persist2.hip, and lstm_persist2x.hip with two tiles per workgroup): ONE definition,
+// floating-point contraction off and the fused operations written out, so that both kernels round every intermediate the same way
+// whatever code surrounds the call (the compiler otherwise decides per call site which a*b+c becomes an fma; the interleaved launches are
+// tested BIT for bit against the consecutive ones) ----
+__device__ __forceinline__ float persist2_tanh(float x) {
+#pragma clang fp contract(off)
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    return __builtin_fmaf(-2.0f, r, 1.0f);
+}
+// forward: pre-activations (recurrent sums already added to the input part) -> activated gates, new cell state, h
+__device__ __forceinline__ float persist2_fwd_cell(const float (&pre)[4], float &cst, float &ig, float &fg, float &gg, float &og) {
+#pragma clang fp contract(off)
+    ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = persist2_tanh(pre[2]); og = fast_sigmoid(pre[3]);
+    cst = __builtin_fmaf(fg, cst, ig * gg);
+    return og * persist2_tanh(cst);
+}
+// backward: dh -> gate gradients w.r.t. the pre-activations; returns the cell gradient carried to the step before
+__device__ __forceinline__ float persist2_bwd_cell(const float (&gv)[4], float cc, float cprev, float dcarry, float dh, float (&dg)[4]) {
+#pragma clang fp contract(off)
+    const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+    const float tc = persist2_tanh(cc);
+    const float dcc = __builtin_fmaf(dh * og, __builtin_fmaf(-tc, tc, 1.f), dcarry);
+    const float d_o = dh * tc;
+    const float d_i = dcc * gg, d_f = dcc * cprev, d_g = dcc * ig;
+    dg[0] = d_i * ig * (1.f - ig);
+    dg[1] = d_f * fg * (1.f - fg);
+    dg[2] = d_g * __builtin_fmaf(-gg, gg, 1.f);
+    dg[3] = d_o * og * (1.f - og);
+    return dcc * fg;
+}
+// a + b * m without contraction (layer 0's incoming gradient: recurrent term + masked gradient from the layer above)
+__device__ __forceinline__ float persist2_add_masked(float a, float b, float m) {
+#pragma clang fp contract(off)
+    const float bm = b * m;
+    return a + bm;
+}
+
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

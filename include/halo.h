@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 13
+#define HALO_ABI_VERSION 14
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -304,6 +304,12 @@ int halo_lstm_persistent_eligible(int B, int H);
  * either forward.  Any batch: the batch rows are independent chains, so more 16-row tiles than the chip has CUs for (H/16 workgroups per
  * tile) run as consecutive launches over the same buffers.  On by default (HALO_LSTM_PERSIST2=0 / halo_set_lstm_persistent2(0): off). */
 int halo_set_lstm_persistent2(int on);
+/* Two batch tiles per workgroup in the two-layer launches (csrc/lstm_persist2x.hip): a batch of more 16-row tiles than one launch holds
+ * workgroups for (more than 64 rows at H = 1024) runs two tiles in each workgroup, interleaved -- while one tile's hand-off is in flight
+ * the workgroup computes the other tile's step on the same register-resident weights -- instead of as consecutive launches.  Same
+ * buffers, images and results as those launches but for the order in which the two tiles' bias-gradient rows are added.  On by
+ * default (HALO_LSTM_INTERLEAVE=0 / halo_set_lstm_interleave(0): consecutive launches).  Per context. */
+int halo_set_lstm_interleave(int on);
 /* Inference with static weights.  stamp != 0 is the caller's promise that the LSTM weights change only when the stamp does: a forward-only
  * call (halo_set_lstm_expect_backward(0)) of the two-layer launch then KEEPS the packed weight images that the previous call with the same
  * reserve buffer, weight pointers, shape and stamp left in that reserve (24 MB read + 12 MB written per call at H = 1024 otherwise), so the

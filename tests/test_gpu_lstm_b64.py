@@ -318,6 +318,40 @@ def test_two_layer_launch_equals_layer_launches(hal, math_mode, T, B, in0, H, p_
 
 
 @pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,p_drop,with_state', [
+    (21, 128, 128, 1024, 0.2, False),       # the bench's B = 128: ONE launch of 256 workgroups, two tiles each (was two launches)
+    (8, 256, 128, 1024, 0.2, False),        # 16 tiles: two interleaved launches of 8
+    (5, 88, 64, 1024, 0.0, True),           # 6 tiles (the last ragged): 3 pairs = 192 workgroups, carried state
+    (6, 72, 128, 1024, 0.2, False),         # 5 tiles: the third workgroup row has ONE tile
+    (4, 144, 128, 1024, 0.1, True),         # 9 tiles: 8 interleaved, the ninth as a plain launch behind them
+    (4, 160, 128, 512, 0.1, False),         # H = 512: 10 tiles, 5 pairs x 32 hidden tiles
+    (3, 272, 64, 256, 0.0, False),          # H = 256: 17 tiles, 9 pairs (the last a single), plain block map
+    (1, 128, 128, 1024, 0.2, True),         # a single time step
+])
+def test_interleaved_tiles_equal_consecutive_launches(hal, math_mode, T, B, in0, H, p_drop, with_state):
+    """csrc/lstm_persist2x.hip (two batch tiles per workgroup, interleaved, when the batch has more tiles than one launch holds) against the
+    consecutive launches of csrc/lstm_persist2.hip over the same buffers: the same products and sums in the same order per tile, so every
+    output is BIT-identical -- but the bias gradients, whose per-tile rows the interleaved launch adds in registers (fp32 regrouping)."""
+    lib = hal['lib']
+    assert lib.lib().halo_lstm_persistent2_eligible(T, B, H, 2) == 1
+    assert (B + 15) // 16 > 256 // (H // 16)                      # more tiles than a plain launch holds
+    a, st_a = _lstm_case(hal, T, B, in0, H, 2, p_drop, 5, with_state)
+    assert lib.lstm_chain_info('bwd')['kernel'] == 'lstm_persist2_bwd_kernel'
+    lib.set_lstm_interleave(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, 2, p_drop, 5, with_state)
+    finally:
+        lib.set_lstm_interleave(True)
+    assert st_a == (0, 0) and st_b == (0, 0)
+    for k in a:
+        if k.startswith('db_'):
+            scale = float(b[k].abs().max()) + 1e-12
+            np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, rtol=0, atol=2e-6, err_msg=k)
+        else:
+            assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
 def test_split_backward_follows_the_two_layer_forward(hal, math_mode):
     """The two-layer forward leaves the reserve the per-layer backward expects: backward called layer by layer (the data-parallel
     step does, haloop_amd/train.py) after the fused forward equals the one-call two-layer backward."""
