@@ -92,12 +92,11 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
     }
     // the NEXT phase's pre-activations x W_ih0^T + biases, requested while this phase's cells are updated
     float pg[4] = {0.f, 0.f, 0.f, 0.f};
+    // (unconditional, on clamped indices: inside a branch the compiler waits for the loads at the end of the branch)
     auto prefetch = [&](int ns, int nq) {
-        const int b = (p.bt0 + 2 * pr + nq) * 16 + ci;
-        if (ns < T && b < B) {
+        const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(ns, T - 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pg[g] = p.gates0[(ns * B + b) * 4 * H + g * H + j0 + cj];
-        }
+        for (int g = 0; g < 4; ++g) pg[g] = p.gates0[(t * B + b) * 4 * H + g * H + j0 + cj];
     };
     prefetch(0, 0);
     Pending pd = {0, 0, 0, 0u, 0u};
@@ -118,9 +117,6 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
             float gin[4], dmul = 1.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) gin[g] = pg[g];
-            // the PREVIOUS phase's pieces (the other tile's): their stores have had the rest of that phase to leave
-            flush_pending(pd, sh.s_published, p.flags, muted, lane);
-            if (wave == 3) stamp(p.stamps, T + 2, s, q ? 13 : 4, lane);
             // ---- epoch s of THIS tile: every workgroup of its group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-3} ----
             bool ok = true;
             if (s > 0 && wave == 1) ok = poll_group(rep_flags + btl * NJ, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
@@ -131,6 +127,12 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
             lds_barrier();                                                             // (A)
             if (*sh.s_abort) return;
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 10 : 1, lane);
+            {
+                // the NEXT phase's pre-activations: requested here, a whole phase before they are needed and long before wave 1's next
+                // poll (a wave's poll result waits for every older memory operation of that wave)
+                const int nq = q + 1 < ntile ? q + 1 : 0;
+                prefetch(nq ? s : s + 1, nq);
+            }
             if (act0) {
                 const int img = ((s * NBT + bt) * nkb + wq * KBQ) * 2048;              // image s = h0_{s-1}
                 bf16x8 ah[KBQ];
@@ -153,12 +155,12 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sh.red[0][wq][g][(4 * qq + e) * 16 + r] = acc[g][e];
             }
+            // the PREVIOUS phase's pieces (the other tile's): this wave's fragment loads have all returned, so the wait is for stores that
+            // have had most of a phase to leave; the tile's own next poll is still half a phase away
+            flush_pending(pd, sh.s_published, p.flags, muted, lane);
+            if (wave == 3) stamp(p.stamps, T + 2, s, q ? 13 : 4, lane);
             lds_barrier();                                                             // (B)
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 11 : 2, lane);
-            {
-                const int nq = q + 1 < ntile ? q + 1 : 0;
-                prefetch(nq ? s : s + 1, nq);
-            }
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f, xv = 0.f;
             if (act0) {
                 if (cell) {
@@ -172,6 +174,12 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
                     }
                     h = persist2_fwd_cell(pre, cst[q], ig, fg, gg, og);
                     if (p.xp) xv = h * dmul;
+                    // (stored here, not behind the pieces: by the next poll these stores are old)
+                    float *gp = p.gates0 + (s * B + b) * 4 * H + j0 + cj;
+                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+                    p.c0[(s + 1) * BH + e0] = cst[q];
+                    p.h0[(s + 1) * BH + e0] = h;
+                    if (p.ydrop) p.ydrop[s * BH + e0] = xv;
                 }
                 sh.hbuf[0][ci][cj] = h;                      // rows >= B: zeros
                 if (p.xp) sh.hbuf[1][ci][cj] = xv;
@@ -215,13 +223,6 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
                     const int r = grow & 127, cc = (kcol & 31) >> 3;
                     *reinterpret_cast<bf16x8 *>(img + blk * 8192 + r * 64 + ((cc ^ ((r >> 2) & 3)) << 4)) = hit;
                 }
-            }
-            if (act0 && cell) {
-                float *gp = p.gates0 + (s * B + b) * 4 * H + j0 + cj;
-                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-                p.c0[(s + 1) * BH + e0] = cst[q];
-                p.h0[(s + 1) * BH + e0] = h;
-                if (p.ydrop) p.ydrop[s * BH + e0] = xv;
             }
         }
     }
@@ -310,17 +311,15 @@ __device__ __forceinline__ void fwd2x_layer1_waves(const Persist2Fwd &p, const F
                         pre[g] = sum + bias[g];
                     }
                     h = persist2_fwd_cell(pre, cst[q], ig, fg, gg, og);
+                    float *gp = p.gates1 + (t * B + b) * 4 * H + j0 + cj;
+                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+                    p.c1[(t + 1) * BH + e0] = cst[q];
+                    p.h1[(t + 1) * BH + e0] = h;
+                    if (p.y_mode != 0) p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
                 }
                 sh.hbuf[2][ci][cj] = h;
             }
             lds_barrier();                                                             // (C)
-            if (act1 && cell) {
-                float *gp = p.gates1 + (t * B + b) * 4 * H + j0 + cj;
-                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-                p.c1[(t + 1) * BH + e0] = cst[q];
-                p.h1[(t + 1) * BH + e0] = h;
-                if (p.y_mode != 0) p.y[(long)t * p.y_stride_t + (long)b * p.y_stride_b + j0 + cj] = p.y_mode == 2 ? fmaxf(h, 0.f) : h;
-            }
             // ---- the NEXT phase's input half (tile nq at time ns - 2): its fragments -- image ns-2 of xp, without dropout image ns-1 of layer 0
             //      -- were complete when that tile's previous poll matched, one phase ago or more ----
 #pragma unroll
@@ -375,6 +374,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2x_fwd_kernel(const Persis
 struct Bwd2xShared {
     float (*red)[4][256];             // [layer 0 recurrent | layer 1 recurrent | from layer 1 into layer 0][K-quarter]
     float (*dgbuf)[4][16][16];        // [layer][gate][batch row][hidden unit]
+    float (*dhinit)[NG][256];         // [layer][tile][cell thread]: the caller's d h_n, used by each layer's FIRST cell update only (parked here:
+                                      // a load in that rare branch would make the compiler wait for every outstanding request in every phase)
     int *s_abort;
     unsigned *s_published;            // [NG]
 };
@@ -402,22 +403,21 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
     for (int q = 0; q < NG; ++q) {
         const int b = (p.bt0 + 2 * pr + q) * 16 + ci;
         dcarry[q] = (q < ntile && b < B && p.dcinit0) ? p.dcinit0[b * H + j0 + cj] : 0.f;
+        sh.dhinit[0][q][u] = (q < ntile && b < B && p.dhinit0) ? p.dhinit0[b * H + j0 + cj] : 0.f;      // (read back by this thread only)
     }
     Bwd2xSaved nx = {{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 1.f};
+    // (unconditional, on clamped indices: inside a branch the compiler waits for the loads at the end of the branch; a phase without a
+    // cell update, or a row past the batch, does not use what it gets)
     auto prefetch = [&](int ns, int nq) {            // layer 0's cell update of combined step ns is at time T - ns (ns >= 1)
-        const int b = (p.bt0 + 2 * pr + nq) * 16 + ci, t = T - ns;
-        if (ns >= 1 && ns <= T && b < B) {
-            const int e0 = b * H + j0 + cj;
+        const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(max(T - ns, 0), T - 1);
+        const int e0 = b * H + j0 + cj;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates0[(t * B + b) * K + g * H + j0 + cj];
-            nx.cc = p.c0[(t + 1) * BH + e0];
-            nx.cprev = p.c0[t * BH + e0];
-        }
+        for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates0[(t * B + b) * K + g * H + j0 + cj];
+        nx.cc = p.c0[(t + 1) * BH + e0];
+        nx.cprev = p.c0[t * BH + e0];
     };
     Pending pd = {0, 0, 0, 0u, 0u};
     const __amdgpu_buffer_rsrc_t dg0_rsrc = make_rsrc(p.dgp0), dg1_rsrc = make_rsrc(p.dgp1);
-    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
-    const unsigned *rep_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER;
     for (int s = 0; s <= T; ++s) {
         const bool act = s >= 1;                     // layer 0 has a cell update in combined step s ...
         const int t = T - s;                          // ... at this time
@@ -428,16 +428,8 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
             const int b = bt * 16 + ci;
             const bool cell = b < B;
             if (wave == 0) stamp(p.stamps, T + 1, s, q ? 9 : 0, lane);
-            // the PREVIOUS phase's pieces (the other tile's): their stores have had the rest of that phase to leave
-            flush_pending(pd, sh.s_published, p.flags, false, lane);
-            if (wave == 3) stamp(p.stamps, T + 1, s, q ? 13 : 4, lane);
-            bool ok = true;
-            if (s > 0 && wave == 1) ok = poll_group(rep_flags + btl * NJ, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
-            if (!ok && lane == 0) {
-                *sh.s_abort = 1;
-                raise_abort(p.abort_word, p.status);
-            }
-            lds_barrier();                                                             // (A)
+            const Bwd2xSaved cur = nx;
+            lds_barrier();                                                             // (A)   (wave 5 polls: these four waves store the pieces, and a wave's poll result waits for all its older stores)
             if (*sh.s_abort) return;
             if (wave == 0) stamp(p.stamps, T + 1, s, q ? 10 : 1, lane);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -470,30 +462,36 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sh.red[0][wq][(4 * qq + e) * 16 + r] = acc[e];
             }
+            // the PREVIOUS phase's pieces (the other tile's): this wave's fragment loads have all returned, so the wait is for stores that
+            // have had most of a phase to leave; the tile's own next poll is still ~2 us away
+            flush_pending(pd, sh.s_published, p.flags, false, lane);
+            if (wave == 3) stamp(p.stamps, T + 1, s, q ? 13 : 4, lane);
             lds_barrier();                                                             // (B)
             if (wave == 0) stamp(p.stamps, T + 1, s, q ? 11 : 2, lane);
+            {
+                // the next phase's saved activations: a whole fragment stream ahead of their use
+                const int nq = q + 1 < ntile ? q + 1 : 0;
+                prefetch(nq ? s : s + 1, nq);
+            }
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
             if (act) {
                 if (cell) {
                     float rec = 0.f, above = 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { rec += sh.red[0][k][u]; above += sh.red[2][k][u]; }
-                    if (s == 1) rec = p.dhinit0 ? p.dhinit0[b * H + j0 + cj] : 0.f;      // (the first cell update: the caller's d h_n, no recurrent term yet)
-                    dcarry[q] = persist2_bwd_cell(nx.gv, nx.cc, nx.cprev, dcarry[q], persist2_add_masked(rec, above, dmul), dg);   // (dmul: layer 0's own output mask)
+                    if (s == 1) rec = sh.dhinit[0][q][u];                                 // (the first cell update: the caller's d h_n, no recurrent term yet)
+                    dcarry[q] = persist2_bwd_cell(cur.gv, cur.cc, cur.cprev, dcarry[q], persist2_add_masked(rec, above, dmul), dg);   // (dmul: layer 0's own output mask)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
+                    float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
+                    gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[0][g][ci][cj] = dg[g];
             }
+            if (wave == 0 && q == 0) stamp(p.stamps, T + 1, s, 7, lane);              // (diagnostic: this half's arrival at barrier C)
             lds_barrier();                                                             // (C)
             if (wave == 0) stamp(p.stamps, T + 1, s, q ? 12 : 3, lane);
-            {
-                // the next phase's saved activations, requested BEFORE this phase's pieces are stored (the deferred publish waits for
-                // everything older than the next phase's fragment loads: these loads then have had the pack and the hand-off's own latency)
-                const int nq = q + 1 < ntile ? q + 1 : 0;
-                prefetch(nq ? s : s + 1, nq);
-            }
             {
                 // pack: wave g takes gate g; lanes 0-31 layer 1's piece (time T-1-s, steps 0 .. T-1), lanes 32-63 layer 0's (time T-s, steps 1 .. T)
                 const int g = wq, lay = lane < 32 ? 1 : 0, kg = (lane >> 4) & 1, row = lane & 15;
@@ -530,10 +528,6 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
                         *reinterpret_cast<bf16x8 *>(img_cols + blk * 8192 + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4)) = hit;
                     }
                 }
-            }
-            if (act && cell) {
-                float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
-                gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
             }
         }
     }
@@ -582,21 +576,24 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
     for (int q = 0; q < NG; ++q) {
         const int b = (p.bt0 + 2 * pr + q) * 16 + ci;
         dcarry[q] = (q < ntile && b < B && p.dcinit1) ? p.dcinit1[b * H + j0 + cj] : 0.f;
+        sh.dhinit[1][q][u] = (q < ntile && b < B && p.dhinit1) ? p.dhinit1[b * H + j0 + cj] : 0.f;
     }
     Bwd2xSaved nx = {{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
+    const float *dyp = p.dy ? p.dy : p.c1;           // (no dy: a load from any valid address, unused)
     auto prefetch = [&](int ns, int nq) {            // layer 1's cell update of combined step ns is at time T - 1 - ns (ns < T)
-        const int b = (p.bt0 + 2 * pr + nq) * 16 + ci, t = T - 1 - ns;
-        if (ns < T && b < B) {
-            const int e0 = b * H + j0 + cj;
+        const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(max(T - 1 - ns, 0), T - 1);
+        const int e0 = b * H + j0 + cj;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates1[(t * B + b) * K + g * H + j0 + cj];
-            nx.cc = p.c1[(t + 1) * BH + e0];
-            nx.cprev = p.c1[t * BH + e0];
-            nx.extra = p.dy ? p.dy[(long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj] : 0.f;
-        }
+        for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates1[(t * B + b) * K + g * H + j0 + cj];
+        nx.cc = p.c1[(t + 1) * BH + e0];
+        nx.cprev = p.c1[t * BH + e0];
+        nx.extra = dyp[p.dy ? (long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj : 0L];
     };
     prefetch(0, 0);
     const __amdgpu_buffer_rsrc_t dg1_rsrc = make_rsrc(p.dgp1);
+    const int NJ = H / 16;
+    const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
+    const unsigned *rep_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER;
     for (int s = 0; s <= T; ++s) {
         const bool act = s < T;                      // layer 1 has a cell update in combined step s ...
         const int t = T - 1 - s;                      // ... at this time
@@ -606,6 +603,15 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
             const int bt = p.bt0 + 2 * pr + q;
             const int b = bt * 16 + ci;
             const bool cell = b < B;
+            const Bwd2xSaved cur = nx;
+            // ---- epoch s of THIS tile: every workgroup of its group has published dG1 of time T-s and dG0 of time T-s+1.  Polled by a
+            //      layer-1 wave: it stores no pieces, and its saved-gate stores and requests are a phase old by now ----
+            bool ok = true;
+            if (s > 0 && wave == 5) ok = poll_group(rep_flags + (2 * pr + q) * NJ, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
+            if (!ok && lane == 0) {
+                *sh.s_abort = 1;
+                raise_abort(p.abort_word, p.status);
+            }
             lds_barrier();                                                             // (A)
             if (*sh.s_abort) return;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -639,39 +645,37 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
                 }
             }
             lds_barrier();                                                             // (B)
+            if (wave == 4 && q == 0) stamp(p.stamps, T + 1, s, 5, lane);              // (diagnostic)
+            {
+                const int nq = q + 1 < ntile ? q + 1 : 0;
+                prefetch(nq ? s : s + 1, nq);
+            }
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
             if (act) {
                 if (cell) {
                     float dh = 0.f;
-                    if (s == 0) dh = p.dhinit1 ? p.dhinit1[b * H + j0 + cj] : 0.f;
+                    if (s == 0) dh = sh.dhinit[1][q][u];
                     else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) dh += sh.red[1][k][u];
                     }
                     if (p.dy) {
-                        const float tc = persist2_tanh(nx.cc);
-                        float d = nx.extra;
-                        if (p.dy_relu && !(nx.gv[3] * tc > 0.f)) d = 0.f;
+                        const float tc = persist2_tanh(cur.cc);
+                        float d = cur.extra;
+                        if (p.dy_relu && !(cur.gv[3] * tc > 0.f)) d = 0.f;
                         dh += d;
                     }
-                    dcarry[q] = persist2_bwd_cell(nx.gv, nx.cc, nx.cprev, dcarry[q], dh, dg);
+                    dcarry[q] = persist2_bwd_cell(cur.gv, cur.cc, cur.cprev, dcarry[q], dh, dg);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
+                    float *gp = p.gates1 + (t * B + b) * K + j0 + cj;
+                    gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[1][g][ci][cj] = dg[g];
             }
+            if (wave == 4 && q == 0) stamp(p.stamps, T + 1, s, 6, lane);              // (diagnostic: this half's arrival at barrier C)
             lds_barrier();                                                             // (C)
-            if (act && cell) {
-                float *gp = p.gates1 + (t * B + b) * K + j0 + cj;
-                gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
-            }
-            {
-                // (behind the cell update, whose operands are dead now: these waves' registers are the fullest of the kernel; the next phase's
-                // fragment stream gives the loads 2.6 us)
-                const int nq = q + 1 < ntile ? q + 1 : 0;
-                prefetch(nq ? s : s + 1, nq);
-            }
         }
     }
 #pragma unroll
@@ -697,6 +701,7 @@ template <int KC>
 __global__ __launch_bounds__(512, 2) void lstm_persist2x_bwd_kernel(const Persist2Bwd p) {
     __shared__ float red[3][4][256];
     __shared__ __attribute__((aligned(16))) float dgbuf[2][4][16][16];
+    __shared__ float dhinit[2][NG][256];
     __shared__ int s_abort;
     __shared__ unsigned s_published[NG];
     extern __shared__ __attribute__((aligned(16))) char wi_lds[];    // [K-quarter][4 KC] W_ih1^T fragments of 1 KiB
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist2x_bwd_kernel(const Persis
     if (tid == 0) { s_abort = 0; s_published[0] = 0; s_published[1] = 0; }
     if (blockIdx.x == 0 && tid == 0 && p.abort_word != p.flags) __hip_atomic_store(p.abort_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave == 0) stamp(p.stamps, p.T + 1, 0, 14, lane);
-    const Bwd2xShared sh = {red, dgbuf, &s_abort, s_published};
+    const Bwd2xShared sh = {red, dgbuf, dhinit, &s_abort, s_published};
     if (wave < 4) bwd2x_layer0_waves<KC>(p, sh, jt, pr, wave, lane, tid & 255);
     else bwd2x_layer1_waves<KC>(p, sh, wi_lds, jt, pr, wave, lane, tid & 255);
     if (wave == 0) stamp(p.stamps, p.T + 1, 0, 15, lane);

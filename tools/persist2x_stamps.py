@@ -58,4 +58,9 @@ _lib.check(_lib.lib().halo_lstm_persist_stamps(stamps.data_ptr()), 'stamps')
 ops.lstm_bwd(x, w_ih, w_hh, dy, (B * H, H), False, reserve, drop=drop, workspace=ws)
 torch.cuda.synchronize()
 _lib.lib().halo_lstm_persist_stamps(None)
-report(stamps.cpu().numpy()[:nblk * (T + 1) * 16].reshape(nblk, T + 1, 16).astype(np.float64) * 0.01, T + 1, 'BACKWARD')
+sb = stamps.cpu().numpy()[:nblk * (T + 1) * 16].reshape(nblk, T + 1, 16).astype(np.float64) * 0.01
+report(sb, T + 1, 'BACKWARD')
+steps = slice(3, T - 1)
+for k, name in ((5, 'tile A: layer-1 wave 4 past barrier B'), (6, 'tile A: layer-1 wave 4 arrives at barrier C'), (7, 'tile A: layer-0 wave 0 arrives at barrier C')):
+    d = sb[:, steps, k] - sb[:, steps, 0]
+    print(f'  {name:46s} +{d.mean():7.3f} us  (min {d.min():6.2f}  max {d.max():6.2f})')
