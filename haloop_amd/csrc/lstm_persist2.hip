@@ -728,7 +728,7 @@ int launch_groups(const A &a0, int steps, F launch_one, FX launch_pairs) {
         a.bt0 = bt0; a.epoch0 = (unsigned)g * (unsigned)(steps + 2);
         int rc;
         if (pairs && left > per) {                   // (a remainder that fits one plain launch runs as one: a workgroup per tile is faster)
-            a.nbt = min(2 * per, left);
+            a.nbt = min(2 * per, left) & ~1;         // every workgroup of the interleaved launch has TWO tiles (an odd last tile: a plain launch)
             rc = launch_pairs(a);
         } else {
             a.nbt = min(per, left);

@@ -18,8 +18,8 @@
 //    requests -- and the wait for those stores (s_waitcnt vmcnt(0); a counted wait would not do: stores and loads retire out of order
 //    with respect to each other) and the epoch store happen at the top of the NEXT phase.  Nobody waits for this tile's epoch before the
 //    other tile's phase is over, so the write-through acknowledgement (0.7-1 us at the end of every step of lstm_persist2.hip) is mostly
-//    off the workgroup's path.  A workgroup with ONE tile (the last pair of an odd
-//    tile count) publishes at once: its own next poll waits for that epoch;
+//    off the workgroup's path.  A launch always has an EVEN number of tiles (the launcher gives an odd last
+//    tile a plain launch of its own): a workgroup with one tile would wait for its own deferred epoch;
 //  * the bias-gradient sums of the two tiles are formed in one register set (written to the first tile's row of bias_part, zeros to the
 //    second's: the launch behind the chain adds the rows).
 #include <stdlib.h>
@@ -68,6 +68,11 @@ __device__ __forceinline__ void flush_pending(Pending &pd, unsigned *s_published
     pd.on = 0;
 }
 
+// Forward, software-pipelined over the phases (a launch always has an EVEN number of tiles: every workgroup has two).  Per phase p = (s, q):
+//     [fragments of p in flight]  flush(p-1) -> MFMA(p) -> partial sums            -> barrier (B)
+//     wave 1 polls the epoch of phase p+1 (the OTHER tile) | cell update of p      -> barrier (AC)
+//     request the fragments of p+1 -> pack and store the pieces of p (publish deferred), operand images, the input half of p+1 (layer 1)
+// so the fragments' latency is covered by the pack / the input half, the poll by the cell update, and two barriers per phase remain.
 template <int KBQ>
 __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const Fwd2xShared sh, int jt, int pr, int wave, int lane, int u) {
     const int wq = wave & 3;
@@ -81,67 +86,53 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
             wr[g][i] = *reinterpret_cast<const bf16x8 *>(p.wp0 + (((long)jt * 4 + g) * nkb + wq * KBQ + i) * 2048 + lane * 16);
     const int ci = u >> 4, cj = u & 15;              // cell thread: (batch row, hidden unit) of the tile
     const int BH = B * H;
-    const int ntile = (2 * pr + 1 < p.nbt) ? 2 : 1;  // the last pair of an odd tile count has one tile
-    const bool defer = ntile == 2;                   // one tile: its own next poll waits for the epoch, so it is published at once
     const bool muted = (int)blockIdx.x == p.mute;
     float cst[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         const int b = (p.bt0 + 2 * pr + q) * 16 + ci;
-        cst[q] = (q < ntile && b < B) ? p.c0[b * H + j0 + cj] : 0.f;
+        cst[q] = b < B ? p.c0[b * H + j0 + cj] : 0.f;
     }
-    // the NEXT phase's pre-activations x W_ih0^T + biases, requested while this phase's cells are updated
-    float pg[4] = {0.f, 0.f, 0.f, 0.f};
-    // (unconditional, on clamped indices: inside a branch the compiler waits for the loads at the end of the branch)
+    // the NEXT phase's pre-activations x W_ih0^T + biases (unconditional, on clamped indices: inside a branch the compiler waits for the
+    // loads at the end of the branch)
+    float pg[4];
     auto prefetch = [&](int ns, int nq) {
         const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(ns, T - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) pg[g] = p.gates0[(t * B + b) * 4 * H + g * H + j0 + cj];
     };
-    prefetch(0, 0);
-    Pending pd = {0, 0, 0, 0u, 0u};
     const __amdgpu_buffer_rsrc_t hp0_rsrc = make_rsrc(p.hp0), hp1_rsrc = make_rsrc(p.hp1);
     const __amdgpu_buffer_rsrc_t x_rsrc = p.xp ? make_rsrc(p.xp) : hp0_rsrc;
     const int my_replica = (xcc_id() + p.replica_shift) % PERSIST_REPLICAS;
     const unsigned *rep_flags = p.flags + my_replica * PERSIST_REPLICA_WORDS + PERSIST_FLAG_HEADER;
+    bf16x8 ah[KBQ];                                  // the fragments of the phase in hand, requested during the phase before
+    auto request = [&](int ns, int nq) {             // image ns of tile nq = h0_{ns-1}
+        const int img = ((ns * NBT + p.bt0 + 2 * pr + nq) * nkb + wq * KBQ) * 2048;
+#pragma unroll
+        for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp0_rsrc, lane * 16, img + i * 2048);
+    };
+    Pending pd = {0, 0, 0, 0u, 0u};
+    prefetch(0, 0);
+    request(0, 0);                                   // (image 0: the initial state, written by the launch ahead)
     for (int s = 0; s <= T + 1; ++s) {
         const bool act0 = s < T, act1 = s >= 2;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (q >= ntile) break;                   // (workgroup-uniform)
             const int btl = 2 * pr + q, bt = p.bt0 + btl;
             const int b = bt * 16 + ci;
             const bool cell = b < B;
             const int e0 = b * H + j0 + cj;
+            const int nq = q ^ 1, ns = q ? s + 1 : s;                    // the next phase: the other tile
+            const bool nexists = ns <= T + 1;
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 9 : 0, lane);
-            float gin[4], dmul = 1.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gin[g] = pg[g];
-            // ---- epoch s of THIS tile: every workgroup of its group has published h0_{s-1}, dropout(h0_{s-1}) and h1_{s-3} ----
-            bool ok = true;
-            if (s > 0 && wave == 1) ok = poll_group(rep_flags + btl * NJ, 0, NJ, p.epoch0 + (unsigned)s, lane, p.nap);
-            if (!ok && lane == 0) {
-                *sh.s_abort = 1;
-                raise_abort(p.flags, p.status);
-            }
-            lds_barrier();                                                             // (A)
-            if (*sh.s_abort) return;
-            if (wave == 0) stamp(p.stamps, T + 2, s, q ? 10 : 1, lane);
-            {
-                // the NEXT phase's pre-activations: requested here, a whole phase before they are needed and long before wave 1's next
-                // poll (a wave's poll result waits for every older memory operation of that wave)
-                const int nq = q + 1 < ntile ? q + 1 : 0;
-                prefetch(nq ? s : s + 1, nq);
-            }
+            // the step's dropout multiplier of h0 (one Philox block per element): drawn while the fragments are on their way
+            float dmul = 1.f;
+            if (act0 && cell && p.xp) dmul = dropout_mult(p.drop, (uint64_t)((long)s * BH + e0));
+            __builtin_amdgcn_sched_barrier(0);
+            // the PREVIOUS phase's pieces (the other tile's): stored a fragment latency ago; its epoch is polled for behind barrier (B)
+            flush_pending(pd, sh.s_published, p.flags, muted, lane);
+            if (wave == 3) stamp(p.stamps, T + 2, s, q ? 13 : 4, lane);
             if (act0) {
-                const int img = ((s * NBT + bt) * nkb + wq * KBQ) * 2048;              // image s = h0_{s-1}
-                bf16x8 ah[KBQ];
-#pragma unroll
-                for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp0_rsrc, lane * 16, img + i * 2048);
-                __builtin_amdgcn_sched_barrier(0);
-                // the step's dropout multiplier of h0 (one Philox block per element): drawn while the fragments are on their way
-                if (cell && p.xp) dmul = dropout_mult(p.drop, (uint64_t)((long)s * BH + e0));
-                __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -155,12 +146,16 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sh.red[0][wq][g][(4 * qq + e) * 16 + r] = acc[g][e];
             }
-            // the PREVIOUS phase's pieces (the other tile's): this wave's fragment loads have all returned, so the wait is for stores that
-            // have had most of a phase to leave; the tile's own next poll is still half a phase away
-            flush_pending(pd, sh.s_published, p.flags, muted, lane);
-            if (wave == 3) stamp(p.stamps, T + 2, s, q ? 13 : 4, lane);
             lds_barrier();                                                             // (B)
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 11 : 2, lane);
+            // ---- epoch ns of the NEXT phase's tile: every workgroup of its group has published h0_{ns-1}, dropout(h0_{ns-1}), h1_{ns-3}.
+            //      (its pieces were published in front of this phase's MFMAs) ----
+            bool ok = true;
+            if (wave == 1 && nexists && ns > 0) ok = poll_group(rep_flags + (2 * pr + nq) * NJ, 0, NJ, p.epoch0 + (unsigned)ns, lane, p.nap);
+            if (!ok && lane == 0) {
+                *sh.s_abort = 1;
+                raise_abort(p.flags, p.status);
+            }
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f, xv = 0.f;
             if (act0) {
                 if (cell) {
@@ -170,11 +165,10 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
                         float sum = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) sum += sh.red[0][k][g][u];
-                        pre[g] = sum + gin[g];
+                        pre[g] = sum + pg[g];
                     }
                     h = persist2_fwd_cell(pre, cst[q], ig, fg, gg, og);
                     if (p.xp) xv = h * dmul;
-                    // (stored here, not behind the pieces: by the next poll these stores are old)
                     float *gp = p.gates0 + (s * B + b) * 4 * H + j0 + cj;
                     gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
                     p.c0[(s + 1) * BH + e0] = cst[q];
@@ -184,8 +178,11 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
                 sh.hbuf[0][ci][cj] = h;                      // rows >= B: zeros
                 if (p.xp) sh.hbuf[1][ci][cj] = xv;
             }
-            lds_barrier();                                                             // (C)
+            lds_barrier();                                                             // (AC)
+            if (*sh.s_abort) return;
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 12 : 3, lane);
+            if (nexists && ns < T) request(ns, nq);
+            prefetch(ns, nq);
             if ((wave == 3 && act0) || (wave == 2 && act1)) {
                 // wave 3: lanes 0-31 the piece of h0_s (image s+1 of layer 0), lanes 32-63 the piece of dropout(h0_s) (image s of xp);
                 // wave 2: lanes 0-31 the piece of h1_{s-2} (image s-1 of layer 1)
@@ -203,7 +200,6 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
                 }
                 // through combined step s layer 0 has stored min(s + 1, T) times, layer 1 max(s - 1, 0) times
                 pd.set(q, btl * NJ + jt, (unsigned)((s + 1 < T ? s + 1 : T) + (s >= 2 ? s - 1 : 0)), p.epoch0 + (unsigned)(s + 1));
-                if (!defer) flush_pending(pd, sh.s_published, p.flags, muted, lane);
             } else if (wave == 3 && !act0 && !act1) {
                 publish_epoch(p.flags, btl * NJ + jt, p.epoch0 + (unsigned)(s + 1), lane);       // T = 1: neither layer has a step here, the epoch still moves
             }
@@ -256,38 +252,34 @@ __device__ __forceinline__ void fwd2x_layer1_waves(const Persist2Fwd &p, const F
         }
     const int ci = u >> 4, cj = u & 15;
     const int BH = B * H;
-    const int ntile = (2 * pr + 1 < p.nbt) ? 2 : 1;
     float cst[NG], bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = p.b_ih1[g * H + j0 + cj] + p.b_hh1[g * H + j0 + cj];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         const int b = (p.bt0 + 2 * pr + q) * 16 + ci;
-        cst[q] = (q < ntile && b < B) ? p.c1[b * H + j0 + cj] : 0.f;
+        cst[q] = b < B ? p.c1[b * H + j0 + cj] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t hp1_rsrc = make_rsrc(p.hp1);
     const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(p.xp ? p.xp : p.hp0);
-    f32x4 xacc[4];                                   // the NEXT phase's input half, dropout(h0_t) W_ih1^T: seeds that phase's accumulators
+    f32x4 xacc[4];                                   // the phase's accumulators, seeded with its input half dropout(h0_t) W_ih1^T during the phase before
 #pragma unroll
     for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ah[KBQ];                                  // the recurrent fragments of the phase in hand (image t of layer 1 = h1_{t-1}), requested behind barrier (AC)
+    bf16x8 ax[KBQ];                                  // the input fragments of the NEXT phase (complete since that tile's previous poll), requested behind barrier (B)
     for (int s = 0; s <= T + 1; ++s) {
         const bool act1 = s >= 2;
         const int t = s - 2;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (q >= ntile) break;
             const int bt = p.bt0 + 2 * pr + q;
             const int b = bt * 16 + ci;
             const bool cell = b < B;
             const int e0 = b * H + j0 + cj;
-            lds_barrier();                                                             // (A)
-            if (*sh.s_abort) return;
+            const int nq = q ^ 1, ns = q ? s + 1 : s;
+            const bool nact1 = ns >= 2 && ns <= T + 1;
+            const int nbt = p.bt0 + 2 * pr + nq;
             if (act1) {
-                const int img = ((t * NBT + bt) * nkb + wq * KBQ) * 2048;              // image t = h1_{t-1}
-                bf16x8 ah[KBQ];
-#pragma unroll
-                for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp1_rsrc, lane * 16, img + i * 2048);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < KBQ; ++i)
 #pragma unroll
@@ -299,6 +291,12 @@ __device__ __forceinline__ void fwd2x_layer1_waves(const Persist2Fwd &p, const F
                     for (int e = 0; e < 4; ++e) sh.red[1][wq][g][(4 * qq + e) * 16 + r] = xacc[g][e];
             }
             lds_barrier();                                                             // (B)
+            if (nact1) {
+                // image ns-2 of xp (without dropout: image ns-1 of layer 0): on its way during this phase's cell update
+                const int ximg = (((p.xp ? ns - 2 : ns - 1) * NBT + nbt) * nkb + wq * KBQ) * 2048;
+#pragma unroll
+                for (int i = 0; i < KBQ; ++i) ax[i] = load_sc1_u(x_rsrc, lane * 16, ximg + i * 2048);
+            }
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
             if (act1) {
                 if (cell) {
@@ -319,19 +317,16 @@ __device__ __forceinline__ void fwd2x_layer1_waves(const Persist2Fwd &p, const F
                 }
                 sh.hbuf[2][ci][cj] = h;
             }
-            lds_barrier();                                                             // (C)
-            // ---- the NEXT phase's input half (tile nq at time ns - 2): its fragments -- image ns-2 of xp, without dropout image ns-1 of layer 0
-            //      -- were complete when that tile's previous poll matched, one phase ago or more ----
+            lds_barrier();                                                             // (AC)
+            if (*sh.s_abort) return;
 #pragma unroll
             for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int nq = q + 1 < ntile ? q + 1 : 0, ns = nq ? s : s + 1;
-            if (ns >= 2 && ns <= T + 1) {
-                const int nbt = p.bt0 + 2 * pr + nq;
-                const int ximg = (((p.xp ? ns - 2 : ns - 1) * NBT + nbt) * nkb + wq * KBQ) * 2048;
-                bf16x8 ax[KBQ];
+            if (nact1) {
+                const int img = (((ns - 2) * NBT + nbt) * nkb + wq * KBQ) * 2048;      // image ns-2 of layer 1 = h1_{ns-3}: the next phase's poll has matched
 #pragma unroll
-                for (int i = 0; i < KBQ; ++i) ax[i] = load_sc1_u(x_rsrc, lane * 16, ximg + i * 2048);
+                for (int i = 0; i < KBQ; ++i) ah[i] = load_sc1_u(hp1_rsrc, lane * 16, img + i * 2048);
                 __builtin_amdgcn_sched_barrier(0);
+                // the next phase's input half, while its recurrent fragments are on their way
 #pragma unroll
                 for (int i = 0; i < KBQ; ++i) {
                     bf16x8 w[4];
