@@ -67,9 +67,11 @@ def parse_args():
                     help="arithmetic of the dense products: 'bf16' rounds the operands to bf16 (one MFMA per product); 'f32' and "
                          "'bf16x3' meet the fp32 parity tolerances")
     ap.add_argument('--no-configs', action='store_true', help='skip the GPT-2 small / attention-ASR legs (BASELINE configs 3 and 5)')
-    ap.add_argument('--dp-algo', choices=['allreduce', 'rs_ag'], default='rs_ag',
+    ap.add_argument('--dp-algo', choices=['allreduce', 'rs_ag', 'rs_ag_flat'], default='rs_ag',
                     help='N > 1: allreduce = every rank averages the whole gradient and updates every parameter (DistributedDataParallel); '
-                         'rs_ag = reduce-scatter, each rank updates its 1/N of the flat parameters, all-gather')
+                         'rs_ag = the span-sharded step: the top LSTM layer\'s matrix gradients reduce-scattered from the middle of the backward, the '
+                         'lower layers\' behind it, small parameters all-reduced, each rank updates its chunks, bf16 all-gather in bf16 arithmetic; '
+                         'rs_ag_flat = one reduce-scatter / fp32 all-gather over the whole flat buffers')
     ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
                     help='wire format of the data-parallel gradient all-reduce (N > 1)')
     return ap.parse_args()
@@ -396,7 +398,7 @@ def main():
     _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
-    dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo == 'rs_ag')
+    dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo != 'allreduce')
     trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True, **dp_kw)
     x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
@@ -476,7 +478,9 @@ def main():
                        'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'launch_mode_probe': mode_probe, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None,
                        'dp_algo': trainer.dp_algo if (world > 1 or args.dp_rehearsal) else None,
-                       'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None},
+                       'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None,
+                       'dp_early_reduce_scatter_overlapped': bool(getattr(trainer, '_early_started', False)) if (world > 1 or args.dp_rehearsal) else None,
+                       'dp_wire_bytes_per_rank': (trainer.sharded.wire_bytes() if hasattr(getattr(trainer, 'sharded', None), 'wire_bytes') else None)},
             'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps + (210 if mode_probe else 0),
             'step_roofline': {'algorithmic_bytes_per_step': step_bytes,

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 14
+HALO_ABI_VERSION = 15
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -66,6 +66,8 @@ SIGNATURES = {
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
     'halo_set_lstm_interleave': (_i, [_i]),
+    'halo_set_lstm_bwd_mid_event': (_i, [_vp]),
+    'halo_lstm_bwd_mid_event_recorded': (_i, []),
     'halo_set_lstm_expect_backward': (_i, [_i]),
     'halo_set_lstm_dx_slabs': (_i, [_i]),
     'halo_set_defer_small_jobs': (_i, [_i]),
@@ -167,6 +169,9 @@ SIGNATURES = {
     'halo_debug_mute_workgroup': (_i, [_i]),
     'halo_debug_mfma_clock': (_i, [_vp, _vp, _i, _i, _i, _u32, _vp]),
     'halo_sumsq': (_i, [_vp, _sz, _vp, _vp]),
+    'halo_sumsq_ranges': (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    'halo_pack_ranges_bf16': (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    'halo_expand_ranges_bf16': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     'halo_clip_coef': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'halo_adamw_multi_tensor_bytes': (_sz, []),
     'halo_adamw_multi_chunk': (_u32, []),
@@ -224,6 +229,12 @@ def set_lstm_fusion(on):
 def set_lstm_persistent(on):
     """Weight-resident persistent LSTM recurrence (one launch per layer and direction) on / off (include/halo.h)."""
     check(lib().halo_set_lstm_persistent(int(bool(on))), 'halo_set_lstm_persistent')
+
+
+def set_lstm_bwd_mid_event(event):
+    """event: a torch.cuda.Event that has been recorded at least once (so that its handle exists), or None.  halo_lstm_bwd records it
+    behind the launch that stores the top LSTM layer's weight gradients (include/halo.h)."""
+    check(lib().halo_set_lstm_bwd_mid_event(None if event is None else C.c_void_p(event.cuda_event)), 'halo_set_lstm_bwd_mid_event')
 
 
 def set_lstm_interleave(on):

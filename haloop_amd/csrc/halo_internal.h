@@ -44,6 +44,8 @@ struct HaloCtx {
     int scratch_slot = 0;
     unsigned *status = nullptr;          // device word, sticky: set to non-zero by a persistent recurrence whose bounded wait timed out
     hipEvent_t chain_ev0 = nullptr, chain_ev1 = nullptr;
+    int bwd_mid_recorded = 0;            // ... times since it was set
+    hipEvent_t bwd_mid_event = nullptr;  // halo_set_lstm_bwd_mid_event: recorded when the top layer's weight gradients have been launched
     unsigned long long *stamps = nullptr;
     // halo_set_grad_sumsq: the squared-norm partials of a training step's clipped gradients, written by the launches that produce those
     // gradients (host bookkeeping: destination, capacity, how many slots are taken, which producers have contributed)

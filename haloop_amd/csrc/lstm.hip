@@ -1485,6 +1485,12 @@ int halo_set_lstm_persistent2(int on) {
     halo_lstm_persist2_enable(on);
     return HALO_OK;
 }
+int halo_set_lstm_bwd_mid_event(void *event) {
+    halo_ctx_cur().bwd_mid_event = (hipEvent_t)event;
+    halo_ctx_cur().bwd_mid_recorded = 0;
+    return HALO_OK;
+}
+int halo_lstm_bwd_mid_event_recorded(void) { return halo_ctx_cur().bwd_mid_recorded; }
 int halo_set_lstm_interleave(int on) {
     halo_lstm_interleave_enable(on);
     return HALO_OK;
@@ -1805,6 +1811,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                                                          dx_slices ? img_g : nullptr, img_wT, T * B, in_lo_dim, 4 * H, din_out, ctx.lstm_dx_slabs,
                                                          &carried, slot, slot ? &parts : nullptr, st));
             if (slot) { ctx.grad_sumsq_n += parts; ctx.grad_sumsq_cover |= 1u; }
+            // the top layer's weight gradients are final behind this point of the stream: a data-parallel caller starts their exchange here
+            if (ctx.bwd_mid_event && hipEventRecord(ctx.bwd_mid_event, st) == hipSuccess) ++ctx.bwd_mid_recorded;
             if (carried) ctx.lstm_dx_slabs_left = carried;
             else
             if (need_din) {     // (masked by the dropout of the layer below's output, which this gradient flows into)
@@ -1824,6 +1832,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         } else {
             HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, hi, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g,
                                          emit1 ? img_gT1 : img_gT, img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));
+            if (ctx.bwd_mid_event && hipEventRecord(ctx.bwd_mid_event, st) == hipSuccess) ++ctx.bwd_mid_recorded;
             HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, lo, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit0, img_g, img_gT, img_hT,
                                          img_inT, img_wT, bias_part0, din, dx, dw_ih, dw_hh, db_ih, db_hh, need_din, st));
         }

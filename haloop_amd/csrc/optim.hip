@@ -22,6 +22,71 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// the same over up to 8 ranges of one buffer, as if they were one concatenated array (the sharded data-parallel update: a rank's
+// chunks of the reduce-scattered spans); every range begins and ends on a multiple of 4 elements
+struct Ranges8 {
+    size_t begin[8], len4[8];          // element offset, length in float4
+    int n;
+};
+__global__ __launch_bounds__(256) void sumsq_ranges_kernel(const float *__restrict__ x, Ranges8 r, float *__restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    size_t base = 0;
+    for (int k = 0; k < r.n; ++k) {
+        const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + r.begin[k]);
+        // (the concatenated index space is dealt to the threads round-robin, as sumsq_kernel deals one array)
+        const size_t stride = (size_t)gridDim.x * 256, me = blockIdx.x * (size_t)256 + threadIdx.x;
+        size_t i = (me + stride - base % stride) % stride;
+        for (; i < r.len4[k]; i += stride) {
+            const f32x4 v = x4[i];
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        base += r.len4[k];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dst (bf16, contiguous) <- the concatenation of up to 8 ranges of src (fp32), 4 elements per thread and pass
+__global__ __launch_bounds__(256) void pack_ranges_bf16_kernel(const float *__restrict__ src, Ranges8 r, __bf16 *__restrict__ dst) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    size_t base = 0;
+    for (int k = 0; k < r.n; ++k) {
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src + r.begin[k]);
+        bf16x4 *d4 = reinterpret_cast<bf16x4 *>(dst) + base;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < r.len4[k]; i += (size_t)gridDim.x * 256) {
+            const f32x4 v = s4[i];
+            bf16x4 o;
+            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+            d4[i] = o;
+        }
+        base += r.len4[k];
+    }
+}
+
+// the inverse on the gathered buffer: stage [world][sum of chunks] bf16, rank-major; span k of dst begins at r.begin[k] and is cut into
+// `world` chunks of r.len4[k] float4 each; chunk `skip` (the caller's own: its fp32 master values stay) is left alone
+__global__ __launch_bounds__(256) void expand_ranges_bf16_kernel(const __bf16 *__restrict__ stage, Ranges8 r, int world, int skip,
+                                                                 float *__restrict__ dst) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    size_t per_rank = 0;
+    for (int k = 0; k < r.n; ++k) per_rank += r.len4[k];
+    size_t off = 0;
+    for (int k = 0; k < r.n; ++k) {
+        const size_t c = r.len4[k], total = c * (size_t)world;
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(dst + r.begin[k]);
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t rk = i / c, j = i - rk * c;
+            if ((int)rk == skip) continue;
+            const bf16x4 v = reinterpret_cast<const bf16x4 *>(stage)[rk * per_rank + off + j];
+            d4[i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+        off += c;
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ partials, int count, float max_norm,
                                                         float *coef, float *norm_out, uint32_t *applied_steps, const uint32_t *status) {
     __shared__ float red[4];
@@ -296,6 +361,52 @@ int halo_scale_add(float *y, const float *x, float alpha, float beta, size_t n, 
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream) {
     HALO_CHECK_ARG(x && partials && ((uintptr_t)x % 16 == 0));
     hipLaunchKernelGGL(sumsq_kernel, dim3(HALO_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    return halo_launch_status();
+}
+
+namespace {
+int make_ranges8(int n, const size_t *begin, const size_t *end, Ranges8 &r, size_t &total4) {
+    if (n < 1 || n > 8 || !begin || !end) return HALO_EINVAL;
+    r.n = n; total4 = 0;
+    for (int k = 0; k < n; ++k) {
+        if (end[k] < begin[k] || begin[k] % 4 || end[k] % 4) return HALO_EINVAL;
+        r.begin[k] = begin[k]; r.len4[k] = (end[k] - begin[k]) / 4;
+        total4 += r.len4[k];
+    }
+    return HALO_OK;
+}
+}  // namespace
+
+int halo_sumsq_ranges(const float *x, int n, const size_t *begin, const size_t *end, float *partials, halo_stream_t stream) {
+    HALO_CHECK_ARG(x && partials && ((uintptr_t)x % 16 == 0));
+    Ranges8 r; size_t total4;
+    { const int rc = make_ranges8(n, begin, end, r, total4); if (rc != HALO_OK) return rc; }
+    hipLaunchKernelGGL(sumsq_ranges_kernel, dim3(HALO_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, x, r, partials);
+    return halo_launch_status();
+}
+
+int halo_pack_ranges_bf16(const float *src, int n, const size_t *begin, const size_t *end, void *dst, halo_stream_t stream) {
+    HALO_CHECK_ARG(src && dst && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0));
+    Ranges8 r; size_t total4;
+    { const int rc = make_ranges8(n, begin, end, r, total4); if (rc != HALO_OK) return rc; }
+    if (total4 == 0) return HALO_OK;
+    const unsigned blocks = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_ranges_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, r, (__bf16 *)dst);
+    return halo_launch_status();
+}
+
+int halo_expand_ranges_bf16(const void *stage, int n, const size_t *begin, const size_t *chunk, int world, int skip_rank, float *dst,
+                            halo_stream_t stream) {
+    HALO_CHECK_ARG(stage && dst && world >= 1 && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)stage % 8 == 0));
+    Ranges8 r; size_t total4;
+    size_t end[8];
+    if (n < 1 || n > 8 || !begin || !chunk) return HALO_EINVAL;
+    for (int k = 0; k < n; ++k) end[k] = begin[k] + chunk[k];
+    { const int rc = make_ranges8(n, begin, end, r, total4); if (rc != HALO_OK) return rc; }
+    if (total4 == 0) return HALO_OK;
+    const size_t all4 = total4 * (size_t)world;
+    const unsigned blocks = (unsigned)((all4 + 255) / 256 < 4096 ? (all4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(expand_ranges_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)stage, r, world, skip_rank, dst);
     return halo_launch_status();
 }
 

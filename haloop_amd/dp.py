@@ -211,3 +211,179 @@ class ShardedUpdate:
             # (gloo copies into the list's tensors: contiguous slices of the flat buffer are written where they belong)
             dist.all_gather([self.params[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], self.params[lo:hi].clone(),
                             group=self.group)
+
+
+class SpanSharded:
+    """The sharded-optimizer data-parallel step with the exchange cut where the backward finishes its gradients and where the forward
+    consumes its weights (DistributedDataParallel overlaps its buckets with backward, ha/attention_loop.py:154,203):
+
+        flat buffers  =  [ small | big ],   big = [ late span | early span ]
+
+    * ``early`` -- the top LSTM layer's two matrices, final when their weight-gradient launch retires: ``reduce_scatter('early')`` is
+      started on a side stream at that point (``after`` = the event the library records there) and runs beside the lower layer's
+      products and the front end's backward; ``late`` -- the lower layers' recurrent matrices, reduce-scattered behind the backward.
+      Rank r owns chunk r of EACH span (fp32 master values, Adam moments, clip + AdamW on those chunks only).
+    * ``small`` -- everything else (biases, front end, input projection, classifier: 5 % of the parameters): one all-reduce(AVG), every
+      rank applies the identical update, nothing to gather.
+    * ``all_gather()`` -- with ``gather_bf16`` (single-pass bf16 arithmetic, where every consumer of those matrices multiplies by their
+      bf16 values) the owners send the bf16 roundings of their updated chunks, HALF the bytes of an fp32 all-gather, in ONE collective
+      over a rank-major staging buffer, and every rank expands the others' records into its flat parameters (its own fp32 masters stay);
+      ``gather_masters()`` exchanges the fp32 masters themselves (checkpoints, evaluation in another arithmetic).  Otherwise the
+      chunks are all-gathered in fp32, in place.
+
+    ``nccl`` (= RCCL) runs reduce_scatter_tensor / all_gather_into_tensor; under ``gloo`` (the CPU tests) a reduce-scatter is one
+    ``reduce`` per owner -- only the owner receives the sum -- and the all-gather the list form."""
+
+    def __init__(self, flat_params, flat_grads, early, late, small, group=None, always=False, gather_bf16=False):
+        self.params, self.grads, self.group = flat_params, flat_grads, group
+        self.always = bool(always) and dist.is_available() and dist.is_initialized()
+        self.world = world_size(group)
+        self.active = self.world > 1 or self.always
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.small = tuple(small)
+        self.spans = {}
+        for name, (lo, hi) in (('late', late), ('early', early)):
+            if hi > lo:
+                if (hi - lo) % (4 * self.world) or lo % 4:
+                    raise ValueError(f'span {name} [{lo}, {hi}) does not cut into {self.world} chunks of whole float4s')
+                self.spans[name] = (lo, hi, (hi - lo) // self.world)
+        self._native = self.active and dist.get_backend(group) == 'nccl'
+        self._avg_op = self._native and _avg_supported(flat_grads, group)
+        self.gather_bf16 = bool(gather_bf16) and bool(self.spans)
+        self._per_rank = sum(c for _, _, c in self.spans.values())
+        self._stage = (torch.empty(self.world * self._per_rank, dtype=torch.bfloat16, device=flat_params.device)
+                       if self.gather_bf16 and self.active else None)
+        self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        self.bytes_on_wire = None
+
+    # ---- ownership ---------------------------------------------------------------------------
+    def own(self, name):
+        lo, _, c = self.spans[name]
+        return (lo + self.rank * c, lo + (self.rank + 1) * c)
+
+    def own_ranges(self):
+        """What this rank updates: its chunk of every reduce-scattered span, and the replicated small range."""
+        out = [self.own(n) for n in self.spans]
+        if self.small[1] > self.small[0]:
+            out.append(self.small)
+        return sorted(out)
+
+    def norm_ranges(self):
+        """Ranges whose squared norms, summed over the ranks, give the whole buffer's: the replicated part counts on rank 0 only."""
+        out = [self.own(n) for n in self.spans]
+        if self.rank == 0 and self.small[1] > self.small[0]:
+            out.append(self.small)
+        return sorted(out)
+
+    # ---- collectives -------------------------------------------------------------------------
+    def reduce_scatter(self, name, after=None):
+        """grads[own chunk of the span] <- mean over the ranks.  ``after``: a recorded torch.cuda.Event -- the collective is issued on a
+        side stream that waits for it (instead of for everything enqueued so far); returns a handle for ``wait``."""
+        if not self.active or name not in self.spans:
+            return None
+        lo, hi, c = self.spans[name]
+        own_lo, own_hi = self.own(name)
+        if self._native:
+            op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+            if after is not None and self._side is not None:
+                self._side.wait_event(after)
+                with torch.cuda.stream(self._side):
+                    work = dist.reduce_scatter_tensor(self.grads[own_lo:own_hi], self.grads[lo:hi], op=op, group=self.group, async_op=True)
+                return ('side', work, name)
+            dist.reduce_scatter_tensor(self.grads[own_lo:own_hi], self.grads[lo:hi], op=op, group=self.group)
+            if not self._avg_op:
+                self.grads[own_lo:own_hi].mul_(1.0 / self.world)
+            return None
+        # gloo: one reduce per owner; only the owner's buffer holds the sum afterwards
+        for dst in range(self.world):
+            piece = self.grads[lo + dst * c:lo + (dst + 1) * c]
+            send = piece if dst == self.rank else piece.clone()
+            dist.reduce(send, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+        self.grads[own_lo:own_hi].mul_(1.0 / self.world)
+        return None
+
+    def wait(self, handle):
+        """Order the current stream behind a side-stream collective started by ``reduce_scatter(after=...)``."""
+        if handle is None:
+            return
+        _, work, name = handle
+        work.wait()
+        if not self._avg_op:
+            own_lo, own_hi = self.own(name)
+            self.grads[own_lo:own_hi].mul_(1.0 / self.world)
+
+    def all_reduce_small(self):
+        lo, hi = self.small
+        if not self.active or hi <= lo:
+            return
+        if self._avg_op:
+            dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            self.grads[lo:hi].mul_(1.0 / self.world)
+
+    def all_reduce_sum(self, t):
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _gather_span_f32(self, name):
+        lo, hi, c = self.spans[name]
+        own_lo, own_hi = self.own(name)
+        if self._native:
+            dist.all_gather_into_tensor(self.params[lo:hi], self.params[own_lo:own_hi], group=self.group)         # in place
+        else:
+            dist.all_gather([self.params[lo + r * c:lo + (r + 1) * c] for r in range(self.world)], self.params[own_lo:own_hi].clone(),
+                            group=self.group)
+
+    def all_gather(self):
+        """Every rank's updated chunks to every rank: bf16 roundings through the staging buffer, or the fp32 values in place."""
+        if not self.active or not self.spans:
+            return
+        if not self.gather_bf16:
+            for name in self.spans:
+                self._gather_span_f32(name)
+            return
+        names = list(self.spans)
+        mine = self._stage[self.rank * self._per_rank:(self.rank + 1) * self._per_rank]
+        if self.params.is_cuda:
+            from . import ops
+            ops.pack_ranges_bf16(self.params, [self.own(n) for n in names], mine)
+        else:
+            off = 0
+            for n in names:
+                a, b = self.own(n)
+                mine[off:off + b - a].copy_(self.params[a:b])
+                off += b - a
+        if self._native:
+            dist.all_gather_into_tensor(self._stage, mine, group=self.group)                                       # in place
+        else:
+            dist.all_gather([self._stage[r * self._per_rank:(r + 1) * self._per_rank] for r in range(self.world)], mine.clone(), group=self.group)
+        if self.params.is_cuda:
+            ops.expand_ranges_bf16(self._stage, [self.spans[n][0] for n in names], [self.spans[n][2] for n in names], self.world, self.rank,
+                                   self.params)
+        else:
+            off = 0
+            for n in names:
+                lo, _, c = self.spans[n]
+                for r in range(self.world):
+                    if r != self.rank:
+                        self.params[lo + r * c:lo + (r + 1) * c].copy_(self._stage[r * self._per_rank + off:r * self._per_rank + off + c])
+                off += c
+
+    def gather_masters(self):
+        """fp32 all-gather of the sharded spans: after it every rank holds every owner's exact master values (checkpoints)."""
+        if self.active:
+            for name in self.spans:
+                self._gather_span_f32(name)
+
+    def wire_bytes(self):
+        """Bytes this rank sends (= receives) per step, by collective: the model DESIGN.md section 7 prices."""
+        w = self.world
+        f = (w - 1) / w if w > 1 else 0.0
+        out = {}
+        for name, (lo, hi, c) in self.spans.items():
+            out['reduce_scatter_' + name] = int(4 * (hi - lo) * f)
+        out['all_reduce_small'] = int(2 * 4 * (self.small[1] - self.small[0]) * f)
+        big = sum(hi - lo for lo, hi, _ in self.spans.values())
+        out['all_gather'] = int((2 if self.gather_bf16 else 4) * big * f)
+        return out

@@ -600,6 +600,34 @@ def sumsq_partials(flat, partials=None):
     return partials
 
 
+def _range_arrays(ranges):
+    n = len(ranges)
+    return n, (C.c_size_t * n)(*[int(r[0]) for r in ranges]), (C.c_size_t * n)(*[int(r[1]) for r in ranges])
+
+
+def sumsq_ranges(flat, ranges, partials):
+    """partials[0:HALO_SUMSQ_PARTS] <- squared-norm partials of the concatenation of flat[lo:hi] for (lo, hi) in ranges (<= 8, multiples of 4)."""
+    n, b, e = _range_arrays(ranges)
+    check(lib().halo_sumsq_ranges(ptr(flat), n, b, e, ptr(partials), _stream()), 'halo_sumsq_ranges')
+    return partials
+
+
+def pack_ranges_bf16(flat, ranges, dst):
+    """dst (bfloat16, contiguous) <- the concatenation of flat[lo:hi] for (lo, hi) in ranges, rounded to nearest-even."""
+    n, b, e = _range_arrays(ranges)
+    check(lib().halo_pack_ranges_bf16(ptr(flat), n, b, e, ptr(dst), _stream()), 'halo_pack_ranges_bf16')
+    return dst
+
+
+def expand_ranges_bf16(stage, spans, chunks, world, skip_rank, flat):
+    """flat[span k] <- the gathered bf16 records of every rank but skip_rank (include/halo.h halo_expand_ranges_bf16)."""
+    n = len(spans)
+    b = (C.c_size_t * n)(*[int(s) for s in spans])
+    c = (C.c_size_t * n)(*[int(x) for x in chunks])
+    check(lib().halo_expand_ranges_bf16(ptr(stage), n, b, c, int(world), int(skip_rank), ptr(flat), _stream()), 'halo_expand_ranges_bf16')
+    return flat
+
+
 GRAD_SUMSQ_ALL = 31        # halo_grad_sumsq_state: both layers' matrices and biases and the conv front end have contributed
 
 

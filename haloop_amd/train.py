@@ -34,28 +34,48 @@ def decay_groups(encoder, recognizer):
     return decay, no_decay
 
 
+def _merge_adjacent(ranges):
+    """Sorted (lo, hi) ranges with touching neighbours joined."""
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out
+
+
 class FlatParams:
     """Re-homes parameters into one flat buffer laid out
 
-        [enc no-decay | enc decay, lower layers | enc decay, top LSTM layer | rec decay | rec no-decay]
+        [rec no-decay | rec decay | enc no-decay | enc decay, small | enc big: lower layers' matrices | enc big: top LSTM layer's matrices]
 
-    so that (a) the encoder (the clipped part, ha/loop.py:184) is one contiguous range, (b) each
-    AdamW launch covers one contiguous (weight-decay, clip-scale) range, and (c) the gradients that
-    are final first in backward -- recognizer and top LSTM layer -- form one contiguous suffix,
-    the first all-reduce bucket of the data-parallel step."""
+    so that (a) the encoder (the clipped part, ha/loop.py:184) is one contiguous range, (b) each AdamW launch covers a few contiguous
+    (weight-decay, clip-scale) ranges, (c) the big matrices (every LSTM ``weight_hh`` and the ``weight_ih`` of the layers above the first:
+    95 % of LC-2x1024) form one contiguous block at the end, in the order their gradients become final -- the block the data-parallel
+    steps exchange in pieces (``big_early``: the top layer's matrices, final first in backward; ``big_late``: the layers below) -- and
+    (d) everything else (``small_range``) is one contiguous prefix."""
 
     def __init__(self, encoder, recognizer, pad_to=4):
-        """pad_to: the buffers' length is rounded up to a multiple of it (the sharded data-parallel update wants equal spans)."""
+        """pad_to: the buffers' length is rounded up to a multiple of it (the flat sharded data-parallel update wants equal spans)."""
         decay, no_decay = decay_groups(encoder, recognizer)
         top = getattr(encoder, 'lstm', None)
-        top_tag = f'_l{top.num_layers - 1}' if top is not None and top.num_layers > 1 else None
-        is_top = lambda n: top_tag is not None and n.startswith('encoder.lstm.') and n.endswith(top_tag)
-        groups = [[(n, p) for n, p in no_decay if n.startswith('encoder.')],
-                  [(n, p) for n, p in decay if n.startswith('encoder.') and not is_top(n)],
-                  [(n, p) for n, p in decay if n.startswith('encoder.') and is_top(n)],
+        nl = top.num_layers if top is not None else 0
+
+        def big_layer(n):            # the LSTM layer a big matrix belongs to, or None
+            if not n.startswith('encoder.lstm.weight_'):
+                return None
+            kind, layer = n[len('encoder.lstm.weight_'):].split('_l')
+            layer = int(layer)
+            return layer if (kind == 'hh' or layer > 0) else None
+        is_top = lambda n: nl > 1 and big_layer(n) == nl - 1
+        enc_decay = [(n, p) for n, p in decay if n.startswith('encoder.')]
+        groups = [[(n, p) for n, p in no_decay if n.startswith('recognizer.')],
                   [(n, p) for n, p in decay if n.startswith('recognizer.')],
-                  [(n, p) for n, p in no_decay if n.startswith('recognizer.')]]
-        decays = [False, True, True, True, False]
+                  [(n, p) for n, p in no_decay if n.startswith('encoder.')],
+                  [(n, p) for n, p in enc_decay if big_layer(n) is None],
+                  sorted([(n, p) for n, p in enc_decay if big_layer(n) is not None and not is_top(n)], key=lambda t: (big_layer(t[0]), t[0])),
+                  sorted([(n, p) for n, p in enc_decay if is_top(n)], key=lambda t: t[0])]
         dev = next(encoder.parameters()).device
         off, bounds, self.slots = 0, [], []
         for g in groups:
@@ -65,12 +85,15 @@ class FlatParams:
                 off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
             bounds.append((start, off))
         self.total = off
-        self.encoder_range = (bounds[0][0], bounds[2][1])
-        self.early_range = (bounds[2][0], off)            # final after the top LSTM layer's backward
-        self.late_range = (0, bounds[2][0])
+        self.encoder_range = (bounds[2][0], off)
+        self.small_range = (0, bounds[4][0])
+        self.big_late = bounds[4]                         # final when the whole backward has run
+        self.big_early = bounds[5]                        # final after the top LSTM layer's weight-gradient launch
+        self.early_range = bounds[5]                      # (the all-reduce step's first bucket)
+        self.late_range = (0, bounds[5][0])
         # AdamW ranges: (begin, end, weight-decayed, clipped)
-        self.ranges = [(bounds[0][0], bounds[0][1], False, True), (bounds[1][0], bounds[2][1], True, True),
-                       (bounds[3][0], bounds[3][1], True, False), (bounds[4][0], bounds[4][1], False, False)]
+        self.ranges = [(bounds[0][0], bounds[0][1], False, False), (bounds[1][0], bounds[1][1], True, False),
+                       (bounds[2][0], bounds[2][1], False, True), (bounds[3][0], off, True, True)]
         self.padded = (off + pad_to - 1) // pad_to * pad_to
         self.params = torch.zeros(self.padded, device=dev, dtype=torch.float32)
         self.grads = torch.zeros(self.padded, device=dev, dtype=torch.float32)
@@ -94,7 +117,7 @@ class LstmCtcTrainer:
 
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
-                 alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False):
+                 alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False, gather_dtype='auto'):
         """use_graph: True -- the step replays from HIP graphs (default); False -- the same launches issued eagerly; 'auto' (one process,
         accumulate == 1) -- both are timed over the first 53 steps and the faster way stays (``auto_choice``): with the two-layer launches a
         step is 13 launches, the host enqueues them in ~0.2 ms against ~0.47 ms on the GPU, and a replay costs ~15 us more than it saves.
@@ -107,9 +130,17 @@ class LstmCtcTrainer:
             ('f32' = DistributedDataParallel's; 'bf16' halves its bytes on the links).
         alias_loss: step() returns ``self.loss`` itself -- ONE device scalar that every later step overwrites -- instead of a
         copy the caller owns (for loops that read each loss before the next step, or never).
-        dp_algo (more than one rank): 'rs_ag' -- the gradients are reduce-scattered, every rank clips and updates ITS 1/world span of
-        the flat parameters (the squared-norm partials are summed over the ranks first: the clip uses the global norm), and the
-        spans are all-gathered; forward + backward stay ONE graph (a 2-layer stack in bf16 mode: the two-layer persistent launches).
+        dp_algo (more than one rank): 'rs_ag' -- the sharded update cut along the step (dp.SpanSharded): the top LSTM layer's matrix
+        gradients are reduce-scattered on a side stream from the moment their launch retires (beside the rest of the backward), the
+        lower layers' matrices behind the backward, the small parameters are all-reduced and updated by every rank; every rank clips
+        (global norm: the partials are summed over the ranks) and updates ITS chunk of each matrix span, and the chunks are
+        all-gathered -- as bf16 roundings when ``gather_dtype`` allows (below).  Forward + backward are launched eagerly or replayed
+        from one graph (a 2-layer stack in bf16 mode: the two-layer persistent launches); the tail is captured in a graph.
+        'rs_ag_flat' -- round 3's form: ONE reduce-scatter / all-gather over the whole flat buffers behind the backward (also what
+        ``grad_dtype='bf16'`` uses).
+        gather_dtype: 'auto' -- bf16 when the arithmetic mode at construction is single-pass bf16 (every consumer of the sharded
+        matrices multiplies by their bf16 values, so the step is the one an fp32 gather gives; the other ranks' fp32 master values
+        are then NOT in this rank's buffers: ``gather_master_weights()`` before a checkpoint), else 'f32'; or 'f32' / 'bf16'.
         (rehearse_dp: take this path on ONE rank of an initialised process group, every collective issued over that one rank --
         how a single GPU exercises the real backend, captured graphs included.)
         'allreduce' -- DistributedDataParallel's shape: every rank averages the whole gradient (two buckets, the first overlapped
@@ -120,13 +151,17 @@ class LstmCtcTrainer:
         self.accumulate = int(accumulate)
         self._micro = 0
         self.betas, self.eps, self.weight_decay, self.clip = betas, eps, weight_decay, clip_grad_norm
-        if dp_algo not in ('rs_ag', 'allreduce'):
-            raise ValueError(f"dp_algo must be 'rs_ag' or 'allreduce', got {dp_algo!r}")
+        if dp_algo not in ('rs_ag', 'rs_ag_flat', 'allreduce'):
+            raise ValueError(f"dp_algo must be 'rs_ag', 'rs_ag_flat' or 'allreduce', got {dp_algo!r}")
+        if gather_dtype not in ('auto', 'f32', 'bf16'):
+            raise ValueError(f"gather_dtype must be 'auto', 'f32' or 'bf16', got {gather_dtype!r}")
         self.world = dp.world_size(process_group)
-        # gradient accumulation and the bf16 wire format live on the all-reduce path
+        # gradient accumulation lives on the all-reduce path; the bf16 gradient wire format on it and on the flat sharded step
         self.dp_algo = dp_algo if ((self.world > 1 or rehearse_dp) and self.accumulate == 1) else 'allreduce'
+        if self.dp_algo == 'rs_ag' and grad_dtype == 'bf16':
+            self.dp_algo = 'rs_ag_flat'
         self._rehearse_dp = bool(rehearse_dp)
-        self.flat = FlatParams(encoder, recognizer, pad_to=4 * self.world if self.dp_algo == 'rs_ag' else 4)
+        self.flat = FlatParams(encoder, recognizer, pad_to=4 * self.world if self.dp_algo != 'allreduce' else 4)
         dev = self.flat.params.device
         # the learning rate lives on the device: the optimizer launch (captured in the step graph) reads it there, so assigning
         # ``trainer.lr`` between steps -- the reference applies its schedule every step, ha/loop.py:191 -- takes effect on replay
@@ -160,8 +195,23 @@ class LstmCtcTrainer:
         self.eager_forward_backward = os.environ.get('HALO_DP_EAGER_FB', '1') != '0'
         self.pg = process_group
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
-        self.sharded = (dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp, wire_dtype=grad_dtype)
-                        if self.dp_algo == 'rs_ag' else None)
+        self.sharded = None
+        if self.dp_algo == 'rs_ag':
+            f = self.flat
+            bf16_gather = gather_dtype == 'bf16' or (gather_dtype == 'auto' and _lib.get_math_mode() == 'bf16')
+            try:
+                self.sharded = dp.SpanSharded(f.params, f.grads, f.big_early, f.big_late, f.small_range, process_group,
+                                              always=self._rehearse_dp, gather_bf16=bf16_gather)
+            except ValueError as e:       # matrix sizes that do not cut into `world` chunks of whole float4s: the flat form pads instead
+                import logging
+                logging.getLogger(__name__).warning('haloop_amd.train: %s; using dp_algo rs_ag_flat', e)
+                self.dp_algo = 'rs_ag_flat'
+            else:
+                self._mid_event = torch.cuda.Event() if dev.type == 'cuda' else None
+                if self._mid_event is not None:
+                    self._mid_event.record()                       # (creates the handle the library records)
+        if self.dp_algo == 'rs_ag_flat':
+            self.sharded = dp.ShardedUpdate(self.flat.params, self.flat.grads, process_group, always=self._rehearse_dp, wire_dtype=grad_dtype)
         # two buckets in readiness order: [top layer + recognizer] then [the rest]
         self.avg_early = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.early_range, wire_dtype=grad_dtype)
         self.avg_late = dp.GradientAverager(self.flat.grads, process_group, span=self.flat.late_range, wire_dtype=grad_dtype)
@@ -337,27 +387,35 @@ class LstmCtcTrainer:
         self._norm_partials()
         self._apply_update()
 
-    def _span(self):
-        return self.sharded.span if self.sharded is not None else (0, self.flat.padded)
+    def _own_ranges(self):
+        """The ranges of the flat buffers this rank's optimizer launch covers."""
+        if isinstance(self.sharded, dp.SpanSharded):
+            return self.sharded.own_ranges()
+        if self.sharded is not None:
+            return [self.sharded.span]
+        return [(0, self.flat.padded)]
 
     def _norm_partials(self):
-        """Squared-norm partials of the clipped (encoder) range -- of this rank's span of it under the sharded update."""
+        """Squared-norm partials of the clipped (encoder) range -- of this rank's share of it under a sharded update (summed over the ranks
+        they give the whole norm: a replicated range counts on rank 0 only)."""
         f = self.flat
-        lo, hi = self._span()
-        e0, e1 = max(f.encoder_range[0], lo), min(f.encoder_range[1], hi)
-        if e1 > e0:
-            ops.sumsq_partials(f.grads[e0:e1], self.partials)
-        else:
+        src = self.sharded.norm_ranges() if isinstance(self.sharded, dp.SpanSharded) else self._own_ranges()
+        cut = [(max(f.encoder_range[0], lo), min(f.encoder_range[1], hi)) for lo, hi in src]
+        cut = _merge_adjacent([(a, b) for a, b in cut if b > a])
+        if not cut:
             self.partials.zero_()
+        elif len(cut) == 1:
+            ops.sumsq_partials(f.grads[cut[0][0]:cut[0][1]], self.partials)
+        else:
+            ops.sumsq_ranges(f.grads, cut, self.partials)
 
     def _apply_update(self, count=None):
         f = self.flat
-        lo, hi = self._span()
         ops.clip_coef(self.partials_p if count else self.partials, count or _lib.HALO_SUMSQ_PARTS, self.clip, self.coef, self.grad_norm,
                       applied_steps=self.adam_step)
-        # all (decay, clip) ranges (cut to this rank's span) and the dropout step counter in one launch
+        # all (decay, clip) ranges (cut to what this rank updates) and the dropout step counter in one launch
         ranges = [(max(a, lo), min(b, hi), self.weight_decay if decays else 0.0, self.coef[0:1] if clipped else self.coef[1:2])
-                  for a, b, decays, clipped in f.ranges if min(b, hi) > max(a, lo)]
+                  for a, b, decays, clipped in f.ranges for lo, hi in _merge_adjacent(self._own_ranges()) if min(b, hi) > max(a, lo)]
         if ranges:
             ops.adamw_ranges(f.params, f.grads, f.exp_avg, f.exp_avg_sq, ranges, self._lr_dev, self.betas[0], self.betas[1], self.eps,
                              self.adam_step, counter=self.counter)
@@ -365,13 +423,27 @@ class LstmCtcTrainer:
             ops.counter_inc(self.counter)
 
     def _sharded_tail(self):
-        """reduce-scatter -> partial norms -> their sum over the ranks -> clip + AdamW on this rank's span -> all-gather."""
+        """Behind the backward: the remaining gradient exchange -> partial norms -> their sum over the ranks -> clip + AdamW on what this
+        rank owns -> all-gather."""
         sh = self.sharded
-        sh.reduce_scatter()
+        if isinstance(sh, dp.SpanSharded):
+            if not self._early_started:
+                sh.reduce_scatter('early')
+            sh.reduce_scatter('late')
+            sh.all_reduce_small()
+        else:
+            sh.reduce_scatter()
         self._norm_partials()
         sh.all_reduce_sum(self.partials)
         self._apply_update()
         sh.all_gather()
+
+    def gather_master_weights(self):
+        """After a bf16 all-gather (``gather_dtype``) a rank's buffers hold the OTHER ranks' matrix chunks as bf16 roundings: exchange the
+        fp32 master values (one fp32 all-gather of the sharded spans) before ``state_dict()`` is saved or evaluated in another arithmetic."""
+        if isinstance(self.sharded, dp.SpanSharded) and self.sharded.gather_bf16:
+            self.sharded.gather_masters()
+            _lib.bump_weights_epoch()
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):
@@ -425,19 +497,43 @@ class LstmCtcTrainer:
             return self.loss
         return self._graph_step(x, input_lengths, targets, target_lengths)
 
+    def _forward_backward_overlapped(self, x, il, tg, tl):
+        """Forward + backward launched eagerly, with the reduce-scatter of the top LSTM layer's matrix gradients started on a side stream
+        the moment the launch that stores them retires (halo_set_lstm_bwd_mid_event): it runs beside the lower layer's weight-gradient
+        products and the front end's backward.  Returns the handle the tail waits for (None: the library did not record the event on
+        this path -- not a two-layer launch -- and the tail reduces that span itself)."""
+        sh = self.sharded
+        ev = self._mid_event if (isinstance(sh, dp.SpanSharded) and sh._native and 'early' in sh.spans) else None
+        if ev is None:
+            self._forward_backward(x, il, tg, tl)
+            return None
+        _lib.set_lstm_bwd_mid_event(ev)
+        try:
+            st = self._forward_backward_top(x, il, tg, tl)
+            recorded = _lib.lib().halo_lstm_bwd_mid_event_recorded() == 1
+        finally:
+            _lib.set_lstm_bwd_mid_event(None)
+        handle = sh.reduce_scatter('early', after=ev) if recorded else None
+        self._backward_rest(st)
+        return handle
+
     def _sharded_step(self, x, il, tg, tl):
-        """world > 1, dp_algo 'rs_ag'.  Graph mode: forward + backward replay from one graph; the tail -- three collectives with two
-        short optimizer pieces between them -- is captured in a second graph when the collective backend can be captured (RCCL
-        can: its kernels are ordinary stream work), else it runs eagerly."""
-        if not self.use_graph:
-            self._forward_backward(x, il, tg, tl)
-            self._sharded_tail()
-            return self.loss
-        if self.eager_forward_backward:
-            # 13-16 launches: the host keeps ahead of the GPU, and eager launches save what a graph replay costs (DESIGN.md section 3)
-            self._forward_backward(x, il, tg, tl)
+        """world > 1 (or a one-rank rehearsal), dp_algo 'rs_ag' / 'rs_ag_flat'.  Graph mode: forward + backward are launched eagerly (13-16
+        launches: the host keeps ahead) -- which is also what lets the first reduce-scatter start in the middle of the
+        backward -- or replayed from one graph; the tail -- the remaining collectives with the optimizer pieces between them -- is captured
+        in a second graph when the collective backend can be captured (RCCL can: its kernels are ordinary stream work), else it runs eagerly."""
+        handle = None
+        self._early_started = False
+        if not self.use_graph or self.eager_forward_backward:
+            handle = self._forward_backward_overlapped(x, il, tg, tl)
         else:
             self._replay_forward_backward(x, il, tg, tl)
+        if handle is not None:
+            self.sharded.wait(handle)                # the current stream continues behind the side stream's collective
+            self._early_started = True
+        if not self.use_graph:
+            self._sharded_tail()
+            return self.loss
         self._tail_calls = getattr(self, '_tail_calls', 0) + 1
         if self._tail_calls == 2 and self.sharded._native and os.environ.get('HALO_DP_CAPTURE', '1') != '0':
             # the first tail ran eagerly (communicator and kernels warm); record the second
@@ -446,14 +542,14 @@ class LstmCtcTrainer:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._sharded_tail()
-                self._tail_graph = g
+                self._tail_graph, self._tail_graph_early = g, self._early_started
             except Exception as e:                       # a backend that cannot live inside a capture: eager collectives
                 import logging
                 logging.getLogger(__name__).warning('haloop_amd.train: capturing the collectives failed (%s: %s); they run eagerly',
                                                     type(e).__name__, e)
                 torch.cuda.synchronize()
                 self._tail_graph = None
-        if getattr(self, '_tail_graph', None) is not None:
+        if getattr(self, '_tail_graph', None) is not None and self._tail_graph_early == self._early_started:
             _lib.bump_weights_epoch()
             self._tail_graph.replay()
         else:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 14
+#define HALO_ABI_VERSION 15
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -310,6 +310,13 @@ int halo_set_lstm_persistent2(int on);
  * buffers, images and results as those launches but for the order in which the two tiles' bias-gradient rows are added.  On by
  * default (HALO_LSTM_INTERLEAVE=0 / halo_set_lstm_interleave(0): consecutive launches).  Per context. */
 int halo_set_lstm_interleave(int on);
+/* Data-parallel overlap hook.  event (a hipEvent_t, or NULL: off): halo_lstm_bwd records it on its stream right behind the launch that
+ * stores the TOP layer's weight gradients (dw_ih[L-1], dw_hh[L-1]) when the call covers the top two layers as one two-layer launch --
+ * the point from which a caller's side stream may start reducing those gradients over the ranks (ha/attention_loop.py:154:
+ * DistributedDataParallel overlaps its buckets with backward) while the lower layer's products and the front end's backward still run.
+ * Not recorded by any other path: halo_lstm_bwd_mid_event_recorded() tells (the caller then waits for the whole call).  Not for use inside a stream capture.  Per context. */
+int halo_set_lstm_bwd_mid_event(void *event);
+int halo_lstm_bwd_mid_event_recorded(void);     /* how many times the event has been recorded since it was set (0: this path has no such point) */
 /* Inference with static weights.  stamp != 0 is the caller's promise that the LSTM weights change only when the stamp does: a forward-only
  * call (halo_set_lstm_expect_backward(0)) of the two-layer launch then KEEPS the packed weight images that the previous call with the same
  * reserve buffer, weight pointers, shape and stamp left in that reserve (24 MB read + 12 MB written per call at H = 1024 otherwise), so the
@@ -744,6 +751,18 @@ int halo_scale_add_guarded(float *y, const float *x, float alpha, float beta, si
 int halo_cast_f32_bf16(const float *x, void *y_bf16, size_t n, halo_stream_t stream);
 int halo_cast_bf16_f32(const void *x_bf16, float *y, float scale, size_t n, halo_stream_t stream);
 int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
+/* The sharded data-parallel update (ha/attention_loop.py:154 semantics, ZeRO-1 shape; haloop_amd/dp.py): a rank owns a chunk of each
+ * reduce-scattered span of the flat buffers.  n <= 8 ranges, each beginning and ending on a multiple of 4 elements.
+ *   halo_sumsq_ranges:       partials[0..HALO_SUMSQ_PARTS) of the concatenation of x[begin[k], end[k]) (fixed order).
+ *   halo_pack_ranges_bf16:   dst (bf16, contiguous) <- the concatenation of src[begin[k], end[k]) rounded to nearest-even: what a rank
+ *                            sends in the all-gather of matrix parameters whose consumers only ever multiply by their bf16 values.
+ *   halo_expand_ranges_bf16: the inverse on the gathered buffer.  stage holds `world` records of sum(chunk[k]) bf16 values, rank-major;
+ *                            span k of dst begins at begin[k] and consists of `world` chunks of chunk[k] elements; every chunk but
+ *                            skip_rank's (the caller's own fp32 master values; -1: none) is overwritten with the gathered values. */
+int halo_sumsq_ranges(const float *x, int n, const size_t *begin, const size_t *end, float *partials, halo_stream_t stream);
+int halo_pack_ranges_bf16(const float *src, int n, const size_t *begin, const size_t *end, void *dst, halo_stream_t stream);
+int halo_expand_ranges_bf16(const void *stage, int n, const size_t *begin, const size_t *chunk, int world, int skip_rank, float *dst,
+                            halo_stream_t stream);
 int halo_clip_coef(const float *partials, int count, float max_norm, float *coef, float *norm_out,
                    halo_stream_t stream);
 /* halo_clip_coef that also advances a device-side update counter (uint32) when the norm is finite: torch's AdamW step count

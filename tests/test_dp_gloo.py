@@ -127,3 +127,79 @@ def test_shard_slice_and_buckets():
     assert a.buckets[0] == (0, 100) and (200, 250) in a.buckets and a.buckets[-1][1] == 1000
     assert sum(b - a_ for a_, b in a.buckets) == 1000
     a.average()                                                           # world 1: no-op, no process group needed
+
+
+def _span_worker(rank, world, port, out, gather_bf16):
+    """dp.SpanSharded over gloo: per-span reduce-scatter (one reduce per owner: only the owner receives the sum), the small range
+    all-reduced, a clipped SGD step on what the rank owns, all-gather (fp32 in place, or bf16 roundings through the staging buffer)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from haloop_amd import dp
+        torch.set_num_threads(1)
+        small, late, early = (0, 104), (104, 104 + 64 * world), (104 + 64 * world, 104 + 64 * world + 96 * world)
+        n = early[1]
+        g = torch.Generator().manual_seed(5)
+        P0 = torch.randn(n, generator=g)                                   # the same parameters on every rank (as after the broadcast)
+        G_all = torch.randn(world, n, generator=g)                         # every rank's own gradient
+        P, G = P0.clone(), G_all[rank].clone()
+        sh = dp.SpanSharded(P, G, early, late, small, gather_bf16=gather_bf16)
+        assert sh.world == world and sh.rank == rank and not sh._native
+        own = sh.own_ranges()
+        assert (small in own) and len(own) == 3 and sum(b - a for a, b in own) == 104 + 64 + 96
+        before = G.clone()
+        assert sh.reduce_scatter('early') is None
+        sh.reduce_scatter('late')
+        sh.all_reduce_small()
+        # a real reduce-scatter: the chunks this rank does not own still hold its OWN gradient (an all-reduce would have summed them)
+        for name in ('early', 'late'):
+            lo, hi, c = sh.spans[name]
+            for r in range(world):
+                if r != rank:
+                    assert torch.equal(G[lo + r * c:lo + (r + 1) * c], before[lo + r * c:lo + (r + 1) * c]), (name, r)
+        part = torch.tensor([sum(float((G[a:b].double() ** 2).sum()) for a, b in sh.norm_ranges())], dtype=torch.float64)
+        sh.all_reduce_sum(part)
+        coef = min(1.0, 0.5 / (float(part.sqrt()) + 1e-6))
+        for a, b in own:
+            P[a:b] -= 0.1 * coef * G[a:b]
+        sh.all_gather()
+        rounded = P.clone()
+        sh.gather_masters()
+        if rank == 0:
+            out.put((P0.numpy(), G_all.numpy(), rounded.numpy(), P.numpy(), float(part.sqrt()), [sh.own('early'), sh.own('late')], sh.wire_bytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('gather_bf16', [False, True])
+def test_span_sharded_update_equals_the_single_process_step(gather_bf16):
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_span_worker, args=(r, world, port, out, gather_bf16)) for r in range(world)]
+    for p in procs:
+        p.start()
+    P0, G_all, rounded, masters, norm, owned, wire = out.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    mean = G_all.astype(np.float64).mean(0)
+    want_norm = float(np.sqrt((mean ** 2).sum()))
+    np.testing.assert_allclose(norm, want_norm, rtol=1e-6)                 # the small range counted once, the chunks once each
+    want = P0 - 0.1 * min(1.0, 0.5 / (want_norm + 1e-6)) * mean
+    np.testing.assert_allclose(masters, want, rtol=1e-5, atol=1e-6)        # after gather_masters: the single-process step, every element
+    if gather_bf16:
+        mine = np.zeros(len(P0), bool)
+        mine[:104] = True
+        for a, b in owned:
+            mine[a:b] = True
+        np.testing.assert_array_equal(rounded[mine], masters[mine])          # own chunks and the small range: fp32 masters
+        others = torch.from_numpy(masters[~mine]).to(torch.bfloat16).float().numpy()
+        np.testing.assert_array_equal(rounded[~mine], others)                # the other rank's chunks: exactly their bf16 roundings
+        assert wire['all_gather'] == 2 * (64 + 96) * world // 2
+    else:
+        np.testing.assert_array_equal(rounded, masters)
+        assert wire['all_gather'] == 4 * (64 + 96) * world // 2
+    assert wire['reduce_scatter_early'] == 4 * 96 * world // 2 and wire['reduce_scatter_late'] == 4 * 64 * world // 2

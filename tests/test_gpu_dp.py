@@ -32,7 +32,7 @@ def _build(seed, c=None):
     return enc.to('cuda:0').eval(), rec.to('cuda:0').eval()
 
 
-def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32', dp_algo='allreduce'):
+def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32', dp_algo='allreduce', math_mode=None):
     import datetime
     import faulthandler
     import traceback
@@ -40,6 +40,9 @@ def _worker(rank, world, port, out, use_graph, cfg=None, grad_dtype='f32', dp_al
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
+        if math_mode:
+            from haloop_amd import _lib
+            _lib.set_math_mode(math_mode)
         _worker_body(rank, world, out, use_graph, cfg or CFG, grad_dtype, dp_algo)
     except Exception:                                   # a dead rank must not leave its peer (or pytest) waiting
         out.put(('error', rank, traceback.format_exc()))
@@ -56,29 +59,37 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
         enc, rec = _build(100 + rank, c)                   # different init per rank: rank 0's must win
         tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype, dp_algo=dp_algo)
         assert tr.dp_algo == dp_algo
+        if dp_algo == 'rs_ag':
+            from haloop_amd import _lib
+            assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded.gather_bf16 == (_lib.get_math_mode() == 'bf16')
         x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
             tr.step(x[sl].cuda(), il[sl].cuda(), tg[sl].cuda(), tl[sl].cuda())
+        tr.gather_master_weights()          # (after a bf16 all-gather: the other rank's fp32 master values)
         torch.cuda.synchronize()
         if rank == 0:
             out.put(('ok', tr.flat.params[:tr.flat.total].cpu().numpy(), float(tr.grad_norm.item())))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('use_graph,cfg_name,grad_dtype,dp_algo', [
-    (False, 'tiny', 'f32', 'allreduce'), (True, 'tiny', 'f32', 'allreduce'),      # True: three captured graphs, all-reduces between them
-    (True, 'persist', 'f32', 'allreduce'), (True, 'persist', 'bf16', 'allreduce'),
-    # the sharded update: reduce-scatter, each rank clips (global norm) and updates its half of the flat parameters, all-gather
-    (False, 'tiny', 'f32', 'rs_ag'), (True, 'tiny', 'f32', 'rs_ag'), (True, 'persist', 'f32', 'rs_ag')])
-def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype, dp_algo):
+@pytest.mark.parametrize('use_graph,cfg_name,grad_dtype,dp_algo,math_mode', [
+    (False, 'tiny', 'f32', 'allreduce', None), (True, 'tiny', 'f32', 'allreduce', None),      # True: three captured graphs, all-reduces between them
+    (True, 'persist', 'f32', 'allreduce', None), (True, 'persist', 'bf16', 'allreduce', None),
+    # the flat sharded update: reduce-scatter, each rank clips (global norm) and updates its half of the flat parameters, all-gather
+    (False, 'tiny', 'f32', 'rs_ag_flat', None), (True, 'tiny', 'f32', 'rs_ag_flat', None), (True, 'persist', 'f32', 'rs_ag_flat', None),
+    # the span-sharded update (dp.SpanSharded): matrix spans reduce-scattered (over gloo: one reduce per owner), the small parameters
+    # all-reduced and updated by both ranks, fp32 all-gather -- and in bf16 arithmetic the bf16 all-gather through the staging buffer
+    (False, 'tiny', 'f32', 'rs_ag', None), (True, 'tiny', 'f32', 'rs_ag', None), (True, 'persist', 'f32', 'rs_ag', None),
+    (True, 'persist', 'f32', 'rs_ag', 'bf16'), (False, 'persist', 'f32', 'rs_ag', 'bf16')])
+def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype, dp_algo, math_mode):
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
     cfg = CFG if cfg_name == 'tiny' else CFG_PERSIST
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph, cfg, grad_dtype, dp_algo)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph, cfg, grad_dtype, dp_algo, math_mode)) for r in range(2)]
     for p in procs:
         p.start()
     import time
@@ -98,19 +109,29 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_nam
     assert msg[0] == 'ok', msg
     _, params2, gnorm2 = msg
     c = cfg
+    from haloop_amd import _lib
+    prev_mode = _lib.get_math_mode()
+    if math_mode:
+        _lib.set_math_mode(math_mode)
     enc, rec = _build(100, c)
     tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=False)
     x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
     for _ in range(2):
         tr.step(x.cuda(), il.cuda(), tg.cuda(), tl.cuda())
+    _lib.set_math_mode(prev_mode)
     if grad_dtype == 'bf16':          # gradients rounded to 8 significant bits on the wire: the update direction survives, not its bits
         np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=2e-2)
         diff = np.abs(params2 - tr.flat.params[:tr.flat.total].cpu().numpy())
         # two Adam steps at lr = 3e-3: an element whose tiny gradient changes sign on the wire moves the other way (<= 4 lr apart)
         assert diff.max() <= 4.2 * 3e-3 and (diff > 2e-3).mean() < 1e-3, (diff.max(), (diff > 2e-3).mean())
     else:
-        np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=1e-4)
-        if cfg_name == 'tiny':
+        np.testing.assert_allclose(gnorm2, tr.grad_norm.item(), rtol=2e-2 if math_mode == 'bf16' else 1e-4)
+        if math_mode == 'bf16':
+            # single-pass bf16 products: the batch split changes which fp32 sums the bf16-rounded state sees, and Adam's normalised update
+            # carries a flipped last bit of a tiny gradient into the weights (<= 2 lr per step): most elements agree closely, none is far
+            diff = np.abs(params2 - tr.flat.params[:tr.flat.total].cpu().numpy())
+            assert diff.max() <= 4.2 * 3e-3 and (diff > 1e-4).mean() < 2e-2, (diff.max(), (diff > 1e-4).mean())
+        elif cfg_name == 'tiny':
             np.testing.assert_allclose(params2, tr.flat.params[:tr.flat.total].cpu().numpy(), atol=5e-6)
         else:       # H = 256 products run split-bf16 with shape-dependent K slicing: the two batch splits round differently, and Adam's
                     # normalised update carries that into a few near-zero-gradient elements (11 of 865 k above 2e-5 when this was set)
@@ -283,7 +304,7 @@ def _rccl_sharded_worker(port, out, math_mode):
     try:
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device('cuda', 0))
-        from haloop_amd import _lib
+        from haloop_amd import _lib, dp
         from haloop_amd.train import LstmCtcTrainer
         from oracle import cpu_ref
         _lib.set_math_mode(math_mode)
@@ -294,10 +315,13 @@ def _rccl_sharded_worker(port, out, math_mode):
             enc, rec = _build(100, c)
             tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=rehearse)
             assert (tr.sharded is not None) == rehearse
+            if rehearse:
+                assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded._native and tr.sharded.gather_bf16 == (math_mode == 'bf16')
             losses = [float(tr.step(x, il, tg, tl).item()) for _ in range(4)]
             torch.cuda.synchronize()
             tr.check_status()
-            res[rehearse] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None)
+            res[rehearse] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None,
+                             bool(getattr(tr, '_early_started', False)))
         # the same with bf16 on the wire of the reduce-scatter (cast, reduce_scatter_tensor on the bf16 buffer, cast back: captured too)
         enc, rec = _build(100, c)
         tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=True, grad_dtype='bf16')
@@ -334,6 +358,9 @@ def test_rccl_backend_runs_the_sharded_step(math_mode):
     assert sharded[1] == plain[1]
     assert np.array_equal(sharded[0], plain[0])
     assert sharded[2], 'the collectives were not captured (they ran eagerly): see the warning in the log'
+    # bf16 arithmetic at this shape runs the two-layer launches: the top layer's reduce-scatter was started from the library's event, on
+    # the side stream, in the middle of the backward; elsewhere the tail reduces that span itself
+    assert sharded[3] == (math_mode == 'bf16'), sharded[3]
     # bf16 on the wire: the first step's loss is the same (same weights), the trajectory follows within the gradients' bf16 rounding
     wire = msg[1]['bf16']
     assert wire[2] and wire[1][0] == plain[1][0]
