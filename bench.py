@@ -152,7 +152,12 @@ def time_chain(device, direction, layers, reps=20):
     grads = {'dw_ih': [torch.zeros_like(w) for w in w_ih], 'dw_hh': [torch.zeros_like(w) for w in w_hh],
              'db_ih': [torch.zeros_like(v) for v in b], 'db_hh': [torch.zeros_like(v) for v in b]}
     ts = []
+    pad = torch.empty(64 << 20, device=device, dtype=torch.float32)
     for i in range(reps + 3):
+        # ~150 us of unrelated GPU work first: the host then enqueues the call's launches while the GPU is still busy, and the bracket
+        # holds the chain alone (on an idle stream it also held the host's launch latency between the event and the kernel: round 3's
+        # forward bracket read 120 us where the kernel trace says 107)
+        pad.zero_(); pad.zero_(); pad.zero_()
         if direction == 'fwd':
             _lib.lstm_chain_events(e0, e1)
         y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b, y_strides=None, y_relu=False, drop=drop)

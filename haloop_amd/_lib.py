@@ -28,6 +28,7 @@ _vp, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c
 # name -> (restype, argtypes); one entry per function declared in include/halo.h
 SIGNATURES = {
     'halo_abi_version': (_i, []),
+    'halo_debug_read': (_i, [_vp, _sz, _i, _sz, _vp, _vp]),
     'halo_strerror': (C.c_char_p, [_i]),
     'halo_device_info': (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
     'halo_set_math_mode': (_i, [_i]),

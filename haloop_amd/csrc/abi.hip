@@ -34,6 +34,44 @@ int halo_side_stream(hipStream_t *side, hipEvent_t *fork_ev, hipEvent_t *join_ev
 }
 int halo_math_mode() { return halo_ctx_cur().math_mode; }
 
+// ---- known-size read kernels for calibrating the FETCH_SIZE counter per access width (halo_debug_read; tools/pmc_calibrate.py) ----
+namespace {
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// pattern 0: 16 B per lane, a wave instruction reads 1 KiB contiguous (global_load_dwordx4)
+// pattern 1:  4 B per lane, a wave instruction reads 256 B contiguous (global_load_dword)
+// pattern 2:  4 B per lane, 16-lane groups read 64 B each in four rows `row_bytes` apart (the recurrences' saved-activation loads)
+// pattern 3: 16 B per lane through a buffer resource with sc1 (the recurrences' fragment loads)
+template <int PATTERN>
+__global__ __launch_bounds__(256) void debug_read_kernel(const char *__restrict__ src, size_t bytes, size_t row_bytes, float *sink) {
+    unsigned acc = 0;
+    const size_t tid = blockIdx.x * (size_t)256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    if (PATTERN == 0) {
+        for (size_t i = tid; i < bytes / 16; i += nthreads) { const u32x4_t v = reinterpret_cast<const u32x4_t *>(src)[i]; acc += v[0] ^ v[1] ^ v[2] ^ v[3]; }
+    } else if (PATTERN == 1) {
+        for (size_t i = tid; i < bytes / 4; i += nthreads) acc += reinterpret_cast<const unsigned *>(src)[i];
+    } else if (PATTERN == 2) {
+        // the buffer as [rows][row_bytes]; a wave covers 4 rows x 64 B per instruction and walks along the rows, then to the next 4 rows
+        const size_t rows = bytes / row_bytes, segs = row_bytes / 64, wave = tid >> 6, nwaves = nthreads >> 6;
+        const int lane = threadIdx.x & 63, r = lane >> 4, c = lane & 15;
+        for (size_t u = wave; u < (rows / 4) * segs; u += nwaves) {
+            const size_t rb = (u / segs) * 4, sg = u % segs;
+            acc += *reinterpret_cast<const unsigned *>(src + (rb + r) * row_bytes + sg * 64 + c * 4);
+        }
+    } else {
+        // 2 GiB windows through a buffer resource
+        for (size_t base = 0; base < bytes; base += ((size_t)1 << 30)) {
+            const size_t len = bytes - base < ((size_t)1 << 30) ? bytes - base : ((size_t)1 << 30);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src + base), 0, 0x7fffffff, 0x00020000);
+            for (size_t i = tid; i < len / 16; i += nthreads) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(i * 16), 0, 16);
+                acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+            }
+        }
+    }
+    if (acc == 0x9e3779b9u) *sink = 1.f;          // (keeps the loads alive)
+}
+}  // namespace
+
 extern "C" {
 
 int halo_set_math_mode(int mode) {
@@ -69,6 +107,20 @@ int halo_set_status_word(uint32_t *device_word) {
     if (device_word && ((uintptr_t)device_word % 4 != 0)) return HALO_EINVAL;
     halo_ctx_cur().status = device_word;
     return HALO_OK;
+}
+
+int halo_debug_read(const void *src, size_t bytes, int pattern, size_t row_bytes, float *sink, void *stream) {
+    if (!src || !sink || bytes < 65536 || bytes % 16 || pattern < 0 || pattern > 3) return HALO_EINVAL;
+    if (pattern == 2 && (row_bytes < 64 || row_bytes % 64 || bytes % (4 * row_bytes))) return HALO_EINVAL;
+    const dim3 grid(256 * 8), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pattern) {
+        case 0: hipLaunchKernelGGL(debug_read_kernel<0>, grid, block, 0, st, (const char *)src, bytes, row_bytes, sink); break;
+        case 1: hipLaunchKernelGGL(debug_read_kernel<1>, grid, block, 0, st, (const char *)src, bytes, row_bytes, sink); break;
+        case 2: hipLaunchKernelGGL(debug_read_kernel<2>, grid, block, 0, st, (const char *)src, bytes, row_bytes, sink); break;
+        default: hipLaunchKernelGGL(debug_read_kernel<3>, grid, block, 0, st, (const char *)src, bytes, row_bytes, sink); break;
+    }
+    return hipGetLastError() == hipSuccess ? HALO_OK : HALO_ELAUNCH;
 }
 
 int halo_abi_version(void) { return HALO_ABI_VERSION; }

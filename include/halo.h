@@ -40,6 +40,12 @@ extern "C" {
 typedef void *halo_stream_t; /* hipStream_t */
 
 int halo_abi_version(void);
+/* Measurement aid (tools/pmc_calibrate.py): one launch that READS exactly `bytes` bytes of src once with a chosen access shape, so that
+ * rocprofv3's FETCH_SIZE counter can be calibrated per load width (MI355X_MICROARCH.md: "other access widths are uncalibrated").
+ * pattern 0: 16 B per lane (global_load_dwordx4); 1: 4 B per lane, 256 B contiguous per wave instruction; 2: 4 B per lane in 64-byte
+ * segments of four rows row_bytes apart (the saved-activation loads of the persistent recurrences); 3: 16 B per lane buffer loads
+ * with sc1 (their fragment loads).  sink: one float nobody reads. */
+int halo_debug_read(const void *src, size_t bytes, int pattern, size_t row_bytes, float *sink, void *stream);
 const char *halo_strerror(int code);
 /* Device sanity for the loader: returns HALO_OK and fills arch (e.g. "gfx950") and CU count. */
 int halo_device_info(int device, char *arch, int arch_len, int *cu_count);
