@@ -152,12 +152,7 @@ def time_chain(device, direction, layers, reps=20):
     grads = {'dw_ih': [torch.zeros_like(w) for w in w_ih], 'dw_hh': [torch.zeros_like(w) for w in w_hh],
              'db_ih': [torch.zeros_like(v) for v in b], 'db_hh': [torch.zeros_like(v) for v in b]}
     ts = []
-    pad = torch.empty(64 << 20, device=device, dtype=torch.float32)
     for i in range(reps + 3):
-        # ~150 us of unrelated GPU work first: the host then enqueues the call's launches while the GPU is still busy, and the bracket
-        # holds the chain alone (on an idle stream it also held the host's launch latency between the event and the kernel: round 3's
-        # forward bracket read 120 us where the kernel trace says 107)
-        pad.zero_(); pad.zero_(); pad.zero_()
         if direction == 'fwd':
             _lib.lstm_chain_events(e0, e1)
         y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b, y_strides=None, y_relu=False, drop=drop)
@@ -335,6 +330,16 @@ def read_traffic(kernel_name):
     return None
 
 
+TRACE_US = {}        # kernel name -> median duration (us) in the rocprofv3 kernel trace of measure_traffic's first pass
+
+
+def trace_us(name):
+    for k, v in TRACE_US.items():
+        if name in k:
+            return round(v, 3)
+    return None
+
+
 def measure_traffic(math):
     """HBM bytes per launch of the recurrent chains, measured IN THIS RUN: two child processes under rocprofv3, one PMC counter per
     pass (FETCH_SIZE, then WRITE_SIZE) as MI355X_MICROARCH.md's HBM section prescribes, on tools/run_lstm2_steps.py (the benchmark's
@@ -361,6 +366,14 @@ def measure_traffic(math):
             if proc.returncode != 0 or not csvs:
                 return None
             found[counter] = pmc_traffic.medians(csvs[0], counter)
+            if counter == 'FETCH_SIZE':          # the same pass's kernel trace: begin / end time stamps of every launch
+                import csv as _csv
+                import statistics
+                per = {}
+                for tr in (os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('kernel_trace.csv')):
+                    for r in _csv.DictReader(open(tr)):
+                        per.setdefault(r['Kernel_Name'], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+                TRACE_US.update({k: statistics.median(v) for k, v in per.items()})
     except (subprocess.TimeoutExpired, OSError):
         return None
     finally:
@@ -523,11 +536,17 @@ def main():
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process (tools/run_lstm2_steps.py), bytes = 2 F + W'
                                    if live else 'committed passes under profiles/ (rocprofv3 not available to this run)'),
                 'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
+                # the same launch in the rocprofv3 kernel trace of this run's counter pass (median over its launches): what the HIP-event
+                # bracket must agree with.  (The forward's bracket is ~10 us longer than its trace: the event in front of it is recorded
+                # behind the input projection's launch and the probe enqueues the call on an idle stream, so the bracket also holds that
+                # launch boundary and the host's launch latency; the backward's call begins with the chain itself.)
+                'avg_launch_us_kernel_trace': trace_us(name_b),
                 'accounting': 'SURVEY.md 8d: every weight matrix the launch multiplies by once per pass (W_hh^T per layer; the two-layer '
                               'launch also W_ih of layer 1) + per step and layer the fp32 activations entering/leaving the chain (gates in, '
                               'c in, dh in, gate gradients out), divided over the launches of the chain',
                 'share_of_step': round(chains * us_b * 1e-3 / ms_per_step, 3),
                 'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
+                                 'avg_launch_us_kernel_trace': trace_us(name_f),
                                  'algorithmic_bytes_per_launch': kf // launches_f,
                                  'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
                                  'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
