@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed line of the round (profiles/r03_bench_n1.json, produced by `python bench.py` on an
+"""The bench.py output contract, checked on the committed line of the round (profiles/r04_bench_n1.json, produced by `python bench.py` on an
 MI355X box) and on bench.py's own argument surface -- no GPU needed: the keys the driver reads are there, typed, and consistent with each other."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -34,10 +34,15 @@ def test_committed_bench_line_meets_the_contract():
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
     assert d['value'] >= 10 * c['value']                                                  # the north star's ">= 10x the CPU path"
     assert d['n_ranks_seen'] == 1
+    # round 4: the fp32-grade step in the parsed config, the stricter accounting beside the bench's, the reference's own model shapes
+    assert d['config']['bf16x3_ms_per_step'] > d['ms_per_step'] and 0 < r['frac_8d_strict'] < r['frac']
+    for leg in ('stock3', 'H1536', 'inference', 'inference_bf16x3'):
+        assert d[leg]['value'] > 0, leg
+    assert d['b_sweep']['B128']['ms_per_step'] < 2 * d['ms_per_step']            # two tiles per workgroup: less than two steps of 64
 
 
 def test_bench_argument_surface():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
-    for flag in ('--gpus', '--steps', '--warmup', '--no-graph', '--graph', '--math', '--dp-algo', '--grad-dtype'):
+    for flag in ('--gpus', '--steps', '--warmup', '--no-graph', '--graph', '--math', '--dp-algo', '--grad-dtype', 'rs_ag_flat'):
         assert flag in out.stdout, flag
