@@ -352,6 +352,43 @@ def test_interleaved_tiles_equal_consecutive_launches(hal, math_mode, T, B, in0,
 
 
 @pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_interleaved_launches_see_fresh_data_through_reused_buffers(hal, math_mode):
+    """The interleaved launches' hand-off images, epoch words and deferred publishes across back-to-back calls that re-use one reserve and one
+    workspace (torch's allocator hands the same blocks back): alternating inputs, forward AND backward, every result bit for bit the one the
+    consecutive launches give for THAT input -- never a piece left over from the call before (MI355X_MICROARCH.md: "test every hand-off ...
+    consumer L1-warm, checking every word") -- and a 1000-frame batch (T' = 251: 253 epochs per tile, image offsets far from the benchmark's)."""
+    lib, ops = hal['lib'], hal['ops']
+    H, L, in0 = 1024, 2, 128
+    g = torch.Generator().manual_seed(21)
+    k = 1.0 / H ** 0.5
+    w_ih = [((torch.rand(4 * H, in0 if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b = [((torch.rand(4 * H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    drop = ops.Dropout(0.2, 99, 5)
+
+    def run(x, dy):
+        y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b, drop=drop)
+        ws = ops.lstm_bwd_workspace(x, w_hh)
+        dx, grads = ops.lstm_bwd(x, w_ih, w_hh, dy, (x.shape[1] * H, H), False, reserve, drop=drop, workspace=ws, want_dx=True)
+        return [y.clone(), dx.clone(), grads['dw_hh'][0].clone(), grads['dw_ih'][1].clone()]
+
+    for T, B, reps in ((21, 128, 3), (251, 128, 1)):
+        xs = [torch.randn(T, B, in0, generator=g).to(DEV) * s for s in (1.0, -0.7, 1.9)]
+        dys = [torch.randn(T, B, H, generator=g).to(DEV) * s for s in (0.5, 1.0, -0.3)]
+        assert lib.lib().halo_lstm_persistent2_eligible(T, B, H, L) == 1
+        lib.set_lstm_interleave(False)
+        try:
+            refs = [run(x, dy) for x, dy in zip(xs, dys)]
+        finally:
+            lib.set_lstm_interleave(True)
+        for rep in range(reps):
+            for i, (x, dy) in enumerate(zip(xs, dys)):
+                got = run(x, dy)
+                for a, r in zip(got, refs[i]):
+                    assert torch.equal(a, r), (T, rep, i)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
 def test_split_backward_follows_the_two_layer_forward(hal, math_mode):
     """The two-layer forward leaves the reserve the per-layer backward expects: backward called layer by layer (the data-parallel
     step does, haloop_amd/train.py) after the fused forward equals the one-call two-layer backward."""
