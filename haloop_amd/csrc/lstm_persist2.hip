@@ -721,7 +721,8 @@ inline bool interleave_on() {
 template <typename A, typename F, typename FX>
 int launch_groups(const A &a0, int steps, F launch_one, FX launch_pairs) {
     const int nbt = (a0.B + 15) / 16, per = tiles_per_launch(a0.H);
-    const bool pairs = nbt > per && interleave_on();
+    // (the interleaved kernels address the saved activations through 2 GiB buffer resources: a longer array keeps the consecutive launches)
+    const bool pairs = nbt > per && interleave_on() && (long)(a0.T + 1) * a0.B * 4 * a0.H * (long)sizeof(float) < (1L << 31);
     for (int bt0 = 0, g = 0; bt0 < nbt; ++g) {
         A a = a0;
         const int left = nbt - bt0;

@@ -87,6 +87,10 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
     const int ci = u >> 4, cj = u & 15;              // cell thread: (batch row, hidden unit) of the tile
     const int BH = B * H;
     const bool muted = (int)blockIdx.x == p.mute;
+    // the dropout stream with the device-side step counter read ONCE: read inside dropout_mult, every draw would be a load followed by
+    // a wait for everything this wave has in flight -- the fragments it was meant to hide behind
+    DropoutCfg drop = p.drop;
+    if (drop.offset_dev) { drop.offset += *drop.offset_dev; drop.offset_dev = nullptr; }
     float cst[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -127,7 +131,7 @@ __device__ __forceinline__ void fwd2x_layer0_waves(const Persist2Fwd &p, const F
             if (wave == 0) stamp(p.stamps, T + 2, s, q ? 9 : 0, lane);
             // the step's dropout multiplier of h0 (one Philox block per element): drawn while the fragments are on their way
             float dmul = 1.f;
-            if (act0 && cell && p.xp) dmul = dropout_mult(p.drop, (uint64_t)((long)s * BH + e0));
+            if (act0 && cell && p.xp) dmul = dropout_mult(drop, (uint64_t)((long)s * BH + e0));
             __builtin_amdgcn_sched_barrier(0);
             // the PREVIOUS phase's pieces (the other tile's): stored a fragment latency ago; its epoch is polled for behind barrier (B)
             flush_pending(pd, sh.s_published, p.flags, muted, lane);
@@ -391,6 +395,8 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
     for (int i = 0; i < KBW; ++i) wr[i] = *reinterpret_cast<const bf16x8 *>(p.wpT0 + ((long)jt * nkb4 + wq * KBW + i) * 2048 + lane * 16);
     const int ci = u >> 4, cj = u & 15;
     const int BH = B * H;
+    DropoutCfg drop = p.drop;                        // (the device-side step counter read once: see the forward)
+    if (drop.offset_dev) { drop.offset += *drop.offset_dev; drop.offset_dev = nullptr; }
     const int ntile = (2 * pr + 1 < p.nbt) ? 2 : 1;
     const bool defer = ntile == 2;
     float dcarry[NG], bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -403,13 +409,23 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
     Bwd2xSaved nx = {{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 1.f};
     // (unconditional, on clamped indices: inside a branch the compiler waits for the loads at the end of the branch; a phase without a
     // cell update, or a row past the batch, does not use what it gets)
-    auto prefetch = [&](int ns, int nq) {            // layer 0's cell update of combined step ns is at time T - ns (ns >= 1)
-        const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(max(T - ns, 0), T - 1);
-        const int e0 = b * H + j0 + cj;
+    // per-thread byte offsets of this thread's element inside one time step's [B][4H] / [B][H] slab, for either tile (rows past the batch
+    // clamped: their loads are unused, their stores masked); the time step's part of an address is wave-uniform (load_f32_u)
+    const __amdgpu_buffer_rsrc_t g0_rsrc = make_rsrc(p.gates0), c0_rsrc = make_rsrc(p.c0);
+    int vg[NG], vc[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates0[(t * B + b) * K + g * H + j0 + cj];
-        nx.cc = p.c0[(t + 1) * BH + e0];
-        nx.cprev = p.c0[t * BH + e0];
+    for (int q = 0; q < NG; ++q) {
+        const int b = min((p.bt0 + 2 * pr + q) * 16 + ci, B - 1);
+        vg[q] = (b * K + j0 + cj) * 4;
+        vc[q] = (b * H + j0 + cj) * 4;
+    }
+    auto prefetch = [&](int ns, int nq) {            // layer 0's cell update of combined step ns is at time T - ns (ns >= 1)
+        const int t = min(max(T - ns, 0), T - 1);
+        const int sg = t * B * K * 4, sc = t * BH * 4, vgn = nq ? vg[1] : vg[0], vcn = nq ? vc[1] : vc[0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nx.gv[g] = load_f32_u(g0_rsrc, vgn, sg + g * H * 4);
+        nx.cc = load_f32_u(c0_rsrc, vcn, sc + BH * 4);
+        nx.cprev = load_f32_u(c0_rsrc, vcn, sc);
     };
     Pending pd = {0, 0, 0, 0u, 0u};
     const __amdgpu_buffer_rsrc_t dg0_rsrc = make_rsrc(p.dgp0), dg1_rsrc = make_rsrc(p.dgp1);
@@ -440,7 +456,7 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
                 for (int cidx = 0; cidx < NBUF - 1; ++cidx) loadc(cidx, cidx);
                 __builtin_amdgcn_sched_barrier(0);
                 // layer 0's output mask at the step's time (one Philox block per element): drawn while the first fragments are on their way
-                if (cell) dmul = dropout_mult(p.drop, (uint64_t)((long)t * BH + b * H + j0 + cj));
+                if (cell) dmul = dropout_mult(drop, (uint64_t)((long)t * BH + b * H + j0 + cj));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int cidx = 0; cidx < NCH; ++cidx) {
@@ -450,7 +466,7 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
                     for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cidx % NBUF][i], wr[cidx * CH + i], acc, 0, 0, 0);
                 }
             } else if (act && cell) {
-                dmul = dropout_mult(p.drop, (uint64_t)((long)t * BH + b * H + j0 + cj));
+                dmul = dropout_mult(drop, (uint64_t)((long)t * BH + b * H + j0 + cj));
             }
             {
                 const int r = lane & 15, qq = lane >> 4;
@@ -478,8 +494,8 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
                     dcarry[q] = persist2_bwd_cell(cur.gv, cur.cc, cur.cprev, dcarry[q], persist2_add_masked(rec, above, dmul), dg);   // (dmul: layer 0's own output mask)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
-                    float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
-                    gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) store_f32_u(g0_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[0][g][ci][cj] = dg[g];
@@ -575,14 +591,25 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
     }
     Bwd2xSaved nx = {{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
     const float *dyp = p.dy ? p.dy : p.c1;           // (no dy: a load from any valid address, unused)
-    auto prefetch = [&](int ns, int nq) {            // layer 1's cell update of combined step ns is at time T - 1 - ns (ns < T)
-        const int b = min((p.bt0 + 2 * pr + nq) * 16 + ci, B - 1), t = min(max(T - 1 - ns, 0), T - 1);
-        const int e0 = b * H + j0 + cj;
+    const __amdgpu_buffer_rsrc_t g1_rsrc = make_rsrc(p.gates1), c1_rsrc = make_rsrc(p.c1);
+    int vg[NG], vc[NG];
+    long vdy[NG];                                    // (dy has the caller's strides: plain pointer arithmetic, one load per phase)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nx.gv[g] = p.gates1[(t * B + b) * K + g * H + j0 + cj];
-        nx.cc = p.c1[(t + 1) * BH + e0];
-        nx.cprev = p.c1[t * BH + e0];
-        nx.extra = dyp[p.dy ? (long)t * p.dy_stride_t + (long)b * p.dy_stride_b + j0 + cj : 0L];
+    for (int q = 0; q < NG; ++q) {
+        const int b = min((p.bt0 + 2 * pr + q) * 16 + ci, B - 1);
+        vg[q] = (b * K + j0 + cj) * 4;
+        vc[q] = (b * H + j0 + cj) * 4;
+        vdy[q] = p.dy ? (long)b * p.dy_stride_b + j0 + cj : 0L;
+    }
+    const long dy_t = p.dy ? p.dy_stride_t : 0L;
+    auto prefetch = [&](int ns, int nq) {            // layer 1's cell update of combined step ns is at time T - 1 - ns (ns < T)
+        const int t = min(max(T - 1 - ns, 0), T - 1);
+        const int sg = t * B * K * 4, sc = t * BH * 4, vgn = nq ? vg[1] : vg[0], vcn = nq ? vc[1] : vc[0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nx.gv[g] = load_f32_u(g1_rsrc, vgn, sg + g * H * 4);
+        nx.cc = load_f32_u(c1_rsrc, vcn, sc + BH * 4);
+        nx.cprev = load_f32_u(c1_rsrc, vcn, sc);
+        nx.extra = dyp[(nq ? vdy[1] : vdy[0]) + (long)t * dy_t];
     };
     prefetch(0, 0);
     const __amdgpu_buffer_rsrc_t dg1_rsrc = make_rsrc(p.dgp1);
@@ -663,8 +690,8 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
                     dcarry[q] = persist2_bwd_cell(cur.gv, cur.cc, cur.cprev, dcarry[q], dh, dg);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
-                    float *gp = p.gates1 + (t * B + b) * K + j0 + cj;
-                    gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) store_f32_u(g1_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[1][g][ci][cj] = dg[g];

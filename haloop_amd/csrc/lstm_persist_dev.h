@@ -30,6 +30,16 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, int byte_off
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
 }
 
+// one float per lane through a buffer resource: the lane part of the address is a per-thread constant (voff, bytes), the part that
+// moves with the time step is wave-uniform and lives in an SGPR (soff, bytes) -- no vector address arithmetic per access
+// (lstm_persist2x.hip: the saved activations of a phase; the arrays must be shorter than 2 GiB: halo_lstm_persist2x_ok)
+__device__ __forceinline__ float load_f32_u(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void store_f32_u(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 // block id -> (hidden tile, batch tile).  Blocks b and b + 8 share an XCD under the dispatcher's round-robin: when the number
 // of batch tiles divides 8, group g takes the XCD labels [g * 8/NBT, (g + 1) * 8/NBT).  Any placement is CORRECT; this one
 // keeps a group's 64 KB .. 256 KB per-step exchange inside one or two L2s.
