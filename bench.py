@@ -536,10 +536,9 @@ def main():
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process (tools/run_lstm2_steps.py), bytes = 2 F + W'
                                    if live else 'committed passes under profiles/ (rocprofv3 not available to this run)'),
                 'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
-                # the same launch in the rocprofv3 kernel trace of this run's counter pass (median over its launches): what the HIP-event
-                # bracket must agree with.  (The forward's bracket is ~10 us longer than its trace: the event in front of it is recorded
-                # behind the input projection's launch and the probe enqueues the call on an idle stream, so the bracket also holds that
-                # launch boundary and the host's launch latency; the backward's call begins with the chain itself.)
+                # the same launch in the kernel trace of this run's FETCH_SIZE counter pass (median over its launches; under the counters
+                # a launch runs ~5 % slower than in a plain `rocprofv3 --kernel-trace --stats`, whose averages are committed under
+                # profiles/ as r04_kernel_stats_step_bf16_graph.md): the HIP-event bracket lies between the two
                 'avg_launch_us_kernel_trace': trace_us(name_b),
                 'accounting': 'SURVEY.md 8d: every weight matrix the launch multiplies by once per pass (W_hh^T per layer; the two-layer '
                               'launch also W_ih of layer 1) + per step and layer the fp32 activations entering/leaving the chain (gates in, '
