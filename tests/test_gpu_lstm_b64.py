@@ -389,6 +389,41 @@ def test_interleaved_launches_see_fresh_data_through_reused_buffers(hal, math_mo
 
 
 @pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_a_mute_workgroup_times_the_interleaved_launch_out_visibly(hal, math_mode):
+    """The interleaved forward with one workgroup that never publishes (halo_debug_mute_workgroup): its peers' bounded waits time out, the
+    launch drains (no hang: every wave leaves behind barrier AC), the call's abort word and the caller's sticky status word are raised; the
+    next call, unmuted, is clean and gives the consecutive launches' bits."""
+    lib, ops = hal['lib'], hal['ops']
+    T, B, in0, H, L = 3, 128, 128, 1024, 2
+    g = torch.Generator().manual_seed(31)
+    k = 1.0 / H ** 0.5
+    x = torch.randn(T, B, in0, generator=g).to(DEV)
+    w_ih = [((torch.rand(4 * H, in0 if l == 0 else H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    w_hh = [((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).to(DEV) for l in range(L)]
+    b = [torch.zeros(4 * H, device=DEV) for l in range(L)]
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    lib.set_status_word(status)
+    try:
+        lib.check(lib.lib().halo_debug_mute_workgroup(5), 'mute')
+        y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b)
+        torch.cuda.synchronize()
+        assert _status(hal, reserve, False, T, B, in0, H, L) != 0 and int(status.item()) != 0
+        lib.check(lib.lib().halo_debug_mute_workgroup(-1), 'unmute')
+        status.zero_()
+        y, _, _, reserve = ops.lstm_fwd(x, w_ih, w_hh, b, b)
+        assert _status(hal, reserve, False, T, B, in0, H, L) == 0 and int(status.item()) == 0
+        lib.set_lstm_interleave(False)
+        try:
+            y2 = ops.lstm_fwd(x, w_ih, w_hh, b, b)[0]
+        finally:
+            lib.set_lstm_interleave(True)
+        assert torch.equal(y, y2)
+    finally:
+        lib.lib().halo_debug_mute_workgroup(-1)
+        lib.set_status_word(None)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
 def test_split_backward_follows_the_two_layer_forward(hal, math_mode):
     """The two-layer forward leaves the reserve the per-layer backward expects: backward called layer by layer (the data-parallel
     step does, haloop_amd/train.py) after the fused forward equals the one-call two-layer backward."""
