@@ -728,8 +728,11 @@ int launch_groups(const A &a0, int steps, F launch_one, FX launch_pairs) {
         const int left = nbt - bt0;
         a.bt0 = bt0; a.epoch0 = (unsigned)g * (unsigned)(steps + 2);
         int rc;
-        if (pairs && left > per) {                   // (a remainder that fits one plain launch runs as one: a workgroup per tile is faster)
-            a.nbt = min(2 * per, left) & ~1;         // every workgroup of the interleaved launch has TWO tiles (an odd last tile: a plain launch)
+        // every workgroup of an interleaved launch has TWO tiles (an odd last tile: a plain launch), and it pays only when it holds more
+        // tiles than a plain launch would (5 tiles at H = 1024: a plain launch of 4, then one of 1 -- not 2 pairs on half the chip)
+        const int two = min(2 * per, left) & ~1;
+        if (pairs && two > per) {
+            a.nbt = two;
             rc = launch_pairs(a);
         } else {
             a.nbt = min(per, left);

@@ -322,10 +322,10 @@ def test_two_layer_launch_equals_layer_launches(hal, math_mode, T, B, in0, H, p_
     (21, 128, 128, 1024, 0.2, False),       # the bench's B = 128: ONE launch of 256 workgroups, two tiles each (was two launches)
     (8, 256, 128, 1024, 0.2, False),        # 16 tiles: two interleaved launches of 8
     (5, 88, 64, 1024, 0.0, True),           # 6 tiles (the last ragged): 3 pairs = 192 workgroups, carried state
-    (6, 72, 128, 1024, 0.2, False),         # 5 tiles: the third workgroup row has ONE tile
+    (6, 104, 128, 1024, 0.2, False),        # 7 tiles (the last ragged): 6 interleaved, the seventh as a plain launch behind them
     (4, 144, 128, 1024, 0.1, True),         # 9 tiles: 8 interleaved, the ninth as a plain launch behind them
     (4, 160, 128, 512, 0.1, False),         # H = 512: 10 tiles, 5 pairs x 32 hidden tiles
-    (3, 272, 64, 256, 0.0, False),          # H = 256: 17 tiles, 9 pairs (the last a single), plain block map
+    (3, 320, 64, 256, 0.0, False),          # H = 256: 20 tiles in one launch of 10 pairs x 16 hidden tiles (plain block map)
     (1, 128, 128, 1024, 0.2, True),         # a single time step
 ])
 def test_interleaved_tiles_equal_consecutive_launches(hal, math_mode, T, B, in0, H, p_drop, with_state):
