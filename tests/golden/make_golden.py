@@ -167,6 +167,39 @@ def save_lc2x1024_b64():
     print('g1_train3_b64 losses', losses, 'gnorms', gnorms)
 
 
+def save_stock3_b64():
+    """The reference's STOCK encoder -- ha.rnn.Encoder(80, 128, 1024) with the 3-layer nn.LSTM it builds itself (ha/rnn.py:6-11; nothing
+    swapped) + TemporalClassifier(1024, 32) -- at B = 64 with ragged lengths, eval mode: loss, feature / gradient slices, sums and norms
+    (the secondary model; the weights are rebuilt from the seed, 86 MB would not fit a fixture)."""
+    cfg = dict(F_=80, C=128, H=1024, L=3, V=32, B=64, T=80, S=10, seed=43)
+    enc_p, rec_p = cpu_ref.make_params(cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'], cfg['seed'])
+    x, il, tg, tl = cpu_ref.synthetic_batch(cfg['B'], cfg['T'], cfg['F_'], cfg['V'], cfg['S'], cfg['seed'])
+    il = torch.tensor([cfg['T'] - 3 * (i % 8) for i in range(cfg['B'])], dtype=torch.int64)
+    enc, rec = build_reference_model(enc_p, rec_p, cfg['F_'], cfg['C'], cfg['H'], cfg['L'], cfg['V'])
+    assert enc.lstm.num_layers == 3                           # the reference's own stack, not a replacement
+    enc.eval(); rec.eval()
+    feats, flen, _ = enc(x, il)
+    feats.retain_grad()
+    loss, _ = rec(feats, tg, flen, tl)
+    loss.backward()
+    with torch.no_grad():
+        lp = rec.log_probs(feats)
+        hyps, hlen, ali, scores, _ = rec.decode(feats, flen, tl)
+    d = {'cfg_' + k: np.array(v) for k, v in cfg.items()}
+    d.update(il=il.numpy(), flen=flen.numpy(), loss=loss.detach().numpy(), ali=ali.numpy(), hlen=hlen.numpy())
+    d['feats_slice'] = feats.detach()[:, :, ::61].numpy()
+    d['feats_sum'] = feats.detach().double().sum().numpy()
+    d['dfeats_slice'] = feats.grad[:, :, ::61].numpy()
+    d['lp_slice'] = lp[::3].numpy()
+    grads = {('encoder.' + k): p.grad for k, p in enc.named_parameters()}
+    grads.update({('recognizer.' + k): p.grad for k, p in rec.named_parameters()})
+    for k, v in grads.items():
+        d['gradnorm.' + k] = v.double().norm().numpy()
+        d['gradslice.' + k] = v.reshape(-1)[::9973].numpy()
+    np.savez_compressed(os.path.join(OUT, 'g1_stock3_b64.npz'), **d)
+    print('g1_stock3_b64 loss', float(loss))
+
+
 def save_train_steps():
     """Three optimizer steps the way ha/loop.py:176-196 runs them (eval-mode dropout)."""
     cfg = dict(F_=12, C=16, H=32, L=2, V=9, B=3, T=41, S=4, seed=11)
@@ -605,6 +638,7 @@ if __name__ == '__main__':
     save_transducer()
     save_rnn_decoder()
     save_lc2x1024_b64()
+    save_stock3_b64()
     save_audio_encoder()
     save_asr()
     save_gpt()

@@ -88,6 +88,76 @@ def test_lc2x1024_b64_bf16_meets_the_bf16_gates_against_the_reference(hal, bf16)
     np.testing.assert_allclose(lp[::3].cpu().numpy(), g['lp_slice'], atol=3e-2)
 
 
+@pytest.mark.parametrize('mode,loss_rtol,feat_atol,norm_rtol,cos_min', [
+    ('bf16', 2e-2, 3e-2, 5e-2, 0.995),          # the headline arithmetic, BASELINE.md section 3's bf16 gates
+    ('bf16x3', 1e-4, 2e-4, 1e-3, 0.99999),      # fp32-grade: three-pass split operands
+    ('f32', 1e-4, 2e-4, 1e-3, 0.99999),
+])
+def test_stock_three_layer_encoder_b64_against_the_reference(hal, mode, loss_rtol, feat_atol, norm_rtol, cos_min):
+    """The reference's STOCK model -- ha.rnn.Encoder's own 3-layer LSTM (ha/rnn.py:6-11) + TemporalClassifier -- at config 2's grid, fixture
+    g1_stock3_b64 (generated by running the reference): one eval-mode step of the HIP path in every math mode, the full gradients compared
+    with the CPU oracle's (pinned to the fixture first); in bf16 the top two layers must have run as the two-layer persistent launch."""
+    from oracle import cpu_ref
+    g = load_golden('g1_stock3_b64')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    enc_p, rec_p = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    il = torch.from_numpy(g['il'])
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc_p.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec_p.items()}
+    loss_o, feats_o, _ = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl)
+    loss_o.backward()
+    np.testing.assert_allclose(loss_o.item(), float(g['loss']), rtol=1e-5)
+    ograd = {**{'encoder.' + k: v.grad for k, v in pe.items()}, **{'recognizer.' + k: v.grad for k, v in pr.items()}}
+    for key, gr in ograd.items():
+        np.testing.assert_allclose(gr.double().norm().item(), float(g['gradnorm.' + key]), rtol=1e-4, err_msg=key)
+
+    prev = hal['lib'].get_math_mode()
+    hal['lib'].set_math_mode(mode)
+    try:
+        enc = hal['rnn'].Encoder(c['F_'], c['C'], c['H'])                      # the default stack: 3 layers, as the reference builds it
+        assert enc.lstm.num_layers == 3
+        rec = hal['recognizer'].TemporalClassifier(c['H'], c['V'])
+        enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+        enc.to(DEV).eval(); rec.to(DEV).eval()
+        feats, flen, _ = enc(x.to(DEV), il.to(DEV))
+        if mode == 'bf16':
+            assert hal['lib'].lib().halo_lstm_persistent2_eligible(int(g['flen'].max()), c['B'], c['H'], c['L']) == 1
+            assert hal['lib'].lstm_chain_info('fwd')['kernel'] == 'lstm_persist2_fwd_kernel'
+        feats.retain_grad()
+        loss, _ = rec(feats, tg.to(DEV), flen, tl.to(DEV))
+        loss.backward()
+        if mode == 'bf16':
+            # backward walks the stack top-down: the last chain it ran is layer 0's own persistent launch, below the pair
+            assert hal['lib'].lstm_chain_info('bwd')['kernel'] == 'lstm_persist_bwd_kernel'
+        with torch.no_grad():
+            lp = rec.log_probs(feats)
+            ali, _, _, hlen = hal['ops'].ctc_greedy(lp.contiguous())
+    finally:
+        hal['lib'].set_math_mode(prev)
+    np.testing.assert_allclose(loss.item(), float(g['loss']), rtol=loss_rtol)
+    np.testing.assert_allclose(feats[:, :, ::61].detach().cpu().numpy(), g['feats_slice'], atol=feat_atol)
+    assert np.array_equal(flen.cpu().numpy(), g['flen'])
+    scale = float(np.abs(g['dfeats_slice']).max())
+    np.testing.assert_allclose(feats.grad[:, :, ::61].cpu().numpy(), g['dfeats_slice'], atol=feat_atol * scale)
+    np.testing.assert_allclose(lp[::3].cpu().numpy(), g['lp_slice'], atol=feat_atol)
+    for k, p in list(enc.named_parameters()) + list(rec.named_parameters()):
+        key = ('recognizer.' if k.startswith('classifier') else 'encoder.') + k
+        np.testing.assert_allclose(p.grad.double().norm().item(), float(g['gradnorm.' + key]), rtol=norm_rtol, err_msg=key)
+        cos = _cos(p.grad.cpu(), ograd[key])
+        assert cos >= cos_min, (key, cos)
+    if mode != 'bf16':
+        # greedy alignments: equal to the reference's wherever its own top two log-probs are further apart than the emissions differ
+        with torch.no_grad():
+            lp_o = cpu_ref.classifier_log_probs(rec_p, feats_o.detach())
+        top2 = torch.topk(lp_o, 2, dim=-1).values
+        decided = ((top2[..., 0] - top2[..., 1]) > 4 * feat_atol).numpy()
+        valid = np.arange(lp.shape[1])[None, :] < g['flen'][:, None]
+        sel = decided & valid
+        assert sel.mean() > 0.5
+        assert np.array_equal(ali.cpu().numpy()[sel], g['ali'][sel])
+
+
 def _train_to_peaked_posteriors(hal, steps, lr):
     """LC-2x1024 (eval mode: no dropout) trained by the HIP trainer on ONE fixed synthetic batch; returns the CPU state dicts."""
     from oracle import cpu_ref

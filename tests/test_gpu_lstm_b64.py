@@ -642,6 +642,7 @@ def test_wide_persistent_recurrence_equals_step_chain(hal, math_mode, T, B, in0,
     (6, 16, 64, 256, 3, 0.2, False),        # the stock 3-layer encoder's shape family (ha/rnn.py:11): layer 0 alone, layers 1 + 2 in one launch
     (5, 32, 128, 512, 3, 0.0, True),        # carried state, no dropout
     (4, 32, 128, 256, 4, 0.25, False),      # two single layers under the pair
+    (21, 64, 128, 1024, 3, 0.2, False),     # the stock encoder itself at BASELINE config 2's grid (bench.py's `stock3` leg)
 ])
 def test_top_pair_of_a_deeper_stack_runs_as_one_launch(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
     """L > 2 in bf16: the stack's top two layers run as the two-layer persistent launch (its lower layer's input projection fed by the layer

@@ -72,6 +72,29 @@ def test_lc2x1024_b64_matches_reference():
             np.testing.assert_allclose(v.grad.reshape(-1)[::9973].numpy(), g['gradslice.' + prefix + k], rtol=1e-4, atol=1e-8, err_msg=k)
 
 
+def test_stock3_b64_matches_reference():
+    """The reference's stock 3-layer encoder (ha/rnn.py:6-11, nothing swapped) at B=64 with ragged lengths: oracle == reference on loss,
+    feature slices, greedy alignments and every gradient's norm and slice."""
+    g = load_golden('g1_stock3_b64')
+    c = {k[4:]: int(v) for k, v in g.items() if k.startswith('cfg_')}
+    assert c['L'] == 3
+    enc, rec = cpu_ref.make_params(c['F_'], c['C'], c['H'], c['L'], c['V'], c['seed'])
+    x, _, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], c['seed'])
+    il = torch.from_numpy(g['il'])
+    pe = {k: v.clone().requires_grad_(True) for k, v in enc.items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in rec.items()}
+    loss, feats, flen = cpu_ref.lstm_ctc_loss(pe, pr, x, il, tg, tl)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-6)
+    np.testing.assert_allclose(feats.detach()[:, :, ::61].numpy(), g['feats_slice'], atol=1e-6)
+    assert np.array_equal(flen.numpy(), g['flen'])
+    assert set('encoder.' + k for k in pe) | set('recognizer.' + k for k in pr) == set(k[9:] for k in g if k.startswith('gradnorm.'))
+    for prefix, d in (('encoder.', pe), ('recognizer.', pr)):
+        for k, v in d.items():
+            np.testing.assert_allclose(v.grad.double().norm().item(), float(g['gradnorm.' + prefix + k]), rtol=1e-5, err_msg=k)
+            np.testing.assert_allclose(v.grad.reshape(-1)[::9973].numpy(), g['gradslice.' + prefix + k], rtol=1e-4, atol=1e-8, err_msg=k)
+
+
 def test_train_steps_b64_match_reference():
     g = load_golden('g1_train3_b64')
     c = {k[4:]: v for k, v in g.items() if k.startswith('cfg_')}
