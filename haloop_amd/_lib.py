@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 15
+HALO_ABI_VERSION = 16
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -96,6 +96,10 @@ SIGNATURES = {
                                _vp, _i, _i, _i, _i, _vp]),
     'halo_ctc_head_bwd': (_i, [_vp, _vp, _f, _u64, _u32, _u32, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i, _i, _i, _i, _vp]),
+    'halo_ctc_head_train_workspace_bytes': (_sz, [_i, _i, _i]),
+    'halo_ctc_head_train_ticket_words': (_sz, [_i, _i]),
+    'halo_ctc_head_train': (_i, [_vp, _vp, _vp, _f, _u64, _u32, _u32, _vp, _vp, _i, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'halo_ctc_greedy': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'halo_set_beam_vector_chunk': (_i, [_i]),
     'halo_logaddexp_aten': (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -13,8 +13,18 @@
 #include <float.h>
 #include "halo_common.h"
 #include "halo_internal.h"
+#include "lstm_persist_dev.h"
+#include <type_traits>
 
 namespace {
+
+// in-kernel stamps of a measurement build (make EXTRA=-DHALO_HEAD_STAMPS; tools/head_stamps.py): [kernel][workgroup][point], 100 MHz clock
+#ifdef HALO_HEAD_STAMPS
+__device__ unsigned long long g_head_stamps[2][1024][16];
+#define HST(k, i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) g_head_stamps[k][blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define HST(k, i) do { } while (0)
+#endif
 
 constexpr int NW = 16;                   // waves per workgroup: K-slices of the H-deep contraction / column tiles of the H-wide outputs
 constexpr int LDT = 33;                  // padded leading dimension of the [32][32] tiles in LDS
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
     const int r = lane & 31, kh = lane >> 5;
     // ---- logits[t][v] = sum_k drop(f[n,t,k]) W[v,k]: K in chunks of KC; rows are read from global memory as whole float4 runs
     //      (coalesced), the MFMA fragments (lane = row) come from LDS; wave w contracts k in [w * KC/NW, (w + 1) * KC/NW) of a chunk ----
+    HST(0, 0);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -119,6 +130,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
 #pragma unroll
         for (int i = 0; i < UPT; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
     }
+    HST(0, 1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r] = acc[e];
     __syncthreads();
@@ -146,6 +158,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
         if (p.lp && i < T && j < V) p.lp[((long)n * T + i) * V + j] = lpv;
     }
     __syncthreads();
+    HST(0, 2);
     if (GREEDY) {
         // one lane per frame (T <= 32): arg max over the classes (first maximum, like torch.max), then unique_consecutive + drop blanks
         if (wave == 0) {
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
             if (lane < S_) alpha[(long)t * S_ + lane] = v;
             if (t == tlast) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
         }
+        HST(0, 3);
         unsigned old = 0;
         if (lane == 0) {
             const float out = il == 0 ? (tl == 0 ? 0.f : INFINITY) : -log_add_exp_fast2(ra, rb);
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(1024) void ctc_head_fwd_kernel(const HeadFwdArgs p)
             old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         old = __builtin_amdgcn_readfirstlane(old);
+        HST(0, 4);
         if (old == (unsigned)p.B - 1u) {
             // reduction='mean' (ha/recognizer.py:71): mean_n(nll[n] / max(tl[n], 1)); the whole wave loads (one utterance per lane and
             // pass), partial sums combine in a fixed order
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H, V = p.V, S_ = 2 * p.S + 1;
     const int Hs = H / (int)gridDim.y, h0 = (int)blockIdx.y * Hs;       // this slice: columns [h0, h0 + Hs), Hs % 32 == 0
+    HST(1, 0);
     if (p.drop.threshold) {               // one Philox call covers four consecutive elements
         for (int u = tid; u < T * Hs / 4; u += 512) {
             const int row = (4 * u) / Hs, col = (4 * u) % Hs;
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
     }
     for (int idx = tid; idx < T * S_; idx += 512) ab[idx / S_][idx % S_] = p.alpha[(long)n * T * S_ + idx];
     __syncthreads();
+    HST(1, 1);
     const float nll = p.nll[n], go = p.grad_out[n];
     if (wave == 0 && il > 0) {            // beta recursion, one state per lane (as ctc_beta_grad_wave_kernel)
         const int lab = lane < S_ ? ext_label2(tg, lane) : 0;
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
         }
     }
     __syncthreads();
+    HST(1, 2);
     for (int u = tid; u < 1024; u += 512) {   // gradient at the log-probs in ATen's convention, then log_softmax backward: dlogit = g - exp(lp) * sum_c g
         const int t = u >> 5, c = u & 31;
         float g = 0.f;
@@ -337,6 +355,7 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
         if (t < T && c < V) dl[t][c] = g - expf(lps[t][c]) * gs;
     }
     __syncthreads();
+    HST(1, 3);
     if (tid < V && blockIdx.y == 0) {
         float s = 0.f;
         for (int t = 0; t < T; ++t) s += dl[t][tid];
@@ -382,6 +401,400 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
                 if (row < V) p.dw_part[((long)n * V + row) * H + c0 + r] = dwp[e];
+            }
+        }
+    }
+    HST(1, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The head of a TRAINING step in ONE launch (halo_ctc_head_train; the two launches above stay for the exact-f32 mode and for callers
+// that want log-probs and alpha).  What the stamps of those two launches showed (tools/head_stamps.py, B = 64, H = 1024: 21 + 21 us):
+// the classifier product 12.5 us (4 x 880-cycle Philox draws per wave in front of 512 exact-f32 MFMAs, on 64 of the 256 CUs), the two
+// lattice recursions 4.9 + 4.2 us one after the other, 5.8 us for the gradient at the logits (target labels fetched from global memory
+// inside its loops), 4.4 us restaging log-probs / alpha / masks in the second launch.  Here:
+//   * grid (B, SL): the SL workgroups of an utterance each take H/SL feature columns -- their share of the dropout mask (kept in LDS as
+//     bytes), of the logits' K range, and later those columns of d features / d W.  The partial logits [32 x 32] meet through global
+//     memory (write-through stores, drained, one arrive counter per utterance: cdna_hip_programming.md Guideline 16 R1 in its counter
+//     form); every workgroup of the utterance then sums the SL partials in slice order and runs the (single-wave) lattice work itself.
+//     B * SL <= 256 workgroups of one per CU: all resident, every wait bounded.
+//   * products on split-bf16 MFMA (v_mfma_f32_32x32x16_bf16; hi*hi + hi*lo + lo*hi: fp32-grade like every `bf16x3` product) with the
+//     fragments loaded straight from global memory in MFMA layout -- no LDS staging, no barrier until the K-slices are added up.
+//   * alpha in wave 0 and beta in wave 1 AT THE SAME TIME; labels, log-probs, alpha + beta stay in LDS.
+struct HeadTrainArgs {
+    const float *feats, *w, *bias;
+    DropoutCfg drop;
+    const int64_t *il, *targets, *tl;
+    long tg_stride;
+    float *lp, *nll, *loss;
+    int64_t *flen;
+    unsigned *ticket;        // [0] the loss ticket, [1] launches so far, [2 ..) the slices' (partial logit, epoch) pairs; zero before the first launch
+    float *dfeats, *dw_part, *db_part;
+    int B, T, H, V, S, ks, stride, pad;
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int TNW = 8, TNT = 64 * TNW;    // 512 threads: 256 VGPRs per lane hold two passes of fragments and two prefetched product tiles
+
+__global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float dynt[];      // [red: TNW x 1024 floats][mask: 32 x Hs bytes]
+    float *red = dynt;
+    unsigned char *mk = reinterpret_cast<unsigned char *>(dynt + TNW * 1024);
+    __shared__ float tile[32][LDT];       // logits, then log-probs
+    __shared__ float dl[32][LDT];         // gradient at the logits (0 outside [T) x [V))
+    __shared__ float al[32][65];          // alpha, then alpha + beta
+    __shared__ float be[32][65];
+    __shared__ int lab_s[64];
+    __shared__ unsigned cmask[32];        // per class: the target positions that carry it
+    __shared__ float s_nll;
+    __shared__ int s_fail;
+    const int n = blockIdx.x, y = blockIdx.y, SL = gridDim.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, H = p.H, V = p.V, S_ = 2 * p.S + 1;
+    const int Hs = H / SL, h0 = y * Hs;
+    const int r = lane & 31, kh = lane >> 5;
+    DropoutCfg drop = p.drop;             // the step counter of a graph replay: read once, not once per draw
+    if (drop.offset_dev) { drop.offset += *drop.offset_dev; drop.offset_dev = nullptr; }
+    const bool masked = drop.threshold != 0;
+    HST(0, 0);
+    if (tid == 0) s_fail = 0;
+    const unsigned epoch = p.ticket[1] + 1u;      // launches so far + 1: what this launch's partial sums are tagged with
+    // ---- requested first, used last: the global-memory operands of this wave's first two product tiles (tiles 0 .. ntl-1: d features,
+    //      their k index runs over W's rows; ntl .. 2 ntl-1: d W, k runs over the features' rows) ----
+    const int ntl = Hs / 32, njobs = 2 * ntl;
+    float pre0[16], pre1[16];
+    // (buffer accesses: rows beyond the operand -- frames >= T, classes >= V -- are addressed out of range, so their loads return 0 and their
+    //  stores are dropped without a branch or a select; the lane part of an address is computed once)
+    const int lane_k = (8 * kh * H + h0 + r) * 4;                // row 8 kh, column h0 + r
+    auto load_job = [&](int jb, float (&o)[16]) {
+        const bool isw = jb < ntl;
+        const int col = (isw ? jb : jb - ntl) * 128, lim = isw ? V : T;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(isw ? p.w : p.feats + (long)n * T * H), 0, lim * H * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int krow = 16 * (i >> 3) + (i & 7);                // + 8 kh: this lane's k index
+            const int off = krow + 8 * kh < lim ? lane_k + krow * H * 4 + col : -16;
+            o[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        }
+    };
+    load_job(min(wave, njobs - 1), pre0);
+    load_job(min(wave + TNW, njobs - 1), pre1);
+    // ---- partial logits over this slice's K range: wave w takes k-steps (16 deep) w, w + 8, ..., two per pass; lane (r, kh) loads
+    //      elements 8 kh .. 8 kh + 7 of row r of both operands (the MFMA's own layout) and draws the row's mask under the loads ----
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nks = Hs / 16;
+    const long frow = ((long)n * T + min(r, T - 1)) * H + h0, wrow = (long)min(r, V - 1) * H + h0;
+    for (int i0 = wave; i0 < nks; i0 += 2 * TNW) {
+        f32x4 fa[2][2], wb[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kb = 16 * min(i0 + TNW * u, nks - 1) + 8 * kh;
+            fa[u][0] = *reinterpret_cast<const f32x4 *>(p.feats + frow + kb);
+            fa[u][1] = *reinterpret_cast<const f32x4 *>(p.feats + frow + kb + 4);
+            wb[u][0] = *reinterpret_cast<const f32x4 *>(p.w + wrow + kb);
+            wb[u][1] = *reinterpret_cast<const f32x4 *>(p.w + wrow + kb + 4);
+        }
+        f32x4 mm[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            mm[u][0] = f32x4{1.f, 1.f, 1.f, 1.f}; mm[u][1] = mm[u][0];
+            const int kb = 16 * min(i0 + TNW * u, nks - 1) + 8 * kh;
+            if (masked && i0 + TNW * u < nks && r < T) {
+                const uint64_t idx = (uint64_t)(((long)n * T + r) * H + h0 + kb);
+                mm[u][0] = dropout_mult4(drop, idx);
+                mm[u][1] = dropout_mult4(drop, idx + 4);
+                unsigned lo4 = 0, hi4 = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo4 |= (mm[u][0][e] != 0.f ? 1u : 0u) << (8 * e); hi4 |= (mm[u][1][e] != 0.f ? 1u : 0u) << (8 * e); }
+                *reinterpret_cast<uint2 *>(mk + r * Hs + kb) = make_uint2(lo4, hi4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool on = i0 + TNW * u < nks;
+            float a8[8], b8[8];
+            const bool arow = on && r < T, brow = on && r < V;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a8[e] = arow ? fa[u][0][e] * mm[u][0][e] : 0.f; a8[4 + e] = arow ? fa[u][1][e] * mm[u][1][e] : 0.f;
+                b8[e] = brow ? wb[u][0][e] : 0.f;               b8[4 + e] = brow ? wb[u][1][e] : 0.f;
+            }
+            bf16x8 ahi, alo, bhi, blo;
+            split8(a8, ahi, alo);
+            split8(b8, bhi, blo);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+        }
+    }
+    HST(0, 1);
+    const int64_t *tg = p.targets + (long)n * p.tg_stride;
+    const int il = feature_length(p.il[n], p.ks, p.stride, p.pad, T);
+    const int tl = max(0, min((int)p.tl[n], p.S));
+    const int states = 2 * tl + 1;
+    if (tid < 64) lab_s[tid] = tid < S_ ? ext_label2(tg, tid) : 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r] = acc[e];
+    __syncthreads();
+    float sum[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        sum[q] = 0.f;
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) sum[q] += red[w * 1024 + tid + TNT * q];
+    }
+    HST(0, 2);
+    if (SL > 1) {
+        // the slices' partial sums meet in global memory.  Every value travels as the 8-byte pair (value, epoch of this launch): one
+        // write-through store per pair, and a reader that finds the epoch has the value -- no drain, no counter, no second round trip
+        // (cdna_hip_programming.md Guideline 16: data and flag in one naturally aligned store).  Everyone adds the SL values in slice order.
+        const __amdgpu_buffer_rsrc_t prs = make_rsrc(p.ticket + 2);
+        const int slot = (n * SL * 1024 + tid) * 8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x2 pr = {__builtin_bit_cast(unsigned, sum[q]), epoch};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, prs, slot + (y * 1024 + TNT * q) * 8, 0, 16);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        u32x2 got[8][2];
+        bool ok = false;
+        while (!ok) {
+#pragma unroll
+            for (int yy = 0; yy < 8; ++yy) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    got[yy][q] = __builtin_amdgcn_raw_buffer_load_b64(prs, slot + (min(yy, SL - 1) * 1024 + TNT * q) * 8, 0, 16);
+            }
+            ok = true;
+#pragma unroll
+            for (int yy = 0; yy < 8; ++yy) ok = ok && got[yy][0][1] == epoch && got[yy][1][1] == epoch;
+            if (!ok && __builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) { s_fail = 1; break; }
+        }
+        sum[0] = sum[1] = 0.f;
+#pragma unroll
+        for (int yy = 0; yy < 8; ++yy) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned bits = got[yy][q][0];
+                sum[q] += yy < SL ? __builtin_bit_cast(float, bits) : 0.f;
+            }
+        }
+    }
+    HST(0, 3);
+    const int tj = tid & 31;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) tile[(tid >> 5) + 16 * q][tj] = (tj < V) ? sum[q] + p.bias[tj] : -INFINITY;
+    __syncthreads();
+    if (s_fail) {                          // a slice that never came (0.2 s; cannot happen on an idle chip): a loud loss instead of a hang
+        if (tid == 0) *p.loss = NAN;
+        return;
+    }
+    // ---- log-softmax over the classes: 32 lanes per frame, two frames per thread ----
+    {
+        float lpv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x = tile[(tid >> 5) + 16 * q][tj];
+            float m = x;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 32));
+            float s = tj < V ? expf(x - m) : 0.f;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
+            lpv[q] = x - m - logf(s);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ti = (tid >> 5) + 16 * q;
+            tile[ti][tj] = lpv[q];
+            dl[ti][tj] = 0.f;
+            if (p.lp && y == 0 && ti < T && tj < V) p.lp[((long)n * T + ti) * V + tj] = lpv[q];
+        }
+    }
+    __syncthreads();
+    HST(0, 4);
+    // ---- the two lattice recursions side by side: alpha in wave 0 (as ctc_head_fwd_kernel), beta in wave 1 (as ctc_head_bwd_kernel) ----
+    if (wave == 0) {
+        const int lab = lab_s[lane];
+        const int lab2 = __shfl_up(lab, 2, 64);
+        const bool can_skip = lane >= 2 && lab != 0 && lab != lab2;
+        const int tlast = il - 1, slast = 2 * tl, sprev = tl > 0 ? 2 * tl - 1 : -1;
+        float prev = (il > 0 && lane < states && lane < 2) ? tile[0][lab] : -INFINITY;
+        al[0][lane] = prev;
+        float ra = 0.f, rb = 0.f;
+        if (tlast == 0) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
+        float em = tile[min(1, T - 1)][lab];
+        for (int t = 1; t < T; ++t) {
+            const float p1 = wave_up1(prev), p2 = wave_up1(p1);
+            const float e = em;
+            em = tile[min(t + 1, T - 1)][lab];
+            float v = -INFINITY;
+            if (t < il && lane < states) {
+                if (lane == 0) v = prev + e;
+                else v = log_add_exp_fast3(prev, p1, (lane >= 2 && can_skip) ? p2 : -INFINITY) + e;
+            }
+            prev = v;
+            al[t][lane] = v;
+            if (t == tlast) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
+        }
+        if (lane == 0) s_nll = il == 0 ? (tl == 0 ? 0.f : INFINITY) : -log_add_exp_fast2(ra, rb);
+    } else if (wave == 1 && il > 0) {
+        const int lab = lab_s[lane];
+        const int labn2 = __shfl_down(lab, 2, 64);
+        const bool can_skip = lane + 2 < states && labn2 != 0 && labn2 != lab;
+        float nxt = -INFINITY;
+        float em = tile[il - 1][lab];
+        for (int t = il - 1; t >= 0; --t) {
+            const float n1 = wave_down1(nxt), n2 = wave_down1(n1);
+            const float e = em;
+            em = tile[max(t - 1, 0)][lab];
+            float v = -INFINITY;
+            if (lane < states) {
+                if (t == il - 1) {
+                    if (lane == states - 1 || lane == states - 2) v = e;
+                } else {
+                    v = log_add_exp_fast3(nxt, lane + 1 < states ? n1 : -INFINITY, can_skip ? n2 : -INFINITY) + e;
+                }
+            }
+            be[t][lane] = v;
+            nxt = v;
+        }
+    } else if (wave == 2 && lane < 32) {
+        unsigned bits = 0;
+        for (int j = 0; j < tl; ++j) bits |= (lab_s[2 * j + 1] == lane ? 1u : 0u) << j;
+        cmask[lane] = bits;
+    }
+    __syncthreads();
+    HST(0, 5);
+    // ---- gradient at the log-probs (ATen's convention), then log_softmax backward: dlogit = g - exp(lp) * sum_c g.  Per frame t:
+    //      e[s] = exp(alpha + beta - their maximum over the states) with the lane = the state (wave w takes frames w, w + 8, ...), the blank's
+    //      share summed in the wave; then thread (t, c) adds the e[s] of the states that carry class c, found through a bit mask over the
+    //      target positions -- no loop over all states, no label fetched twice ----
+    for (int t = wave; t < il; t += TNW) {
+        const float x = lane < states ? al[t][lane] + be[t][lane] : -INFINITY;
+        const float m = wave_max(x);
+        const float e = x > -INFINITY ? __expf(x - m) : 0.f;
+        al[t][lane] = e;
+        const float blank = wave_sum((lane & 1) ? 0.f : e);
+        if (lane == 0) { be[t][64] = m; al[t][64] = blank; }
+    }
+    __syncthreads();
+    {
+        const float nll = s_nll, go = 1.0f / (fmaxf((float)p.tl[n], 1.0f) * (float)p.B);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = (tid >> 5) + 16 * q, c = tj;
+            float g = 0.f;
+            if (t < il && c < V) {
+                float sm = al[t][64];
+                if (c != 0) {
+                    sm = 0.f;
+                    for (unsigned bits = cmask[c]; bits; bits &= bits - 1u) sm += al[t][2 * (__builtin_ctz(bits)) + 1];
+                }
+                const float lcab = sm > 0.f ? be[t][64] + __logf(sm) : -INFINITY;
+                const float l = tile[t][c];
+                g = (__expf(l) - __expf(lcab + nll - l)) * go;
+            }
+            float gs = g;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) gs += __shfl_xor(gs, d, 32);
+            if (t < T && c < V) dl[t][c] = g - expf(tile[t][c]) * gs;
+        }
+    }
+    __syncthreads();
+    HST(0, 6);
+    // ---- the two products of this slice's columns, one 32-column tile per wave and pass (split-bf16, K = 32 classes / 32 frames) ----
+    const __amdgpu_buffer_rsrc_t df_rs = __builtin_amdgcn_make_buffer_rsrc(p.dfeats + (long)n * T * H, 0, T * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dw_rs = __builtin_amdgcn_make_buffer_rsrc(p.dw_part + (long)n * V * H, 0, V * H * 4, 0x00020000);
+    const int lane_o = (4 * kh * H + h0 + r) * 4;                // accumulator row 4 kh, column h0 + r
+    auto do_job = [&](auto isw_c, int ti, const float (&pre)[16]) {
+        constexpr bool isw = decltype(isw_c)::value;
+        const int m0 = ti * 32;
+        // the mask bytes this tile needs, all requested at once (rows clamped: the unused ones are never looked at): d W multiplies the
+        // DROPPED features (rows = its k index), d features is masked on the way out (rows = the accumulator's rows)
+        unsigned mb[16];
+        if (masked) {
+            const unsigned char *mcol = mk + m0 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = isw ? (i & 3) + 8 * (i >> 2) + 4 * kh : 16 * (i >> 3) + 8 * kh + (i & 7);
+                mb[i] = mcol[min(row, T - 1) * Hs];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mb[i] = 1u;
+        }
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * s2 + 8 * kh + e;
+                const float bv = pre[8 * s2 + e];
+                b8[e] = isw ? bv : (mb[8 * s2 + e] ? bv * drop.scale : 0.f);
+                a8[e] = isw ? dl[r][kk] : dl[kk][r];
+            }
+            bf16x8 ahi, alo, bhi, blo;
+            split8(a8, ahi, alo);
+            split8(b8, bhi, blo);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rowc = (e & 3) + 8 * (e >> 2);                 // + 4 kh: the accumulator element's row
+            const int off = rowc + 4 * kh < (isw ? T : V) ? lane_o + rowc * H * 4 + ti * 128 : -16;
+            const float ov = isw ? (mb[e] ? o[e] * drop.scale : 0.f) : o[e];      // (a scalar first: bit_cast of a vector ELEMENT reads element 0)
+            if (isw) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), df_rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), dw_rs, off, 0, 0);
+        }
+    };
+    auto run_job = [&](int jb, const float (&pre)[16]) {
+        if (jb < ntl) do_job(std::true_type{}, jb, pre);
+        else do_job(std::false_type{}, jb - ntl, pre);
+    };
+    if (wave < njobs) run_job(wave, pre0);
+    if (wave + TNW < njobs) run_job(wave + TNW, pre1);
+    for (int jb = wave + 2 * TNW; jb < njobs; jb += TNW) {
+        load_job(jb, pre0);
+        run_job(jb, pre0);
+    }
+    if (wave == TNW - 1 && lane < V && y == 0) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += dl[t][lane];
+        p.db_part[(long)n * V + lane] = s;
+    }
+    HST(0, 7);
+    // ---- the utterance's loss terms and, in the workgroup that finishes last, the mean (as ctc_head_fwd_kernel) ----
+    if (y == 0 && wave == 0) {
+        unsigned old = 0;
+        if (lane == 0) {
+            __hip_atomic_store(p.nll + n, s_nll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.flen[n] = il;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == (unsigned)p.B - 1u) {
+            float s = 0.f;
+            for (int i0 = 0; i0 < p.B; i0 += 64) {
+                const int i = i0 + lane;
+                float v = 0.f;
+                if (i < p.B) v = __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / fmaxf((float)p.tl[i], 1.0f);
+                s += wave_sum(v);
+            }
+            if (lane == 0) {
+                *p.loss = s / (float)p.B;
+                __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.ticket + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -490,5 +903,63 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
     hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)q.blocks), dim3(256), 0, (hipStream_t)stream, q);
     return halo_launch_status();
 }
+
+static int head_train_slices(int B, int H) {
+    // slices of H per utterance: as many as keep the grid within the chip's CUs (4 at B = 64), whole 32-column tiles per slice.  All
+    // B * slices workgroups must be resident at once (the slices of an utterance wait for each other): <= 256, one per CU
+    int slices = 1;
+    while (slices < 8 && (H / 32) % (2 * slices) == 0 && (long)B * 2 * slices <= 256) slices *= 2;
+    return slices;
+}
+
+size_t halo_ctc_head_train_workspace_bytes(int B, int H, int V) { return halo_ctc_head_workspace_bytes(B, H, V); }
+
+size_t halo_ctc_head_train_ticket_words(int B, int H) {
+    if (B <= 0 || H <= 0) return 0;
+    const int slices = head_train_slices(B, H);
+    return 2 + (slices > 1 ? (size_t)B * slices * 1024 * 2 : 0);       // loss ticket, launch count, the slices' (partial logit, epoch) pairs
+}
+
+int halo_ctc_head_train(const float *features, const float *weight, const float *bias, float p_drop, uint64_t seed, uint32_t stream_id,
+                        uint32_t offset, const uint32_t *offset_dev, const int64_t *input_lengths, int ks, int stride, int pad,
+                        const int64_t *targets, long tg_stride, int S, const int64_t *target_lengths, float *lp, float *nll,
+                        int64_t *feature_lengths, float *loss, uint32_t *ticket, float *dfeatures, float *dweight, float *dbias,
+                        void *workspace, int B, int T, int H, int V, halo_stream_t stream) {
+    HALO_CHECK_ARG(features && weight && bias && input_lengths && targets && target_lengths && nll && feature_lengths && loss && ticket &&
+                   dfeatures && dweight && dbias && workspace && B > 0);
+    if (!halo_ctc_head_supported(T, H, V, S) || halo_math_mode() == HALO_MATH_F32) return HALO_ENOTSUP;
+    if ((long)32 * H * 4 >= (1l << 31)) return HALO_ENOTSUP;
+    HALO_CHECK_ARG(((uintptr_t)features % 16 == 0) && ((uintptr_t)weight % 16 == 0));
+    const int slices = head_train_slices(B, H);
+    const size_t lds = (size_t)TNW * 1024 * sizeof(float) + (p_drop > 0.f ? (size_t)32 * (H / slices) : 0);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)ctc_head_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TNW * 1024 * sizeof(float) + 32 * 2048)) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    if (H / slices > 2048) return HALO_ENOTSUP;
+    HeadTrainArgs a;
+    a.feats = features; a.w = weight; a.bias = bias;
+    a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
+    a.il = input_lengths; a.targets = targets; a.tl = target_lengths; a.tg_stride = tg_stride;
+    a.lp = lp; a.nll = nll; a.loss = loss; a.flen = feature_lengths; a.ticket = ticket;
+    a.dfeats = dfeatures; a.dw_part = (float *)workspace; a.db_part = a.dw_part + (size_t)B * V * H;
+    a.B = B; a.T = T; a.H = H; a.V = V; a.S = S; a.ks = ks; a.stride = stride; a.pad = pad;
+    hipLaunchKernelGGL(ctc_head_train_kernel, dim3(B, slices), dim3(TNT), lds, (hipStream_t)stream, a);
+    int rc = halo_launch_status();
+    if (rc != HALO_OK) return rc;
+    HaloSmallJob j = {};
+    j.kind = 1; j.n = B; j.m = V; j.len = (long)V * H; j.a = a.dw_part; j.b = a.db_part; j.o1 = dweight; j.o2 = dbias;
+    if (halo_defer_small_job(j)) return HALO_OK;
+    HaloSmallJobs q = {};
+    q.n = 1; q.job[0] = j; q.job[0].blocks = q.blocks = halo_small_job_blocks(j);
+    hipLaunchKernelGGL(ctc_head_reduce_kernel, dim3((unsigned)q.blocks), dim3(256), 0, (hipStream_t)stream, q);
+    return halo_launch_status();
+}
+
+#ifdef HALO_HEAD_STAMPS
+int halo_debug_head_stamps(void *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_head_stamps), sizeof(g_head_stamps)) == hipSuccess ? HALO_OK : HALO_ELAUNCH; }
+#endif
 
 }  // extern "C"

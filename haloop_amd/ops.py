@@ -512,6 +512,41 @@ def ctc_head_fwd(feats, weight, bias, drop, stream_id, input_lengths, targets, t
     return lp, alpha, nll, flen, grad_out, (tg, tl)
 
 
+def ctc_head_train_workspace(B, H, V, device):
+    return torch.empty(lib().halo_ctc_head_train_workspace_bytes(B, H, V), device=device, dtype=torch.uint8)
+
+
+def ctc_head_train_ticket(B, H, device):
+    """The zero-initialised words ``ctc_head_train`` keeps between calls (loss ticket, launch count, the slices' tagged partial logits)."""
+    return torch.zeros(lib().halo_ctc_head_train_ticket_words(B, H), device=device, dtype=torch.int32)
+
+
+def ctc_head_train(feats, weight, bias, drop, stream_id, input_lengths, targets, target_lengths, loss, ticket, dweight, dbias,
+                   workspace=None, want_lp=False, ks=5, stride=4, pad=3):
+    """The CTC head of a training step, forward and backward, in ONE launch (include/halo.h: halo_ctc_head_train; not in the exact-f32
+    mode).  feats [B,T,H] -> (d features [B,T,H], nll [B], feature_lengths [B], lp or None); the mean loss goes to ``loss``, the classifier's
+    gradients to dweight / dbias (deferred like ``ctc_head_bwd``'s).  ``ticket``: ``ctc_head_train_ticket(B, H, device)``, the caller's to keep between calls."""
+    _f32c(feats, 'features')
+    B, T, H = feats.shape
+    V = weight.shape[0]
+    tg = _i64c(targets, 'targets')
+    il, tl = _i64c(input_lengths, 'input_lengths'), _i64c(target_lengths, 'target_lengths')
+    need = lib().halo_ctc_head_train_ticket_words(B, H)
+    if ticket.numel() < need:
+        raise ValueError(f'ctc_head_train: ticket must hold {need} words (ctc_head_train_ticket), has {ticket.numel()}')
+    dev = feats.device
+    lp = torch.empty(B, T, V, device=dev, dtype=torch.float32) if want_lp else None
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    flen = torch.empty(B, device=dev, dtype=torch.int64)
+    dfeats = torch.empty_like(feats)
+    ws = workspace if workspace is not None else ctc_head_train_workspace(B, H, V, dev)
+    check(lib().halo_ctc_head_train(ptr(feats), ptr(weight), ptr(bias), drop.p, drop.seed, stream_id, drop.offset, drop.counter_ptr,
+                                    ptr(il), ks, stride, pad, ptr(tg), tg.stride(0), tg.shape[1], ptr(tl), ptr(lp) if want_lp else None,
+                                    ptr(nll), ptr(flen), ptr(loss), ptr(ticket), ptr(dfeats), ptr(dweight), ptr(dbias), ptr(ws),
+                                    B, T, H, V, _stream()), 'halo_ctc_head_train')
+    return dfeats, nll, flen, lp
+
+
 def ctc_head_workspace(B, H, V, device):
     return torch.empty(lib().halo_ctc_head_workspace_bytes(B, H, V), device=device, dtype=torch.uint8)
 

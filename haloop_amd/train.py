@@ -117,7 +117,7 @@ class LstmCtcTrainer:
 
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
-                 alias_loss=False, fused_head=True, dp_algo='rs_ag', rehearse_dp=False, gather_dtype='auto'):
+                 alias_loss=False, fused_head=True, head_one_launch=True, dp_algo='rs_ag', rehearse_dp=False, gather_dtype='auto'):
         """use_graph: True -- the step replays from HIP graphs (default); False -- the same launches issued eagerly; 'auto' (one process,
         accumulate == 1) -- both are timed over the first 53 steps and the faster way stays (``auto_choice``): with the two-layer launches a
         step is 13 launches, the host enqueues them in ~0.2 ms against ~0.47 ms on the GPU, and a replay costs ~15 us more than it saves.
@@ -147,6 +147,7 @@ class LstmCtcTrainer:
         with the lower layers' backward) and updates every parameter.  Both give the single-process step on the concatenated batch."""
         self.alias_loss = bool(alias_loss)
         self.fused_head = fused_head
+        self.head_one_launch = head_one_launch
         self.encoder, self.recognizer = encoder, recognizer
         self.accumulate = int(accumulate)
         self._micro = 0
@@ -293,6 +294,16 @@ class LstmCtcTrainer:
             # the whole head in three launches: dropout + Linear + log_softmax + lengths + CTC alpha + mean loss; then CTC beta +
             # log_softmax backward + d features + per-utterance d W / d b; then their fixed-order sum (csrc/head.hip)
             sid = _lib.HALO_STREAM_CLASSIFIER
+            if self.head_one_launch and _lib.get_math_mode() != 'f32':
+                # ... or, outside the exact-f32 mode, forward and backward in ONE launch (halo_ctc_head_train) + the deferred sum
+                if getattr(self, '_head_tws', None) is None or self._head_tws_dims != (B, H, V):
+                    self._head_tws, self._head_tws_dims = ops.ctc_head_train_workspace(B, H, V, x.device), (B, H, V)
+                    self._head_ticket = ops.ctc_head_train_ticket(B, H, x.device)
+                dfeats, _, _, _ = ops.ctc_head_train(feats, rec.classifier.weight, rec.classifier.bias, cdrop, sid, il, tg, tl, self.loss,
+                                                     self._head_ticket, gv['recognizer.classifier.weight'], gv['recognizer.classifier.bias'],
+                                                     workspace=self._head_tws)
+                return self._lstm_backward_top(x, y_sub, col, w_ih, w_hh, reserve, grads, drop, dfeats.view(B * Tp, H),
+                                               (B, T, F, Cc, H, Tp, L))
             lp, alpha, nll, flen, grad_out, (tg64, tl64) = ops.ctc_head_fwd(feats, rec.classifier.weight, rec.classifier.bias, cdrop, sid,
                                                                            il, tg, tl, self.loss, self._ticket)
             if getattr(self, '_head_ws', None) is None or self._head_ws_dims != (B, H, V):

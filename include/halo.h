@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 15
+#define HALO_ABI_VERSION 16
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -451,6 +451,25 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
                       long tg_stride, int S, const int64_t *target_lengths, const float *lp, const float *alpha,
                       const float *nll, const float *grad_out, float *dfeatures, float *dweight, float *dbias,
                       void *workspace, int B, int T, int H, int V, halo_stream_t stream);
+
+/* The same head, forward AND backward, in ONE launch -- for a caller that runs both every step (a training step: ha/loop.py:176-196
+ * calls the loss and loss.backward() back to back).  replaces: halo_ctc_head_fwd + halo_ctc_head_bwd, i.e. ha/recognizer.py:43-46,61-73
+ * and their autograd backward.  Same shape limits (halo_ctc_head_supported); products on split-bf16 MFMA (fp32-grade: the `bf16x3`
+ * arithmetic), so HALO_ENOTSUP in the exact-f32 mode -- the caller then uses the two launches above.  grid = B x slices workgroups,
+ * the slices of an utterance (H/slices feature columns each) exchanging their partial logits once; alpha and beta run side by side.
+ *   lp [B,T,V]: optional (NULL: not written); nll [B], feature_lengths [B], loss out as halo_ctc_head_fwd;
+ *   dfeatures [B,T,H], dweight [V,H], dbias [V] out as halo_ctc_head_bwd (the partials' sum may be deferred the same way);
+ *   workspace: halo_ctc_head_train_workspace_bytes(); ticket: halo_ctc_head_train_ticket_words(B, H) device uint32 words (8-byte
+ *   aligned), all 0 before the first call, the caller's to keep between calls: the loss ticket, the count of launches, and the
+ *   slices' partial logits, each stored with that count as its tag.
+ * A slice that never arrives (0.2 s) makes the loss NaN instead of hanging the launch. */
+size_t halo_ctc_head_train_workspace_bytes(int B, int H, int V);
+size_t halo_ctc_head_train_ticket_words(int B, int H);
+int halo_ctc_head_train(const float *features, const float *weight, const float *bias, float p_drop, uint64_t seed,
+                        uint32_t stream_id, uint32_t offset, const uint32_t *offset_dev, const int64_t *input_lengths, int ks,
+                        int stride, int pad, const int64_t *targets, long tg_stride, int S, const int64_t *target_lengths,
+                        float *lp, float *nll, int64_t *feature_lengths, float *loss, uint32_t *ticket, float *dfeatures,
+                        float *dweight, float *dbias, void *workspace, int B, int T, int H, int V, halo_stream_t stream);
 
 /* Greedy decode.   replaces: logits.max(-1) + unique_consecutive + drop-0 loop, recognizer.py:51-55
  *   lp [N,T,C] contiguous; alignments [N,T] int64, scores [N,T] f32, hyp [N,T] int64 (first

@@ -66,6 +66,68 @@ def test_fused_head_equals_separate_operators(B, T_in, H, V, S, p):
             assert not np.isfinite(loss.item())
 
 
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('B,T_in,H,V,S,p', [(64, 80, 1024, 32, 10, 0.2), (3, 41, 64, 9, 4, 0.0), (5, 120, 256, 32, 12, 0.3), (1, 9, 128, 5, 1, 0.0),
+                                            (128, 80, 1024, 32, 10, 0.2), (256, 80, 1024, 32, 10, 0.2), (1, 80, 1024, 32, 10, 0.2),
+                                            (40, 60, 1536, 29, 7, 0.1)])
+def test_head_in_one_launch_equals_the_two_launches(B, T_in, H, V, S, p, mode):
+    """halo_ctc_head_train (forward + backward of the head in one launch: slices of an utterance exchanging partial logits, split-bf16
+    products, alpha and beta side by side) against the two exact-f32 launches it replaces, at fp32-grade tolerances: 8 / 4 / 2 / 1
+    slices per utterance, ragged lengths, an infeasible and an empty target, with and without classifier dropout; run three times
+    over the same ticket words (each launch's partial sums carry its own tag)."""
+    from haloop_amd import _lib, ops
+    _lib.lib(); _lib.lend_scratch()
+    T = (T_in + 6 - 5) // 4 + 1
+    assert ops.ctc_head_supported(T, H, V, S)
+    g = torch.Generator().manual_seed(B * 7 + H)
+    feats = torch.randn(B, T, H, generator=g).relu().to(DEV)
+    W = (torch.randn(V, H, generator=g) / H ** 0.5).to(DEV)
+    b = (torch.randn(V, generator=g) * 0.1).to(DEV)
+    il = torch.tensor([T_in - 3 * (i % 5) for i in range(B)], dtype=torch.int64)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+    if B >= 3:
+        il[1] = 9; tg[1] = 1; tl[1] = min(S, 4)
+        tl[2] = 0
+    il, tg, tl = il.to(DEV), tg.to(DEV), tl.to(DEV)
+    drop = ops.Dropout(p, 0x1234ABCD5678, 5) if p > 0 else ops.NO_DROPOUT
+    sid = _lib.HALO_STREAM_CLASSIFIER
+    loss0 = torch.zeros((), device=DEV)
+    t0 = torch.zeros(1, device=DEV, dtype=torch.int32)
+    dW0, db0 = torch.empty_like(W), torch.empty_like(b)
+    lp0, alpha0, nll0, flen0, go0, (tg64, tl64) = ops.ctc_head_fwd(feats, W, b, drop, sid, il, tg, tl, loss0, t0)
+    dfeats0 = ops.ctc_head_bwd(feats, W, drop, sid, flen0, tg64, tl64, lp0, alpha0, nll0, go0, dW0, db0)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        loss = torch.full((), -1.0, device=DEV)
+        ticket = ops.ctc_head_train_ticket(B, H, DEV)
+        dW, db = torch.empty_like(W), torch.empty_like(b)
+        for rep in range(3):
+            dfeats, nll, flen, lp = ops.ctc_head_train(feats, W, b, drop, sid, il, tg, tl, loss, ticket, dW, db, want_lp=True)
+            assert ticket[:2].tolist() == [0, rep + 1]                   # the loss ticket back at zero, the launches counted
+            assert torch.equal(flen, flen0)
+            np.testing.assert_allclose(lp.cpu().numpy(), lp0.cpu().numpy(), atol=3e-5)
+            fin = torch.isfinite(nll0).cpu().numpy()
+            assert np.array_equal(np.isfinite(nll.cpu().numpy()), fin)
+            np.testing.assert_allclose(nll.cpu().numpy()[fin], nll0.cpu().numpy()[fin], rtol=2e-5, atol=2e-5)
+            if fin.all():
+                np.testing.assert_allclose(loss.item(), loss0.item(), rtol=2e-5)
+                for k, got, ref in (('dW', dW, dW0), ('db', db, db0), ('dfeats', dfeats, dfeats0)):
+                    ref = ref.cpu().numpy()
+                    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=3e-4, atol=1e-6 + 3e-5 * np.abs(ref).max(), err_msg=k)
+            else:
+                assert not np.isfinite(loss.item())
+                ok = fin[:, None, None] & np.ones((1, T, H), dtype=bool)
+                np.testing.assert_allclose(dfeats.cpu().numpy()[ok], dfeats0.cpu().numpy()[ok], rtol=3e-4,
+                                           atol=1e-6 + 3e-5 * np.abs(dfeats0.cpu().numpy()[ok]).max())
+        _lib.set_math_mode('f32')
+        with pytest.raises(Exception):                       # the exact-f32 mode keeps its exact-f32 launches
+            ops.ctc_head_train(feats, W, b, drop, sid, il, tg, tl, loss, ticket, dW, db)
+    finally:
+        _lib.set_math_mode(prev)
+
+
 def test_fused_head_refuses_unsupported_shapes():
     from haloop_amd import ops
     assert not ops.ctc_head_supported(40, 1024, 32, 10)      # more than 32 frames
