@@ -67,6 +67,7 @@ SIGNATURES = {
     'halo_lstm_persistent_eligible': (_i, [_i, _i]),
     'halo_set_lstm_persistent2': (_i, [_i]),
     'halo_set_lstm_interleave': (_i, [_i]),
+    'halo_set_gemm256': (_i, [_i]),
     'halo_set_lstm_bwd_mid_event': (_i, [_vp]),
     'halo_lstm_bwd_mid_event_recorded': (_i, []),
     'halo_set_lstm_expect_backward': (_i, [_i]),
@@ -240,6 +241,10 @@ def set_lstm_bwd_mid_event(event):
     """event: a torch.cuda.Event that has been recorded at least once (so that its handle exists), or None.  halo_lstm_bwd records it
     behind the launch that stores the top LSTM layer's weight gradients (include/halo.h)."""
     check(lib().halo_set_lstm_bwd_mid_event(None if event is None else C.c_void_p(event.cuda_event)), 'halo_set_lstm_bwd_mid_event')
+
+
+def set_gemm256(on):
+    check(lib().halo_set_gemm256(1 if on else 0), 'halo_set_gemm256')
 
 
 def set_lstm_interleave(on):

@@ -76,6 +76,21 @@ int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int
 int halo_gemm_bf16x3_tiled_nsplit_carry(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                         const void *rA, const void *rB, int rM, int rN, int rK, float *rslab, int want, int *slices,
                                         float *sumsq_part, int *sumsq_parts, hipStream_t st);
+// up to three plain-sum products C [| C2] = A x B^T over tiled operand images in ONE launch of 256 x 256 tiles (gemm256.hip; single-pass bf16
+// only).  kslices > 1: K-slice s goes to C + s * slab_stride.  On return tiles = the workgroups the problem used (= sumsq partials written,
+// when sumsq != NULL and kslices == 1) and kslices = the slices actually cut.
+struct HaloG256Problem {
+    const void *A, *B;
+    int M, N, K;
+    float *C; int ldc;
+    int n_split; float *C2; int ldc2;      // n_split == N: one output
+    int kslices; long slab_stride;
+    float *sumsq;
+    int tiles;
+};
+int halo_gemm256_enabled();
+int halo_gemm256_fits(const HaloG256Problem &q);
+int halo_gemm256_launch(HaloG256Problem *probs, int n, hipStream_t st);
 int halo_math_mode();
 int halo_lstm_fusion();   // 1: run multi-layer LSTMs as layer-diagonal fused launches (halo_set_lstm_fusion)   // 0 = exact f32 MFMA, 1 = split-bf16 (3-pass) for the large LSTM GEMMs
 

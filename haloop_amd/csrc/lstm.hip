@@ -1806,6 +1806,32 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             // (and each launch leaves the squared-norm partials of the gradients it stores when the caller collects them)
             auto sumsq_slot = [&](int tiles) { return ctx.grad_sumsq && ctx.grad_sumsq_n + tiles <= ctx.grad_sumsq_cap ? ctx.grad_sumsq + ctx.grad_sumsq_n : nullptr; };
             int parts = 0;
+            // both layers' weight gradients (and the input gradient's K-slices) as ONE launch of 256 x 256 tiles (gemm256.hip): 208 + 48
+            // workgroups at H = 1024, one per CU, where the 128 x 128-tile kernel below runs two launches of 512 + 288 (+ 88 carried)
+            HaloG256Problem gp[3] = {};
+            gp[0].A = img_gT1; gp[0].B = hT1; gp[0].M = 4 * H; gp[0].N = 2 * H; gp[0].K = T * B;
+            gp[0].C = dw_hh[hi]; gp[0].ldc = H; gp[0].n_split = H; gp[0].C2 = dw_ih[hi]; gp[0].ldc2 = H; gp[0].kslices = 1;
+            gp[1].A = img_gT; gp[1].B = hT0; gp[1].M = 4 * H; gp[1].N = H + in_lo_dim; gp[1].K = T * B;
+            gp[1].C = dw_hh[lo]; gp[1].ldc = H; gp[1].n_split = H; gp[1].C2 = dw_ih[lo]; gp[1].ldc2 = in_lo_dim; gp[1].kslices = 1;
+            gp[2].A = img_g; gp[2].B = img_wT; gp[2].M = T * B; gp[2].N = in_lo_dim; gp[2].K = 4 * H;
+            gp[2].C = din_out; gp[2].ldc = in_lo_dim; gp[2].n_split = in_lo_dim; gp[2].kslices = ctx.lstm_dx_slabs; gp[2].slab_stride = (long)T * B * in_lo_dim;
+            const int ngp = dx_slices ? 3 : 2;
+            bool all256 = halo_gemm256_enabled() != 0;
+            for (int i = 0; i < ngp && all256; ++i) all256 = halo_gemm256_fits(gp[i]) != 0;
+            if (all256) {
+                const int t0 = ((4 * H + 255) / 256) * ((2 * H + 255) / 256), t1 = ((4 * H + 255) / 256) * ((H + in_lo_dim + 255) / 256);
+                float *slot2 = sumsq_slot(t0 + t1);
+                gp[0].sumsq = slot2; gp[1].sumsq = slot2 ? slot2 + t0 : nullptr;
+                HALO_TRY(halo_gemm256_launch(gp, ngp, st));
+                if (slot2) { ctx.grad_sumsq_n += gp[0].tiles + gp[1].tiles; ctx.grad_sumsq_cover |= 3u; }
+                if (ctx.bwd_mid_event && hipEventRecord(ctx.bwd_mid_event, st) == hipSuccess) ++ctx.bwd_mid_recorded;
+                if (dx_slices) ctx.lstm_dx_slabs_left = gp[2].kslices;
+                else if (need_din) {
+                    const DropoutCfg ddrop = make_dropout(lo > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(lo > 0 ? lo - 1 : 0), offset,
+                                                          offset_dev);
+                    HALO_TRY(halo_gemm_bf16x3_tiled(img_g, img_wT, T * B, in_lo_dim, 4 * H, din_out, in_lo_dim, nullptr, nullptr, 0, &ddrop, st));
+                }
+            } else {
             float *slot = sumsq_slot(((4 * H + 63) / 64) * ((2 * H + 127) / 128));       // (room for the most workgroups the launch may use: half-height tiles)
             HALO_TRY(halo_gemm_bf16x3_tiled_nsplit_carry(img_gT1, hT1, 4 * H, 2 * H, T * B, dw_hh[hi], H, H, dw_ih[hi], H,
                                                          dx_slices ? img_g : nullptr, img_wT, T * B, in_lo_dim, 4 * H, din_out, ctx.lstm_dx_slabs,
@@ -1829,6 +1855,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             HALO_TRY(halo_gemm_bf16x3_tiled_nsplit_carry(img_gT, hT0, 4 * H, H + in_lo_dim, T * B, dw_hh[lo], H, H, dw_ih[lo], in_lo_dim, nullptr,
                                                          nullptr, 0, 0, 0, nullptr, 0, nullptr, slot, slot ? &parts : nullptr, st));
             if (slot) { ctx.grad_sumsq_n += parts; ctx.grad_sumsq_cover |= 2u; }
+            }
         } else {
             HALO_TRY(lstm_bwd_layer_tail(x, w_ih, reserve, hi, in0, T, B, H, L, p_drop, seed, offset, offset_dev, false, emit1, img_g,
                                          emit1 ? img_gT1 : img_gT, img_hT, img_inT, img_wT, bias_part1, din, dx, dw_ih, dw_hh, db_ih, db_hh, false, st));

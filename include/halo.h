@@ -316,6 +316,11 @@ int halo_set_lstm_persistent2(int on);
  * buffers, images and results as those launches but for the order in which the two tiles' bias-gradient rows are added.  On by
  * default (HALO_LSTM_INTERLEAVE=0 / halo_set_lstm_interleave(0): consecutive launches).  Per context. */
 int halo_set_lstm_interleave(int on);
+/* The two-layer launches' weight-gradient products on 256 x 256 workgroup tiles (csrc/gemm256.h): in single-pass `bf16` arithmetic both
+ * layers' dW_hh | dW_ih and the K-slices of the caller's input gradient run as ONE launch of one workgroup per CU instead of two launches
+ * of the 128 x 128-tile kernel.  Same operand images, same sums up to the order of the k-blocks' additions inside a tile.  On by default
+ * (HALO_GEMM256=0 / halo_set_gemm256(0): the 128 x 128-tile launches).  Process-wide. */
+int halo_set_gemm256(int on);
 /* Data-parallel overlap hook.  event (a hipEvent_t, or NULL: off): halo_lstm_bwd records it on its stream right behind the launch that
  * stores the TOP layer's weight gradients (dw_ih[L-1], dw_hh[L-1]) when the call covers the top two layers as one two-layer launch --
  * the point from which a caller's side stream may start reducing those gradients over the ranks (ha/attention_loop.py:154:

@@ -668,6 +668,63 @@ def test_top_pair_of_a_deeper_stack_runs_as_one_launch(hal, math_mode, T, B, in0
 
 
 @pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+@pytest.mark.parametrize('T,B,in0,H,L,p_drop,with_state', [
+    (21, 64, 128, 1024, 2, 0.2, False),     # the benchmark's grid: 128 + 80 tiles of 256 x 256
+    (6, 16, 128, 768, 2, 0.25, False),      # H = 768: the outputs are cut at column 768 = 3 tiles; the lower layer's last tile is half empty
+    (7, 5, 40, 256, 2, 0.0, True),          # 40 input features: the second output is 40 columns wide, its row block the image's last
+    (5, 32, 128, 512, 3, 0.0, True),        # the top pair of a deeper stack
+    (43, 128, 128, 1024, 2, 0.2, False),    # K = 5504: the interleaved launches' images
+])
+def test_weight_gradients_on_256_tiles_equal_the_128_tile_launches(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
+    """csrc/gemm256.h (both layers' dW_hh | dW_ih in ONE launch of 256 x 256 tiles) against the two 128 x 128-tile launches it replaces: the
+    same operand images, the same bf16 products, fp32 sums in a different order."""
+    lib = hal['lib']
+    a, st_a = _lstm_case(hal, T, B, in0, H, L, p_drop, 9, with_state)
+    lib.set_gemm256(False)
+    try:
+        b, st_b = _lstm_case(hal, T, B, in0, H, L, p_drop, 9, with_state)
+    finally:
+        lib.set_gemm256(True)
+    assert st_a == (0, 0) and st_b == (0, 0)
+    for k in a:
+        if k.startswith('dw_'):
+            scale = float(b[k].abs().max()) + 1e-12
+            np.testing.assert_allclose(a[k].numpy() / scale, b[k].numpy() / scale, rtol=0, atol=2e-6, err_msg=k)
+        else:
+            assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
+def test_training_step_with_the_input_gradient_slices_in_the_256_tile_launch(hal, math_mode):
+    """The trainer's step hands the conv backward K-slices of the LSTM's input gradient (halo_set_lstm_dx_slabs): with gemm256 they ride
+    as the third problem of the one launch.  Two steps from the same weights, with and without it, agree to summation order."""
+    from oracle import cpu_ref
+    from haloop_amd.train import LstmCtcTrainer
+    F_, C, H, L, V, B, T, S = 80, 128, 1024, 2, 32, 64, 80, 10
+    res = []
+    for on in (True, False):
+        hal['lib'].set_gemm256(on)
+        try:
+            enc_p, rec_p = cpu_ref.make_params(F_, C, H, L, V, 7)
+            enc = hal['rnn'].Encoder(F_, C, H, num_layers=L); rec = hal['recognizer'].TemporalClassifier(H, V)
+            enc.load_state_dict(enc_p); rec.load_state_dict(rec_p)
+            enc.to(DEV).train(); rec.to(DEV).train()
+            tr = LstmCtcTrainer(enc, rec, lr=1e-3, use_graph=False, seed=5)
+            for step in range(2):
+                batch = tuple(t.to(DEV) for t in cpu_ref.synthetic_batch(B, T, F_, V, S, 300 + step))
+                loss = tr.step(*batch)
+            tr.check_status()
+            hal['lib'].set_status_word(None)
+            res.append((loss.item(), tr.grad_norm.item(), {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}))
+        finally:
+            hal['lib'].set_gemm256(True)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-4)
+    for k in res[0][2]:
+        np.testing.assert_allclose(res[0][2][k].numpy(), res[1][2][k].numpy(), atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('math_mode', ['bf16'], indirect=True)
 @pytest.mark.parametrize('use_graph', [True, False])
 def test_recognizer_keeps_packed_weights_only_while_the_weights_stand(hal, math_mode, use_graph):
     """infer.LstmCtcRecognizer at the two-layer launch's shape: the packed weight images stay in the recognizer's reserve between calls
