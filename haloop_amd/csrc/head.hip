@@ -551,37 +551,45 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
         // the slices' partial sums meet in global memory.  Every value travels as the 8-byte pair (value, epoch of this launch): one
         // write-through store per pair, and a reader that finds the epoch has the value -- no drain, no counter, no second round trip
         // (cdna_hip_programming.md Guideline 16: data and flag in one naturally aligned store).  Everyone adds the SL values in slice order.
+        // Only the frames below T travel; a thread whose element lies in a padding row polls row 0's element of its column instead (the
+        // same few lines as wave 0's lanes) and stores nothing.
         const __amdgpu_buffer_rsrc_t prs = make_rsrc(p.ticket + 2);
-        const int slot = (n * SL * 1024 + tid) * 8;
+        int slot[2];
+        bool need[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            need[q] = (tid >> 5) + 16 * q < T;
+            slot[q] = (n * SL * 1024 + (need[q] ? tid + TNT * q : (tid & 31))) * 8;
             u32x2 pr = {__builtin_bit_cast(unsigned, sum[q]), epoch};
-            __builtin_amdgcn_raw_buffer_store_b64(pr, prs, slot + (y * 1024 + TNT * q) * 8, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(pr, prs, need[q] ? slot[q] + y * 8192 : -16, 0, 16);      // (-16: out of range, dropped)
         }
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        u32x2 got[8][2];
-        bool ok = false;
-        while (!ok) {
+        auto gather = [&](auto ns_c) {
+            constexpr int NS = decltype(ns_c)::value;
+            u32x2 got[NS][2];
+            bool ok = false;
+            while (!ok) {
 #pragma unroll
-            for (int yy = 0; yy < 8; ++yy) {
+                for (int yy = 0; yy < NS; ++yy)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    got[yy][q] = __builtin_amdgcn_raw_buffer_load_b64(prs, slot + (min(yy, SL - 1) * 1024 + TNT * q) * 8, 0, 16);
+                    for (int q = 0; q < 2; ++q) got[yy][q] = __builtin_amdgcn_raw_buffer_load_b64(prs, slot[q] + min(yy, SL - 1) * 8192, 0, 16);
+                ok = true;
+#pragma unroll
+                for (int yy = 0; yy < NS; ++yy) ok = ok && got[yy][0][1] == epoch && got[yy][1][1] == epoch;
+                if (!ok && __builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) { s_fail = 1; break; }
             }
-            ok = true;
+            sum[0] = sum[1] = 0.f;
 #pragma unroll
-            for (int yy = 0; yy < 8; ++yy) ok = ok && got[yy][0][1] == epoch && got[yy][1][1] == epoch;
-            if (!ok && __builtin_amdgcn_s_memrealtime() - t0 > SPIN_TIMEOUT_TICKS) { s_fail = 1; break; }
-        }
-        sum[0] = sum[1] = 0.f;
+            for (int yy = 0; yy < NS; ++yy)
 #pragma unroll
-        for (int yy = 0; yy < 8; ++yy) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned bits = got[yy][q][0];
-                sum[q] += yy < SL ? __builtin_bit_cast(float, bits) : 0.f;
-            }
-        }
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned bits = got[yy][q][0];
+                    sum[q] += yy < SL ? __builtin_bit_cast(float, bits) : 0.f;
+                }
+        };
+        if (SL <= 2) gather(std::integral_constant<int, 2>{});
+        else if (SL <= 4) gather(std::integral_constant<int, 4>{});
+        else gather(std::integral_constant<int, 8>{});
     }
     HST(0, 3);
     const int tj = tid & 31;
@@ -617,49 +625,55 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
     }
     __syncthreads();
     HST(0, 4);
-    // ---- the two lattice recursions side by side: alpha in wave 0 (as ctc_head_fwd_kernel), beta in wave 1 (as ctc_head_bwd_kernel) ----
+    // ---- the two lattice recursions side by side: alpha in wave 0, beta in wave 1, one lattice state per lane (the recursions of
+    //      ctc_head_fwd_kernel / ctc_head_bwd_kernel).  A step is a dependent chain, so it is kept short: values in log2 units (v_exp_f32 /
+    //      v_log_f32 are base-2: no scaling inside the chain), the lane's masks folded into -inf operands instead of branches (the clamped
+    //      maximum keeps -inf - -inf out: every term then underflows to 0 and log2(0) = -inf), only the frames below the feature length ----
+    constexpr float L2E = 1.4426950408889634f, LN2 = 0.6931471805599453f, NEG = -3.0e38f;
+    auto lse3 = [](float x0, float x1, float x2) {
+        const float m = fmaxf(fmaxf(fmaxf(x0, x1), x2), NEG);
+        return m + __builtin_amdgcn_logf((__builtin_amdgcn_exp2f(x0 - m) + __builtin_amdgcn_exp2f(x1 - m)) + __builtin_amdgcn_exp2f(x2 - m));
+    };
     if (wave == 0) {
         const int lab = lab_s[lane];
         const int lab2 = __shfl_up(lab, 2, 64);
-        const bool can_skip = lane >= 2 && lab != 0 && lab != lab2;
-        const int tlast = il - 1, slast = 2 * tl, sprev = tl > 0 ? 2 * tl - 1 : -1;
-        float prev = (il > 0 && lane < states && lane < 2) ? tile[0][lab] : -INFINITY;
+        const bool skip = lane >= 2 && lab != 0 && lab != lab2, live = lane < states;
+        const int slast = 2 * tl, sprev = tl > 0 ? 2 * tl - 1 : slast;
+        float prev = (il > 0 && live && lane < 2) ? tile[0][lab] * L2E : -INFINITY;
         al[0][lane] = prev;
-        float ra = 0.f, rb = 0.f;
-        if (tlast == 0) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
-        float em = tile[min(1, T - 1)][lab];
-        for (int t = 1; t < T; ++t) {
-            const float p1 = wave_up1(prev), p2 = wave_up1(p1);
+        float em = tile[min(1, T - 1)][lab] * L2E;
+        for (int t = 1; t < il; ++t) {
+            float p1 = wave_up1(prev), p2 = wave_up1(p1);
+            p1 = lane >= 1 ? p1 : -INFINITY;
+            p2 = skip ? p2 : -INFINITY;
             const float e = em;
-            em = tile[min(t + 1, T - 1)][lab];
-            float v = -INFINITY;
-            if (t < il && lane < states) {
-                if (lane == 0) v = prev + e;
-                else v = log_add_exp_fast3(prev, p1, (lane >= 2 && can_skip) ? p2 : -INFINITY) + e;
-            }
+            em = tile[min(t + 1, T - 1)][lab] * L2E;
+            const float v = live ? lse3(prev, p1, p2) + e : -INFINITY;
             prev = v;
             al[t][lane] = v;
-            if (t == tlast) { ra = __shfl(prev, slast, 64); rb = sprev >= 0 ? __shfl(prev, sprev, 64) : -INFINITY; }
         }
-        if (lane == 0) s_nll = il == 0 ? (tl == 0 ? 0.f : INFINITY) : -log_add_exp_fast2(ra, rb);
+        if (lane == 0) {
+            float out = tl == 0 ? 0.f : INFINITY;                 // no frames: only the empty target is reachable
+            if (il > 0) {
+                const float ra = al[il - 1][slast], rb = tl > 0 ? al[il - 1][sprev] : -INFINITY;
+                out = -lse3(ra, rb, -INFINITY) * LN2;
+            }
+            s_nll = out;
+        }
     } else if (wave == 1 && il > 0) {
         const int lab = lab_s[lane];
         const int labn2 = __shfl_down(lab, 2, 64);
-        const bool can_skip = lane + 2 < states && labn2 != 0 && labn2 != lab;
-        float nxt = -INFINITY;
-        float em = tile[il - 1][lab];
-        for (int t = il - 1; t >= 0; --t) {
-            const float n1 = wave_down1(nxt), n2 = wave_down1(n1);
+        const bool skip = lane + 2 < states && labn2 != 0 && labn2 != lab, live = lane < states, has1 = lane + 1 < states;
+        float nxt = (lane == states - 1 || lane == states - 2) ? tile[il - 1][lab] * L2E : -INFINITY;
+        be[il - 1][lane] = nxt;
+        float em = tile[max(il - 2, 0)][lab] * L2E;
+        for (int t = il - 2; t >= 0; --t) {
+            float n1 = wave_down1(nxt), n2 = wave_down1(n1);
+            n1 = has1 ? n1 : -INFINITY;
+            n2 = skip ? n2 : -INFINITY;
             const float e = em;
-            em = tile[max(t - 1, 0)][lab];
-            float v = -INFINITY;
-            if (lane < states) {
-                if (t == il - 1) {
-                    if (lane == states - 1 || lane == states - 2) v = e;
-                } else {
-                    v = log_add_exp_fast3(nxt, lane + 1 < states ? n1 : -INFINITY, can_skip ? n2 : -INFINITY) + e;
-                }
-            }
+            em = tile[max(t - 1, 0)][lab] * L2E;
+            const float v = live ? lse3(nxt, n1, n2) + e : -INFINITY;
             be[t][lane] = v;
             nxt = v;
         }
@@ -674,10 +688,10 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
     //      e[s] = exp(alpha + beta - their maximum over the states) with the lane = the state (wave w takes frames w, w + 8, ...), the blank's
     //      share summed in the wave; then thread (t, c) adds the e[s] of the states that carry class c, found through a bit mask over the
     //      target positions -- no loop over all states, no label fetched twice ----
-    for (int t = wave; t < il; t += TNW) {
+    for (int t = wave; t < il; t += TNW) {                       // (alpha, beta: log2 units)
         const float x = lane < states ? al[t][lane] + be[t][lane] : -INFINITY;
         const float m = wave_max(x);
-        const float e = x > -INFINITY ? __expf(x - m) : 0.f;
+        const float e = x > -INFINITY ? __builtin_amdgcn_exp2f(x - m) : 0.f;
         al[t][lane] = e;
         const float blank = wave_sum((lane & 1) ? 0.f : e);
         if (lane == 0) { be[t][64] = m; al[t][64] = blank; }
@@ -695,7 +709,7 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
                     sm = 0.f;
                     for (unsigned bits = cmask[c]; bits; bits &= bits - 1u) sm += al[t][2 * (__builtin_ctz(bits)) + 1];
                 }
-                const float lcab = sm > 0.f ? be[t][64] + __logf(sm) : -INFINITY;
+                const float lcab = sm > 0.f ? (be[t][64] + __builtin_amdgcn_logf(sm)) * LN2 : -INFINITY;
                 const float l = tile[t][c];
                 g = (__expf(l) - __expf(lcab + nll - l)) * go;
             }

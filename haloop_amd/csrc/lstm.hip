@@ -1286,6 +1286,13 @@ int lstm_bwd_layer_tail(const float *x, const float *const *w_ih, float *reserve
     if (tiled && H % 128 == 0 && img_inT == img_hT + halo_tiled_image_bytes(H, T * B) && pair_dw_enabled()) {
         // dW_hh | dW_ih = dG^T x (h_prev^T stacked on in^T)^T: ONE launch over the two images, which lie one after the other
         // (512 tiles at H = 1024 instead of 2 x 256: one launch's fill and drain instead of two)
+        HaloG256Problem gp = {};
+        gp.A = img_gT; gp.B = img_hT; gp.M = 4 * H; gp.N = H + in_dim; gp.K = T * B;
+        gp.C = dw_hh[l]; gp.ldc = H; gp.n_split = H; gp.C2 = dw_ih[l]; gp.ldc2 = in_dim; gp.kslices = 1;
+        // (on 256 x 256 tiles -- gemm256.hip, one workgroup per CU -- when its rounds of 256 tiles are at least 55 % full)
+        const long t256 = (long)((4 * H + 255) / 256) * ((H + in_dim + 255) / 256);
+        if (halo_gemm256_enabled() && halo_gemm256_fits(gp) && 100 * t256 >= 55 * ((t256 + 255) / 256) * 256) rc = halo_gemm256_launch(&gp, 1, side);
+        else
         rc = halo_gemm_bf16x3_tiled_nsplit(img_gT, img_hT, 4 * H, H + in_dim, T * B, dw_hh[l], H, H, dw_ih[l], in_dim, side);
     } else if (tiled) {
         rc = halo_gemm_bf16x3_tiled(img_gT, img_hT, 4 * H, H, T * B, dw_hh[l], H, nullptr, nullptr, 0, nullptr, side);

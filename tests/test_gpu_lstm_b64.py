@@ -674,6 +674,7 @@ def test_top_pair_of_a_deeper_stack_runs_as_one_launch(hal, math_mode, T, B, in0
     (7, 5, 40, 256, 2, 0.0, True),          # 40 input features: the second output is 40 columns wide, its row block the image's last
     (5, 32, 128, 512, 3, 0.0, True),        # the top pair of a deeper stack
     (43, 128, 128, 1024, 2, 0.2, False),    # K = 5504: the interleaved launches' images
+    (9, 32, 128, 1536, 2, 0.2, False),      # H = 1536: one layer per launch; 288 and 168 tiles of 256 x 256 (the second round of the first: 32)
 ])
 def test_weight_gradients_on_256_tiles_equal_the_128_tile_launches(hal, math_mode, T, B, in0, H, L, p_drop, with_state):
     """csrc/gemm256.h (both layers' dW_hh | dW_ih in ONE launch of 256 x 256 tiles) against the two 128 x 128-tile launches it replaces: the

@@ -116,6 +116,30 @@ int main(int argc, char **argv) {
         }
         printf("%-44s best %.2f us (%.0f TFLOP/s), mean %.2f us\n", name, best * 1e3, flops / (best * 1e-3) * 1e-12, sum / 4 * 1e3);
     };
+    {   // the four-wave kernel: verify, then time
+        for (size_t q = 0; q < probs.size(); ++q) CK(hipMemset(dC[q], 0xff, (size_t)probs[q].M * probs[q].N * probs[q].kslices * 4));
+        CK(halo_g256::launch_w4<0>(a, first, 0));
+        CK(hipDeviceSynchronize());
+        for (size_t q = 0; q < probs.size(); ++q) {
+            const Prob &pr = probs[q];
+            std::vector<float> c((size_t)pr.M * pr.N * pr.kslices), ref((size_t)pr.M * pr.N);
+            CK(hipMemcpy(c.data(), dC[q], c.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ref.data(), dRef[q], ref.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0, scale = 0;
+            for (size_t i = 0; i < ref.size(); ++i) {
+                double s = 0;
+                for (int k = 0; k < pr.kslices; ++k) s += c[(size_t)k * ref.size() + i];
+                worst = fmax(worst, fabs(s - ref[i]));
+                scale = fmax(scale, fabs((double)ref[i]));
+            }
+            printf("4 waves: problem %zu max |diff| %.3e of %.3e %s\n", q, worst, scale, worst <= 2e-5 * scale * sqrt((double)pr.K) ? "ok" : "MISMATCH");
+        }
+    }
+    timeit("4 waves: the product", [&] { return halo_g256::launch_w4<0>(a, first, 0); });
+    timeit("4 waves: no epilogue stores", [&] { return halo_g256::launch_w4<8>(a, first, 0); });
+    timeit("4 waves: no prefetch", [&] { return halo_g256::launch_w4<1 | 8>(a, first, 0); });
+    timeit("4 waves: no fragment reads", [&] { return halo_g256::launch_w4<4 | 8>(a, first, 0); });
+    timeit("4 waves: neither", [&] { return halo_g256::launch_w4<1 | 4 | 8>(a, first, 0); });
     timeit("the product", [&] { return halo_g256::launch<0>(a, first, 0); });
     timeit("no epilogue stores", [&] { return halo_g256::launch<8>(a, first, 0); });
     timeit("no prefetch issues (and no wait)", [&] { return halo_g256::launch<1 | 8>(a, first, 0); });
