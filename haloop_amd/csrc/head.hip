@@ -777,8 +777,8 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
     };
     if (wave < njobs) run_job(wave, pre0);
     if (wave + TNW < njobs) run_job(wave + TNW, pre1);
-    for (int jb = wave + 2 * TNW; jb < njobs; jb += TNW) {
-        load_job(jb, pre0);
+    for (int jb = wave + 2 * TNW; jb < njobs; jb += TNW) {       // (more tiles than two per wave: batches above 64 rows; a rotation that
+        load_job(jb, pre0);                                      //  requests two tiles ahead measured slower at every batch size)
         run_job(jb, pre0);
     }
     if (wave == TNW - 1 && lane < V && y == 0) {

@@ -1829,9 +1829,17 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
                 const int t0 = ((4 * H + 255) / 256) * ((2 * H + 255) / 256), t1 = ((4 * H + 255) / 256) * ((H + in_lo_dim + 255) / 256);
                 float *slot2 = sumsq_slot(t0 + t1);
                 gp[0].sumsq = slot2; gp[1].sumsq = slot2 ? slot2 + t0 : nullptr;
-                HALO_TRY(halo_gemm256_launch(gp, ngp, st));
+                if (ctx.bwd_mid_event) {
+                    // a data-parallel caller starts reducing the TOP layer's gradients behind this event (halo_set_lstm_bwd_mid_event): its
+                    // product goes first, alone (128 tiles, ~23 us), the lower layer's and the input gradient's behind it -- 3 us more
+                    // compute than the one launch, and the exchange starts 20 us earlier
+                    HALO_TRY(halo_gemm256_launch(gp, 1, st));
+                    if (hipEventRecord(ctx.bwd_mid_event, st) == hipSuccess) ++ctx.bwd_mid_recorded;
+                    HALO_TRY(halo_gemm256_launch(gp + 1, ngp - 1, st));
+                } else {
+                    HALO_TRY(halo_gemm256_launch(gp, ngp, st));
+                }
                 if (slot2) { ctx.grad_sumsq_n += gp[0].tiles + gp[1].tiles; ctx.grad_sumsq_cover |= 3u; }
-                if (ctx.bwd_mid_event && hipEventRecord(ctx.bwd_mid_event, st) == hipSuccess) ++ctx.bwd_mid_recorded;
                 if (dx_slices) ctx.lstm_dx_slabs_left = gp[2].kslices;
                 else if (need_din) {
                     const DropoutCfg ddrop = make_dropout(lo > 0 ? p_drop : 0.f, seed, HALO_STREAM_LSTM_LAYER0 + (uint32_t)(lo > 0 ? lo - 1 : 0), offset,
