@@ -1775,6 +1775,9 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         a.img_cols1 = emit1 ? img_gT1 : nullptr;
         a.bias_part0 = emit0 ? bias_part0 : nullptr;
         a.bias_part1 = emit1 ? bias_part1 : nullptr;
+        // a layer whose operand images and bias partials the chain writes itself has no reader left for its fp32 gate gradients
+        { static int keep = -1; if (keep < 0) { const char *e = getenv("HALO_LSTM_KEEP_DG"); keep = (e && e[0] == '1') ? 1 : 0; }
+          a.skip_dg0 = !keep && emit0 && (!need_din || a.img_rows0); a.skip_dg1 = !keep && emit1; }
         a.T = T; a.B = B; a.H = H;
         chain_begin(st);
         HALO_TRY(halo_lstm_persist2_bwd(a, st));

@@ -126,6 +126,7 @@ struct Persist2Bwd {
     // is formed in this kernel), column images of both
     char *img_rows0, *img_cols0, *img_cols1;
     float *bias_part0, *bias_part1;   // [ceil(B/16)][4H] per layer, may be NULL
+    int skip_dg0, skip_dg1;           // the layer's fp32 gate gradients are not stored back into its gates buffer: every consumer reads the emitted images / partials
     int poll_mode, replica_shift, nap;
     int T, B, H;
     // the launch works on batch tiles [bt0, bt0 + nbt) of the ceil(B/16) (a batch larger than the chip holds workgroups for runs as several

@@ -485,7 +485,7 @@ __device__ __forceinline__ void bwd2_layer0_waves(const Persist2Bwd &p, const Bw
         }
         if (act && cell) {
             float *gp = p.gates0 + (t * B + b) * K + j0 + cj;
-            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
+            if (!p.skip_dg0) { gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3]; }
             if (t > 0) {
                 dmul = dropout_mult(p.drop, (uint64_t)((long)(t - 1) * BH + e0));
 #pragma unroll
@@ -608,7 +608,7 @@ __device__ __forceinline__ void bwd2_layer1_waves(const Persist2Bwd &p, const Bw
         lds_barrier();                                                             // (C)
         if (act && cell) {
             float *gp = p.gates1 + (t * B + b) * K + j0 + cj;
-            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3];
+            if (!p.skip_dg1) { gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * H] = dg[2]; gp[3 * H] = dg[3]; }
             if (t > 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) c.gv[g] = p.gates1[((t - 1) * B + b) * K + g * H + j0 + cj];

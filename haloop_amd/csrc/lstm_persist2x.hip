@@ -495,7 +495,7 @@ __device__ __forceinline__ void bwd2x_layer0_waves(const Persist2Bwd &p, const B
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) store_f32_u(g0_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
+                    for (int g = 0; g < 4; ++g) if (!p.skip_dg0) store_f32_u(g0_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[0][g][ci][cj] = dg[g];
@@ -691,7 +691,7 @@ __device__ __forceinline__ void bwd2x_layer1_waves(const Persist2Bwd &p, const B
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bsum[g] += dg[g];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) store_f32_u(g1_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
+                    for (int g = 0; g < 4; ++g) if (!p.skip_dg1) store_f32_u(g1_rsrc, vg[q], (t * B * K + g * H) * 4, dg[g]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sh.dgbuf[1][g][ci][cj] = dg[g];
