@@ -1924,6 +1924,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.img_rows = emit && need_din_l ? img_g : nullptr;
             a.img_cols = emit ? img_gT : nullptr;
             a.bias_part = emit ? (float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES) : nullptr;
+            a.skip_dg = emit && (!need_din_l || a.img_rows) && !(getenv("HALO_LSTM_KEEP_DG") && getenv("HALO_LSTM_KEEP_DG")[0] == '1');      // (as the two-layer launch: no reader left)
             a.T = T; a.B = B; a.H = H;
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_bwd(a, st));

@@ -51,6 +51,7 @@ struct PersistBwd {
     // the input gradient), img_cols = dG^T as [4H rows][T*B] (both weight gradients).  Either may be NULL.  Needs B % 32 == 0; rows of
     // img_rows past T*B must have been zeroed by the launch ahead (lstm.hip).
     char *img_rows, *img_cols;
+    int skip_dg;                   // the fp32 gate gradients are not stored back into the gates buffer: every consumer reads the emitted images / partials
     // optional: this workgroup's share of the bias gradient, sum over its 16 batch rows and all T of dG, to bias_part[bt][4H] (the
     // batch tiles are summed by the launch behind the chain, lstm.hip): the column sums of dG without re-reading it
     float *bias_part;

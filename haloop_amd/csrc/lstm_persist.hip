@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd_kernel(const PersistB
         }
         if (cell) {
             float *gp = p.gates + ((long)t * B + b) * K + j0 + cj;
-            gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3];
+            if (!p.skip_dg) { gp[0] = dg[0]; gp[H] = dg[1]; gp[2 * (long)H] = dg[2]; gp[3 * (long)H] = dg[3]; }
             if (t > 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) gv[g] = p.gates[((long)(t - 1) * B + b) * K + (long)g * H + j0 + cj];

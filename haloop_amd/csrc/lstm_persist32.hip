@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_bwd32_kernel(const Persis
             for (int u = 0; u < 2; ++u) {
                 if (!cell[u]) continue;
                 float *gp = p.gates + (t * B + brow[u]) * K + j0 + cj;
-                gp[0] = dg[u][0]; gp[H] = dg[u][1]; gp[2 * H] = dg[u][2]; gp[3 * H] = dg[u][3];
+                if (!p.skip_dg) { gp[0] = dg[u][0]; gp[H] = dg[u][1]; gp[2 * H] = dg[u][2]; gp[3 * H] = dg[u][3]; }
                 if (t > 0) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) gv[u][g] = p.gates[((t - 1) * B + brow[u]) * K + g * H + j0 + cj];
