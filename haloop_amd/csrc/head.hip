@@ -814,6 +814,100 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
     }
 }
 
+// TemporalClassifier.decode's launch (halo_ctc_head_greedy) with the classifier product on split-bf16 MFMA, fragments straight from global
+// memory as in ctc_head_train_kernel (every mode but exact f32, which keeps ctc_head_fwd_kernel<true>): 512 exact-f32 MFMAs behind four
+// staged chunks were 12 of that launch's 17 us.  One workgroup per utterance, eight waves over the 16-deep k-steps, two per pass.
+__global__ __launch_bounds__(TNT) void ctc_head_greedy2_kernel(const HeadFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float redg[];      // [TNW][1024]
+    __shared__ float tile[32][LDT];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, H = p.H, V = p.V;
+    const int r = lane & 31, kh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nks = H / 16;
+    const long frow = ((long)n * T + min(r, T - 1)) * H, wrow = (long)min(r, V - 1) * H;
+    for (int i0 = wave; i0 < nks; i0 += 2 * TNW) {
+        f32x4 fa[2][2], wb[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kb = 16 * min(i0 + TNW * u, nks - 1) + 8 * kh;
+            fa[u][0] = *reinterpret_cast<const f32x4 *>(p.feats + frow + kb);
+            fa[u][1] = *reinterpret_cast<const f32x4 *>(p.feats + frow + kb + 4);
+            wb[u][0] = *reinterpret_cast<const f32x4 *>(p.w + wrow + kb);
+            wb[u][1] = *reinterpret_cast<const f32x4 *>(p.w + wrow + kb + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool on = i0 + TNW * u < nks;
+            const bool arow = on && r < T, brow = on && r < V;
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a8[e] = arow ? fa[u][0][e] : 0.f; a8[4 + e] = arow ? fa[u][1][e] : 0.f;
+                b8[e] = brow ? wb[u][0][e] : 0.f; b8[4 + e] = brow ? wb[u][1][e] : 0.f;
+            }
+            bf16x8 ahi, alo, bhi, blo;
+            split8(a8, ahi, alo);
+            split8(b8, bhi, blo);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) redg[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r] = acc[e];
+    __syncthreads();
+    const int tj = tid & 31;
+    float lpv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) sum += redg[w * 1024 + tid + TNT * q];
+        const float x = (tj < V) ? sum + p.bias[tj] : -INFINITY;
+        float m = x;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 32));
+        float sm = tj < V ? expf(x - m) : 0.f;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) sm += __shfl_xor(sm, d, 32);
+        lpv[q] = x - m - logf(sm);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ti = (tid >> 5) + 16 * q;
+        tile[ti][tj] = lpv[q];
+        if (p.lp && ti < T && tj < V) p.lp[((long)n * T + ti) * V + tj] = lpv[q];
+    }
+    __syncthreads();
+    // one lane per frame (T <= 32): arg max over the classes (first maximum, like torch.max), then unique_consecutive + drop blanks
+    if (wave == 0) {
+        const int t = lane;
+        int best = -1;
+        float bv = -INFINITY;
+        if (t < T) {
+            best = 0; bv = tile[t][0];
+            for (int c = 1; c < V; ++c) {
+                const float v = tile[t][c];
+                if (v > bv) { bv = v; best = c; }
+            }
+            p.ali[(long)n * T + t] = best;
+            p.scores[(long)n * T + t] = bv;
+        }
+        int left = __shfl_up(best, 1, 64);
+        if (lane == 0) left = -1;
+        const bool keep = (t < T) && best != left && best != 0;
+        const unsigned long long mask = __ballot(keep);
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull)), count = __popcll(mask);
+        if (keep) p.hyp[(long)n * T + pos] = best;
+        if (t < T && t >= count) p.hyp[(long)n * T + t] = 0;
+        if (lane == 0) p.hyp_len[n] = count;
+    }
+}
+
 // dW[v][k] = sum_n dw_part[n][v][k], db[v] = sum_n db_part[n][v]: small_jobs.h kind 1 (a block takes 64 consecutive elements, its four
 // waves a quarter of the utterances each); this launch when the caller does not defer small reductions
 __global__ __launch_bounds__(256) void ctc_head_reduce_kernel(const HaloSmallJobs q) {
@@ -874,6 +968,10 @@ int halo_ctc_head_greedy(const float *features, const float *weight, const float
     a.drop = make_dropout(0.f, 0, 0, 0, nullptr);
     a.lp = lp; a.ali = alignments; a.scores = scores; a.hyp = hyp; a.hyp_len = hyp_len;
     a.B = B; a.T = T; a.H = H; a.V = V;
+    if (halo_math_mode() != HALO_MATH_F32) {
+        hipLaunchKernelGGL(ctc_head_greedy2_kernel, dim3(B), dim3(TNT), (size_t)TNW * 1024 * sizeof(float), (hipStream_t)stream, a);
+        return halo_launch_status();
+    }
     hipLaunchKernelGGL(ctc_head_fwd_kernel<true>, dim3(B), dim3(1024), HEAD_FWD_LDS, (hipStream_t)stream, a);
     return halo_launch_status();
 }

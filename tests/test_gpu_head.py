@@ -177,7 +177,7 @@ def test_head_greedy_matches_the_separate_launches(B, T, H, V):
     ali, scores, hyp, hyp_len, lp = ops.ctc_head_greedy(feats, W, b, want_lp=True)
     logits = ops.gemm(feats.view(B * T, H), W, True, True, B * T, V, H, bias1=b)
     lp2 = ops.log_softmax_fwd(logits).view(B, T, V)
-    torch.testing.assert_close(lp, lp2, rtol=0, atol=2e-5)
+    torch.testing.assert_close(lp, lp2, rtol=0, atol=5e-5)            # (both products split-bf16 outside the exact-f32 mode: fp32-grade)
     ali2, scores2, hyp2, len2 = ops.ctc_greedy(lp)            # the same log-probs: index results are exact
     assert torch.equal(ali, ali2) and torch.equal(hyp, hyp2) and torch.equal(hyp_len, len2)
     assert torch.equal(scores, scores2)
