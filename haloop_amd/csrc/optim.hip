@@ -263,15 +263,18 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor *__re
         f32x4 *p4 = reinterpret_cast<f32x4 *>(t.p), *m4 = reinterpret_cast<f32x4 *>(t.m), *v4 = reinterpret_cast<f32x4 *>(t.v);
         const f32x4 *g4 = reinterpret_cast<const f32x4 *>(tg);
         for (size_t i = begin / 4 + threadIdx.x; i < e4; i += 256) {
-            f32x4 p = p4[i], m = m4[i], v = v4[i];
-            const f32x4 g = g4[i];
+            // (moments and gradient past the caches, as adamw_ranges_kernel: touched once per step)
+            f32x4 p = p4[i], m = __builtin_nontemporal_load(m4 + i), v = __builtin_nontemporal_load(v4 + i);
+            const f32x4 g = __builtin_nontemporal_load(g4 + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pe = p[e], me = m[e], ve = v[e];
                 update(pe, me, ve, g[e]);
                 p[e] = pe; m[e] = me; v[e] = ve;
             }
-            p4[i] = p; m4[i] = m; v4[i] = v;
+            p4[i] = p;
+            __builtin_nontemporal_store(m, m4 + i);
+            __builtin_nontemporal_store(v, v4 + i);
         }
         done = e4 * 4;
     }
