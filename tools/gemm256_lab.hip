@@ -10,6 +10,185 @@
 #include <vector>
 #include "gemm256.h"
 
+// ==== lab only: the four-wave variant of the 256 x 256 tile (measured equal to the eight-wave kernel the library links: DESIGN.md 3.1e) ====
+namespace halo_g256 {
+
+// ---- the same tile on FOUR waves of 128 x 128 (one wave per SIMD, the 256 accumulator registers in AGPRs) ----------------------------------
+// LDS traffic per k-block: 4 waves x 16 KiB of fragment reads + 32 KiB of LDS-DMA = 96 KiB against the eight-wave kernel's 128 KiB (= the
+// LDS pipe's whole bandwidth for the time the MFMAs take).  No second wave on a SIMD to cover for a waiting one, so the wave software-
+// pipelines itself: the fragments of phase f + 1 are read into a second register set BETWEEN the 16 MFMAs of phase f, the LDS-DMA of
+// k-block j + 4 is issued there too, and there is ONE barrier per k-block:
+//   phase (j, 0): MFMAs on set 0;  reads (j, 1) -> set 1;  issue B(j + 3)... see the schedule below
+//   start of phase (j, 1): lgkmcnt(0) [every read of k-block j is in registers]; vmcnt(16) [k-block j + 1 landed: behind it A, B of j + 2 and
+//   j + 3 = 16 loads]; barrier B_j.  Behind B_j every wave has k-block j in registers -> slot j % 4 is free for k-block j + 4, and k-block
+//   j + 1 has landed for everyone -> its first reads follow in this phase.
+//   phase (j, 1): MFMAs on set 1;  reads (j + 1, 0) -> set 0;  issue A(j + 4) -> slot j % 4
+//   phase (j + 1, 0): MFMAs on set 0;  reads (j + 1, 1) -> set 1;  issue B(j + 4) -> slot j % 4
+// A k-block is requested three k-blocks (6 phases x 512 MFMA cycles) before its first read.
+// the instruction order of one phase (hipcc would otherwise put the 16 MFMAs first and the reads behind them, where they land too late):
+// one fragment read behind each of the first eight MFMAs, one LDS-DMA issue behind each of the next four
+__device__ __forceinline__ void w4_phase_order() {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (the LDS-DMA)
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+}
+
+template <int LAB = 0>
+__global__ __launch_bounds__(256) void gemm256w4_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    int q = 0;
+    if (a.nprob > 1 && (int)blockIdx.x >= a.p[1].first) q = 1;
+    if (a.nprob > 2 && (int)blockIdx.x >= a.p[2].first) q = 2;
+    const Prob &g = a.p[q];
+    const int local = (int)blockIdx.x - g.first, ntile = g.tiles_m * g.tiles_n;
+    const int kslice = local / ntile;
+    const int tile = xcd_order(local % ntile, ntile);
+    const int grp = tile / (4 * g.tiles_n), gm0 = grp * 4, gh = min(4, g.tiles_m - gm0), ing = tile % (4 * g.tiles_n);
+    const int tile_m = gm0 + ing % gh, tile_n = ing / gh;
+    const int KT = g.KT;
+    const int kt0 = kslice * g.ktper, nkb = min(KT, kt0 + g.ktper) - kt0;
+    // LDS-DMA: a pair of parts = 16 wave-instructions of 1 KiB, four per wave: wave w takes the 1-KiB pieces 2 w, 2 w + 1 of both parts
+    const char *srcA[2] = {g.A + ((long)min(2 * tile_m, g.rbA - 1) * KT + kt0) * BLOCK, g.A + ((long)min(2 * tile_m + 1, g.rbA - 1) * KT + kt0) * BLOCK};
+    const char *srcB[2] = {g.B + ((long)min(2 * tile_n, g.rbB - 1) * KT + kt0) * BLOCK, g.B + ((long)min(2 * tile_n + 1, g.rbB - 1) * KT + kt0) * BLOCK};
+    const int dma_off = wave * 2048 + lane * 16;
+    auto issue = [&](const char *const (&src)[2], int part0, int kb, int slot) {
+        const long o = (long)min(kb, nkb - 1) * BLOCK + dma_off;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) dma16(src[part] + o + u * 1024, lds + slot * SLOT + (part0 + part) * PART + wave * 2048 + u * 1024);
+    };
+    int aoff[2][4], boff[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            aoff[p][i] = wr * PART + swz(32 * i + lr, 2 * p + lh);
+            boff[p][i] = (2 + wc) * PART + swz(32 * i + lr, 2 * p + lh);
+        }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+    issue(srcA, 0, 0, 0); issue(srcB, 2, 0, 0); issue(srcA, 0, 1, 1); issue(srcB, 2, 1, 1);
+    issue(srcA, 0, 2, 2); issue(srcB, 2, 2, 2); issue(srcA, 0, 3, 3); issue(srcB, 2, 3, 3);
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    bf16x8 f0a[4], f0b[4], f1a[4], f1b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f0a[i] = *reinterpret_cast<const bf16x8 *>(lds + aoff[0][i]); f0b[i] = *reinterpret_cast<const bf16x8 *>(lds + boff[0][i]); }
+    for (int j = 0; j < nkb; ++j) {
+        const char *cur = lds + (j & 3) * SLOT, *nxt = lds + ((j + 1) & 3) * SLOT;
+        // ---- phase (j, 0): MFMAs on set 0; between them the reads of (j, 1) into set 1 and the B pieces of k-block j + 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0a[i], f0b[jn], acc[i][jn], 0, 0, 0);
+                const int n = 4 * i + jn;
+                if (!(LAB & 4)) {
+                    if (n < 4) f1a[n] = *reinterpret_cast<const bf16x8 *>(cur + aoff[1][n]);
+                    else if (n < 8) f1b[n - 4] = *reinterpret_cast<const bf16x8 *>(cur + boff[1][n - 4]);
+                }
+                if (n == 8 && j >= 1 && !(LAB & 1)) issue(srcB, 2, j + 3, (j + 3) & 3);
+            }
+        w4_phase_order();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- start of phase (j, 1): k-block j is in registers, k-block j + 1 has landed -- for every wave behind the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(LAB & 3)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1a[i], f1b[jn], acc[i][jn], 0, 0, 0);
+                const int n = 4 * i + jn;
+                if (!(LAB & 4)) {
+                    if (n < 4) f0a[n] = *reinterpret_cast<const bf16x8 *>(nxt + aoff[0][n]);
+                    else if (n < 8) f0b[n - 4] = *reinterpret_cast<const bf16x8 *>(nxt + boff[0][n - 4]);
+                }
+                if (n == 8 && !(LAB & 1)) issue(srcA, 0, j + 4, j & 3);
+            }
+        w4_phase_order();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    const int m0 = tile_m * 256 + wr * 128, n0 = tile_n * 256 + wc * 128;
+    const bool second = tile_n * 256 >= g.n_split;
+    float *cq = (second ? g.C2 : g.C) + (long)kslice * g.slab_stride;
+    const int ldq = second ? g.ldc2 : g.ldc, cshift = second ? g.n_split : 0;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(cq, 0, 0x40000000, 0x00020000);
+    constexpr int FAR = 0x7ffffff0;
+    float ssj[4] = {0.f, 0.f, 0.f, 0.f};
+    bool colok[4];
+    int voff[4];
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+        const int col = n0 + 32 * jn + lr;
+        colok[jn] = col < g.N;
+        voff[jn] = colok[jn] ? (4 * lh * ldq + col - cshift) * 4 : FAR;
+    }
+    const bool inner = m0 + 128 <= g.M;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2);
+            const int soff = row * ldq * 4;
+            const bool rowok = inner || row + 4 * lh < g.M;
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const float v = acc[i][jn][r];
+                if (!(LAB & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, rowok ? voff[jn] : FAR, soff, 0);
+                ssj[jn] += rowok ? v * v : 0.f;
+            }
+        }
+    float ss = ((colok[0] ? ssj[0] : 0.f) + (colok[1] ? ssj[1] : 0.f)) + ((colok[2] ? ssj[2] : 0.f) + (colok[3] ? ssj[3] : 0.f));
+    if (g.sumsq) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) g.sumsq[local] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+template <int LAB = 0>
+static inline hipError_t launch_w4(const Args &a, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute((const void *)gemm256w4_kernel<LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm256w4_kernel<LAB>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
+
+}  // namespace halo_g256
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 static unsigned short f2bf(float f) {
