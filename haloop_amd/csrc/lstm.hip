@@ -1226,6 +1226,13 @@ inline bool persist_emit_enabled() {
     return v != 0;
 }
 
+// HALO_LSTM_KEEP_DG=1: the persistent backward launches store their fp32 gate gradients back into the gates buffers even where no
+// launch reads them any more (the chain emits the operand images and bias partials itself) -- the behaviour before round 4's last day
+inline bool keep_dg_switch() {
+    static const bool on = getenv("HALO_LSTM_KEEP_DG") && getenv("HALO_LSTM_KEEP_DG")[0] == '1';
+    return on;
+}
+
 inline bool pair_dw_enabled() {
     static const bool on = !(getenv("HALO_LSTM_PAIR_DW") && atoi(getenv("HALO_LSTM_PAIR_DW")) == 0);
     return on;
@@ -1776,8 +1783,8 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
         a.bias_part0 = emit0 ? bias_part0 : nullptr;
         a.bias_part1 = emit1 ? bias_part1 : nullptr;
         // a layer whose operand images and bias partials the chain writes itself has no reader left for its fp32 gate gradients
-        { static int keep = -1; if (keep < 0) { const char *e = getenv("HALO_LSTM_KEEP_DG"); keep = (e && e[0] == '1') ? 1 : 0; }
-          a.skip_dg0 = !keep && emit0 && (!need_din || a.img_rows0); a.skip_dg1 = !keep && emit1; }
+        a.skip_dg0 = !keep_dg_switch() && emit0 && (!need_din || a.img_rows0);
+        a.skip_dg1 = !keep_dg_switch() && emit1;
         a.T = T; a.B = B; a.H = H;
         chain_begin(st);
         HALO_TRY(halo_lstm_persist2_bwd(a, st));
@@ -1924,7 +1931,7 @@ int halo_lstm_bwd(const float *x, const float *const *w_ih, const float *const *
             a.img_rows = emit && need_din_l ? img_g : nullptr;
             a.img_cols = emit ? img_gT : nullptr;
             a.bias_part = emit ? (float *)((char *)workspace + bwd_flags_offset(T, B, in0, H, L) + PERSIST_FLAG_BYTES) : nullptr;
-            a.skip_dg = emit && (!need_din_l || a.img_rows) && !(getenv("HALO_LSTM_KEEP_DG") && getenv("HALO_LSTM_KEEP_DG")[0] == '1');      // (as the two-layer launch: no reader left)
+            a.skip_dg = emit && (!need_din_l || a.img_rows) && !keep_dg_switch();      // (as the two-layer launch: no reader left)
             a.T = T; a.B = B; a.H = H;
             chain_begin(st);
             HALO_TRY(halo_lstm_persist_bwd(a, st));
