@@ -463,8 +463,8 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
     //      their k index runs over W's rows; ntl .. 2 ntl-1: d W, k runs over the features' rows) ----
     const int ntl = Hs / 32, njobs = 2 * ntl;
     float pre0[16], pre1[16];
-    // (buffer accesses: rows beyond the operand -- frames >= T, classes >= V -- are addressed out of range, so their loads return 0 and their
-    //  stores are dropped without a branch or a select; the lane part of an address is computed once)
+    // (buffer accesses through descriptors that end with the operand's last row: rows beyond it -- frames >= T, classes >= V -- lie out of
+    //  range, their loads return 0 and their stores are dropped without a branch, a compare or a select)
     const int lane_k = (8 * kh * H + h0 + r) * 4;                // row 8 kh, column h0 + r
     auto load_job = [&](int jb, float (&o)[16]) {
         const bool isw = jb < ntl;
@@ -473,9 +473,8 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(isw ? p.w : p.feats + (long)n * T * H), 0, lim * H * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int krow = 16 * (i >> 3) + (i & 7);                // + 8 kh: this lane's k index
-            const int off = krow + 8 * kh < lim ? lane_k + krow * H * 4 + col : -16;
-            o[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            const int krow = 16 * (i >> 3) + (i & 7);                // + 8 kh: this lane's k index; a row >= lim lies beyond the descriptor: 0
+            o[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_k + krow * H * 4 + col, 0, 0));
         }
     };
     load_job(min(wave, njobs - 1), pre0);
@@ -764,8 +763,8 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int rowc = (e & 3) + 8 * (e >> 2);                 // + 4 kh: the accumulator element's row
-            const int off = rowc + 4 * kh < (isw ? T : V) ? lane_o + rowc * H * 4 + ti * 128 : -16;
+            const int rowc = (e & 3) + 8 * (e >> 2);                 // + 4 kh: the accumulator element's row; beyond T / V: beyond the descriptor
+            const int off = lane_o + rowc * H * 4 + ti * 128;
             const float ov = isw ? (mb[e] ? o[e] * drop.scale : 0.f) : o[e];      // (a scalar first: bit_cast of a vector ELEMENT reads element 0)
             if (isw) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), df_rs, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), dw_rs, off, 0, 0);
