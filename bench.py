@@ -72,6 +72,10 @@ def parse_args():
                          'rs_ag = the span-sharded step: the top LSTM layer\'s matrix gradients reduce-scattered from the middle of the backward, the '
                          'lower layers\' behind it, small parameters all-reduced, each rank updates its chunks, bf16 all-gather in bf16 arithmetic; '
                          'rs_ag_flat = one reduce-scatter / fp32 all-gather over the whole flat buffers')
+    ap.add_argument('--gather-dtype', choices=['auto', 'f32', 'bf16'], default='auto',
+                    help="N > 1, rs_ag: wire format of the parameter all-gather.  'auto' (this benchmark's choice; the trainer's own default is "
+                         "'f32') = bf16 roundings in single-pass bf16 arithmetic, where every consumer multiplies by the bf16 values anyway: "
+                         "the same step at half the bytes; LstmCtcTrainer.state_dict() exchanges the fp32 masters before a checkpoint")
     ap.add_argument('--grad-dtype', choices=['f32', 'bf16'], default='f32',
                     help='wire format of the data-parallel gradient all-reduce (N > 1)')
     return ap.parse_args()
@@ -319,9 +323,12 @@ def cpu_baseline(params):
 
 def read_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py writes the
-    file from the FETCH_SIZE / WRITE_SIZE CSVs with the guide's gfx950 corrections); null unless it is for THIS kernel."""
-    for fname in ('r03_lstm2_chain_traffic.json', 'lstm_chain_traffic.json'):      # round 3: the two-layer launches; round 2: one layer per launch
-        tpath = os.path.join(ROOT, 'profiles', fname)
+    file from the FETCH_SIZE / WRITE_SIZE CSVs with the guide's gfx950 corrections); null unless it is for THIS kernel.  The newest
+    round's file first (profiles/rNN_lstm2_chain_traffic.json), the one-layer-per-launch file of round 2 last."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_lstm2_chain_traffic.json')), reverse=True)
+    names.append(os.path.join(ROOT, 'profiles', 'lstm_chain_traffic.json'))
+    for tpath in names:
         if not os.path.exists(tpath):
             continue
         for rec in json.load(open(tpath)).get('kernels', []):
@@ -416,7 +423,7 @@ def main():
     _lib.set_math_mode(args.math)
 
     enc, rec, params = build_model(device)
-    dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo != 'allreduce')
+    dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo != 'allreduce', gather_dtype=args.gather_dtype)
     trainer = LstmCtcTrainer(enc, rec, seed=1337 + rank, use_graph=not args.no_graph, grad_dtype=args.grad_dtype, alias_loss=True, **dp_kw)
     x, il, tg, tl = (t.to(device) for t in synth.synthetic_batch(B_PER_GPU, T, F, V, S, 42 + rank))
 
@@ -496,6 +503,7 @@ def main():
                        'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'launch_mode_probe': mode_probe, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None,
                        'dp_algo': trainer.dp_algo if (world > 1 or args.dp_rehearsal) else None,
+                       'dp_gather_dtype': (('bf16' if getattr(trainer.sharded, 'gather_bf16', False) else 'f32') if (world > 1 or args.dp_rehearsal) else None),
                        'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None,
                        'dp_early_reduce_scatter_overlapped': bool(getattr(trainer, '_early_started', False)) if (world > 1 or args.dp_rehearsal) else None,
                        'dp_wire_bytes_per_rank': (trainer.sharded.wire_bytes() if hasattr(getattr(trainer, 'sharded', None), 'wire_bytes') else None)},
@@ -523,37 +531,42 @@ def main():
                         if name in k:
                             return v
                 return read_traffic(name)
-            ach = kb / launches_b / (us_b / launches_b * 1e-6) / 1e9
+            # `frac` = SURVEY.md 8d's own byte count (weights once + the 6H saved values per step, layer and utterance); `frac_10h` keeps
+            # the rounds 1-4 yardstick (the 10H fp32 values a per-layer chain reads and writes; the two-layer launch no longer stores
+            # the 4H fp32 gate gradients that yardstick credits it with)
             kb_s, kf_s = chain_algorithmic_bytes(B_PER_GPU, 'bwd', cl, strict=True), chain_algorithmic_bytes(B_PER_GPU, 'fwd', cl, strict=True)
+            ach = kb_s / launches_b / (us_b / launches_b * 1e-6) / 1e9
             out['roofline'] = {
                 'bound': 'hbm', 'kernel': name_b, 'launches_per_chain': launches_b, 'chains_per_step': chains, 'layers_per_chain': cl,
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                # the same launch under SURVEY.md 8d's own activation term (the 6H saved values per step and layer instead of the 10H
-                # this launch reads and writes): the stricter reading of the two
-                'frac_8d_strict': round(kb_s / (us_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                'algorithmic_bytes_per_launch_8d_strict': kb_s // launches_b,
+                'frac_10h': round(kb / (us_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                'algorithmic_bytes_per_launch_10h': kb // launches_b,
                 'traffic': traffic(name_b),
                 'traffic_source': ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this process (tools/run_lstm2_steps.py), bytes = 2 F + W'
                                    if live else 'committed passes under profiles/ (rocprofv3 not available to this run)'),
-                'algorithmic_bytes_per_launch': kb // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
+                'algorithmic_bytes_per_launch': kb_s // launches_b, 'avg_launch_us': round(us_b / launches_b, 3),
                 # the same launch in the kernel trace of this run's FETCH_SIZE counter pass (median over its launches; under the counters
                 # a launch runs ~5 % slower than in a plain `rocprofv3 --kernel-trace --stats`, whose averages are committed under
-                # profiles/ as r04_kernel_stats_step_bf16_graph.md): the HIP-event bracket lies between the two
+                # profiles/): the HIP-event bracket lies between the two
                 'avg_launch_us_kernel_trace': trace_us(name_b),
                 'accounting': 'SURVEY.md 8d: every weight matrix the launch multiplies by once per pass (W_hh^T per layer; the two-layer '
-                              'launch also W_ih of layer 1) + per step and layer the fp32 activations entering/leaving the chain (gates in, '
-                              'c in, dh in, gate gradients out), divided over the launches of the chain',
+                              'launch also W_ih of layer 1) at 4 B per parameter + per step, layer and utterance the 6H saved fp32 values '
+                              '(gates, c, h), divided over the launches of the chain',
                 'share_of_step': round(chains * us_b * 1e-3 / ms_per_step, 3),
                 'forward_twin': {'kernel': name_f, 'launches_per_chain': launches_f, 'avg_launch_us': round(us_f / launches_f, 3),
                                  'avg_launch_us_kernel_trace': trace_us(name_f),
-                                 'algorithmic_bytes_per_launch': kf // launches_f,
-                                 'achieved': round(kf / (us_f * 1e-6) / 1e9, 1),
-                                 'frac': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 'frac_8d_strict': round(kf_s / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic(name_f),
+                                 'algorithmic_bytes_per_launch': kf_s // launches_f,
+                                 'achieved': round(kf_s / (us_f * 1e-6) / 1e9, 1),
+                                 'frac': round(kf_s / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 'frac_10h': round(kf / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic(name_f),
                                  'share_of_step': round(chains * us_f * 1e-3 / ms_per_step, 3)}}
         if world == 1 and not args.no_extras:
             out['inference'] = time_inference(enc, rec, x, max(20, args.steps // 2))
             out['inference']['dtype'] = MATH_DTYPE[args.math]
+            fwd_bytes = 4 * param_count() + 28_300 * B_PER_GPU          # SURVEY.md 8d, forward only: 4P + 28.3e3 B = 54.6 MB at B = 64
+            out['inference']['roofline'] = {'bound': 'hbm', 'algorithmic_bytes_per_batch': fwd_bytes, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                            'achieved': round(fwd_bytes / (out['inference']['ms_per_batch'] * 1e-3) / 1e9, 1),
+                                            'frac': round(fwd_bytes / (out['inference']['ms_per_batch'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if args.math != 'bf16x3':
                 # the same leg in the fp32-grade arithmetic, the mode whose greedy alignments are exact on the reference's random-init
                 # fixtures (bf16's are exact on peaked posteriors: tests/test_gpu_bf16_contract.py)

@@ -1,12 +1,43 @@
 // ABI bookkeeping: version, error strings, device probe.
 #include <string.h>
 #include <new>
+#include <atomic>
 #include "halo_common.h"
 #include "halo_internal.h"
 
 static HaloCtx g_default_ctx;
 static thread_local HaloCtx *t_ctx = nullptr;
 HaloCtx &halo_ctx_cur() { return t_ctx ? *t_ctx : g_default_ctx; }
+
+// per-device facts, indexed by the HIP device ordinal (relaxed atomics: racing host threads write the same value)
+namespace {
+constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 8;
+std::atomic<int> g_cus[MAX_DEVICES];
+std::atomic<unsigned char> g_attr[ATTR_SLOTS][MAX_DEVICES];
+int cur_device() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES) ? dev : -1;
+}
+}  // namespace
+int halo_cu_count() {
+    const int dev = cur_device();
+    if (dev < 0) return -1;
+    int n = g_cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+        g_cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+bool halo_func_attr_done(int slot) {
+    const int dev = cur_device();
+    return dev >= 0 && slot >= 0 && slot < ATTR_SLOTS && g_attr[slot][dev].load(std::memory_order_relaxed) != 0;
+}
+void halo_func_attr_set(int slot) {
+    const int dev = cur_device();
+    if (dev >= 0 && slot >= 0 && slot < ATTR_SLOTS) g_attr[slot][dev].store(1, std::memory_order_relaxed);
+}
 int halo_lstm_fusion() { return halo_ctx_cur().lstm_fusion; }
 // the scratch is cut in two halves so that work forked onto a side stream (slot 1) never shares
 // split-K slabs with the main stream (slot 0)

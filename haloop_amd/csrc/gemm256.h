@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "halo_internal.h"
 
 namespace halo_g256 {
 
@@ -233,11 +234,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Args a) {
 
 template <int LAB = 0>
 static inline hipError_t launch(const Args &a, int nwg, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    if (!halo_func_attr_done(1 + (LAB != 0))) {         // per device (halo_internal.h)
         const hipError_t e = hipFuncSetAttribute((const void *)gemm256_kernel<LAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr = true;
+        halo_func_attr_set(1 + (LAB != 0));
     }
     hipLaunchKernelGGL(gemm256_kernel<LAB>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, a);
     return hipGetLastError();

@@ -70,6 +70,12 @@ struct HaloCtx {
     int mute_block = -1;                 // test hook (halo_debug_mute_workgroup): this workgroup of a persistent forward never publishes
 };
 HaloCtx &halo_ctx_cur();
+// CUs of the current device (hipDeviceProp_t::multiProcessorCount, cached per device; <= 0: the query failed)
+int halo_cu_count();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: one flag per (kernel slot, device) instead of a process-wide bool.
+// Slots: 0 ctc_head_train_kernel, 1 gemm256_kernel<0>, 2 gemm256 GPT epilogues, 3 .. 7 free
+bool halo_func_attr_done(int slot);
+void halo_func_attr_set(int slot);
 // C | C2 = A x (B stacked on B2)^T in one launch (columns [n_split, N) of the result go to C2); plain sums
 int halo_gemm_bf16x3_tiled_nsplit(const void *Aimg, const void *Bimg, int M, int N, int K, float *C, int ldc, int n_split, float *C2, int ldc2,
                                   hipStream_t st);

@@ -415,9 +415,11 @@ __global__ __launch_bounds__(512) void ctc_head_bwd_kernel(const HeadBwdArgs p) 
 // inside its loops), 4.4 us restaging log-probs / alpha / masks in the second launch.  Here:
 //   * grid (B, SL): the SL workgroups of an utterance each take H/SL feature columns -- their share of the dropout mask (kept in LDS as
 //     bytes), of the logits' K range, and later those columns of d features / d W.  The partial logits [32 x 32] meet through global
-//     memory (write-through stores, drained, one arrive counter per utterance: cdna_hip_programming.md Guideline 16 R1 in its counter
-//     form); every workgroup of the utterance then sums the SL partials in slice order and runs the (single-wave) lattice work itself.
-//     B * SL <= 256 workgroups of one per CU: all resident, every wait bounded.
+//     memory as 8-byte (value, launch count) pairs, ONE write-through store each (MI355X_MICROARCH.md's data-tagged granule: a reader
+//     that sees this launch's count has the value; no drain, no counter, nothing to reset); every workgroup of the utterance then sums
+//     the SL partials in slice order and runs the (single-wave) lattice work itself.  B * SL <= the device's CU count, one workgroup
+//     per CU: all resident; every wait bounded (0.2 s), and a wait given up raises the caller's status word and still takes its loss
+//     ticket, so the launch count advances and the next launch starts clean.
 //   * products on split-bf16 MFMA (v_mfma_f32_32x32x16_bf16; hi*hi + hi*lo + lo*hi: fp32-grade like every `bf16x3` product) with the
 //     fragments loaded straight from global memory in MFMA layout -- no LDS staging, no barrier until the K-slices are added up.
 //   * alpha in wave 0 and beta in wave 1 AT THE SAME TIME; labels, log-probs, alpha + beta stay in LDS.
@@ -429,6 +431,8 @@ struct HeadTrainArgs {
     float *lp, *nll, *loss;
     int64_t *flen;
     unsigned *ticket;        // [0] the loss ticket, [1] launches so far, [2 ..) the slices' (partial logit, epoch) pairs; zero before the first launch
+    unsigned *status;        // optional caller-owned sticky word (halo_set_status_word): set to 1 when the slice exchange gives up its bounded wait
+    int mute;                // test hook (halo_debug_mute_workgroup): the workgroup with this linear index (n * slices + y) never publishes
     float *dfeats, *dw_part, *db_part;
     int B, T, H, V, S, ks, stride, pad;
 };
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
             need[q] = (tid >> 5) + 16 * q < T;
             slot[q] = (n * SL * 1024 + (need[q] ? tid + TNT * q : (tid & 31))) * 8;
             u32x2 pr = {__builtin_bit_cast(unsigned, sum[q]), epoch};
-            __builtin_amdgcn_raw_buffer_store_b64(pr, prs, need[q] ? slot[q] + y * 8192 : -16, 0, 16);      // (-16: out of range, dropped)
+            __builtin_amdgcn_raw_buffer_store_b64(pr, prs, (need[q] && n * SL + y != p.mute) ? slot[q] + y * 8192 : -16, 0, 16);      // (-16: out of range, dropped)
         }
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         auto gather = [&](auto ns_c) {
@@ -595,10 +599,18 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
 #pragma unroll
     for (int q = 0; q < 2; ++q) tile[(tid >> 5) + 16 * q][tj] = (tj < V) ? sum[q] + p.bias[tj] : -INFINITY;
     __syncthreads();
-    if (s_fail) {                          // a slice that never came (0.2 s; cannot happen on an idle chip): a loud loss instead of a hang
-        if (tid == 0) *p.loss = NAN;
-        return;
+    // A slice that never came (0.2 s: the utterance's workgroups were not all resident -- a CU-masked or partitioned device, a foreign kernel
+    // holding CUs): loud, and the launch still ENDS in a clean state.  The workgroup raises the caller's sticky status word (the clip
+    // launch then applies no update and LstmCtcTrainer.check_status() raises), poisons the utterance's loss term and skips the lattice
+    // and the products (its d features / d W slots keep stale values nobody applies), but it still takes its loss ticket below: the
+    // ticket reaches B, the last finisher resets it and advances the launch count, and the next launch's epoch matches none of the
+    // pairs this one left behind.
+    const bool failed = s_fail != 0;
+    if (failed && tid == 0) {
+        if (p.status) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_nll = NAN;
     }
+    if (!failed) {
     // ---- log-softmax over the classes: 32 lanes per frame, two frames per thread ----
     {
         float lpv[2];
@@ -786,6 +798,7 @@ __global__ __launch_bounds__(TNT) void ctc_head_train_kernel(const HeadTrainArgs
         p.db_part[(long)n * V + lane] = s;
     }
     HST(0, 7);
+    }   // (!failed)
     // ---- the utterance's loss terms and, in the workgroup that finishes last, the mean (as ctc_head_fwd_kernel) ----
     if (y == 0 && wave == 0) {
         unsigned old = 0;
@@ -1017,9 +1030,11 @@ int halo_ctc_head_bwd(const float *features, const float *weight, float p_drop, 
 
 static int head_train_slices(int B, int H) {
     // slices of H per utterance: as many as keep the grid within the chip's CUs (4 at B = 64), whole 32-column tiles per slice.  All
-    // B * slices workgroups must be resident at once (the slices of an utterance wait for each other): <= 256, one per CU
+    // B * slices workgroups must be resident at once (the slices of an utterance wait for each other): one per CU of THIS device (a
+    // partitioned or CU-masked gfx950 reports fewer than 256); a batch that does not fit runs one slice per utterance, which waits for nobody
+    const int cus = halo_cu_count() > 0 ? halo_cu_count() : 1;
     int slices = 1;
-    while (slices < 8 && (H / 32) % (2 * slices) == 0 && (long)B * 2 * slices <= 256) slices *= 2;
+    while (slices < 8 && (H / 32) % (2 * slices) == 0 && (long)B * 2 * slices <= cus) slices *= 2;
     return slices;
 }
 
@@ -1043,11 +1058,10 @@ int halo_ctc_head_train(const float *features, const float *weight, const float 
     HALO_CHECK_ARG(((uintptr_t)features % 16 == 0) && ((uintptr_t)weight % 16 == 0));
     const int slices = head_train_slices(B, H);
     const size_t lds = (size_t)TNW * 1024 * sizeof(float) + (p_drop > 0.f ? (size_t)32 * (H / slices) : 0);
-    static bool attr = false;
-    if (!attr) {
+    if (!halo_func_attr_done(0)) {         // (the attribute is per device: one flag per device and kernel, halo_internal.h)
         if (hipFuncSetAttribute((const void *)ctc_head_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TNW * 1024 * sizeof(float) + 32 * 2048)) != hipSuccess)
             return HALO_ELAUNCH;
-        attr = true;
+        halo_func_attr_set(0);
     }
     if (H / slices > 2048) return HALO_ENOTSUP;
     HeadTrainArgs a;
@@ -1055,6 +1069,8 @@ int halo_ctc_head_train(const float *features, const float *weight, const float 
     a.drop = make_dropout(p_drop, seed, stream_id, offset, offset_dev);
     a.il = input_lengths; a.targets = targets; a.tl = target_lengths; a.tg_stride = tg_stride;
     a.lp = lp; a.nll = nll; a.loss = loss; a.flen = feature_lengths; a.ticket = ticket;
+    a.status = halo_ctx_cur().status;
+    a.mute = halo_ctx_cur().mute_block;
     a.dfeats = dfeatures; a.dw_part = (float *)workspace; a.db_part = a.dw_part + (size_t)B * V * H;
     a.B = B; a.T = T; a.H = H; a.V = V; a.S = S; a.ks = ks; a.stride = stride; a.pad = pad;
     hipLaunchKernelGGL(ctc_head_train_kernel, dim3(B, slices), dim3(TNT), lds, (hipStream_t)stream, a);

@@ -12,6 +12,7 @@ gradients averaged with one RCCL all-reduce per step over the flat gradient buff
 semantics of DistributedDataParallel in ha/attention_loop.py:154.
 """
 import os
+import re
 import time
 
 import torch
@@ -62,12 +63,12 @@ class FlatParams:
         top = getattr(encoder, 'lstm', None)
         nl = top.num_layers if top is not None else 0
 
-        def big_layer(n):            # the LSTM layer a big matrix belongs to, or None
-            if not n.startswith('encoder.lstm.weight_'):
+        def big_layer(n):            # the LSTM layer a big matrix belongs to, or None (anything else: the small range)
+            m = re.fullmatch(r'encoder\.lstm\.weight_(ih|hh)_l(\d+)', n)
+            if m is None:
                 return None
-            kind, layer = n[len('encoder.lstm.weight_'):].split('_l')
-            layer = int(layer)
-            return layer if (kind == 'hh' or layer > 0) else None
+            layer = int(m.group(2))
+            return layer if (m.group(1) == 'hh' or layer > 0) else None
         is_top = lambda n: nl > 1 and big_layer(n) == nl - 1
         enc_decay = [(n, p) for n, p in decay if n.startswith('encoder.')]
         groups = [[(n, p) for n, p in no_decay if n.startswith('recognizer.')],
@@ -117,7 +118,7 @@ class LstmCtcTrainer:
 
     def __init__(self, encoder, recognizer, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
                  clip_grad_norm=0.1, seed=None, use_graph=True, process_group=None, accumulate=1, grad_dtype='f32',
-                 alias_loss=False, fused_head=True, head_one_launch=True, dp_algo='rs_ag', rehearse_dp=False, gather_dtype='auto'):
+                 alias_loss=False, fused_head=True, head_one_launch=True, dp_algo='rs_ag', rehearse_dp=False, gather_dtype='f32'):
         """use_graph: True -- the step replays from HIP graphs (default); False -- the same launches issued eagerly; 'auto' (one process,
         accumulate == 1) -- both are timed over the first 53 steps and the faster way stays (``auto_choice``): with the two-layer launches a
         step is 13 launches, the host enqueues them in ~0.2 ms against ~0.47 ms on the GPU, and a replay costs ~15 us more than it saves.
@@ -138,9 +139,12 @@ class LstmCtcTrainer:
         from one graph (a 2-layer stack in bf16 mode: the two-layer persistent launches); the tail is captured in a graph.
         'rs_ag_flat' -- round 3's form: ONE reduce-scatter / all-gather over the whole flat buffers behind the backward (also what
         ``grad_dtype='bf16'`` uses).
-        gather_dtype: 'auto' -- bf16 when the arithmetic mode at construction is single-pass bf16 (every consumer of the sharded
-        matrices multiplies by their bf16 values, so the step is the one an fp32 gather gives; the other ranks' fp32 master values
-        are then NOT in this rank's buffers: ``gather_master_weights()`` before a checkpoint), else 'f32'; or 'f32' / 'bf16'.
+        gather_dtype: 'f32' (default) -- the owners' fp32 values are all-gathered: every rank's parameters (= ``state_dict()``) are
+        exact after every step.  'auto' / 'bf16' -- opt-in, half the all-gather's bytes: 'auto' = bf16 when the arithmetic mode at
+        construction is single-pass bf16 (every consumer of the sharded matrices multiplies by their bf16 values, so the step is the
+        one an fp32 gather gives), else f32.  The other ranks' fp32 master values are then NOT in this rank's buffers between steps
+        (``masters_stale``): ``trainer.state_dict()`` / ``gather_master_weights()`` exchange them (a collective: call on every rank),
+        and a step taken after the arithmetic mode has changed does so by itself and continues with fp32 gathers.
         (rehearse_dp: take this path on ONE rank of an initialised process group, every collective issued over that one rank --
         how a single GPU exercises the real backend, captured graphs included.)
         'allreduce' -- DistributedDataParallel's shape: every rank averages the whole gradient (two buckets, the first overlapped
@@ -197,9 +201,12 @@ class LstmCtcTrainer:
         self.pg = process_group
         dp.broadcast_parameters(self.flat.params, process_group)          # DDP ctor semantics (C2)
         self.sharded = None
+        self.masters_stale = False             # a bf16 all-gather has run since the fp32 masters were last exchanged
+        self._gather_mode = None
         if self.dp_algo == 'rs_ag':
             f = self.flat
             bf16_gather = gather_dtype == 'bf16' or (gather_dtype == 'auto' and _lib.get_math_mode() == 'bf16')
+            self._gather_mode = _lib.get_math_mode()              # the arithmetic the bf16 gather was chosen under
             try:
                 self.sharded = dp.SpanSharded(f.params, f.grads, f.big_early, f.big_late, f.small_range, process_group,
                                               always=self._rehearse_dp, gather_bf16=bf16_gather)
@@ -455,6 +462,14 @@ class LstmCtcTrainer:
         if isinstance(self.sharded, dp.SpanSharded) and self.sharded.gather_bf16:
             self.sharded.gather_masters()
             _lib.bump_weights_epoch()
+        self.masters_stale = False
+
+    def state_dict(self):
+        """{'encoder': ..., 'recognizer': ...} with every rank's fp32 master values in place (after a bf16 all-gather the other ranks'
+        chunks are exchanged first: a collective, so call it on every rank) -- what a checkpoint should save (ha/loop.py:104-111)."""
+        if self.masters_stale:
+            self.gather_master_weights()
+        return {'encoder': self.encoder.state_dict(), 'recognizer': self.recognizer.state_dict()}
 
     # ---- public -------------------------------------------------------------------------------
     def step(self, x, input_lengths, targets, target_lengths):
@@ -496,6 +511,12 @@ class LstmCtcTrainer:
             return self._accumulating_step(x, input_lengths, targets, target_lengths)
         self.step_count += 1
         if self.sharded is not None:
+            if self._gather_mode is not None and getattr(self.sharded, 'gather_bf16', False) and _lib.get_math_mode() != self._gather_mode:
+                # the arithmetic changed under a bf16 gather (every rank switches together): the replicas would multiply by different
+                # values.  Exchange the masters and gather in fp32 from here on (the captured tail is rebuilt).
+                self.gather_master_weights()
+                self.sharded.gather_bf16 = False
+                self._tail_graph, self._tail_calls = None, 0
             return self._sharded_step(x, input_lengths, targets, target_lengths)
         if not self.use_graph:
             st = self._forward_backward_top(x, input_lengths, targets, target_lengths)
@@ -535,6 +556,7 @@ class LstmCtcTrainer:
         in a second graph when the collective backend can be captured (RCCL can: its kernels are ordinary stream work), else it runs eagerly."""
         handle = None
         self._early_started = False
+        self.masters_stale = bool(getattr(self.sharded, 'gather_bf16', False))      # this step's all-gather sends bf16 roundings
         if not self.use_graph or self.eager_forward_backward:
             handle = self._forward_backward_overlapped(x, il, tg, tl)
         else:

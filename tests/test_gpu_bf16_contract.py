@@ -154,7 +154,7 @@ def test_stock_three_layer_encoder_b64_against_the_reference(hal, mode, loss_rto
         decided = ((top2[..., 0] - top2[..., 1]) > 4 * feat_atol).numpy()
         valid = np.arange(lp.shape[1])[None, :] < g['flen'][:, None]
         sel = decided & valid
-        assert sel.mean() > 0.5
+        assert sel.mean() >= 0.9, sel.mean()
         assert np.array_equal(ali.cpu().numpy()[sel], g['ali'][sel])
 
 
@@ -246,7 +246,7 @@ def test_integer_outputs_are_exact_in_bf16_on_a_model_with_peaked_posteriors(hal
     print(f'beam-16: lists fully equal on {exact_all}/{lp.shape[0]} utterances, best hypothesis equal on {best_equal}, {checked_ranks} leading ranks '
           f'equal, score error on them <= {score_err:.3e}; oracle gap at the first differing rank: {sorted(first_diff_gap)}')
     assert checked_ranks >= 4 * lp.shape[0], checked_ranks
-    assert best_equal >= 0.9 * lp.shape[0], best_equal
+    assert best_equal >= lp.shape[0] - 3, best_equal                # observed: all 64, or all but one or two (score-tie twins)
     assert all(g <= 4 * score_err + 1e-3 for g in first_diff_gap), (first_diff_gap, score_err)
     # and the kernel itself on the oracle's emissions: all 16 ranks of all utterances, token ids and scores bit for bit
     out2, sc2 = hal['beam'].decode_batch(lp_o.to(DEV).contiguous(), 16, True)

@@ -57,8 +57,11 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
         from haloop_amd.train import LstmCtcTrainer
         from oracle import cpu_ref
         enc, rec = _build(100 + rank, c)                   # different init per rank: rank 0's must win
-        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype, dp_algo=dp_algo)
+        # (gather_dtype: the trainer's default is 'f32' -- exact parameters on every rank after every step; 'auto' opts into the bf16
+        #  all-gather in bf16 arithmetic, which this test exercises together with the exchange of the masters)
+        tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype, dp_algo=dp_algo, gather_dtype='auto')
         assert tr.dp_algo == dp_algo
+        assert LstmCtcTrainer.__init__.__kwdefaults__ is None and 'f32' in LstmCtcTrainer.__init__.__defaults__
         if dp_algo == 'rs_ag':
             from haloop_amd import _lib
             assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded.gather_bf16 == (_lib.get_math_mode() == 'bf16')
@@ -66,7 +69,9 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
             tr.step(x[sl].cuda(), il[sl].cuda(), tg[sl].cuda(), tl[sl].cuda())
-        tr.gather_master_weights()          # (after a bf16 all-gather: the other rank's fp32 master values)
+        assert tr.masters_stale == bool(getattr(tr.sharded, 'gather_bf16', False))
+        sd = tr.state_dict()                # (after a bf16 all-gather: exchanges the other rank's fp32 master values first)
+        assert not tr.masters_stale and set(sd) == {'encoder', 'recognizer'}
         torch.cuda.synchronize()
         if rank == 0:
             out.put(('ok', tr.flat.params[:tr.flat.total].cpu().numpy(), float(tr.grad_norm.item())))

@@ -128,6 +128,50 @@ def test_head_in_one_launch_equals_the_two_launches(B, T_in, H, V, S, p, mode):
         _lib.set_math_mode(prev)
 
 
+def test_a_slice_that_never_publishes_is_loud_and_the_next_launch_is_clean():
+    """The one-launch head with one slice of one utterance made mute by the test hook (halo_debug_mute_workgroup): its peers' bounded
+    waits give up, the caller's sticky status word is raised, the loss is not finite -- and the launch still ends with its loss ticket
+    back at zero and its launch count advanced, so the next launch (unmuted) matches none of the stale pairs and gives the clean
+    result bit for bit."""
+    from haloop_amd import _lib, ops
+    _lib.lib(); _lib.lend_scratch()
+    B, T_in, H, V, S = 16, 80, 1024, 32, 10
+    T = (T_in + 6 - 5) // 4 + 1
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(B, T, H, generator=g).relu().to(DEV)
+    W = (torch.randn(V, H, generator=g) / H ** 0.5).to(DEV)
+    b = (torch.randn(V, generator=g) * 0.1).to(DEV)
+    il = torch.full((B,), T_in, dtype=torch.int64).to(DEV)
+    tg = torch.randint(1, V, (B, S), generator=g).to(DEV)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g).to(DEV)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    _lib.set_status_word(status)
+    try:
+        loss = torch.zeros((), device=DEV)
+        ticket = ops.ctc_head_train_ticket(B, H, DEV)
+        assert ticket.numel() > 2                                  # more than one slice per utterance: there is an exchange to break
+        dW, db = torch.empty_like(W), torch.empty_like(b)
+        sid = _lib.HALO_STREAM_CLASSIFIER
+        dfeats, nll, _, _ = ops.ctc_head_train(feats, W, b, ops.NO_DROPOUT, sid, il, tg, tl, loss, ticket, dW, db)
+        clean = (loss.clone(), dfeats.clone(), nll.clone(), dW.clone())
+        assert int(status.item()) == 0 and ticket[:2].tolist() == [0, 1]
+        _lib.check(_lib.lib().halo_debug_mute_workgroup(5), 'mute')
+        ops.ctc_head_train(feats, W, b, ops.NO_DROPOUT, sid, il, tg, tl, loss, ticket, dW, db)
+        assert int(status.item()) != 0 and not np.isfinite(loss.item())
+        assert ticket[:2].tolist() == [0, 2]                       # every utterance took its ticket; the count advanced
+        _lib.check(_lib.lib().halo_debug_mute_workgroup(-1), 'unmute')
+        status.zero_()
+        dfeats, nll, _, _ = ops.ctc_head_train(feats, W, b, ops.NO_DROPOUT, sid, il, tg, tl, loss, ticket, dW, db)
+        assert int(status.item()) == 0 and ticket[:2].tolist() == [0, 3]
+        assert torch.equal(loss, clean[0]) and torch.equal(dfeats, clean[1]) and torch.equal(nll, clean[2]) and torch.equal(dW, clean[3])
+    finally:
+        _lib.lib().halo_debug_mute_workgroup(-1)
+        _lib.set_status_word(None)
+        _lib.set_math_mode(prev)
+
+
 def test_fused_head_refuses_unsupported_shapes():
     from haloop_amd import ops
     assert not ops.ctc_head_supported(40, 1024, 32, 10)      # more than 32 frames

@@ -51,6 +51,7 @@ def main():
         med = statistics.median(per[pat])
         out[pat] = BYTES / (med * 1024)
         print(f'| {NAMES[pat]} | {med:.0f} | {out[pat]:.3f} |')
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump({'bytes_read': BYTES, 'factor_by_pattern': out, 'patterns': NAMES}, open(os.path.join(ROOT, 'gpurun_out', 'fetch_size_calibration.json'), 'w'), indent=1)
 
 

@@ -4,7 +4,7 @@ import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d.get('roofline', {})
-print('headline', d['value'], d['unit'], d['ms_per_step'], 'ms; roofline frac', r.get('frac'), 'strict', r.get('frac_8d_strict'), 'bwd us', r.get('avg_launch_us'),
+print('headline', d['value'], d['unit'], d['ms_per_step'], 'ms; roofline frac', r.get('frac'), 'strict', r.get('frac_8d_strict'), '10h', r.get('frac_10h'), 'bwd us', r.get('avg_launch_us'),
       'fwd us', r.get('forward_twin', {}).get('avg_launch_us'))
 for k in ('inference', 'inference_bf16x3'):
     if k in d:
