@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 16
+HALO_ABI_VERSION = 17
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -45,6 +45,13 @@ SIGNATURES = {
     'halo_cast_bf16': (_i, [_vp, _vp, _sz, _vp]),
     'halo_gelu_bf16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_bf16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'halo_gelu_b16': (_i, [_vp, _vp, _sz, _i, _vp]),
+    'halo_gelu_bwd_b16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'halo_gemm_rows_supported': (_i, [_i, _i, _i]),
+    'halo_gemm_rows': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    'halo_gemm_rows_ce_workspace_bytes': (_sz, [_i, _i]),
+    'halo_gemm_rows_ce': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
+    'halo_cross_entropy_bwd_bf16': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),
     'halo_gemm_split_ce_workspace_bytes': (_sz, [_i, _i]),
     'halo_gemm_split_ce': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp]),
     'halo_image_pair': (_i, [_vp, _vp, _i, _i, _l, _l, _i, _vp, _vp, _vp]),

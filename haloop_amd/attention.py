@@ -224,15 +224,35 @@ def rowmajor_train_ok(cfg, blocks, M, training):
     return all(blk.attn.c_attn.bias is None and blk.mlp.c_fc.bias is None for blk in blocks)
 
 
+def rows_ok(M, C):
+    """The 256-row-tile products (halo_gemm_rows: single-pass bf16 arithmetic) take every Linear of a block of width C at M rows."""
+    return os.environ.get('HALO_GPT_ROWS', '1') != '0' and ops.gemm_rows_supported(M, C, C) and C % 32 == 0
+
+
 def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
     C, H, M = cfg.n_embd, cfg.n_head, B * T
     w = lambda lin: images.split((lin.weight,))
+    rows = rows_ok(M, C)
+    s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
+    if rows:
+        # round 5: every activation-by-weight product on halo_gemm_rows (256-row tiles cut to whole rounds of the CUs, A staged from the
+        # row-major bf16 rows the producing launch left); c_fc's result and the MLP's hidden activations stay bf16 (what the reference's
+        # autocast path holds there, ha/attention_loop.py:164) -- the fp32 [M, 4C] round trip between c_fc and new_gelu is gone
+        h1b = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias)
+        qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
+        y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
+                                            drop=s_att[0], stream_id=s_att[1])
+        x1 = ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, residual=x0)
+        h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
+        a = ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True)
+        gb = ops.gelu_b16(a)
+        x = ops.gemm_rows(gb, w(blk.mlp.c_proj), M, C, 4 * C, residual=x1)
+        return x, (x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att)
     # (the normalised rows twice from one launch: the tiled image for the forward product, which stages an image 10-15 % faster than
     # rows from cold caches, and the row-major rows for the weight-gradient product)
     h1b, h1i = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias, want_image=True)
     qkv = ops.gemm_split(h1i, w(blk.attn.c_attn), M, 3 * C, C)
     del h1i
-    s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
     y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
                                         drop=s_att[0], stream_id=s_att[1])
     x1 = ops.gemm_split_io((yb, None), w(blk.attn.c_proj), M, C, C, residual=x0)
@@ -249,22 +269,26 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     C, H, M = cfg.n_embd, cfg.n_head, B * T
     wt = lambda lin: images.split_t((lin.weight,))
     x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att = saved
+    rows = a.dtype == torch.bfloat16                     # the forward ran on halo_gemm_rows
     # x = x1 + c_proj(gelu(c_fc(ln_2(x1))))
     put(blk.mlp.c_proj.weight, ops.gemm_tn(dxb, gb))
-    dab = ops.gelu_bwd_bf16(ops.gemm_split_io((dxb, None), wt(blk.mlp.c_proj), M, 4 * C, C), a)       # d a = (dx W) gelu'(a)
+    if rows:
+        dab = ops.gelu_bwd_b16(ops.gemm_rows(dxb, wt(blk.mlp.c_proj), M, 4 * C, C, out_bf16=True), a)    # d a = (dx W) gelu'(a), bf16 throughout
+    else:
+        dab = ops.gelu_bwd_bf16(ops.gemm_split_io((dxb, None), wt(blk.mlp.c_proj), M, 4 * C, C), a)
     put(blk.mlp.c_fc.weight, ops.gemm_tn(dab, h2b))
-    d_ln2 = ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
+    d_ln2 = ops.gemm_rows(dab, wt(blk.mlp.c_fc), M, C, 4 * C) if rows else ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
     del dab
     dx1, dw, db, dx1b = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None, want_bf16=True)
     put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
     # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
     put(blk.attn.c_proj.weight, ops.gemm_tn(dx1b, yb))
-    dy = ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
+    dy = ops.gemm_rows(dx1b, wt(blk.attn.c_proj), M, C, C) if rows else ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
     dqkvb = torch.empty(M, 3 * C, device=dx.device, dtype=torch.bfloat16)
     ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
                            B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
     put(blk.attn.c_attn.weight, ops.gemm_tn(dqkvb, h1b))
-    d_ln1 = ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
+    d_ln1 = ops.gemm_rows(dqkvb, wt(blk.attn.c_attn), M, C, 3 * C) if rows else ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
     dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)
     put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
     return dx0, dx0b
@@ -360,6 +384,27 @@ class GPT(nn.Module):
             self._linear(h, blk.mlp.c_proj, out=x, accumulate=True)                      # x += mlp(h)
         return ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias), present
 
+    @torch.no_grad()
+    def _trunk_rows(self, input_ids):
+        """Embedding + blocks + ln_f in single-pass bf16 arithmetic on halo_gemm_rows (scoring without a KV cache): the residual stream
+        fp32, updated in place by the products' residual epilogues; every Linear input row-major bf16.  -> ln_f(x) as row-major bf16."""
+        cfg = self.config
+        B, T = input_ids.shape
+        assert T <= cfg.block_size, f'Cannot forward sequence of length {T}, block size is only {cfg.block_size}'
+        C, H, M = cfg.n_embd, cfg.n_head, B * T
+        tr = self.transformer
+        w = lambda lin: self._images.split((lin.weight,))
+        x, _ = self._embed(input_ids, 0)
+        for blk in tr.h:
+            h1b = ops.layernorm_bf16(x, blk.ln_1.weight, blk.ln_1.bias)
+            qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
+            _, _, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
+            ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, out=x, residual=x)                   # x += c_proj(y)
+            h2b = ops.layernorm_bf16(x, blk.ln_2.weight, blk.ln_2.bias)
+            gb = ops.gelu_b16(ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True))
+            ops.gemm_rows(gb, w(blk.mlp.c_proj), M, C, 4 * C, out=x, residual=x)                # x += mlp(x)
+        return ops.layernorm_bf16(x, tr.ln_f.weight, tr.ln_f.bias)
+
     def forward_all(self, input_ids, target_ids, past=None, reduction='mean'):
         if not input_ids.is_cuda:
             raise _lib.HaloError('haloop_amd.attention.GPT runs on the HIP device only (no CPU path)')
@@ -373,9 +418,12 @@ class GPT(nn.Module):
             return self._reduce(loss, target_ids.reshape(-1), reduction)
         if self.training and self.config.dropout > 0:
             raise NotImplementedError('training-mode dropout is built into the autograd path only: enable grad, or call .eval()')
-        x, _ = self._trunk(input_ids, past)
         targets = target_ids.reshape(-1)
         C = self.config.n_embd
+        if past is None and B * T > SMALL_M and V % 8 == 0 and rows_ok(B * T, C) and rowmajor_train_ok(self.config, self.transformer.h, B * T, False):
+            loss, _, _ = ops.gemm_rows_ce(self._trunk_rows(input_ids), self._images.split((self.lm_head.weight,)), B * T, V, C, targets, ignore_index=0)
+            return self._reduce(loss, targets, reduction)
+        x, _ = self._trunk(input_ids, past)
         if use_split(B * T, V, C) and B * T > SMALL_M:
             # lm_head + cross-entropy in the GEMM's epilogue: the [rows, V] logits are never written
             loss, _, _ = ops.gemm_split_ce(ops.split_image(x), self._images.split((self.lm_head.weight,)), B * T, V, C, targets, ignore_index=0)
@@ -419,8 +467,15 @@ class GPT(nn.Module):
         for blk in tr.h:
             x, sv = fwd(self._images, blk, x, B, T, cfg, sites)
             blocks.append(sv)
-        xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         targets = target_ids.reshape(-1)
+        if fwd is block_forward_train_rm and rows_ok(B * T, C) and cfg.vocab_size % 8 == 0:
+            # round 5: ln_f's rows as row-major bf16, the lm_head product on halo_gemm_rows with the cross-entropy statistics in its
+            # epilogue (from the fp32 accumulators) and the logits KEPT AS bf16 (1.65 GB of fp32 at B = 8, T = 1024 no longer written)
+            xf = ops.layernorm_bf16(x, tr.ln_f.weight, tr.ln_f.bias)
+            loss, row_lse, logits = ops.gemm_rows_ce(xf, self._images.split((self.lm_head.weight,)), B * T, cfg.vocab_size, C, targets,
+                                                     ignore_index=0, want_logits=True, want_lse=True)
+            return loss, (input_ids, targets, blocks, x, xf, logits, row_lse, s_emb, emb_saved)
+        xf = ops.layernorm_fwd(x, tr.ln_f.weight, tr.ln_f.bias)
         if use_split(B * T, cfg.vocab_size, C) and B * T > SMALL_M:          # statistics in the GEMM epilogue; the logits are kept for the backward
             loss, row_lse, logits = ops.gemm_split_ce(ops.split_image(xf), self._images.split((self.lm_head.weight,)), B * T, cfg.vocab_size, C,
                                                       targets, ignore_index=0, want_logits=True, want_lse=True)
@@ -444,7 +499,13 @@ class GPT(nn.Module):
                 grads[id(p)] = g if id(p) not in grads else grads[id(p)] + g
 
         M, V = logits.shape
-        if use_split(M, C, V) and use_split(V, C, M):
+        if logits.dtype == torch.bfloat16:
+            # the stored bf16 logits become d loss / d logits IN PLACE: the row-major bf16 operand of both gradient products
+            dl = ops.cross_entropy_bwd_bf16_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
+            dw_head = ops.gemm_tn(dl, xf)                                                    # [V, C]; the tied wte gradient lands here too
+            dxf = ops.gemm_rows(dl, img.split_t((self.lm_head.weight,)), M, C, V)
+            del dl, logits
+        elif use_split(M, C, V) and use_split(V, C, M):
             # d loss / d logits goes straight into the two operand images of the lm_head's backward products
             dl_img, dl_img_t = ops.cross_entropy_bwd_images(logits, targets, row_lse, grad_per_tok, ignore_index=0)
             dw_head = linear_dw(None, xf, dy_image_t=dl_img_t, shapes=((M, V), xf.shape))    # [V, C]; the tied wte gradient lands here too

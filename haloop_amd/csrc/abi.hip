@@ -11,7 +11,7 @@ HaloCtx &halo_ctx_cur() { return t_ctx ? *t_ctx : g_default_ctx; }
 
 // per-device facts, indexed by the HIP device ordinal (relaxed atomics: racing host threads write the same value)
 namespace {
-constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 8;
+constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 40;
 std::atomic<int> g_cus[MAX_DEVICES];
 std::atomic<unsigned char> g_attr[ATTR_SLOTS][MAX_DEVICES];
 int cur_device() {

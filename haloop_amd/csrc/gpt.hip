@@ -328,6 +328,27 @@ __global__ __launch_bounds__(256) void gelu_bf16_kernel(const float *__restrict_
     }
 }
 
+// ... and with bf16 on both sides (the c_fc product left its result as row-major bf16: halo_gemm_rows): y = gelu(a), da = dy * gelu'(a);
+// the arithmetic in fp32 on the bf16 values
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_b16_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ a, __bf16 *__restrict__ y, long n8,
+                                                       int exact) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a + 8 * i);
+        bf16x8 o;
+        if (BWD) {
+            const bf16x8 dv = *reinterpret_cast<const bf16x8 *>(dy + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)dv[e] * gelu_grad((float)av[e], exact));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)gemm_activation((float)av[e], exact ? 8 : 2);
+        }
+        *reinterpret_cast<bf16x8 *>(y + 8 * i) = o;
+    }
+}
+
 int layernorm_bwd_impl(const float *dy, const float *x, const float *weight, const float *dres, float *dx, __bf16 *dxb, float *dweight,
                               float *dbias, void *workspace, int rows, int C, float eps, hipStream_t st) {
     float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
@@ -420,6 +441,22 @@ int halo_gelu_bwd_bf16(const float *dy, const float *a, void *da_bf16, size_t n,
     const long n8 = (long)(n / 8), want = (n8 + 255) / 256;
     hipLaunchKernelGGL(gelu_bf16_kernel<true>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream, dy, a,
                        (__bf16 *)da_bf16, n8, exact);
+    return halo_launch_status();
+}
+
+int halo_gelu_b16(const void *a_bf16, void *y_bf16, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(a_bf16 && y_bf16 && n > 0 && n % 8 == 0 && (((uintptr_t)a_bf16 | (uintptr_t)y_bf16) % 16) == 0);
+    const size_t want = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(gelu_b16_kernel<false>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream, nullptr,
+                       (const __bf16 *)a_bf16, (__bf16 *)y_bf16, (long)(n / 8), exact);
+    return halo_launch_status();
+}
+
+int halo_gelu_bwd_b16(const void *dy_bf16, const void *a_bf16, void *da_bf16, size_t n, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy_bf16 && a_bf16 && da_bf16 && n > 0 && n % 8 == 0 && (((uintptr_t)dy_bf16 | (uintptr_t)a_bf16 | (uintptr_t)da_bf16) % 16) == 0);
+    const size_t want = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(gelu_b16_kernel<true>, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)dy_bf16, (const __bf16 *)a_bf16, (__bf16 *)da_bf16, (long)(n / 8), exact);
     return halo_launch_status();
 }
 

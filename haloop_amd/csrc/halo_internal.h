@@ -73,7 +73,7 @@ HaloCtx &halo_ctx_cur();
 // CUs of the current device (hipDeviceProp_t::multiProcessorCount, cached per device; <= 0: the query failed)
 int halo_cu_count();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: one flag per (kernel slot, device) instead of a process-wide bool.
-// Slots: 0 ctc_head_train_kernel, 1 gemm256_kernel<0>, 2 gemm256 GPT epilogues, 3 .. 7 free
+// Slots: 0 ctc_head_train_kernel, 1 / 2 gemm256_kernel (product / lab variants), 8 .. 31 the gemm_rows_kernel instantiations
 bool halo_func_attr_done(int slot);
 void halo_func_attr_set(int slot);
 // C | C2 = A x (B stacked on B2)^T in one launch (columns [n_split, N) of the result go to C2); plain sums

@@ -237,6 +237,88 @@ def gemm_split_ce(a_img, b_img, M, N, K, targets, ignore_index=0, bias=None, wan
     return loss, lse, logits
 
 
+def gemm_rows_supported(M, N, K):
+    """halo_gemm_rows takes this shape in the current arithmetic mode (single-pass bf16 only)."""
+    return bool(lib().halo_gemm_rows_supported(M, N, K))
+
+
+def gemm_rows(a, b_img, M, N, K, out=None, residual=None, out_bf16=False):
+    """C [M, N] = A [M, K] B [N, K]^T on the 256-row tiles of halo_gemm_rows (single-pass bf16).  ``a``: row-major bf16 [M, K] or an operand
+    image (uint8).  Result: fp32 ``out`` (fresh by default), ``residual`` [M, N] fp32 added when given; or, with ``out_bf16``, row-major
+    bf16 [M, N]."""
+    a_img = a_rm = None
+    lda = 0
+    if a.dtype == torch.bfloat16:
+        if a.dim() != 2 or a.shape != (M, K) or a.stride(1) != 1:
+            raise ValueError('gemm_rows: a = row-major bf16 [M, K]')
+        a_rm, lda = a, a.stride(0)
+    else:
+        a_img = a
+    dev = b_img.device
+    ob = None
+    if out_bf16:
+        if residual is not None or out is not None:
+            raise ValueError('gemm_rows: a bf16 result takes neither out= nor residual=')
+        ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    elif out is None:
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    if residual is not None:
+        _f32c(residual, 'residual')
+        if residual.shape != (M, N):
+            raise ValueError('gemm_rows: residual must be [M, N]')
+    check(lib().halo_gemm_rows(ptr(a_img), ptr(a_rm), lda, ptr(b_img), M, N, K, ptr(out), N if out is not None else 0, ptr(residual),
+                               N if residual is not None else 0, ptr(ob), N if ob is not None else 0, _stream()), 'halo_gemm_rows')
+    return ob if out_bf16 else out
+
+
+def gemm_rows_ce(a, b_img, M, N, K, targets, ignore_index=0, want_logits=False, want_lse=False):
+    """Per-row cross-entropy of logits = A B^T from halo_gemm_rows_ce's epilogue: -> (loss [M], lse [M] or None, logits [M, N] as
+    row-major bf16 or None).  ``a``: row-major bf16 [M, K] or an operand image."""
+    tg = _i64c(targets.reshape(-1), 'targets')
+    a_img = a_rm = None
+    lda = 0
+    if a.dtype == torch.bfloat16:
+        a_rm, lda = a, a.stride(0)
+    else:
+        a_img = a
+    dev = b_img.device
+    ws = torch.empty(lib().halo_gemm_rows_ce_workspace_bytes(M, N), device=dev, dtype=torch.uint8)
+    loss = torch.empty(M, device=dev, dtype=torch.float32)
+    lse = torch.empty(M, device=dev, dtype=torch.float32) if want_lse else None
+    logits = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if want_logits else None
+    check(lib().halo_gemm_rows_ce(ptr(a_img), ptr(a_rm), lda, ptr(b_img), M, N, K, ptr(tg), ignore_index, ptr(ws), ptr(loss), ptr(lse),
+                                  ptr(logits), N if logits is not None else 0, _stream()), 'halo_gemm_rows_ce')
+    return loss, lse, logits
+
+
+def cross_entropy_bwd_bf16_(logits_bf16, targets, lse, grad_rows, ignore_index=0):
+    """In place: bf16 logits [rows, V] -> (softmax - onehot) * grad_rows[row] as row-major bf16 (0 on ignored rows)."""
+    if logits_bf16.dtype != torch.bfloat16 or logits_bf16.dim() != 2 or logits_bf16.stride(1) != 1:
+        raise ValueError('cross_entropy_bwd_bf16_: row-major bf16 logits')
+    tg = _i64c(targets.reshape(-1), 'targets')
+    rows, V = logits_bf16.shape
+    g = grad_rows.reshape(-1)
+    _f32c(g, 'grad_rows'); _f32c(lse, 'lse')
+    stride = 0 if g.numel() == 1 else 1
+    check(lib().halo_cross_entropy_bwd_bf16(ptr(logits_bf16), ptr(tg), ptr(lse), ptr(g), stride, rows, V, logits_bf16.stride(0), ignore_index,
+                                            _stream()), 'halo_cross_entropy_bwd_bf16')
+    return logits_bf16
+
+
+def gelu_b16(a, exact=False):
+    """gelu(a), bf16 -> bf16."""
+    y = torch.empty_like(a)
+    check(lib().halo_gelu_b16(ptr(a), ptr(y), a.numel(), int(exact), _stream()), 'halo_gelu_b16')
+    return y
+
+
+def gelu_bwd_b16(dy, a, exact=False):
+    """dy * gelu'(a), bf16 x bf16 -> bf16."""
+    y = torch.empty_like(a)
+    check(lib().halo_gelu_bwd_b16(ptr(dy), ptr(a), ptr(y), a.numel(), int(exact), _stream()), 'halo_gelu_bwd_b16')
+    return y
+
+
 def dropout_fwd(x, drop, stream_id):
     _f32c(x, 'x')
     y = torch.empty_like(x)

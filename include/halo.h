@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 16
+#define HALO_ABI_VERSION 17
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -145,6 +145,10 @@ int halo_cast_bf16(const float *x, void *y, size_t n, halo_stream_t stream);
  * producing GEMM's epilogue (GPT training direction): the separate pass is hidden under its HBM stream, the epilogue is not. */
 int halo_gelu_bf16(const float *a, void *y_bf16, size_t n, int exact, halo_stream_t stream);
 int halo_gelu_bwd_bf16(const float *dy, const float *a, void *da_bf16, size_t n, int exact, halo_stream_t stream);
+/* ... and with bf16 on BOTH sides (round 5: the c_fc product and the c_proj input-gradient product leave their results as row-major
+ * bf16, halo_gemm_rows -- what the reference's autocast path holds there, ha/attention_loop.py:164): fp32 arithmetic on the bf16 values. */
+int halo_gelu_b16(const void *a_bf16, void *y_bf16, size_t n, int exact, halo_stream_t stream);
+int halo_gelu_bwd_b16(const void *dy_bf16, const void *a_bf16, void *da_bf16, size_t n, int exact, halo_stream_t stream);
 /* One read of an fp32 matrix src [rows][cols] (leading dimension ld), optionally through an elementwise operator, written as
  * BOTH split images a Linear's backward consumes: image_rows = halo_split_image(value [rows][cols]) (the A operand of
  * dx = dy W, ha/attention.py:117-129,141) and image_cols = halo_split_image(value^T [cols][rows]) (the operand of dW = dy^T x);
@@ -198,6 +202,30 @@ int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, i
 int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, long lda, const void *b_image, int M, int N, int K, float *C,
                        int ldc, void *out_hi, void *out_lo, long ldo, const float *residual, int ldr, const float *bias1,
                        const float *bias2, int flags, halo_stream_t stream);
+
+/* Round 5: the activation-by-weight products of the GPT path on 256-row x 96 / 192 / 288-column workgroup tiles (csrc/gemm_rows.h), single-pass
+ * bf16 arithmetic only (HALO_ENOTSUP in the other modes; halo_gemm_rows_supported says so up front).  C [M][N] = A [M][K] x B [N][K]^T with
+ * A either a tiled image (a_image) or ROW-MAJOR bf16 a_bf16 [M][lda] (lda % 8 == 0), B a tiled image (halo_split_image of the weight, or
+ * of its transpose for an input gradient), K % 32 == 0, N % 8 == 0, and exactly one result: fp32 C [M][ldc] (+ residual [M][ldr] when
+ * given: x1 = x0 + c_proj(y), ha/attention.py:178-179, no copy of x0 first), or row-major bf16 out_bf16 [M][ldo] (what the next launch's
+ * operand staging, the GELU passes and the attention kernels read).  The tile width is chosen per shape so that the tiles fill whole
+ * rounds of the device's CUs: N = 768 -> 96 columns, 2304 -> 288, 3072 -> 192 at M = 8192.
+ * replaces: F.linear in nn.Linear.forward of c_attn / c_proj / c_fc (ha/attention.py:96-144) and its input-gradient matmul under autograd. */
+int halo_gemm_rows_supported(int M, int N, int K);
+int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, float *C, long ldc,
+                   const float *residual, long ldr, void *out_bf16, long ldo, halo_stream_t stream);
+/* ... and the lm_head product with the cross-entropy statistics in its epilogue (as halo_gemm_split_ce: loss[m] = logsumexp(logits[m, :]) -
+ * logits[m, targets[m]], 0 on ignored rows; lse optional) and the logits kept as ROW-MAJOR bf16 logits_bf16 [M][ldo] (NULL: scoring,
+ * nothing of size M x N is written) -- the reference's autocast lm_head output, ha/attention.py:228-231.  The statistics and the target's
+ * logit are taken from the fp32 accumulators, so the loss does not see the rounding of the stored logits.
+ * halo_cross_entropy_bwd_bf16 then turns the stored logits IN PLACE into (softmax - onehot(target)) * grad[m * grad_stride] (0 on
+ * ignored rows; V % 8 == 0): the row-major bf16 operand of the lm_head's two gradient products (halo_gemm_tn_bf16, halo_gemm_rows).
+ * replaces: F.cross_entropy(lm_head(x), targets, ignore_index=0) and its backward to the logits. */
+size_t halo_gemm_rows_ce_workspace_bytes(int M, int N);
+int halo_gemm_rows_ce(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, const int64_t *targets,
+                      long ignore_index, void *workspace, float *loss, float *lse, void *logits_bf16, long ldo, halo_stream_t stream);
+int halo_cross_entropy_bwd_bf16(void *logits_bf16, const int64_t *targets, const float *lse, const float *grad, long grad_stride, int rows,
+                                int V, long ld, long ignore_index, halo_stream_t stream);
 
 /* lm_head + cross-entropy without materialising the logits (ha/attention.py:228-231): the split GEMM
  * logits[M,N] = A B^T (+ bias[N]) whose epilogue reduces each 64-column strip of a row to (max, sum exp) and picks out the

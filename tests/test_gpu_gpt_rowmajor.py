@@ -14,6 +14,7 @@ DEV = 'cuda'
 def _run(monkeypatch, rowmajor, seed=3):
     from haloop_amd import _lib, attention
     monkeypatch.setenv('HALO_GPT_ROWMAJOR', '1' if rowmajor else '0')
+    monkeypatch.setenv('HALO_GPT_ROWS', '0')            # (the 128-tile launches this test was written for; tests/test_gpu_gemm_rows.py holds the row tiles)
     torch.manual_seed(seed)
     cfg = attention.GPTConfig(block_size=1024, vocab_size=2048, n_layer=2, n_head=12, n_embd=768)
     model = attention.GPT(cfg).to(DEV).train()

@@ -10,6 +10,12 @@
 #include <vector>
 #include "gemm256.h"
 
+// (the library keeps these per device in abi.hip; a one-device lab binary needs no more)
+static bool g_attr_done[8];
+int halo_cu_count() { return 256; }
+bool halo_func_attr_done(int slot) { return g_attr_done[slot]; }
+void halo_func_attr_set(int slot) { g_attr_done[slot] = true; }
+
 // ==== lab only: the four-wave variant of the 256 x 256 tile (measured equal to the eight-wave kernel the library links: DESIGN.md 3.1e) ====
 namespace halo_g256 {
 

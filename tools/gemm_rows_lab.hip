@@ -1,0 +1,195 @@
+// Laboratory build of csrc/gemm_rows.h (256 x 32 TN tiles, a wave = 32 rows x all columns) on the GPT-2 small product shapes, verified on sampled
+// elements against a plain dot product and timed against the library's 128 x 128-tile kernel (halo_gemm_split_io) in the same process:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I haloop_amd/csrc -I include tools/gemm_rows_lab.hip -L haloop_amd/csrc -lhalo \
+//         -Wl,-rpath,$PWD/haloop_amd/csrc -o gpurun_out/gemm_rows_lab && gpurun_out/gemm_rows_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include "halo.h"
+#include "gemm_rows.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(float *x, long n, unsigned seed, float scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = seed ^ (unsigned)(i * 2654435761u);
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5; h *= 0x9E3779B1u; h ^= h >> 15;
+        x[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.0f);
+    }
+}
+__global__ void to_bf16_kernel(const float *x, __bf16 *y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];
+}
+// sample s -> element (m, n): fp32 dot product of the bf16-rounded operands (+ the residual)
+__global__ void sample_ref_kernel(const __bf16 *A, const float *B, const float *R, int M, int N, int K, int nsamp, int *sm, int *sn, float *out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamp) return;
+    unsigned h = 0x1234567u + s * 2654435761u; h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
+    int m = h % M; h = h * 1664525u + 1013904223u; int n = (h >> 4) % N;
+    if (s < 64) { m = (s & 1) ? M - 1 - (s >> 1) % 40 : (s >> 1) % 40; n = (s & 2) ? N - 1 - (s >> 2) % 16 : (s >> 2) % 16; }      // the corners
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += (float)A[(long)m * K + k] * (float)(__bf16)B[(long)n * K + k];
+    if (R) acc += R[(long)m * N + n];
+    sm[s] = m; sn[s] = n; out[s] = acc;
+}
+
+template <typename F>
+static float time_us(F f, int reps = 20) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0)); f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+template <int TN, int EPI, int LAB>
+static void lab_launch(const halo_gr::Args *a) { (void)halo_gr::launch<TN, EPI, false, LAB>(*a, nullptr); }
+
+template <int TN, int EPI>
+static void run(const char *name, int M, int N, int K, bool check_ce = false) {
+    using namespace halo_gr;
+    float *Af, *Bf, *C, *Cold, *R = nullptr;
+    __bf16 *A, *O;
+    CK(hipMalloc(&Af, (size_t)M * K * 4)); CK(hipMalloc(&Bf, (size_t)N * K * 4));
+    CK(hipMalloc(&A, (size_t)M * K * 2));
+    const bool big = (size_t)M * N > (1u << 28);
+    CK(hipMalloc(&C, big ? 16 : (size_t)M * N * 4)); CK(hipMalloc(&Cold, big ? 16 : (size_t)M * N * 4)); CK(hipMalloc(&O, (size_t)M * N * 2));
+    fill_kernel<<<1024, 256>>>(Af, (long)M * K, 1u, 1.0f);
+    fill_kernel<<<1024, 256>>>(Bf, (long)N * K, 2u, 1.0f);
+    to_bf16_kernel<<<1024, 256>>>(Af, A, (long)M * K);
+    if (EPI == EPI_RESID) { CK(hipMalloc(&R, (size_t)M * N * 4)); fill_kernel<<<1024, 256>>>(R, (long)M * N, 3u, 4.0f); }
+    void *img; CK(hipMalloc(&img, halo_split_image_bytes(N, K)));
+    if (halo_split_image(Bf, N, K, K, 0, img, nullptr) != HALO_OK) { printf("image failed\n"); exit(1); }
+    float *part = nullptr, *tlog = nullptr; int64_t *tgt = nullptr;
+    Args a = {};
+    a.a_rm = A; a.lda = K; a.b_img = (const char *)img; a.M = M; a.N = N; a.KT = K / 32;
+    a.tiles_m = (M + 255) / 256; a.tiles_n = (N + Cfg<TN>::BN - 1) / Cfg<TN>::BN;
+    a.C = C; a.ldc = N; a.R = R; a.ldr = N; a.O = O; a.ldo = N;
+    if (EPI == EPI_CE) {
+        CK(hipMalloc(&part, (size_t)M * a.tiles_n * 8)); CK(hipMalloc(&tlog, (size_t)M * 4)); CK(hipMalloc(&tgt, (size_t)M * 8));
+        std::vector<int64_t> h(M); for (int i = 0; i < M; ++i) h[i] = (i * 7919L + 13) % N;
+        CK(hipMemcpy(tgt, h.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+        a.ce_target = tgt; a.ce_part = part; a.ce_tlogit = tlog;
+    }
+    CK(hipDeviceSynchronize());
+    auto mine = [&]() { if (launch<TN, EPI, false>(a, nullptr) != hipSuccess) { printf("launch failed\n"); exit(1); } };
+    mine(); CK(hipDeviceSynchronize());
+    // ---- check
+    const int NS = 1 << 16;
+    int *sm, *sn; float *sref; CK(hipMalloc(&sm, NS * 4)); CK(hipMalloc(&sn, NS * 4)); CK(hipMalloc(&sref, NS * 4));
+    sample_ref_kernel<<<NS / 256, 256>>>(A, Bf, R, M, N, K, NS, sm, sn, sref);
+    std::vector<int> hm(NS), hn(NS); std::vector<float> href(NS);
+    CK(hipMemcpy(hm.data(), sm, NS * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hn.data(), sn, NS * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(href.data(), sref, NS * 4, hipMemcpyDeviceToHost));
+    double maxd = 0, maxr = 0; int bad = 0;
+    const bool bf = EPI == EPI_BF16 || EPI == EPI_CE;
+    std::vector<float> got(NS);
+    {
+        // gather the sampled outputs on the device side (one element copies would take forever): a tiny kernel via hipMemcpy2D is overkill -- copy rows
+        std::vector<__bf16> rowb; std::vector<float> rowf;
+        int last_m = -1;
+        std::vector<int> order(NS); for (int i = 0; i < NS; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return hm[x] < hm[y]; });
+        if (bf) rowb.resize(N); else rowf.resize(N);
+        for (int idx : order) {
+            if (hm[idx] != last_m) {
+                last_m = hm[idx];
+                if (bf) CK(hipMemcpy(rowb.data(), O + (size_t)last_m * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+                else CK(hipMemcpy(rowf.data(), C + (size_t)last_m * N, (size_t)N * 4, hipMemcpyDeviceToHost));
+            }
+            got[idx] = bf ? (float)rowb[hn[idx]] : rowf[hn[idx]];
+        }
+    }
+    for (int i = 0; i < NS; ++i) {
+        const double d = fabs((double)got[i] - href[i]);
+        const double tol = bf ? 8e-3 * fabs(href[i]) + 2e-2 : 1e-3 + 2e-5 * fabs(href[i]) * sqrt((double)K);
+        if (d > tol) { if (bad < 5) printf("  mismatch at (%d, %d): got %g want %g\n", hm[i], hn[i], got[i], href[i]); ++bad; }
+        maxd = std::max(maxd, d); maxr = std::max(maxr, (double)fabs(href[i]));
+    }
+    if (EPI == EPI_CE) {           // every row's (max, sum exp) merged over the tile columns against the bf16 logits it wrote; the target logit
+        std::vector<float> hp((size_t)M * a.tiles_n * 2), ht(M); std::vector<__bf16> row(N);
+        CK(hipMemcpy(hp.data(), part, hp.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ht.data(), tlog, (size_t)M * 4, hipMemcpyDeviceToHost));
+        double worst = 0, worst_t = 0;
+        for (int mrow : {0, 1, 31, 32, 255, 256, M / 2 + 1, M - 1}) {
+            CK(hipMemcpy(row.data(), O + (size_t)mrow * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+            double mx = -1e30; for (int n = 0; n < N; ++n) mx = std::max(mx, (double)(float)row[n]);
+            double s = 0; for (int n = 0; n < N; ++n) s += exp((double)(float)row[n] - mx);
+            double gm = -1e30; for (int t = 0; t < a.tiles_n; ++t) gm = std::max(gm, (double)hp[((size_t)mrow * a.tiles_n + t) * 2]);
+            double gs = 0; for (int t = 0; t < a.tiles_n; ++t) gs += hp[((size_t)mrow * a.tiles_n + t) * 2 + 1] * exp(hp[((size_t)mrow * a.tiles_n + t) * 2] - gm);
+            worst = std::max(worst, fabs((gm + log(gs)) - (mx + log(s))));
+            worst_t = std::max(worst_t, fabs((double)ht[mrow] - (double)(float)row[(mrow * 7919L + 13) % N]));
+        }
+        printf("  CE: |lse - lse(bf16 logits)| <= %.3e, |target logit - bf16 logit| <= %.3e\n", worst, worst_t);
+        if (worst > 0.2 || worst_t > 0.2) ++bad;          // (against the ROUNDED logits: a bf16 ulp at |logit| ~ 40 is 0.25)
+    }
+    // ---- the library's kernel on the same operands (fp32 or bf16 result, residual add)
+    halo_set_math_mode(HALO_MATH_BF16);
+    float t_old = -1.f;
+    if (EPI != EPI_CE) {
+        auto old = [&]() {
+            int rc;
+            if (EPI == EPI_BF16) rc = halo_gemm_split_io(nullptr, A, nullptr, K, img, M, N, K, nullptr, 0, O, nullptr, N, nullptr, 0, nullptr, nullptr, 0, nullptr);
+            else if (EPI == EPI_F32) rc = halo_gemm_split_io(nullptr, A, nullptr, K, img, M, N, K, Cold, N, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr);
+            else rc = halo_gemm_split_io(nullptr, A, nullptr, K, img, M, N, K, Cold, N, nullptr, nullptr, 0, R, N, nullptr, nullptr, HALO_GEMM_ACCUM, nullptr);
+            if (rc != HALO_OK) { printf("library product failed: %d\n", rc); exit(1); }
+        };
+        if (EPI == EPI_BF16) t_old = -2.f;            // (the library has no bf16-only result from a row-major A in single-pass mode: timed as fp32)
+        if (EPI != EPI_BF16) t_old = time_us(old);
+    }
+    const float t_new = time_us(mine);
+    const double gf = 2.0 * M * N * K / 1e9;
+    if (getenv("LAB_AIMG") && EPI != EPI_CE) {          // the same product with A as a tiled image (1-KiB contiguous pieces instead of 16 x 64-byte row segments)
+        void *imgA; CK(hipMalloc(&imgA, halo_split_image_bytes(M, K)));
+        if (halo_split_image(Af, M, K, K, 0, imgA, nullptr) != HALO_OK) { printf("image failed\n"); exit(1); }
+        Args b = a; b.a_img = (const char *)imgA; b.a_rm = nullptr;
+        auto vi = [&]() { (void)launch<TN, EPI, true>(b, nullptr); };
+        printf("   A as image: %.1f us\n", time_us(vi));
+        CK(hipFree(imgA));
+    }
+    if (getenv("LAB_ABLATE") && EPI != EPI_CE) {
+        auto v1 = [&]() { lab_launch<TN, EPI, 1>(&a); }; auto v2 = [&]() { lab_launch<TN, EPI, 2>(&a); };
+        auto v3 = [&]() { lab_launch<TN, EPI, 3>(&a); }; auto v4 = [&]() { lab_launch<TN, EPI, 4>(&a); };
+        auto v8 = [&]() { lab_launch<TN, EPI, 8>(&a); }; auto v7 = [&]() { lab_launch<TN, EPI, 7>(&a); };
+        auto v12 = [&]() { lab_launch<TN, EPI, 12>(&a); };
+        printf("   ablations (us): no DMA %.1f | no reads %.1f | neither %.1f | no stores %.1f | no MFMA %.1f | no MFMA no stores %.1f | MFMA + barriers only %.1f\n",
+               time_us(v1), time_us(v2), time_us(v3), time_us(v4), time_us(v8), time_us(v12), time_us(v7));
+    }
+    printf("%-34s M %5d N %5d K %5d TN %d: %s  max|diff| %.3e of max|ref| %.3e   new %7.1f us (%5.0f TF)", name, M, N, K, TN, bad ? "MISMATCH" : "ok", maxd, maxr,
+           t_new, gf / t_new * 1e3);
+    if (t_old > 0) printf("   128-tile kernel %7.1f us (%5.0f TF)", t_old, gf / t_old * 1e3);
+    printf("\n");
+    for (void *q : {(void *)Af, (void *)Bf, (void *)A, (void *)C, (void *)Cold, (void *)O, img, (void *)R, (void *)sm, (void *)sn, (void *)sref, (void *)part, (void *)tlog, (void *)tgt})
+        if (q) CK(hipFree(q));
+}
+
+int main(int argc, char **argv) {
+    const int which = argc > 1 ? atoi(argv[1]) : -1;
+    void *scratch; CK(hipMalloc(&scratch, 256u << 20)); halo_set_scratch(scratch, 256u << 20);
+    if (which < 0 || which == 0) run<9, halo_gr::EPI_F32>("c_attn forward (fp32 out)", 8192, 2304, 768);
+    if (which < 0 || which == 0) run<9, halo_gr::EPI_BF16>("c_attn forward (bf16 out)", 8192, 2304, 768);
+    if (which < 0 || which == 1) run<3, halo_gr::EPI_RESID>("attention c_proj forward (+resid)", 8192, 768, 768);
+    if (which < 0 || which == 1) run<3, halo_gr::EPI_F32>("attention c_proj dx", 8192, 768, 768);
+    if (which < 0 || which == 2) run<6, halo_gr::EPI_F32>("c_fc forward (fp32 out)", 8192, 3072, 768);
+    if (which < 0 || which == 2) run<6, halo_gr::EPI_BF16>("c_fc forward / c_proj dx (bf16 out)", 8192, 3072, 768);
+    if (which < 0 || which == 3) run<3, halo_gr::EPI_RESID>("mlp c_proj forward (+resid)", 8192, 768, 3072);
+    if (which < 0 || which == 3) run<3, halo_gr::EPI_F32>("c_fc dx", 8192, 768, 3072);
+    if (which < 0 || which == 4) run<3, halo_gr::EPI_F32>("c_attn dx", 8192, 768, 2304);
+    if (which < 0 || which == 5) run<6, halo_gr::EPI_CE>("lm_head + CE (bf16 logits)", 8192, 50304, 768);
+    if (which < 0 || which == 6) run<3, halo_gr::EPI_F32>("lm_head dx", 8192, 768, 50304);
+    if (which < 0 || which == 7) {                    // ragged shapes: rows and columns that do not fill their last tile
+        run<3, halo_gr::EPI_F32>("ragged 3", 1000, 200, 160);
+        run<6, halo_gr::EPI_BF16>("ragged 6", 777, 1000, 96);
+        run<9, halo_gr::EPI_RESID>("ragged 9", 300, 584, 64);
+        run<6, halo_gr::EPI_CE>("ragged CE", 515, 1000, 128);
+    }
+    return 0;
+}
