@@ -47,6 +47,8 @@ struct Args {
     const char *b_img;                   // tiled image of B [N][K]
     int M, N, KT;                        // KT: 32-deep k-blocks
     int tiles_m, tiles_n;
+    int kslices, ktper;                  // EPI_F32 only: the k-blocks cut into kslices runs of ktper; workgroup b takes slice b / tiles and writes its
+    long slab_stride;                    // plain sums to C + slice * slab_stride (a reduce launch adds the slabs)
     float *C; long ldc;                  // EPI_F32 / EPI_RESID: fp32 result
     const float *R; long ldr;            // EPI_RESID: C = R + A B^T (R may be C)
     __bf16 *O; long ldo;                 // EPI_BF16: bf16 result; EPI_CE: optional bf16 logits
@@ -94,10 +96,13 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const Args a) {
     // tile order inside an XCD's contiguous run: groups of four tile rows, walked column by column -- the ~32 tiles resident on one XCD
     // cover 4 A panels x 8 B panels (both stay in its L2) instead of one tile row x 32 columns
     const int ntile = a.tiles_m * a.tiles_n;
-    const int tile = xcd_order((int)blockIdx.x, ntile);
+    const int kslice = EPI == EPI_F32 ? (int)blockIdx.x / ntile : 0;
+    const int tile = xcd_order((int)blockIdx.x - kslice * ntile, ntile);
     const int grp = tile / (4 * a.tiles_n), gm0 = grp * 4, gh = min(4, a.tiles_m - gm0), ing = tile % (4 * a.tiles_n);
     const int tile_m = gm0 + ing % gh, tile_n = ing / gh;
-    const int KT = a.KT;
+    // this workgroup's k-blocks: [kb0, kb0 + KT) of the operands' KTall
+    const int KTall = a.KT, kb0 = EPI == EPI_F32 ? kslice * a.ktper : 0;
+    const int KT = EPI == EPI_F32 ? min(a.ktper, KTall - kb0) : KTall;
 
     // ---- LDS-DMA sources: P pieces per wave and k-block; piece pc < 16: rows 16 pc .. of the A tile, else rows 16 (pc - 16) .. of the B tile
     const char *src[P];
@@ -109,19 +114,19 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const Args a) {
             dst[i] = pc * 1024;
             if (AIMG) {
                 const int g0 = tile_m * 256 + 16 * pc, rbmax = (a.M + 127) / 128 - 1;
-                src[i] = a.a_img + (long)min(g0 >> 7, rbmax) * KT * BLOCK + (g0 & 127) * 64 + lane * 16;
+                src[i] = a.a_img + ((long)min(g0 >> 7, rbmax) * KTall + kb0) * BLOCK + (g0 & 127) * 64 + lane * 16;
                 kstride[i] = BLOCK;
             } else {
                 // lane l of the piece lands at (row 16 pc + l / 4, position l % 4) of the slot's 64-byte rows; the swizzled image keeps
                 // logical chunk pos ^ ((row >> 2) & 3) there, so the lane FETCHES that chunk
                 const int row = min(tile_m * 256 + 16 * pc + (lane >> 2), a.M - 1), chunk = (lane & 3) ^ ((lane >> 4) & 3);
-                src[i] = reinterpret_cast<const char *>(a.a_rm + (long)row * a.lda + chunk * 8);
+                src[i] = reinterpret_cast<const char *>(a.a_rm + (long)row * a.lda + kb0 * 32 + chunk * 8);
                 kstride[i] = 64;
             }
         } else {
             const int q = pc - 16, n0 = tile_n * BN + 16 * q, rbmax = (a.N + 127) / 128 - 1;
             dst[i] = A_BYTES + q * 1024;
-            src[i] = a.b_img + (long)min(n0 >> 7, rbmax) * KT * BLOCK + (n0 & 127) * 64 + lane * 16;
+            src[i] = a.b_img + ((long)min(n0 >> 7, rbmax) * KTall + kb0) * BLOCK + (n0 & 127) * 64 + lane * 16;
             kstride[i] = BLOCK;
         }
     }
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const Args a) {
     const bool rowok = m < a.M;
     const int ncol0 = tile_n * BN;
     if constexpr (EPI == EPI_F32 || EPI == EPI_RESID) {
-        float *crow = a.C + (long)m * a.ldc + ncol0 + 4 * lh;
+        float *crow = a.C + (long)kslice * a.slab_stride + (long)m * a.ldc + ncol0 + 4 * lh;
         const float *rrow = EPI == EPI_RESID ? a.R + (long)m * a.ldr + ncol0 + 4 * lh : nullptr;
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
@@ -305,7 +310,8 @@ static inline hipError_t launch(const Args &a, hipStream_t st) {
         if (e != hipSuccess) return e;
         if (!LAB) halo_func_attr_set(slot);
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<TN, EPI, AIMG, LAB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), Cfg<TN>::LDS_BYTES, st, a);
+    const int ks = EPI == EPI_F32 && a.kslices > 1 ? a.kslices : 1;
+    hipLaunchKernelGGL((gemm_rows_kernel<TN, EPI, AIMG, LAB>), dim3((unsigned)(a.tiles_m * a.tiles_n * ks)), dim3(512), Cfg<TN>::LDS_BYTES, st, a);
     return hipGetLastError();
 }
 

@@ -31,11 +31,26 @@ template <int EPI, bool AIMG>
 int launch_tn(int tn, Args &a, hipStream_t st) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 32 * tn - 1) / (32 * tn);
+    if (a.kslices < 1) { a.kslices = 1; a.ktper = a.KT; }
     hipError_t e;
     if (tn == 9) e = launch<9, EPI, AIMG>(a, st);
     else if (tn == 6) e = launch<6, EPI, AIMG>(a, st);
     else e = launch<3, EPI, AIMG>(a, st);
     return e == hipSuccess ? HALO_OK : HALO_ELAUNCH;
+}
+
+// C [M][ldc] = slab 0 + slab 1 (+ ...), four columns per thread (N % 4 == 0): the K-slices of a long contraction
+__global__ __launch_bounds__(256) void rows_slab_sum_kernel(const float *__restrict__ slab, long slab_stride, int nslab, float *__restrict__ C, long ldc,
+                                                            int M, int N4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * N4) return;
+    const int r = (int)(idx / N4), c = (int)(idx % N4) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4 *>(slab + (long)r * (N4 * 4) + c);
+    for (int k = 1; k < nslab; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + k * slab_stride + (long)r * (N4 * 4) + c);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    *reinterpret_cast<f32x4 *>(C + (long)r * ldc + c) = s;
 }
 
 // loss[row] = logsumexp over the tile columns' (max, sum exp) - target logit; 0 (and lse 0) on ignored rows; one wave per row
@@ -103,8 +118,26 @@ int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void
     a.a_img = (const char *)a_image; a.a_rm = (const __bf16 *)a_bf16; a.lda = lda; a.b_img = (const char *)b_image;
     a.M = M; a.N = N; a.KT = K / 32;
     a.C = C; a.ldc = ldc; a.R = residual; a.ldr = ldr; a.O = (__bf16 *)out_bf16; a.ldo = ldo;
-    const int tn = pick_tn(M, N);
+    int tn = pick_tn(M, N);
     hipStream_t st = (hipStream_t)stream;
+    // A very long contraction under few output tiles (the lm_head's input gradient: K = 50304 under 8192 x 768): the narrow tile that fills
+    // the chip in one round is paced by its operand stream (22 KB per 384 MFMA cycles and CU), so it runs on tiles twice as wide and the
+    // k-blocks in two slices instead -- fp32 slabs in the scratch lent by halo_set_scratch, added by a second launch
+    if (C && !residual && !getenv("HALO_GEMM_ROWS_TN") && tn == 3 && K >= 16384 && N % 4 == 0) {
+        const int cus = halo_cu_count() > 0 ? halo_cu_count() : 256;
+        const long tiles6 = (long)((M + 255) / 256) * ((N + 191) / 192);
+        void *scratch; size_t bytes;
+        halo_get_scratch(&scratch, &bytes);
+        if (2 * tiles6 <= cus && scratch && bytes >= (size_t)2 * M * N * sizeof(float)) {
+            a.kslices = 2; a.ktper = (a.KT + 1) / 2;
+            a.C = (float *)scratch; a.ldc = N; a.slab_stride = (long)M * N;
+            const int rc = a_image ? launch_tn<EPI_F32, true>(6, a, st) : launch_tn<EPI_F32, false>(6, a, st);
+            if (rc != HALO_OK) return rc;
+            const long n4 = (long)M * (N / 4);
+            hipLaunchKernelGGL(rows_slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)scratch, a.slab_stride, 2, C, ldc, M, N / 4);
+            return halo_launch_status();
+        }
+    }
     if (a_image) {
         if (out_bf16) return launch_tn<EPI_BF16, true>(tn, a, st);
         return residual ? launch_tn<EPI_RESID, true>(tn, a, st) : launch_tn<EPI_F32, true>(tn, a, st);

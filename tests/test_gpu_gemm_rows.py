@@ -54,6 +54,27 @@ def test_rows_product_matches_fp64(bf16_mode, monkeypatch, M, N, K, tn):
     assert torch.equal(ops.gemm_rows(ops.split_image(a.float()), img, M, N, K), got)
 
 
+@pytest.mark.parametrize('M,N,K', [(2048, 768, 16384), (8192, 768, 50304)])
+def test_a_very_long_contraction_runs_as_two_k_slices(bf16_mode, M, N, K):
+    """K >= 16384 under a result that the narrow tiles would cover in one round (the lm_head's input gradient): wider tiles, two K-slices
+    through the lent scratch and a sum launch -- the fp64 product of the same bf16 values; without scratch the one-launch form, same values."""
+    from haloop_amd import _lib, ops
+    a, w, g = _operands(M, N, K, 7)
+    img = ops.split_image(w)
+    rows = torch.randint(0, M, (48,), generator=g).to(DEV)
+    want = a[rows].double() @ w.bfloat16().double().t()
+    got = ops.gemm_rows(a, img, M, N, K)
+    tol = 2e-6 * K ** 0.5 * 16 + 1e-5
+    assert (got[rows].double() - want).abs().max().item() <= tol
+    _lib.lib().halo_set_scratch(None, 0)
+    try:
+        one = ops.gemm_rows(a, img, M, N, K)
+    finally:
+        _lib.check(_lib.lib().halo_set_scratch(_lib._scratch.data_ptr(), _lib._scratch.numel()), 'halo_set_scratch')
+    assert (one[rows].double() - want).abs().max().item() <= tol
+    assert (one - got).abs().max().item() <= 2 * tol
+
+
 def test_rows_product_refusals(bf16_mode):
     from haloop_amd import _lib, ops
     a, w, _ = _operands(64, 64, 48, 1)                                  # K % 32 != 0
