@@ -45,6 +45,7 @@ SIGNATURES = {
     'halo_cast_bf16': (_i, [_vp, _vp, _sz, _vp]),
     'halo_gelu_bf16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_bf16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'halo_gemm_tn_bf16_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'halo_gelu_b16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_b16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_gemm_rows_supported': (_i, [_i, _i, _i]),

@@ -270,27 +270,39 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     wt = lambda lin: images.split_t((lin.weight,))
     x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att = saved
     rows = a.dtype == torch.bfloat16                     # the forward ran on halo_gemm_rows
+    # the four weight gradients contract over the same M token rows: collected here, ONE grouped launch at the end of the block
+    # (whole-K tiles, no K-slices or reduce launches); HALO_GPT_DW_GROUP=0: one launch each, as round 4
+    grouped = os.environ.get('HALO_GPT_DW_GROUP', '1') != '0' and M % 32 == 0
+    todo = []
+
+    def dweight(p, dy_b, x_b):
+        if grouped:
+            todo.append((p, dy_b, x_b))
+        else:
+            put(p, ops.gemm_tn(dy_b, x_b))
     # x = x1 + c_proj(gelu(c_fc(ln_2(x1))))
-    put(blk.mlp.c_proj.weight, ops.gemm_tn(dxb, gb))
+    dweight(blk.mlp.c_proj.weight, dxb, gb)
     if rows:
         dab = ops.gelu_bwd_b16(ops.gemm_rows(dxb, wt(blk.mlp.c_proj), M, 4 * C, C, out_bf16=True), a)    # d a = (dx W) gelu'(a), bf16 throughout
     else:
         dab = ops.gelu_bwd_bf16(ops.gemm_split_io((dxb, None), wt(blk.mlp.c_proj), M, 4 * C, C), a)
-    put(blk.mlp.c_fc.weight, ops.gemm_tn(dab, h2b))
+    dweight(blk.mlp.c_fc.weight, dab, h2b)
     d_ln2 = ops.gemm_rows(dab, wt(blk.mlp.c_fc), M, C, 4 * C) if rows else ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
-    del dab
     dx1, dw, db, dx1b = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None, want_bf16=True)
     put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
     # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
-    put(blk.attn.c_proj.weight, ops.gemm_tn(dx1b, yb))
+    dweight(blk.attn.c_proj.weight, dx1b, yb)
     dy = ops.gemm_rows(dx1b, wt(blk.attn.c_proj), M, C, C) if rows else ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
     dqkvb = torch.empty(M, 3 * C, device=dx.device, dtype=torch.bfloat16)
     ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
                            B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
-    put(blk.attn.c_attn.weight, ops.gemm_tn(dqkvb, h1b))
+    dweight(blk.attn.c_attn.weight, dqkvb, h1b)
     d_ln1 = ops.gemm_rows(dqkvb, wt(blk.attn.c_attn), M, C, 3 * C) if rows else ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
     dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)
     put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
+    if todo:
+        for (p, _, _), g in zip(todo, ops.gemm_tn_group([(d, x_) for _, d, x_ in todo])):
+            put(p, g)
     return dx0, dx0b
 
 

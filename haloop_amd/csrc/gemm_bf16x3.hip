@@ -295,8 +295,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // IO: bit 0 = A staged from row-major bf16 (stage_rowmajor), bit 1 = bf16 row-major output; both only in their own instantiations
 // TI: 32-row blocks per wave = 2 (a 128 x 128 workgroup tile) or 1 (64 x 128: the single-pass, whole-K products whose 128-row tiles would
 // number 257 .. 511 -- one or two workgroups on a CU that holds three -- run on twice as many half-height tiles, three per CU)
-template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0, int IO = 0, int TI = 2>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
+// (the body as a device function of the arguments and the workgroup's index: gemm_bf16x3_kernel runs it on blockIdx.x, the grouped TN
+//  launch -- several products in one grid -- on the index inside the product the workgroup belongs to)
+template <int NSTAGE, int PASSES, bool CE, int EPI, int IO, int TI>
+__device__ __forceinline__ void gemm_tile(const TiledGemmArgs &p, const int block) {
     static_assert(TI == 2 || (TI == 1 && PASSES == 1 && !CE && !(IO & 8)), "64-row tiles: single pass, plain epilogues");
     constexpr int TRM = 64 * TI;
     constexpr int LOADS = PASSES == 3 ? LOADS_PER_STAGE : (TI == 2 ? LOADS_PER_STAGE / 2 : 3);
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
     constexpr int OPERB = PASSES == 3 ? BLOCK_BYTES : PART_BYTES, OPER = OPERB * TI / 2, SLOT = OPER + OPERB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // a carried product's workgroup (IO & 4, TI == 2 launches only) works on the rider's operands and tile grid
-    const bool rider = (IO & 4) && TI == 2 && p.rider_first > 0 && (int)blockIdx.x >= p.rider_first;
-    const int bid = rider ? blockIdx.x - p.rider_first : blockIdx.x;
+    const bool rider = (IO & 4) && TI == 2 && p.rider_first > 0 && block >= p.rider_first;
+    const int bid = rider ? block - p.rider_first : block;
     const int ntiles = rider ? p.r_ntiles : p.ntiles, tiles_n = rider ? p.r_tiles_n : p.tiles_n, KT = rider ? p.rKT : p.KT;
     const int ktper = rider ? p.r_ktper : p.ktper;
     const char *Aimg = rider ? p.rA : p.A, *Bimg = rider ? p.rB : p.B;
@@ -597,8 +599,39 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p)
         float *red = reinterpret_cast<float *>(lds);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (threadIdx.x == 0) p.sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) p.sumsq_part[block] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+}
+
+template <int NSTAGE, int PASSES, bool CE = false, int EPI = 0, int IO = 0, int TI = 2>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const TiledGemmArgs p) {
+    gemm_tile<NSTAGE, PASSES, CE, EPI, IO, TI>(p, (int)blockIdx.x);
+}
+
+// Several TN products (C_i [M_i][N_i] = A_i^T B_i over the SAME contraction length) in ONE grid, each on whole-K 128 x 128 tiles: the four
+// weight gradients of a GPT block (ha/attention.py:96-144 under autograd) contract over the B T = 8192 token rows, and alone each has so
+// few output tiles (36 .. 144) that it ran as three K-slices + a reduce launch; together they are 432 tiles -- no slabs, no reduces.
+constexpr int TN_GROUP_MAX = 4;
+struct TnGroup {
+    const __bf16 *a[TN_GROUP_MAX], *b[TN_GROUP_MAX];
+    float *c[TN_GROUP_MAX];
+    long lda[TN_GROUP_MAX], ldb[TN_GROUP_MAX];
+    int ldc[TN_GROUP_MAX], M[TN_GROUP_MAX], N[TN_GROUP_MAX], first[TN_GROUP_MAX];
+    int n, KT, accumulate;
+};
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnGroup g) {
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.first[i]) q = i;
+    TiledGemmArgs p = {};
+    p.Arm_hi = g.a[q]; p.lda = g.lda[q]; p.Brm = g.b[q]; p.ldb = g.ldb[q];
+    p.C = g.c[q]; p.R = g.c[q]; p.ldc = g.ldc[q]; p.ldr = g.ldc[q];
+    p.M = g.M[q]; p.N = g.N[q]; p.KT = g.KT; p.ktper = g.KT; p.ksplit = 1;
+    p.tiles_n = (p.N + TR - 1) / TR;
+    p.ntiles = ((p.M + TR - 1) / TR) * p.tiles_n;
+    gemm_tile<3, 1, false, EPI, 8, 2>(p, (int)blockIdx.x - g.first[q]);
 }
 
 
@@ -1083,6 +1116,28 @@ static int gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M,
     return halo_splitk_reduce(p.slab, p.ksplit, M, N, C, ldc, nullptr, nullptr, flags, p.drop, 0, st);
 }
 
+static int gemm_tn_bf16_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
+                              float *const *C, const int *ldc, int flags, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)gemm_tn_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gemm_tn_group_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES / 2) != hipSuccess)
+            return HALO_ELAUNCH;
+        attr = true;
+    }
+    TnGroup g = {};
+    g.n = n; g.KT = K / TK; g.accumulate = (flags & HALO_GEMM_ACCUM) ? 1 : 0;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        g.a[i] = (const __bf16 *)a[i]; g.lda[i] = lda[i]; g.b[i] = (const __bf16 *)b[i]; g.ldb[i] = ldb[i];
+        g.c[i] = C[i]; g.ldc[i] = ldc[i]; g.M[i] = M[i]; g.N[i] = N[i]; g.first[i] = total;
+        total += ((M[i] + TR - 1) / TR) * ((N[i] + TR - 1) / TR);
+    }
+    if (g.accumulate) hipLaunchKernelGGL(gemm_tn_group_kernel<3>, dim3((unsigned)total), dim3(256), 3 * STAGE_BYTES / 2, st, g);
+    else hipLaunchKernelGGL(gemm_tn_group_kernel<1>, dim3((unsigned)total), dim3(256), 3 * STAGE_BYTES / 2, st, g);
+    return halo_launch_status();
+}
+
 // Diagnostic (halo_debug_mfma_clock): the clock the chip holds under a bare bf16 MFMA loop on random operands -- fragments in
 // registers, no memory traffic, four independent accumulators per wave, one wave per SIMD -- as delta s_memtime / delta s_memrealtime
 // x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6), and with it the matrix pipes' sustained rate.  SHAPE 0: 32x32x16, 1: 16x16x32.
@@ -1140,6 +1195,17 @@ int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, i
     HALO_CHECK_ARG(K % TK == 0 && M % 8 == 0 && N % 8 == 0 && lda >= M && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0);
     HALO_CHECK_ARG(((uintptr_t)a | (uintptr_t)b) % 16 == 0 && (flags & ~HALO_GEMM_ACCUM) == 0);
     return gemm_tn_bf16(a, lda, b, ldb, M, N, K, C, ldc, flags, (hipStream_t)stream);
+}
+
+int halo_gemm_tn_bf16_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
+                            float *const *C, const int *ldc, int flags, halo_stream_t stream) {
+    HALO_CHECK_ARG(n >= 1 && n <= TN_GROUP_MAX && a && lda && b && ldb && M && N && C && ldc && K > 0 && K % TK == 0 && (flags & ~HALO_GEMM_ACCUM) == 0);
+    for (int i = 0; i < n; ++i) {
+        HALO_CHECK_ARG(a[i] && b[i] && C[i] && M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0);
+        HALO_CHECK_ARG(lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i] && lda[i] % 8 == 0 && ldb[i] % 8 == 0);
+        HALO_CHECK_ARG(((uintptr_t)a[i] | (uintptr_t)b[i]) % 16 == 0);
+    }
+    return gemm_tn_bf16_group(n, a, lda, b, ldb, M, N, K, C, ldc, flags, (hipStream_t)stream);
 }
 
 size_t halo_split_image_bytes(int rows, int k) {

@@ -223,6 +223,29 @@ def gemm_tn(a, b, out=None, accumulate=False):
     return out
 
 
+def gemm_tn_group(pairs):
+    """[a_i [K, M_i]^T b_i [K, N_i] for (a_i, b_i) in pairs] -> list of fp32 [M_i, N_i], row-major bf16 operands with ONE contraction length
+    K: up to four products per launch on whole-K tiles (halo_gemm_tn_bf16_group) -- a GPT block's four weight gradients."""
+    import ctypes as C
+    outs = []
+    for i0 in range(0, len(pairs), 4):
+        grp = pairs[i0:i0 + 4]
+        n = len(grp)
+        K = grp[0][0].shape[0]
+        for a, b in grp:
+            if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.dim() != 2 or b.dim() != 2 or a.shape[0] != K or b.shape[0] != K \
+                    or a.stride(1) != 1 or b.stride(1) != 1:
+                raise ValueError('gemm_tn_group: row-major bf16 a [K, M], b [K, N] with one K')
+        cs = [torch.empty(a.shape[1], b.shape[1], device=a.device, dtype=torch.float32) for a, b in grp]
+        vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        check(lib().halo_gemm_tn_bf16_group(n, vp([a for a, _ in grp]), (C.c_long * n)(*[a.stride(0) for a, _ in grp]),
+                                            vp([b for _, b in grp]), (C.c_long * n)(*[b.stride(0) for _, b in grp]),
+                                            (C.c_int * n)(*[a.shape[1] for a, _ in grp]), (C.c_int * n)(*[b.shape[1] for _, b in grp]), K,
+                                            vp(cs), (C.c_int * n)(*[c.stride(0) for c in cs]), 0, _stream()), 'halo_gemm_tn_bf16_group')
+        outs += cs
+    return outs
+
+
 def gemm_split_ce(a_img, b_img, M, N, K, targets, ignore_index=0, bias=None, want_logits=False, want_lse=False):
     """Per-row cross-entropy of logits = A B^T (+ bias) straight from the split GEMM's epilogue: -> (loss [M], lse [M] or None,
     logits [M, N] or None).  Without want_logits nothing of size M x N is written."""

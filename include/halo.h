@@ -191,6 +191,11 @@ int halo_gemm_split_residual(const void *a_image, const void *b_image, int M, in
  * through the scratch lent by halo_set_scratch. */
 int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, int N, int K, float *C, int ldc, int flags,
                       halo_stream_t stream);
+/* n <= 4 such products over the SAME contraction length K in ONE launch, each on whole-K tiles (no K-slices, no scratch, no reduce
+ * launches): the four weight gradients of a GPT block -- c_attn, attention c_proj, c_fc, MLP c_proj -- all contract over the B T token
+ * rows and have 36 .. 144 output tiles each; together they fill the chip.  Arrays of n entries; flags: 0 or HALO_GEMM_ACCUM for all. */
+int halo_gemm_tn_bf16_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
+                            float *const *C, const int *ldc, int flags, halo_stream_t stream);
 
 /* halo_gemm_split with row-major bf16 activations on either side, so that consecutive Linears hand their activations on without an
  * operand-image pass (ha/attention.py:136-143: c_fc -> gelu -> c_proj).  A comes either from an image (a_image) or from a row-major

@@ -100,3 +100,26 @@ def test_half_height_tiles_equal_the_full_tiles(monkeypatch, M, N, K):
         assert (out['half'][0][:64].double() - want).abs().max().item() <= 2e-3
     finally:
         _lib.set_math_mode(prev)
+
+
+def test_grouped_tn_products_equal_the_single_launches():
+    """Four TN products over one contraction length in ONE launch on whole-K tiles (a GPT block's weight gradients) against the fp64 products
+    of the same bf16 values and against the one-product launches (which cut K into slices: equal up to the summation order)."""
+    from haloop_amd import _lib, ops
+    _lib.lend_scratch(256 << 20)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    try:
+        g = torch.Generator().manual_seed(11)
+        K = 8192
+        shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (40, 8)]           # five: a launch of four and a launch of one
+        pairs = [(torch.randn(K, M, generator=g).cuda().bfloat16(), torch.randn(K, N, generator=g).cuda().bfloat16()) for M, N in shapes]
+        outs = ops.gemm_tn_group(pairs)
+        assert [tuple(o.shape) for o in outs] == shapes
+        for (a, b), o in zip(pairs, outs):
+            rows = torch.randint(0, a.shape[1], (32,), generator=g).cuda()
+            want = a.double()[:, rows].t() @ b.double()
+            assert (o[rows].double() - want).abs().max().item() <= 2e-6 * K ** 0.5 * 16 + 1e-5
+            torch.testing.assert_close(o, ops.gemm_tn(a, b), rtol=0, atol=2e-3)
+    finally:
+        _lib.set_math_mode(prev)

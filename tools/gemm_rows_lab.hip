@@ -73,7 +73,7 @@ static void run(const char *name, int M, int N, int K, bool check_ce = false) {
     Args a = {};
     a.a_rm = A; a.lda = K; a.b_img = (const char *)img; a.M = M; a.N = N; a.KT = K / 32;
     a.tiles_m = (M + 255) / 256; a.tiles_n = (N + Cfg<TN>::BN - 1) / Cfg<TN>::BN;
-    a.C = C; a.ldc = N; a.R = R; a.ldr = N; a.O = O; a.ldo = N;
+    a.C = C; a.ldc = N; a.R = R; a.ldr = N; a.O = O; a.ldo = N; a.kslices = 1; a.ktper = a.KT;
     if (EPI == EPI_CE) {
         CK(hipMalloc(&part, (size_t)M * a.tiles_n * 8)); CK(hipMalloc(&tlog, (size_t)M * 4)); CK(hipMalloc(&tgt, (size_t)M * 8));
         std::vector<int64_t> h(M); for (int i = 0; i < M; ++i) h[i] = (i * 7919L + 13) % N;
@@ -147,6 +147,13 @@ static void run(const char *name, int M, int N, int K, bool check_ce = false) {
     }
     const float t_new = time_us(mine);
     const double gf = 2.0 * M * N * K / 1e9;
+    if (getenv("LAB_KSLICE") && EPI == EPI_F32 && N == 768) {          // the same product on 192-column tiles, the k-blocks in two slices (slabs, no sum launch)
+        float *slab; CK(hipMalloc(&slab, (size_t)2 * M * N * 4));
+        Args b = a; b.C = slab; b.kslices = 2; b.ktper = (b.KT + 1) / 2; b.slab_stride = (long)M * N; b.tiles_n = (N + 191) / 192;
+        auto vs = [&]() { (void)launch<6, EPI_F32, false>(b, nullptr); };
+        printf("   192-column tiles, two K-slices (no sum): %.1f us\n", time_us(vs));
+        CK(hipFree(slab));
+    }
     if (getenv("LAB_AIMG") && EPI != EPI_CE) {          // the same product with A as a tiled image (1-KiB contiguous pieces instead of 16 x 64-byte row segments)
         void *imgA; CK(hipMalloc(&imgA, halo_split_image_bytes(M, K)));
         if (halo_split_image(Af, M, K, K, 0, imgA, nullptr) != HALO_OK) { printf("image failed\n"); exit(1); }
