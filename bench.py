@@ -110,6 +110,16 @@ def algorithmic_step_bytes(B, hidden=H, layers=L):
     return 10 * 4 * param_count(hidden, layers) + per_utt * B
 
 
+MFMA_BF16_PEAK_TFS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def algorithmic_step_flops(B, hidden=H, layers=L):
+    """forward = 2 x (conv 128 x 80 x 5 + per layer 4 hidden x (in + hidden) + classifier hidden x 32) MACs per frame
+    x T' frames per utterance; a training step = 3 x forward (554 MFLOP -> 1.66 GFLOP per utterance for LC-2x1024)."""
+    per_frame = C_SUB * F * 5 + sum(4 * hidden * ((C_SUB if l == 0 else hidden) + hidden) for l in range(layers)) + hidden * V
+    return 3 * 2 * per_frame * T_SUB * B
+
+
 def chain_algorithmic_bytes(B, direction, layers=1, strict=False):
     """Bytes ONE launch of the recurrent chain must move over its T' steps, SURVEY.md 8d accounting: every weight matrix the launch
     multiplies by once per pass (4 bytes per parameter), plus per step, utterance and layer the fp32 activations that enter or leave.
@@ -244,17 +254,23 @@ def time_other_mode(mode, device, batch, warmup, steps, use_graph, hidden=H, lay
     tr.check_status()
     B = batch[0].shape[0]
     nbytes = algorithmic_step_bytes(B, hidden, layers)
+    flops = algorithmic_step_flops(B, hidden, layers)
     return {'value': round(B * steps / dt, 1), 'unit': 'utterances/s', 'ms_per_step': round(1e3 * dt / steps, 4), 'batch': B,
             'dtype': MATH_DTYPE[mode], 'final_loss': round(tr.loss.item(), 5), 'hip_graph': tr.use_graph,
-            'step_frac_of_hbm_peak': round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+            'step_frac_of_hbm_peak': round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+            # the same step against the dense bf16 MFMA roof (forward 554 MFLOP per utterance at LC-2x1024, a training step 3x):
+            # the bound that takes over from HBM as the batch grows (bytes(B) = 528 MB + 2.1 MB B, flops(B) = 1.66 GFLOP B)
+            'step_frac_of_mfma_peak': round(flops / (dt / steps) / 1e12 / MFMA_BF16_PEAK_TFS, 4),
+            'bound_us': {'hbm': round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1), 'mfma': round(flops / (MFMA_BF16_PEAK_TFS * 1e12) * 1e6, 1)}}
 
 
 def batch_sweep(mode, device, warmup, steps, use_graph):
-    """'larger B raises the achieved fraction.  Report both.'  The same step at B = 128 and 256 per GPU
-    (bytes(B) = 10*4*P + 2.12e6*B); in bf16 arithmetic the two-layer persistent launches run once per 64 batch rows."""
+    """'larger B raises the achieved fraction.  Report both.'  The same step at B = 128, 256 and 512 per GPU
+    (bytes(B) = 10*4*P + 2.12e6*B, flops(B) = 1.66e9*B): against the HBM roof and against the MFMA roof, which takes over as the
+    batch grows; in bf16 arithmetic the two-layer persistent launches take two batch tiles per workgroup."""
     from haloop_amd import _lib, synth
     out = {}
-    for B in (128, 256):
+    for B in (128, 256, 512):
         batch = tuple(t.to(device) for t in synth.synthetic_batch(B, T, F, V, S, 42))
         r = time_other_mode(mode, device, batch, warmup, steps, use_graph)
         r['recurrence'] = _lib.lstm_chain_info('bwd')['kernel']
@@ -487,6 +503,11 @@ def main():
         n_ranks_seen = int(ones.item())
     loss = trainer.loss.item()
     trainer.check_status()        # a persistent recurrence that gave up a wait during the run: fail the bench, loudly
+    dp_components = None
+    if (world > 1 or args.dp_rehearsal) and trainer.sharded is not None:
+        # after the timed region: the same step launched eagerly with a HIP event behind every collective and optimizer piece (rank 0's
+        # view; every rank takes part in the collectives)
+        dp_components = trainer.profile_dp_components(x, il, tg, tl, steps=5)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -506,7 +527,13 @@ def main():
                        'dp_gather_dtype': (('bf16' if getattr(trainer.sharded, 'gather_bf16', False) else 'f32') if (world > 1 or args.dp_rehearsal) else None),
                        'dp_collectives_captured': getattr(trainer, '_tail_graph', None) is not None if (world > 1 or args.dp_rehearsal) else None,
                        'dp_early_reduce_scatter_overlapped': bool(getattr(trainer, '_early_started', False)) if (world > 1 or args.dp_rehearsal) else None,
-                       'dp_wire_bytes_per_rank': (trainer.sharded.wire_bytes() if hasattr(getattr(trainer, 'sharded', None), 'wire_bytes') else None)},
+                       'dp_wire_bytes_per_rank': (trainer.sharded.wire_bytes() if hasattr(getattr(trainer, 'sharded', None), 'wire_bytes') else None),
+                       'dp_components_us': dp_components,
+                       'dp_launch_modes': ({'forward_backward': 'eager launches' if (not use_graph or trainer.eager_forward_backward) else 'graph replay',
+                                            'tail (collectives + optimizer)': 'graph replay' if getattr(trainer, '_tail_graph', None) is not None else 'eager launches',
+                                            'note': 'the N = 1 line of a scaling curve runs the plain step (graph replay or eager launches, whichever its probe '
+                                                    'chose: config.hip_graph / launch_mode_probe); N > 1 skips the probe'}
+                                           if (world > 1 or args.dp_rehearsal) else None)},
             'n_ranks_seen': n_ranks_seen,
             'final_loss': round(loss, 5), 'steps_trained': args.warmup + args.steps + (210 if mode_probe else 0),
             'step_roofline': {'algorithmic_bytes_per_step': step_bytes,

@@ -50,6 +50,7 @@ SIGNATURES = {
     'halo_gelu_bwd_b16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_gemm_rows_supported': (_i, [_i, _i, _i]),
     'halo_gemm_rows': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    'halo_gemm_rows_gelu': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _vp, _l, _i, _vp]),
     'halo_gemm_rows_ce_workspace_bytes': (_sz, [_i, _i]),
     'halo_gemm_rows_ce': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
     'halo_cross_entropy_bwd_bf16': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp]),

@@ -244,8 +244,12 @@ def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
                                             drop=s_att[0], stream_id=s_att[1])
         x1 = ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, residual=x0)
         h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
-        a = ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True)
-        gb = ops.gelu_b16(a)
+        if os.environ.get('HALO_GPT_GELU_EPILOGUE', '0') != '0':         # new_gelu in the c_fc product's epilogue (built, measured, off: at one
+            # workgroup per CU nothing covers the epilogue's arithmetic -- 13.57 against 13.45 ms per step on one box)
+            gb, a = ops.gemm_rows_gelu(h2b, w(blk.mlp.c_fc), M, 4 * C, C, keep_pre=True)
+        else:
+            a = ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True)
+            gb = ops.gelu_b16(a)
         x = ops.gemm_rows(gb, w(blk.mlp.c_proj), M, C, 4 * C, residual=x1)
         return x, (x0, h1b, qkv, y, yb, lse, x1, h2b, a, gb, s_att)
     # (the normalised rows twice from one launch: the tiled image for the forward product, which stages an image 10-15 % faster than
@@ -413,7 +417,10 @@ class GPT(nn.Module):
             _, _, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
             ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, out=x, residual=x)                   # x += c_proj(y)
             h2b = ops.layernorm_bf16(x, blk.ln_2.weight, blk.ln_2.bias)
-            gb = ops.gelu_b16(ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True))
+            if os.environ.get('HALO_GPT_GELU_EPILOGUE', '0') != '0':
+                gb = ops.gemm_rows_gelu(h2b, w(blk.mlp.c_fc), M, 4 * C, C)
+            else:
+                gb = ops.gelu_b16(ops.gemm_rows(h2b, w(blk.mlp.c_fc), M, 4 * C, C, out_bf16=True))
             ops.gemm_rows(gb, w(blk.mlp.c_proj), M, C, 4 * C, out=x, residual=x)                # x += mlp(x)
         return ops.layernorm_bf16(x, tr.ln_f.weight, tr.ln_f.bias)
 

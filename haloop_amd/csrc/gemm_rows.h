@@ -26,6 +26,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include "halo_common.h"
 #include "halo_internal.h"
 
 namespace halo_gr {
@@ -52,6 +54,8 @@ struct Args {
     float *C; long ldc;                  // EPI_F32 / EPI_RESID: fp32 result
     const float *R; long ldr;            // EPI_RESID: C = R + A B^T (R may be C)
     __bf16 *O; long ldo;                 // EPI_BF16: bf16 result; EPI_CE: optional bf16 logits
+    int act;                             // EPI_BF16: 0, or the GELU flag of gemm_activation (2 tanh form, 8 erf form): O = gelu(A B^T) ...
+    __bf16 *O2;                          // ... and, when given, O2 [M][ldo] = A B^T itself (the pre-activation a backward pass keeps)
     // EPI_CE: per row and tile column the (max, sum exp) of the logits -> ce_part[(row * tiles_n + tile_n) * 2], the target's logit -> ce_tlogit[row]
     const int64_t *ce_target; float *ce_part, *ce_tlogit;
 };
@@ -276,28 +280,46 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const Args a) {
         if (EPI == EPI_CE && !a.O) return;                   // (uniform: scoring keeps no logits)
         // bf16 rows: pack column pairs, then per pair of register groups (g, g + 1) one v_permlane32_swap per dword: lanes 0-31 end up with
         // columns 8 g .. 8 g + 7 of their row, lanes 32-63 with 8 (g + 1) .. 8 (g + 1) + 7 -> one 16-byte store each (T21)
-        __bf16 *orow = a.O + (long)m * a.ldo + ncol0 + 8 * lh;
+        const long ooff = (long)m * a.ldo + ncol0 + 8 * lh;
+        // (every index static: a lambda instantiated per form, not a loop over the forms)
+        auto store_rows = [&](__bf16 *base, auto activate_c) {
+            constexpr bool activate = decltype(activate_c)::value;
+            __bf16 *orow = base + ooff;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            unsigned d[4][2];
+            for (int t = 0; t < TN; ++t) {
+                unsigned d[4][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                    const bf16x2 pk = {(__bf16)acc[t][4 * g + 2 * h], (__bf16)acc[t][4 * g + 2 * h + 1]};
-                    d[g][h] = __builtin_bit_cast(unsigned, pk);
+                    for (int h = 0; h < 2; ++h) {
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        float v0 = acc[t][4 * g + 2 * h], v1 = acc[t][4 * g + 2 * h + 1];
+                        if (activate) {
+                            v0 = gemm_activation((float)(__bf16)v0, a.act);
+                            v1 = gemm_activation((float)(__bf16)v1, a.act);
+                        }
+                        const bf16x2 pk = {(__bf16)v0, (__bf16)v1};
+                        d[g][h] = __builtin_bit_cast(unsigned, pk);
+                    }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    u32x4v o;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(d[g][h], d[g + 1][h], false, false);
+                        o[h] = sw[0]; o[2 + h] = sw[1];
+                    }
+                    if (rowok && ncol0 + 32 * t + 8 * (g + lh) < a.N) *reinterpret_cast<u32x4v *>(orow + 32 * t + 8 * g) = o;
                 }
-#pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                u32x4v o;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(d[g][h], d[g + 1][h], false, false);
-                    o[h] = sw[0]; o[2 + h] = sw[1];
-                }
-                if (rowok && ncol0 + 32 * t + 8 * (g + lh) < a.N) *reinterpret_cast<u32x4v *>(orow + 32 * t + 8 * g) = o;
             }
+        };
+        // EPI_BF16 with an activation: the rounded pre-activation first when the caller keeps it, then the activation of the ROUNDED value --
+        // what a separate pass over the stored bf16 rows computes
+        if (EPI == EPI_BF16 && a.act) {
+            if (a.O2) store_rows(a.O2, std::false_type{});
+            store_rows(a.O, std::true_type{});
+        } else {
+            store_rows(a.O, std::false_type{});
         }
     }
 }

@@ -105,8 +105,8 @@ int halo_gemm_rows_supported(int M, int N, int K) {
     return halo_math_mode() == HALO_MATH_BF16 && M > 0 && N > 0 && K > 0 && K % 32 == 0 && N % 8 == 0;
 }
 
-int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, float *C, long ldc,
-                   const float *residual, long ldr, void *out_bf16, long ldo, halo_stream_t stream) {
+static int gemm_rows_impl(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, float *C, long ldc,
+                          const float *residual, long ldr, void *out_bf16, long ldo, int act, void *pre_bf16, halo_stream_t stream) {
     HALO_CHECK_ARG(b_image && M > 0 && N > 0 && K > 0 && (a_image != nullptr) != (a_bf16 != nullptr) && (C != nullptr) != (out_bf16 != nullptr));
     HALO_CHECK_ARG(K % 32 == 0 && N % 8 == 0);
     if (halo_math_mode() != HALO_MATH_BF16) return HALO_ENOTSUP;
@@ -118,6 +118,7 @@ int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void
     a.a_img = (const char *)a_image; a.a_rm = (const __bf16 *)a_bf16; a.lda = lda; a.b_img = (const char *)b_image;
     a.M = M; a.N = N; a.KT = K / 32;
     a.C = C; a.ldc = ldc; a.R = residual; a.ldr = ldr; a.O = (__bf16 *)out_bf16; a.ldo = ldo;
+    a.act = act; a.O2 = (__bf16 *)pre_bf16;
     int tn = pick_tn(M, N);
     hipStream_t st = (hipStream_t)stream;
     // A very long contraction under few output tiles (the lm_head's input gradient: K = 50304 under 8192 x 768): the narrow tile that fills
@@ -144,6 +145,17 @@ int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void
     }
     if (out_bf16) return launch_tn<EPI_BF16, false>(tn, a, st);
     return residual ? launch_tn<EPI_RESID, false>(tn, a, st) : launch_tn<EPI_F32, false>(tn, a, st);
+}
+
+int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, float *C, long ldc,
+                   const float *residual, long ldr, void *out_bf16, long ldo, halo_stream_t stream) {
+    return gemm_rows_impl(a_image, a_bf16, lda, b_image, M, N, K, C, ldc, residual, ldr, out_bf16, ldo, 0, nullptr, stream);
+}
+
+int halo_gemm_rows_gelu(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, void *out_bf16,
+                        void *pre_bf16, long ldo, int exact, halo_stream_t stream) {
+    HALO_CHECK_ARG(out_bf16 && (!pre_bf16 || (uintptr_t)pre_bf16 % 16 == 0));
+    return gemm_rows_impl(a_image, a_bf16, lda, b_image, M, N, K, nullptr, 0, nullptr, 0, out_bf16, ldo, exact ? HALO_GEMM_GELU_ERF : HALO_GEMM_GELU, pre_bf16, stream);
 }
 
 static int ce_tn(int M, int N) {

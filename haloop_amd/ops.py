@@ -294,6 +294,21 @@ def gemm_rows(a, b_img, M, N, K, out=None, residual=None, out_bf16=False):
     return ob if out_bf16 else out
 
 
+def gemm_rows_gelu(a, b_img, M, N, K, exact=False, keep_pre=False):
+    """gelu(A B^T) as row-major bf16 [M, N] from halo_gemm_rows' epilogue; ``keep_pre``: -> (gelu, pre-activation), both bf16 -- the same
+    bits as gemm_rows(out_bf16=True) followed by gelu_b16."""
+    a_img = a_rm = None
+    lda = 0
+    if a.dtype == torch.bfloat16:
+        a_rm, lda = a, a.stride(0)
+    else:
+        a_img = a
+    g = torch.empty(M, N, device=b_img.device, dtype=torch.bfloat16)
+    pre = torch.empty(M, N, device=b_img.device, dtype=torch.bfloat16) if keep_pre else None
+    check(lib().halo_gemm_rows_gelu(ptr(a_img), ptr(a_rm), lda, ptr(b_img), M, N, K, ptr(g), ptr(pre), N, int(exact), _stream()), 'halo_gemm_rows_gelu')
+    return (g, pre) if keep_pre else g
+
+
 def gemm_rows_ce(a, b_img, M, N, K, targets, ignore_index=0, want_logits=False, want_lse=False):
     """Per-row cross-entropy of logits = A B^T from halo_gemm_rows_ce's epilogue: -> (loss [M], lse [M] or None, logits [M, N] as
     row-major bf16 or None).  ``a``: row-major bf16 [M, K] or an operand image."""

@@ -442,19 +442,71 @@ class LstmCtcTrainer:
 
     def _sharded_tail(self):
         """Behind the backward: the remaining gradient exchange -> partial norms -> their sum over the ranks -> clip + AdamW on what this
-        rank owns -> all-gather."""
+        rank owns -> all-gather.  (``_dp_marks``: profile_dp_components() brackets the pieces with events.)"""
         sh = self.sharded
+        mark = self._dp_mark
         if isinstance(sh, dp.SpanSharded):
             if not self._early_started:
                 sh.reduce_scatter('early')
+            mark('reduce_scatter_early_tail')
             sh.reduce_scatter('late')
+            mark('reduce_scatter_late')
             sh.all_reduce_small()
+            mark('all_reduce_small')
         else:
             sh.reduce_scatter()
+            mark('reduce_scatter')
         self._norm_partials()
         sh.all_reduce_sum(self.partials)
+        mark('norm_partials_and_their_all_reduce')
         self._apply_update()
+        mark('clip_and_adamw_on_owned_ranges')
         sh.all_gather()
+        mark('all_gather')
+
+    _dp_marks = None
+
+    def _dp_mark(self, name):
+        if self._dp_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._dp_marks.append((name, ev))
+
+    def profile_dp_components(self, x, il, tg, tl, steps=5):
+        """Sharded data-parallel step (dp_algo rs_ag / rs_ag_flat), launched EAGERLY, with a HIP event behind every piece of the step on the
+        compute stream: -> {piece: average microseconds} over ``steps`` steps (after one warm-up).  ``forward_backward`` ends where the tail
+        starts; ``wait_early_reduce_scatter`` is what of the side-stream reduce-scatter (started from the middle of the backward) is
+        still exposed there; the rest are the tail's pieces in order.  A measurement aid (bench.py --gpus N prints it as
+        config.dp_components_us): every event costs a host call, so the pieces sum to a little more than the untimed step."""
+        if self.sharded is None:
+            return None
+        was_graph, self.use_graph = self.use_graph, False
+        acc = {}
+        try:
+            for it in range(steps + 1):
+                self._dp_marks = []
+                start = torch.cuda.Event(enable_timing=True)
+                start.record()
+                self._early_started = False
+                self.masters_stale = bool(getattr(self.sharded, 'gather_bf16', False))
+                handle = self._forward_backward_overlapped(x, il, tg, tl)
+                self._dp_mark('forward_backward')
+                if handle is not None:
+                    self.sharded.wait(handle)
+                    self._early_started = True
+                self._dp_mark('wait_early_reduce_scatter')
+                self._sharded_tail()
+                torch.cuda.synchronize()
+                if it > 0:
+                    prev = start
+                    for name, ev in self._dp_marks:
+                        acc[name] = acc.get(name, 0.0) + 1e3 * prev.elapsed_time(ev) / steps
+                        prev = ev
+                    acc['step_total'] = acc.get('step_total', 0.0) + 1e3 * start.elapsed_time(prev) / steps
+        finally:
+            self._dp_marks = None
+            self.use_graph = was_graph
+        return {k: round(v, 1) for k, v in acc.items()}
 
     def gather_master_weights(self):
         """After a bf16 all-gather (``gather_dtype``) a rank's buffers hold the OTHER ranks' matrix chunks as bf16 roundings: exchange the

@@ -219,6 +219,12 @@ int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, 
 int halo_gemm_rows_supported(int M, int N, int K);
 int halo_gemm_rows(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, float *C, long ldc,
                    const float *residual, long ldr, void *out_bf16, long ldo, halo_stream_t stream);
+/* ... with new_gelu / F.gelu in the epilogue (exact: 0 tanh form ha/attention.py:12-17, 1 erf form): out_bf16 = gelu(bf16(A B^T)), and, when
+ * pre_bf16 is given, pre_bf16 = bf16(A B^T) as well (the pre-activation a training step keeps for the backward) -- bit for bit what
+ * halo_gemm_rows (bf16 result) followed by halo_gelu_b16 writes, without the pass over the [M][N] rows between them.
+ * replaces: self.c_fc + new_gelu in MLP.forward (ha/attention.py:136-140). */
+int halo_gemm_rows_gelu(const void *a_image, const void *a_bf16, long lda, const void *b_image, int M, int N, int K, void *out_bf16,
+                        void *pre_bf16, long ldo, int exact, halo_stream_t stream);
 /* ... and the lm_head product with the cross-entropy statistics in its epilogue (as halo_gemm_split_ce: loss[m] = logsumexp(logits[m, :]) -
  * logits[m, targets[m]], 0 on ignored rows; lse optional) and the logits kept as ROW-MAJOR bf16 logits_bf16 [M][ldo] (NULL: scoring,
  * nothing of size M x N is written) -- the reference's autocast lm_head output, ha/attention.py:228-231.  The statistics and the target's

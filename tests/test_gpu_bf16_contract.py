@@ -154,7 +154,7 @@ def test_stock_three_layer_encoder_b64_against_the_reference(hal, mode, loss_rto
         decided = ((top2[..., 0] - top2[..., 1]) > 4 * feat_atol).numpy()
         valid = np.arange(lp.shape[1])[None, :] < g['flen'][:, None]
         sel = decided & valid
-        assert sel.mean() >= 0.9, sel.mean()
+        assert sel.sum() >= 0.9 * valid.sum(), (sel.sum(), valid.sum())          # of the frames inside the utterances (observed: 0.93)
         assert np.array_equal(ali.cpu().numpy()[sel], g['ali'][sel])
 
 

@@ -318,7 +318,7 @@ def _rccl_sharded_worker(port, out, math_mode):
         res = {}
         for rehearse in (False, True):
             enc, rec = _build(100, c)
-            tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=rehearse)
+            tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=rehearse, gather_dtype='auto')
             assert (tr.sharded is not None) == rehearse
             if rehearse:
                 assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded._native and tr.sharded.gather_bf16 == (math_mode == 'bf16')
@@ -327,6 +327,14 @@ def _rccl_sharded_worker(port, out, math_mode):
             tr.check_status()
             res[rehearse] = (tr.flat.params[:tr.flat.total].cpu().numpy(), losses, getattr(tr, '_tail_graph', None) is not None,
                              bool(getattr(tr, '_early_started', False)))
+            if rehearse:
+                # the step's pieces bracketed by events (bench.py --gpus N prints them): every piece there, their sum = the step
+                comp = tr.profile_dp_components(x, il, tg, tl, steps=2)
+                want = {'forward_backward', 'wait_early_reduce_scatter', 'reduce_scatter_early_tail', 'reduce_scatter_late', 'all_reduce_small',
+                        'norm_partials_and_their_all_reduce', 'clip_and_adamw_on_owned_ranges', 'all_gather', 'step_total'}
+                assert set(comp) == want and all(v >= 0 for v in comp.values()), comp
+                assert abs(sum(v for k, v in comp.items() if k != 'step_total') - comp['step_total']) <= 0.02 * comp['step_total'] + 1.0, comp
+                tr.check_status()
         # the same with bf16 on the wire of the reduce-scatter (cast, reduce_scatter_tensor on the bf16 buffer, cast back: captured too)
         enc, rec = _build(100, c)
         tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=True, rehearse_dp=True, grad_dtype='bf16')

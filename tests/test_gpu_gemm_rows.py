@@ -125,6 +125,18 @@ def test_gelu_on_bf16_rows(bf16_mode):
         assert torch.equal(ops.gelu_bwd_b16(dg, a, exact), ops.gelu_bwd(dg.float(), a.float(), exact).bfloat16())
 
 
+def test_gelu_in_the_epilogue_equals_the_separate_pass(bf16_mode):
+    from haloop_amd import ops
+    for M, N, K in ((8192, 3072, 768), (300, 584, 64)):
+        a, w, _ = _operands(M, N, K, 9)
+        img = ops.split_image(w)
+        pre = ops.gemm_rows(a, img, M, N, K, out_bf16=True)
+        for exact in (False, True):
+            g, p2 = ops.gemm_rows_gelu(a, img, M, N, K, exact=exact, keep_pre=True)
+            assert torch.equal(p2, pre) and torch.equal(g, ops.gelu_b16(pre, exact))
+            assert torch.equal(ops.gemm_rows_gelu(a, img, M, N, K, exact=exact), g)
+
+
 def _train(monkeypatch, rows, seed=3):
     from haloop_amd import attention
     monkeypatch.setenv('HALO_GPT_ROWS', '1' if rows else '0')

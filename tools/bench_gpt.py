@@ -74,14 +74,57 @@ C, L, V = cfg.n_embd, cfg.n_layer, cfg.vocab_size
 p_nonemb = sum(p.numel() for n, p in model.named_parameters() if 'wte' not in n and 'wpe' not in n and 'lm_head' not in n)
 fwd_flops = B * (2 * p_nonemb * T + 4 * T * T * C * L // 2 + 2 * C * V * T)
 train_flops = 3 * fwd_flops
-# dominant kernel: the split GEMM on the MLP up-projection shape [B*T, 768] x [3072, 768]^T, timed with HIP events on the launch stream
+# the path's product kernel on the MLP up-projection shape [B*T, 768] x [3072, 768]^T, as the step launches it (bf16 arithmetic: halo_gemm_rows,
+# row-major bf16 activations -> bf16 result; otherwise the split GEMM on operand images), timed with HIP events on the launch stream
 M, N, K = B * T, 4 * C, C
-a_img = ops.split_image(torch.randn(M, K, device='cuda'))
 b_img = ops.split_image(torch.randn(N, K, device='cuda'))
-out = torch.empty(M, N, device='cuda')
-gemm_us = event_us(lambda: ops.gemm_split(a_img, b_img, M, N, K, out=out))
+rows_kernel = ops.gemm_rows_supported(M, N, K)
+if rows_kernel:
+    a_b = torch.randn(M, K, device='cuda').bfloat16()
+    gemm_us = event_us(lambda: ops.gemm_rows(a_b, b_img, M, N, K, out_bf16=True))
+    kname = 'gemm_rows_kernel<6, 0, false> (256 x 192 tiles, 1 bf16 MFMA pass, bf16 result)'
+else:
+    a_img = ops.split_image(torch.randn(M, K, device='cuda'))
+    out = torch.empty(M, N, device='cuda')
+    gemm_us = event_us(lambda: ops.gemm_split(a_img, b_img, M, N, K, out=out))
 passes = 1 if math_mode == 'bf16' else 3
+if not rows_kernel:
+    kname = f'gemm_bf16x3_kernel ({passes} bf16 MFMA pass(es))'
 gemm_tflops = passes * 2.0 * M * N * K / (gemm_us * 1e-6) / 1e12
+
+
+def pmc_traffic():
+    """HBM bytes per launch of that product: two rocprofv3 --pmc child passes on tools/pmc_gemm.py (FETCH_SIZE, then WRITE_SIZE), bytes =
+    2 F + W with the guide's gfx950 correction (MI355X_MICROARCH.md, HBM).  None when rocprofv3 is not there or a pass fails."""
+    import shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3')
+    if not exe or '--no-pmc' in sys.argv:
+        return None
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pmc_traffic as pt
+    work = tempfile.mkdtemp(prefix='halo_pmc_gpt_', dir='/tmp')
+    vals = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(work, counter)
+            proc = subprocess.run([exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
+                                   os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_gemm.py'), str(M), str(N), str(K)],
+                                  env=dict(os.environ, HALO_MATH=math_mode, TMPDIR='/tmp'), cwd='/tmp', capture_output=True, text=True, timeout=150)
+            csvs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
+            if proc.returncode != 0 or not csvs:
+                return None
+            med = pt.medians(csvs[0], counter)
+            hit = [v for k, v in med.items() if ('gemm_rows_kernel' in k if rows_kernel else 'gemm_bf16x3_kernel' in k)]
+            if not hit:
+                return None
+            vals[counter] = hit[0][0]
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return int(round(2 * vals['FETCH_SIZE'] * 1024 + vals['WRITE_SIZE'] * 1024))
+
+
 res = {
     'metric': 'tokens/sec, GPT-2 small LM seq_len 1024 (BASELINE config 3): train step (fwd + bwd + AdamW) and scoring',
     'value': round(B * T / t_train, 1), 'unit': 'tokens/s', 'n_gpus': 1, 'ms_per_step': round(t_train * 1e3, 3),
@@ -91,11 +134,14 @@ res = {
     'step_mfma': {'algorithmic_tflop_per_train_step': round(train_flops / 1e12, 3),
                   'achieved_tflops': round(train_flops / t_train / 1e12, 1),
                   'mfma_tflops_issued': round(passes * train_flops / t_train / 1e12, 1), 'peak': MFMA_BF16_PEAK},
-    'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16x3_kernel ({passes} bf16 MFMA pass(es)), M={M} N={N} K={K}',
+    'roofline': {'bound': 'mfma', 'kernel': f'{kname}, M={M} N={N} K={K}',
                  'achieved': round(gemm_tflops, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(gemm_tflops / MFMA_BF16_PEAK, 4),
-                 'traffic': None, 'avg_launch_us': round(gemm_us, 1)},
+                 'traffic': None, 'algorithmic_bytes_per_launch': 2 * (M * K + N * K + M * N), 'avg_launch_us': round(gemm_us, 1)},
 }
 
+torch.cuda.synchronize()
+res['roofline']['traffic'] = pmc_traffic()
+res['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (tools/pmc_gemm.py), bytes = 2 F + W' if res['roofline']['traffic'] else None
 if '--no-cpu-baseline' not in sys.argv:
     from oracle import gpt_ref                            # the checker and the CPU baseline: nothing above touches oracle/
     # nats/token parity and the CPU baseline on ONE sequence (the oracle = stock torch CPU ops = what the reference runs on CPU)
