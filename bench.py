@@ -67,11 +67,13 @@ def parse_args():
                     help="arithmetic of the dense products: 'bf16' rounds the operands to bf16 (one MFMA per product); 'f32' and "
                          "'bf16x3' meet the fp32 parity tolerances")
     ap.add_argument('--no-configs', action='store_true', help='skip the GPT-2 small / attention-ASR legs (BASELINE configs 3 and 5)')
-    ap.add_argument('--dp-algo', choices=['allreduce', 'rs_ag', 'rs_ag_flat'], default='rs_ag',
+    ap.add_argument('--dp-algo', choices=['allreduce', 'rs_ag', 'rs_ag_flat', 'direct'], default='rs_ag',
                     help='N > 1: allreduce = every rank averages the whole gradient and updates every parameter (DistributedDataParallel); '
                          'rs_ag = the span-sharded step: the top LSTM layer\'s matrix gradients reduce-scattered from the middle of the backward, the '
                          'lower layers\' behind it, small parameters all-reduced, each rank updates its chunks, bf16 all-gather in bf16 arithmetic; '
-                         'rs_ag_flat = one reduce-scatter / fp32 all-gather over the whole flat buffers')
+                         'rs_ag_flat = one reduce-scatter / fp32 all-gather over the whole flat buffers; direct = the cut of rs_ag with this '
+                         'library\'s own exchange over HIP-IPC-mapped peer buffers (each rank writes its pieces straight into the owners\' memory: '
+                         'csrc/dp_direct.hip) instead of RCCL collectives')
     ap.add_argument('--gather-dtype', choices=['auto', 'f32', 'bf16'], default='auto',
                     help="N > 1, rs_ag: wire format of the parameter all-gather.  'auto' (this benchmark's choice; the trainer's own default is "
                          "'f32') = bf16 roundings in single-pass bf16 arithmetic, where every consumer multiplies by the bf16 values anyway: "

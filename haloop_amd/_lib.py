@@ -48,6 +48,14 @@ SIGNATURES = {
     'halo_gemm_tn_bf16_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'halo_gelu_b16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_b16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    'halo_dx_alloc': (_i, [_sz, _vp, _vp]),
+    'halo_dx_open': (_i, [_vp, _vp]),
+    'halo_dx_close': (_i, [_vp]),
+    'halo_dx_free': (_i, [_vp]),
+    'halo_dx_push': (_i, [_vp, _sz, _sz, _i, _vp, _sz, _i, _i, _vp]),
+    'halo_dx_signal': (_i, [_vp, _sz, _i, _i, _u32, _vp]),
+    'halo_dx_wait': (_i, [_vp, _i, _i, _u32, _vp]),
+    'halo_dx_reduce': (_i, [_vp, _vp, _sz, _i, _i, _f, _vp]),
     'halo_gemm_rows_supported': (_i, [_i, _i, _i]),
     'halo_gemm_rows': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     'halo_gemm_rows_gelu': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _vp, _l, _i, _vp]),

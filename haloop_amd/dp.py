@@ -387,3 +387,188 @@ class SpanSharded:
         big = sum(hi - lo for lo, hi, _ in self.spans.values())
         out['all_gather'] = int((2 if self.gather_bf16 else 4) * big * f)
         return out
+
+
+class _RawDeviceArray:
+    """A window of device memory the library allocated (halo_dx_alloc) as a torch tensor: torch.as_tensor reads __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+
+
+class DirectExchange(SpanSharded):
+    """``SpanSharded`` with every collective done by THIS library over HIP-IPC-mapped peer arenas instead of by RCCL (SURVEY.md section 5.8 /
+    8e's "direct reduce-scatter + all-gather across the 7 links"; csrc/dp_direct.hip): a rank writes its 1/N pieces straight into the
+    owners' arenas -- all peers at once, one point-to-point link each -- signals an epoch word per peer, and each owner waits (bounded)
+    for its peers' words and reduces the received pieces in rank order.  Same spans, ownership, clip / AdamW ranges and bf16 staging of
+    the all-gather as ``SpanSharded``; the bootstrap (one exchange of 64-byte IPC handles) goes over ``group`` -- any backend.
+
+    One process per GPU on a node, or several processes on ONE GPU (the tests: correctness only).  The small replicated range is
+    all-reduced as "everybody pushes to everybody, everybody sums in rank order": bit-identical on every rank."""
+
+    KINDS = ('early', 'late', 'small', 'norm', 'gather')
+
+    def __init__(self, flat_params, flat_grads, early, late, small, group=None, gather_bf16=False, norm_parts=None):
+        super().__init__(flat_params, flat_grads, early, late, small, group, always=False, gather_bf16=gather_bf16)
+        if not flat_grads.is_cuda:
+            raise ValueError('DirectExchange needs HIP device buffers (the CPU tests use SpanSharded over gloo)')
+        from . import _lib
+        import ctypes as C
+        self._lib, self._C = _lib, C
+        self._native = False                       # (no RCCL collectives to capture: the tail runs as eager launches, epochs are launch arguments)
+        self.side_ok = True                        # the early reduce-scatter may start from the library's mid-backward event
+        w = max(self.world, 1)
+        self._norm_parts = int(norm_parts or _lib.HALO_SUMSQ_PARTS)
+        lo_s, hi_s = self.small
+        a16 = lambda n: (n + 15) // 16 * 16
+        off = 4096                                 # [0, 4096): the flag blocks, 64 bytes per kind
+        self._off = {}
+        for name in ('early', 'late'):
+            if name in self.spans:
+                self._off[name] = off
+                off += a16(w * self.spans[name][2] * 4)
+        self._off['small'] = off
+        off += a16(w * max(hi_s - lo_s, 4) * 4)
+        self._off['norm'] = off
+        off += a16(w * self._norm_parts * 4)
+        self._off['gather'] = off
+        self._esz = 2 if self.gather_bf16 else 4
+        off += a16(w * max(self._per_rank, 8) * self._esz)
+        self._bytes = off
+        handle = C.create_string_buffer(64)
+        base = C.c_void_p()
+        _lib.check(_lib.lib().halo_dx_alloc(self._bytes, C.byref(base), handle), 'halo_dx_alloc')
+        self._base = base.value
+        self._arena = torch.as_tensor(_RawDeviceArray(self._base, self._bytes), device=flat_grads.device)      # uint8 view of the own arena
+        handles = [None] * w
+        if self.active:
+            dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+        self._peer = [None] * w
+        self._opened = []
+        for r in range(w):
+            if r == self.rank or not self.active:
+                self._peer[r] = self._base
+            else:
+                p = C.c_void_p()
+                _lib.check(_lib.lib().halo_dx_open(handles[r], C.byref(p)), 'halo_dx_open')
+                self._peer[r] = p.value
+                self._opened.append(p.value)
+        self._peers = (C.c_void_p * w)(*self._peer)
+        self._epoch = {k: 0 for k in self.KINDS}
+        stage_bytes = w * self._per_rank * self._esz
+        self._stage = self._arena[self._off['gather']:self._off['gather'] + stage_bytes].view(torch.bfloat16 if self.gather_bf16 else torch.float32) \
+            if self._per_rank else None
+        if self.active:
+            dist.barrier(group=self.group)         # every arena is mapped everywhere before the first push
+
+    def close(self):
+        for p in self._opened:
+            self._lib.lib().halo_dx_close(p)
+        self._opened = []
+        if self._base:
+            self._arena = self._stage = None
+            self._lib.lib().halo_dx_free(self._base)
+            self._base = None
+
+    # ---- the three launches of a collective -----------------------------------------------------
+    def _stream(self):
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+    def _exchange(self, kind, src_ptr, piece_bytes, stride_bytes, same):
+        L, st = self._lib.lib(), self._stream()
+        self._epoch[kind] += 1
+        flag_off = 64 * self.KINDS.index(kind)
+        self._lib.check(L.halo_dx_push(src_ptr, piece_bytes, stride_bytes, int(same), self._peers, self._off[kind], self.world, self.rank, st), 'halo_dx_push')
+        self._lib.check(L.halo_dx_signal(self._peers, flag_off, self.world, self.rank, self._epoch[kind], st), 'halo_dx_signal')
+        self._lib.check(L.halo_dx_wait(self._base + flag_off, self.world, self.rank, self._epoch[kind], st), 'halo_dx_wait')
+
+    def _reduce(self, kind, own, scale):
+        self._lib.check(self._lib.lib().halo_dx_reduce(own.data_ptr(), self._base + self._off[kind], own.numel(), self.world, self.rank, scale,
+                                                       self._stream()), 'halo_dx_reduce')
+
+    # ---- collectives (SpanSharded's interface) ----------------------------------------------------
+    def reduce_scatter(self, name, after=None):
+        if not self.active or name not in self.spans:
+            return None
+        lo, hi, c = self.spans[name]
+        own_lo, own_hi = self.own(name)
+
+        def run():
+            self._exchange(name, self.grads[lo:hi].data_ptr(), c * 4, c * 4, False)
+            self._reduce(name, self.grads[own_lo:own_hi], 1.0 / self.world)
+        if after is not None and self._side is not None:
+            self._side.wait_event(after)
+            with torch.cuda.stream(self._side):
+                run()
+                done = torch.cuda.Event()
+                done.record()
+            return ('side', done, name)
+        run()
+        return None
+
+    def wait(self, handle):
+        if handle is not None:
+            torch.cuda.current_stream().wait_event(handle[1])
+
+    def all_reduce_small(self):
+        lo, hi = self.small
+        if not self.active or hi <= lo:
+            return
+        own = self.grads[lo:hi]
+        self._exchange('small', own.data_ptr(), (hi - lo) * 4, 0, True)
+        self._reduce('small', own, 1.0 / self.world)
+
+    def all_reduce_sum(self, t):
+        if not self.active:
+            return
+        if t.numel() != self._norm_parts or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f'DirectExchange.all_reduce_sum: {self._norm_parts} contiguous fp32 partials')
+        self._exchange('norm', t.data_ptr(), t.numel() * 4, 0, True)
+        self._reduce('norm', t, 1.0)
+
+    def _gather(self, as_bf16):
+        from . import ops
+        names = list(self.spans)
+        esz = 2 if as_bf16 else 4
+        stage = self._stage if as_bf16 == self.gather_bf16 else self._stage32()
+        mine = stage[self.rank * self._per_rank:(self.rank + 1) * self._per_rank]
+        if as_bf16:
+            ops.pack_ranges_bf16(self.params, [self.own(n) for n in names], mine)
+        else:
+            off = 0
+            for n in names:
+                a, b = self.own(n)
+                mine[off:off + b - a].copy_(self.params[a:b])
+                off += b - a
+        # my record -> slot `rank` of every peer's staging buffer
+        self._exchange('gather', mine.data_ptr(), self._per_rank * esz, 0, True)
+        if as_bf16:
+            ops.expand_ranges_bf16(stage, [self.spans[n][0] for n in names], [self.spans[n][2] for n in names], self.world, self.rank, self.params)
+        else:
+            off = 0
+            for n in names:
+                lo, _, c = self.spans[n]
+                for r in range(self.world):
+                    if r != self.rank:
+                        self.params[lo + r * c:lo + (r + 1) * c].copy_(stage[r * self._per_rank + off:r * self._per_rank + off + c])
+                off += c
+
+    def _stage32(self):
+        """fp32 staging for gather_masters() under a bf16 all-gather: a second arena region would need a second mapping on every peer, so
+        the masters travel through RCCL / gloo instead."""
+        raise NotImplementedError
+
+    def all_gather(self):
+        if self.active and self.spans:
+            self._gather(self.gather_bf16)
+
+    def gather_masters(self):
+        if not self.active:
+            return
+        if not self.gather_bf16:
+            self._gather(False)
+            return
+        for name in self.spans:                    # (a checkpoint-time exchange: the bootstrap group's own all-gather)
+            lo, hi, c = self.spans[name]
+            own_lo, own_hi = self.own(name)
+            dist.all_gather([self.params[lo + r * c:lo + (r + 1) * c] for r in range(self.world)], self.params[own_lo:own_hi].clone(), group=self.group)

@@ -137,6 +137,9 @@ class LstmCtcTrainer:
         (global norm: the partials are summed over the ranks) and updates ITS chunk of each matrix span, and the chunks are
         all-gathered -- as bf16 roundings when ``gather_dtype`` allows (below).  Forward + backward are launched eagerly or replayed
         from one graph (a 2-layer stack in bf16 mode: the two-layer persistent launches); the tail is captured in a graph.
+        'direct' -- the same cut and ownership as 'rs_ag' with every collective done by this library over HIP-IPC-mapped peer arenas
+        (dp.DirectExchange, csrc/dp_direct.hip: each rank writes its pieces straight into the owners' buffers over the point-to-point
+        links, epoch words, bounded waits) instead of by RCCL; ``process_group`` only carries the one-time exchange of IPC handles.
         'rs_ag_flat' -- round 3's form: ONE reduce-scatter / all-gather over the whole flat buffers behind the backward (also what
         ``grad_dtype='bf16'`` uses).
         gather_dtype: 'f32' (default) -- the owners' fp32 values are all-gathered: every rank's parameters (= ``state_dict()``) are
@@ -156,14 +159,14 @@ class LstmCtcTrainer:
         self.accumulate = int(accumulate)
         self._micro = 0
         self.betas, self.eps, self.weight_decay, self.clip = betas, eps, weight_decay, clip_grad_norm
-        if dp_algo not in ('rs_ag', 'rs_ag_flat', 'allreduce'):
-            raise ValueError(f"dp_algo must be 'rs_ag', 'rs_ag_flat' or 'allreduce', got {dp_algo!r}")
+        if dp_algo not in ('rs_ag', 'rs_ag_flat', 'allreduce', 'direct'):
+            raise ValueError(f"dp_algo must be 'rs_ag', 'direct', 'rs_ag_flat' or 'allreduce', got {dp_algo!r}")
         if gather_dtype not in ('auto', 'f32', 'bf16'):
             raise ValueError(f"gather_dtype must be 'auto', 'f32' or 'bf16', got {gather_dtype!r}")
         self.world = dp.world_size(process_group)
         # gradient accumulation lives on the all-reduce path; the bf16 gradient wire format on it and on the flat sharded step
         self.dp_algo = dp_algo if ((self.world > 1 or rehearse_dp) and self.accumulate == 1) else 'allreduce'
-        if self.dp_algo == 'rs_ag' and grad_dtype == 'bf16':
+        if self.dp_algo in ('rs_ag', 'direct') and grad_dtype == 'bf16':
             self.dp_algo = 'rs_ag_flat'
         self._rehearse_dp = bool(rehearse_dp)
         self.flat = FlatParams(encoder, recognizer, pad_to=4 * self.world if self.dp_algo != 'allreduce' else 4)
@@ -203,13 +206,17 @@ class LstmCtcTrainer:
         self.sharded = None
         self.masters_stale = False             # a bf16 all-gather has run since the fp32 masters were last exchanged
         self._gather_mode = None
-        if self.dp_algo == 'rs_ag':
+        if self.dp_algo in ('rs_ag', 'direct'):
             f = self.flat
             bf16_gather = gather_dtype == 'bf16' or (gather_dtype == 'auto' and _lib.get_math_mode() == 'bf16')
             self._gather_mode = _lib.get_math_mode()              # the arithmetic the bf16 gather was chosen under
             try:
-                self.sharded = dp.SpanSharded(f.params, f.grads, f.big_early, f.big_late, f.small_range, process_group,
-                                              always=self._rehearse_dp, gather_bf16=bf16_gather)
+                if self.dp_algo == 'direct':
+                    self.sharded = dp.DirectExchange(f.params, f.grads, f.big_early, f.big_late, f.small_range, process_group,
+                                                     gather_bf16=bf16_gather, norm_parts=self.partials.numel())
+                else:
+                    self.sharded = dp.SpanSharded(f.params, f.grads, f.big_early, f.big_late, f.small_range, process_group,
+                                                  always=self._rehearse_dp, gather_bf16=bf16_gather)
             except ValueError as e:       # matrix sizes that do not cut into `world` chunks of whole float4s: the flat form pads instead
                 import logging
                 logging.getLogger(__name__).warning('haloop_amd.train: %s; using dp_algo rs_ag_flat', e)
@@ -587,7 +594,7 @@ class LstmCtcTrainer:
         products and the front end's backward.  Returns the handle the tail waits for (None: the library did not record the event on
         this path -- not a two-layer launch -- and the tail reduces that span itself)."""
         sh = self.sharded
-        ev = self._mid_event if (isinstance(sh, dp.SpanSharded) and sh._native and 'early' in sh.spans) else None
+        ev = self._mid_event if (isinstance(sh, dp.SpanSharded) and (sh._native or getattr(sh, 'side_ok', False)) and 'early' in sh.spans) else None
         if ev is None:
             self._forward_backward(x, il, tg, tl)
             return None

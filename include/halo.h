@@ -828,6 +828,27 @@ int halo_sumsq(const float *x, size_t n, float *partials, halo_stream_t stream);
  *   halo_expand_ranges_bf16: the inverse on the gathered buffer.  stage holds `world` records of sum(chunk[k]) bf16 values, rank-major;
  *                            span k of dst begins at begin[k] and consists of `world` chunks of chunk[k] elements; every chunk but
  *                            skip_rank's (the caller's own fp32 master values; -1: none) is overwritten with the gathered values. */
+/* Round 5: direct peer exchange for the data-parallel step (csrc/dp_direct.hip; replaces the NCCL collectives
+ * DistributedDataParallel issues, ha/attention_loop.py:154,203, with writes over the point-to-point xGMI links).
+ *   halo_dx_alloc / open / close / free: an ARENA of device memory peers can write (uncached where the runtime allows) and its 64-byte HIP
+ *       IPC handle; a peer maps it with halo_dx_open.  The arena starts zeroed; its first 4096 bytes are flag blocks (64 bytes each).
+ *   halo_dx_push:   piece p of src (piece_bytes each, piece_stride_bytes apart; same != 0: src itself for every peer) -> peer p's arena at
+ *       dst_offset + rank * piece_bytes, every peer p != rank, one launch.  16-byte granules.
+ *   halo_dx_signal: epoch -> word `rank` of the flag block at flag_offset of every peer's arena (system-scope release).
+ *   halo_dx_wait:   one workgroup waits until every peer's word of own_flags carries epoch (or later); BOUNDED (5 s): a timeout raises the
+ *       status word of halo_set_status_word and returns.
+ *   halo_dx_reduce: own [elems] <- scale * (sum in RANK ORDER of own (at position rank) and the inbox pieces p != rank, elems apart).
+ * peer_bases: `world` (<= 16) mapped arena pointers, own rank's the local one. */
+int halo_dx_alloc(size_t bytes, void **ptr, void *handle64);
+int halo_dx_open(const void *handle64, void **ptr);
+int halo_dx_close(void *ptr);
+int halo_dx_free(void *ptr);
+int halo_dx_push(const void *src, size_t piece_bytes, size_t piece_stride_bytes, int same, void *const *peer_bases, size_t dst_offset, int world,
+                 int rank, halo_stream_t stream);
+int halo_dx_signal(void *const *peer_bases, size_t flag_offset, int world, int rank, uint32_t epoch, halo_stream_t stream);
+int halo_dx_wait(const void *own_flags, int world, int rank, uint32_t epoch, halo_stream_t stream);
+int halo_dx_reduce(float *own, const float *inbox, size_t elems, int world, int rank, float scale, halo_stream_t stream);
+
 int halo_sumsq_ranges(const float *x, int n, const size_t *begin, const size_t *end, float *partials, halo_stream_t stream);
 int halo_pack_ranges_bf16(const float *src, int n, const size_t *begin, const size_t *end, void *dst, halo_stream_t stream);
 int halo_expand_ranges_bf16(const void *stage, int n, const size_t *begin, const size_t *chunk, int world, int skip_rank, float *dst,

@@ -62,9 +62,10 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
         tr = LstmCtcTrainer(enc, rec, lr=3e-3, use_graph=use_graph, grad_dtype=grad_dtype, dp_algo=dp_algo, gather_dtype='auto')
         assert tr.dp_algo == dp_algo
         assert LstmCtcTrainer.__init__.__kwdefaults__ is None and 'f32' in LstmCtcTrainer.__init__.__defaults__
-        if dp_algo == 'rs_ag':
+        if dp_algo in ('rs_ag', 'direct'):
             from haloop_amd import _lib
             assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded.gather_bf16 == (_lib.get_math_mode() == 'bf16')
+            assert isinstance(tr.sharded, dp.DirectExchange) == (dp_algo == 'direct')
         x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
@@ -72,6 +73,7 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
         assert tr.masters_stale == bool(getattr(tr.sharded, 'gather_bf16', False))
         sd = tr.state_dict()                # (after a bf16 all-gather: exchanges the other rank's fp32 master values first)
         assert not tr.masters_stale and set(sd) == {'encoder', 'recognizer'}
+        tr.check_status()                   # (a direct exchange that gave up a wait raised the status word)
         torch.cuda.synchronize()
         if rank == 0:
             out.put(('ok', tr.flat.params[:tr.flat.total].cpu().numpy(), float(tr.grad_norm.item())))
@@ -86,7 +88,10 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
     # the span-sharded update (dp.SpanSharded): matrix spans reduce-scattered (over gloo: one reduce per owner), the small parameters
     # all-reduced and updated by both ranks, fp32 all-gather -- and in bf16 arithmetic the bf16 all-gather through the staging buffer
     (False, 'tiny', 'f32', 'rs_ag', None), (True, 'tiny', 'f32', 'rs_ag', None), (True, 'persist', 'f32', 'rs_ag', None),
-    (True, 'persist', 'f32', 'rs_ag', 'bf16'), (False, 'persist', 'f32', 'rs_ag', 'bf16')])
+    (True, 'persist', 'f32', 'rs_ag', 'bf16'), (False, 'persist', 'f32', 'rs_ag', 'bf16'),
+    # the same cut with the library's own exchange (dp.DirectExchange): two PROCESSES on one GPU, each writing its pieces into the other's
+    # HIP-IPC-mapped arena (epoch words, bounded waits); fp32 gather, and the bf16 gather of bf16 arithmetic
+    (False, 'tiny', 'f32', 'direct', None), (True, 'persist', 'f32', 'direct', None), (False, 'persist', 'f32', 'direct', 'bf16')])
 def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype, dp_algo, math_mode):
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
