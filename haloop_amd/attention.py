@@ -413,8 +413,13 @@ class GPT(nn.Module):
         x, _ = self._embed(input_ids, 0)
         for blk in tr.h:
             h1b = ops.layernorm_bf16(x, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
-            _, _, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
+            if C // H == 64 and os.environ.get('HALO_GPT_ATTN_B16', '1') != '0':
+                # q | k | v stay bf16 between the c_attn product and the attention launch, which stages them as they are
+                qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C, out_bf16=True)
+                _, _, yb = ops.attention_fwd_b16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
+            else:
+                qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
+                _, _, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal)
             ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, out=x, residual=x)                   # x += c_proj(y)
             h2b = ops.layernorm_bf16(x, blk.ln_2.weight, blk.ln_2.bias)
             if os.environ.get('HALO_GPT_GELU_EPILOGUE', '0') != '0':

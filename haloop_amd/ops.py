@@ -1245,6 +1245,21 @@ def attention_fwd_bf16(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, key_le
     return y, lse, yb
 
 
+def attention_fwd_b16(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, want_y=False, want_lse=False):
+    """Attention forward from row-major bf16 q / k / v views [N * T, heads * head_dim] (halo_attention_fwd_b16: bf16 arithmetic, head_dim 64)
+    -> (y fp32 or None, lse or None, y as row-major bf16)."""
+    C = heads * head_dim
+    dev = q.device
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise ValueError('attention_fwd_b16: bf16 q, k, v')
+    y = torch.empty(N * Tq, C, device=dev, dtype=torch.float32) if want_y else None
+    yb = torch.empty(N * Tq, C, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(N, heads, Tq, device=dev, dtype=torch.float32) if want_lse else None
+    check(lib().halo_attention_fwd_b16(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(y), C, C * Tq,
+                                       ptr(yb), C, C * Tq, ptr(lse), N, heads, head_dim, Tq, Tk, int(causal), _stream()), 'halo_attention_fwd_b16')
+    return y, lse, yb
+
+
 def attention_bwd_bf16(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT,
                        stream_id=0):
     """attention_bwd with dq / dk / dv bf16 views of one row stride (the column blocks of a packed [rows, 3C] bf16 buffer)."""

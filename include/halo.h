@@ -208,6 +208,15 @@ int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, 
                        int ldc, void *out_hi, void *out_lo, long ldo, const float *residual, int ldr, const float *bias1,
                        const float *bias2, int flags, halo_stream_t stream);
 
+/* Round 5: softmax attention forward from ROW-MAJOR bf16 q / k / v (the c_attn product's bf16 result, heads packed inside a row: head h at
+ * columns [64 h, 64 h + 64)), single-pass bf16 arithmetic, head_dim 64, causal or full, no key lengths, no dropout (csrc/attn_b16.hip: K / V
+ * tiles straight from bf16 rows into the LDS images, two tiles in flight).  y (fp32) and y_bf16 are both optional outputs (at least one);
+ * lse optional.  HALO_ENOTSUP outside bf16 mode / head_dim 64: the callers keep halo_attention_fwd_bf16.
+ * replaces: F.scaled_dot_product_attention in MonitoredSelfAttention.forward (ha/attention.py:96-129) under the reference's autocast. */
+int halo_attention_fwd_b16(const void *q, long q_row_stride, long q_batch_stride, const void *k, const void *v, long kv_row_stride,
+                           long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, void *y_bf16, long yb_row_stride,
+                           long yb_batch_stride, float *lse, int N, int heads, int head_dim, int Tq, int Tk, int causal, halo_stream_t stream);
+
 /* Round 5: the activation-by-weight products of the GPT path on 256-row x 96 / 192 / 288-column workgroup tiles (csrc/gemm_rows.h), single-pass
  * bf16 arithmetic only (HALO_ENOTSUP in the other modes; halo_gemm_rows_supported says so up front).  C [M][N] = A [M][K] x B [N][K]^T with
  * A either a tiled image (a_image) or ROW-MAJOR bf16 a_bf16 [M][lda] (lda % 8 == 0), B a tiled image (halo_split_image of the weight, or

@@ -169,3 +169,30 @@ def test_gpt_step_on_the_row_tiles_against_the_128_tile_path(bf16_mode, monkeypa
         cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
         assert cos >= 0.998, (k, cos)
         assert abs(float(a.norm()) - float(b.norm())) <= 2e-2 * float(b.norm()), k
+
+
+@pytest.mark.parametrize('N,T,heads,causal', [(8, 1024, 12, True), (2, 200, 3, True), (3, 129, 2, False), (1, 64, 1, True)])
+def test_attention_forward_from_bf16_rows(bf16_mode, N, T, heads, causal):
+    """halo_attention_fwd_b16 (bf16 q / k / v rows, two tiles in flight) against fp64 softmax attention of the same bf16 values and against
+    the fp32-input matrix-core launch on those values."""
+    from haloop_amd import ops
+    hd, C = 64, heads * 64
+    g = torch.Generator().manual_seed(T + heads)
+    qkv = (torch.randn(N * T, 3 * C, generator=g) * 0.7).to(DEV).bfloat16()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    y, lse, yb = ops.attention_fwd_b16(q, k, v, N, heads, hd, T, T, causal=causal, want_y=True, want_lse=True)
+    qf = qkv.float()
+    y0, lse0, _ = ops.attention_fwd_bf16(qf[:, :C], qf[:, C:2 * C], qf[:, 2 * C:], N, heads, hd, T, T, causal=causal)
+    torch.testing.assert_close(y, y0, rtol=0, atol=2e-2)
+    torch.testing.assert_close(lse, lse0, rtol=0, atol=2e-2)
+    assert torch.equal(yb, y.bfloat16())
+    n0 = N - 1
+    Q = q[n0 * T:(n0 + 1) * T].double().view(T, heads, hd).transpose(0, 1)
+    K = k[n0 * T:(n0 + 1) * T].double().view(T, heads, hd).transpose(0, 1)
+    V = v[n0 * T:(n0 + 1) * T].double().view(T, heads, hd).transpose(0, 1)
+    S = Q @ K.transpose(1, 2) / 8.0
+    if causal:
+        S = S.masked_fill(torch.ones(T, T, device=DEV).triu(1).bool(), float('-inf'))
+    want = (torch.softmax(S, -1) @ V).transpose(0, 1).reshape(T, C)
+    assert (y[n0 * T:(n0 + 1) * T].double() - want).abs().max().item() <= 2e-2
+    np.testing.assert_allclose(lse[n0].double().cpu().numpy(), torch.logsumexp(S, -1).cpu().numpy(), atol=2e-2)
