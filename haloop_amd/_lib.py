@@ -57,6 +57,7 @@ SIGNATURES = {
     'halo_dx_wait': (_i, [_vp, _i, _i, _u32, _vp]),
     'halo_dx_reduce': (_i, [_vp, _vp, _sz, _i, _i, _f, _vp]),
     'halo_attention_fwd_b16': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'halo_attention_bwd_b16': (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp]),
     'halo_gemm_rows_supported': (_i, [_i, _i, _i]),
     'halo_gemm_rows': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     'halo_gemm_rows_gelu': (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _vp, _vp, _l, _i, _vp]),

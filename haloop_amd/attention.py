@@ -239,9 +239,15 @@ def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
         # row-major bf16 rows the producing launch left); c_fc's result and the MLP's hidden activations stay bf16 (what the reference's
         # autocast path holds there, ha/attention_loop.py:164) -- the fp32 [M, 4C] round trip between c_fc and new_gelu is gone
         h1b = ops.layernorm_bf16(x0, blk.ln_1.weight, blk.ln_1.bias)
-        qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
-        y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
-                                            drop=s_att[0], stream_id=s_att[1])
+        if C // H == 64 and os.environ.get('HALO_GPT_ATTN_B16', '1') != '0':
+            # q | k | v stay bf16 between the c_attn product and the attention launches (forward and backward stage the rows as they are, two
+            # tiles in flight: csrc/attn_b16.hip); the attention output is kept as bf16 only
+            qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C, out_bf16=True)
+            y, lse, yb = ops.attention_fwd_b16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal, want_lse=True)
+        else:
+            qkv = ops.gemm_rows(h1b, w(blk.attn.c_attn), M, 3 * C, C)
+            y, lse, yb = ops.attention_fwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, C // H, T, T, causal=cfg.causal,
+                                                drop=s_att[0], stream_id=s_att[1])
         x1 = ops.gemm_rows(yb, w(blk.attn.c_proj), M, C, C, residual=x0)
         h2b = ops.layernorm_bf16(x1, blk.ln_2.weight, blk.ln_2.bias)
         if os.environ.get('HALO_GPT_GELU_EPILOGUE', '0') != '0':         # new_gelu in the c_fc product's epilogue (built, measured, off: at one
@@ -296,10 +302,15 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
     # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
     dweight(blk.attn.c_proj.weight, dx1b, yb)
-    dy = ops.gemm_rows(dx1b, wt(blk.attn.c_proj), M, C, C) if rows else ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
     dqkvb = torch.empty(M, 3 * C, device=dx.device, dtype=torch.bfloat16)
-    ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
-                           B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
+    if qkv.dtype == torch.bfloat16:                      # the forward kept q | k | v as bf16 rows: the output gradient arrives as bf16 rows too
+        dyb = ops.gemm_rows(dx1b, wt(blk.attn.c_proj), M, C, C, out_bf16=True)
+        ops.attention_bwd_b16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], yb, dyb, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
+                              B, H, C // H, T, T, causal=cfg.causal)
+    else:
+        dy = ops.gemm_rows(dx1b, wt(blk.attn.c_proj), M, C, C) if rows else ops.gemm_split_io((dx1b, None), wt(blk.attn.c_proj), M, C, C)
+        ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
+                               B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
     dweight(blk.attn.c_attn.weight, dqkvb, h1b)
     d_ln1 = ops.gemm_rows(dqkvb, wt(blk.attn.c_attn), M, C, 3 * C) if rows else ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
     dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)

@@ -1260,6 +1260,18 @@ def attention_fwd_b16(q, k, v, N, heads, head_dim, Tq, Tk, causal=False, want_y=
     return y, lse, yb
 
 
+def attention_bwd_b16(q, k, v, yb, dyb, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False):
+    """Backward of attention_fwd_b16: every operand row-major bf16 (q, k, v views of the c_attn rows; yb the forward's bf16 output; dyb the
+    output gradient), dq / dk / dv bf16 views written in place."""
+    for t in (q, k, v, yb, dyb, dq, dk, dv):
+        if t.dtype != torch.bfloat16:
+            raise ValueError('attention_bwd_b16: bf16 operands')
+    delta = torch.empty(N * heads * Tq, device=q.device, dtype=torch.float32)
+    check(lib().halo_attention_bwd_b16(ptr(q), q.stride(0), q.stride(0) * Tq, ptr(k), ptr(v), k.stride(0), k.stride(0) * Tk, ptr(yb), ptr(dyb),
+                                       yb.stride(0), yb.stride(0) * Tq, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dq.stride(0),
+                                       dq.stride(0) * Tq, N, heads, head_dim, Tq, Tk, int(causal), _stream()), 'halo_attention_bwd_b16')
+
+
 def attention_bwd_bf16(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, Tk, causal=False, key_lengths=None, drop=NO_DROPOUT,
                        stream_id=0):
     """attention_bwd with dq / dk / dv bf16 views of one row stride (the column blocks of a packed [rows, 3C] bf16 buffer)."""

@@ -216,6 +216,13 @@ int halo_gemm_split_io(const void *a_image, const void *a_hi, const void *a_lo, 
 int halo_attention_fwd_b16(const void *q, long q_row_stride, long q_batch_stride, const void *k, const void *v, long kv_row_stride,
                            long kv_batch_stride, float *y, long y_row_stride, long y_batch_stride, void *y_bf16, long yb_row_stride,
                            long yb_batch_stride, float *lse, int N, int heads, int head_dim, int Tq, int Tk, int causal, halo_stream_t stream);
+/* ... and its backward: q / k / v, the forward's bf16 output y and the output gradient dy all as row-major bf16 rows (y and dy with one pair
+ * of strides), lse from the forward; delta [N * heads * Tq] is scratch the first sweep writes (rowsum(dy * y)) and the second reads; dq / dk /
+ * dv leave as row-major bf16 (one pair of strides), the operands of the c_attn Linear's two gradient products.  Same limits as the forward. */
+int halo_attention_bwd_b16(const void *q, long q_row_stride, long q_batch_stride, const void *k, const void *v, long kv_row_stride,
+                           long kv_batch_stride, const void *y_bf16, const void *dy_bf16, long y_row_stride, long y_batch_stride, const float *lse,
+                           float *delta, void *dq_bf16, void *dk_bf16, void *dv_bf16, long d_row_stride, long d_batch_stride, int N, int heads,
+                           int head_dim, int Tq, int Tk, int causal, halo_stream_t stream);
 
 /* Round 5: the activation-by-weight products of the GPT path on 256-row x 96 / 192 / 288-column workgroup tiles (csrc/gemm_rows.h), single-pass
  * bf16 arithmetic only (HALO_ENOTSUP in the other modes; halo_gemm_rows_supported says so up front).  C [M][N] = A [M][K] x B [N][K]^T with

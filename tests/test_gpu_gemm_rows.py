@@ -196,3 +196,40 @@ def test_attention_forward_from_bf16_rows(bf16_mode, N, T, heads, causal):
     want = (torch.softmax(S, -1) @ V).transpose(0, 1).reshape(T, C)
     assert (y[n0 * T:(n0 + 1) * T].double() - want).abs().max().item() <= 2e-2
     np.testing.assert_allclose(lse[n0].double().cpu().numpy(), torch.logsumexp(S, -1).cpu().numpy(), atol=2e-2)
+
+
+@pytest.mark.parametrize('N,T,heads,causal', [(8, 1024, 12, True), (2, 200, 3, True), (3, 129, 2, False)])
+def test_attention_backward_from_bf16_rows(bf16_mode, N, T, heads, causal):
+    """halo_attention_bwd_b16 against autograd through fp64 softmax attention of the same bf16 q / k / v / dy (sampled batch entry), and
+    against the fp32-input matrix-core backward on those values."""
+    from haloop_amd import ops
+    hd, C = 64, heads * 64
+    g = torch.Generator().manual_seed(T * 3 + heads)
+    qkv = (torch.randn(N * T, 3 * C, generator=g) * 0.7).to(DEV).bfloat16()
+    dyb = (torch.randn(N * T, C, generator=g) * 0.5).to(DEV).bfloat16()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    _, lse, yb = ops.attention_fwd_b16(q, k, v, N, heads, hd, T, T, causal=causal, want_lse=True)
+    d = torch.empty_like(qkv)
+    ops.attention_bwd_b16(q, k, v, yb, dyb, lse, d[:, :C], d[:, C:2 * C], d[:, 2 * C:], N, heads, hd, T, T, causal=causal)
+    # the fp32-input launches on the same values
+    qf = qkv.float()
+    y0, lse0, _ = ops.attention_fwd_bf16(qf[:, :C], qf[:, C:2 * C], qf[:, 2 * C:], N, heads, hd, T, T, causal=causal)
+    d0 = torch.empty_like(qkv)
+    ops.attention_bwd_bf16(qf[:, :C], qf[:, C:2 * C], qf[:, 2 * C:], y0, dyb.float(), lse0, d0[:, :C], d0[:, C:2 * C], d0[:, 2 * C:], N, heads, hd, T, T,
+                           causal=causal)
+    scale = d0.float().abs().max().item()
+    assert (d.float() - d0.float()).abs().max().item() <= 3e-2 * scale
+    # autograd in fp64 on one batch entry
+    n0 = N - 1
+    x = qkv[n0 * T:(n0 + 1) * T].double().clone().requires_grad_(True)
+    Q, K, V = (x[:, i * C:(i + 1) * C].view(T, heads, hd).transpose(0, 1) for i in range(3))
+    S = Q @ K.transpose(1, 2) / 8.0
+    if causal:
+        S = S.masked_fill(torch.ones(T, T, device=DEV).triu(1).bool(), float('-inf'))
+    Y = (torch.softmax(S, -1) @ V).transpose(0, 1).reshape(T, C)
+    Y.backward(dyb[n0 * T:(n0 + 1) * T].double())
+    want = x.grad
+    got = d[n0 * T:(n0 + 1) * T].double()
+    cos = float((got * want).sum() / (got.norm() * want.norm()))
+    assert cos >= 0.9995, cos
+    assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item()
