@@ -168,6 +168,7 @@ SIGNATURES = {
     'halo_layernorm_bwd_workspace_bytes': (_sz, [_i, _i]),
     'halo_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_layernorm_bwd_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'halo_layernorm_bwd_b16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'halo_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_cross_entropy_fwd_lse': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _l, _vp]),

@@ -283,6 +283,9 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     # the four weight gradients contract over the same M token rows: collected here, ONE grouped launch at the end of the block
     # (whole-K tiles, no K-slices or reduce launches); HALO_GPT_DW_GROUP=0: one launch each, as round 4
     grouped = os.environ.get('HALO_GPT_DW_GROUP', '1') != '0' and M % 32 == 0
+    # the two input gradients that only a LayerNorm backward reads leave their products as bf16 rows (that launch adds the fp32 residual
+    # gradient to them in fp32)
+    b16_ln = rows and C % 4 == 0 and C <= 2048 and os.environ.get('HALO_GPT_DLN_B16', '0') != '0'        # (measured: no gain, 12.40 against 12.40 ms; off)
     todo = []
 
     def dweight(p, dy_b, x_b):
@@ -297,7 +300,7 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
     else:
         dab = ops.gelu_bwd_bf16(ops.gemm_split_io((dxb, None), wt(blk.mlp.c_proj), M, 4 * C, C), a)
     dweight(blk.mlp.c_fc.weight, dab, h2b)
-    d_ln2 = ops.gemm_rows(dab, wt(blk.mlp.c_fc), M, C, 4 * C) if rows else ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
+    d_ln2 = ops.gemm_rows(dab, wt(blk.mlp.c_fc), M, C, 4 * C, out_bf16=b16_ln) if rows else ops.gemm_split_io((dab, None), wt(blk.mlp.c_fc), M, C, 4 * C)
     dx1, dw, db, dx1b = ops.layernorm_bwd(d_ln2, x1, blk.ln_2.weight, dx, blk.ln_2.bias is not None, want_bf16=True)
     put(blk.ln_2.weight, dw); put(blk.ln_2.bias, db)
     # x1 = x0 + c_proj(attention(c_attn(ln_1(x0))))
@@ -312,7 +315,7 @@ def block_backward_rm(images, blk, saved, dx, dxb, B, T, cfg, put):
         ops.attention_bwd_bf16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], y, dy, lse, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:],
                                B, H, C // H, T, T, causal=cfg.causal, drop=s_att[0], stream_id=s_att[1])
     dweight(blk.attn.c_attn.weight, dqkvb, h1b)
-    d_ln1 = ops.gemm_rows(dqkvb, wt(blk.attn.c_attn), M, C, 3 * C) if rows else ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
+    d_ln1 = ops.gemm_rows(dqkvb, wt(blk.attn.c_attn), M, C, 3 * C, out_bf16=b16_ln) if rows else ops.gemm_split_io((dqkvb, None), wt(blk.attn.c_attn), M, C, 3 * C)
     dx0, dw, db, dx0b = ops.layernorm_bwd(d_ln1, x0, blk.ln_1.weight, dx1, blk.ln_1.bias is not None, want_bf16=True)
     put(blk.ln_1.weight, dw); put(blk.ln_1.bias, db)
     if todo:

@@ -129,7 +129,9 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                   const float *__restrict__ w, const float *__restrict__ dres,
                                                                   float *__restrict__ dx, float *__restrict__ pw, float *__restrict__ pb,
-                                                                  int rows, int C, float eps, __bf16 *__restrict__ dxb = nullptr) {
+                                                                  int rows, int C, float eps, __bf16 *__restrict__ dxb = nullptr,
+                                                                  const __bf16 *__restrict__ dy16 = nullptr) {
+    // (dy16: the incoming gradient as row-major bf16 instead of fp32 dy -- the input-gradient product's bf16 result, halo_gemm_rows)
     extern __shared__ float red[];                       // [2][C]: cross-wave sums of the partials
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int C4 = C >> 2;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
     }
     const float inv_c = 1.0f / (float)C;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float *xr = x + (long)row * C, *dyr = dy + (long)row * C;
+        const float *xr = x + (long)row * C, *dyr = dy16 ? nullptr : dy + (long)row * C;
+        const __bf16 *dyr16 = dy16 ? dy16 + (long)row * C : nullptr;
         f32x4 xv[MAXV], dv[MAXV];
         float s = 0.f;
 #pragma unroll
@@ -151,7 +154,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *_
             const int q = v * 64 + lane;
             const bool in = q < C4;
             xv[v] = in ? *reinterpret_cast<const f32x4 *>(xr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            dv[v] = in ? *reinterpret_cast<const f32x4 *>(dyr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dy16) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                const bf16x4 d4 = in ? *reinterpret_cast<const bf16x4 *>(dyr16 + 4 * q) : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                dv[v] = f32x4{(float)d4[0], (float)d4[1], (float)d4[2], (float)d4[3]};
+            } else {
+                dv[v] = in ? *reinterpret_cast<const f32x4 *>(dyr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
         }
         const float mean = wave_sum(s) * inv_c;
@@ -350,16 +359,17 @@ __global__ __launch_bounds__(256) void gelu_b16_kernel(const __bf16 *__restrict_
 }
 
 int layernorm_bwd_impl(const float *dy, const float *x, const float *weight, const float *dres, float *dx, __bf16 *dxb, float *dweight,
-                              float *dbias, void *workspace, int rows, int C, float eps, hipStream_t st) {
+                              float *dbias, void *workspace, int rows, int C, float eps, hipStream_t st, const __bf16 *dy16 = nullptr) {
     float *stats = (float *)workspace, *pw = stats + (size_t)rows * 2, *pb = pw + (size_t)HALO_LN_BWD_CHUNKS * C;
-    const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0;
+    const bool aligned = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx) % 16) == 0 && (uintptr_t)dy16 % 8 == 0;
+    if (dy16 && !(C % 4 == 0 && C <= 2048 && aligned)) return HALO_ENOTSUP;
     if (C % 4 == 0 && C <= 2048 && aligned) {
         const int wgs = min(HALO_LN_BWD_CHUNKS, (rows + 3) / 4);
         const size_t lds = (size_t)2 * C * sizeof(float);
         if (C <= 1024)
-            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<4>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb);
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<4>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb, dy16);
         else
-            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<8>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb);
+            hipLaunchKernelGGL(layernorm_bwd_fused_kernel<8>, dim3(wgs), dim3(256), lds, st, dy, x, weight, dres, dx, pw, pb, rows, C, eps, dxb, dy16);
         if (halo_launch_status() != HALO_OK) return HALO_ELAUNCH;
         return halo_colsum2(pw, wgs, C, C, dweight, nullptr, st) || (dbias ? halo_colsum2(pb, wgs, C, C, dbias, nullptr, st) : HALO_OK);
     }
@@ -473,6 +483,15 @@ int halo_layernorm_bwd_bf16(const float *dy, const float *x, const float *weight
     return layernorm_bwd_impl(dy, x, weight, dres, dx, (__bf16 *)dx_bf16, dweight, dbias, workspace, rows, C, eps, (hipStream_t)stream);
 }
 
+
+int halo_layernorm_bwd_b16(const void *dy_bf16, const float *x, const float *weight, const float *dres, float *dx, void *dx_bf16, float *dweight,
+                           float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream) {
+    HALO_CHECK_ARG(dy_bf16 && x && weight && dx && dweight && workspace && rows > 0 && C > 0);
+    HALO_CHECK_ARG(C % 4 == 0 && C <= 2048 && (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)dres | (uintptr_t)dx | (uintptr_t)dx_bf16) % 16) == 0 &&
+                   (uintptr_t)dy_bf16 % 8 == 0);
+    return layernorm_bwd_impl(nullptr, x, weight, dres, dx, (__bf16 *)dx_bf16, dweight, dbias, workspace, rows, C, eps, (hipStream_t)stream,
+                              (const __bf16 *)dy_bf16);
+}
 
 int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream) {
     HALO_CHECK_ARG(a && y && n > 0);

@@ -1287,9 +1287,21 @@ def attention_bwd_bf16(q, k, v, y, dy, lse, dq, dk, dv, N, heads, head_dim, Tq, 
 
 
 def layernorm_bwd(dy, x2d, weight, dres=None, has_bias=False, eps=1e-5, want_bf16=False):
-    """-> (dx = dres + dLN, dweight, dbias or None[, dx as row-major bf16 with ``want_bf16``])"""
-    _f32c(dy, 'dy'); _f32c(x2d, 'x')
+    """-> (dx = dres + dLN, dweight, dbias or None[, dx as row-major bf16 with ``want_bf16``]).  dy: fp32, or row-major bf16 (the
+    input-gradient product's bf16 result)."""
+    _f32c(x2d, 'x')
     rows, C = x2d.shape
+    if dy.dtype == torch.bfloat16:
+        dev = x2d.device
+        dx = torch.empty_like(x2d)
+        dw = torch.empty(C, device=dev, dtype=torch.float32)
+        db = torch.empty(C, device=dev, dtype=torch.float32) if has_bias else None
+        ws = torch.empty(lib().halo_layernorm_bwd_workspace_bytes(rows, C), device=dev, dtype=torch.uint8)
+        dxb = torch.empty(rows, C, device=dev, dtype=torch.bfloat16) if want_bf16 else None
+        check(lib().halo_layernorm_bwd_b16(ptr(dy), ptr(x2d), ptr(weight), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db), ptr(ws), rows, C,
+                                           eps, _stream()), 'halo_layernorm_bwd_b16')
+        return (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
+    _f32c(dy, 'dy')
     dev = x2d.device
     dx = torch.empty_like(x2d)
     dw = torch.empty(C, device=dev, dtype=torch.float32)

@@ -765,6 +765,10 @@ int halo_layernorm_bwd(const float *dy, const float *x, const float *weight, con
  * output gradient of the Linear below, whose two gradient products read it as bf16 */
 int halo_layernorm_bwd_bf16(const float *dy, const float *x, const float *weight, const float *dres, float *dx, void *dx_bf16,
                             float *dweight, float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream);
+/* ... with the incoming gradient dy as ROW-MAJOR bf16 (round 5: the input-gradient product's bf16 result, halo_gemm_rows); dx_bf16 optional.
+ * C % 4 == 0, C <= 2048. */
+int halo_layernorm_bwd_b16(const void *dy_bf16, const float *x, const float *weight, const float *dres, float *dx, void *dx_bf16, float *dweight,
+                           float *dbias, void *workspace, int rows, int C, float eps, halo_stream_t stream);
 int halo_gelu_fwd(const float *a, float *y, size_t n, int exact, halo_stream_t stream);
 int halo_gelu_bwd(const float *dy, const float *a, float *da, size_t n, int exact, halo_stream_t stream);
 int halo_cross_entropy_fwd_lse(const float *logits, const int64_t *targets, float *loss, float *lse, int rows, int V,

@@ -233,3 +233,17 @@ def test_attention_backward_from_bf16_rows(bf16_mode, N, T, heads, causal):
     cos = float((got * want).sum() / (got.norm() * want.norm()))
     assert cos >= 0.9995, cos
     assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item()
+
+
+def test_layernorm_backward_from_bf16_gradient_rows(bf16_mode):
+    """halo_layernorm_bwd_b16 = halo_layernorm_bwd_bf16 on the same (bf16-valued) incoming gradient, bit for bit."""
+    from haloop_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1000, 768, generator=g).to(DEV)
+    dres = torch.randn(1000, 768, generator=g).to(DEV)
+    w = (torch.rand(768, generator=g) + 0.5).to(DEV)
+    dyb = torch.randn(1000, 768, generator=g).to(DEV).bfloat16()
+    a = ops.layernorm_bwd(dyb, x, w, dres, has_bias=False, want_bf16=True)
+    b = ops.layernorm_bwd(dyb.float(), x, w, dres, has_bias=False, want_bf16=True)
+    for u, v in zip(a, b):
+        assert (u is None and v is None) or torch.equal(u, v)
