@@ -2,10 +2,10 @@
 # One GPU call that refreshes the round's profile set (run from the repo root on the GPU box; writes under gpurun_out/):
 #   bench line, rocprofv3 --kernel-trace --stats of the bench command, one step's kernel timeline, in-kernel stamps, PMC traffic passes.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CMD="bench.py --no-cpu-baseline --no-extras --no-configs --steps 100 --warmup 10"
-timeout -k 10 300 python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench_n1.err
+timeout -k 10 480 python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench_n1.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -- python3 $CMD > gpurun_out/${R}_prof.log 2>&1
 s=$(find gpurun_out/${R}_prof -name "*kernel_stats.csv" | head -1)
 k=$(find gpurun_out/${R}_prof -name "*kernel_trace.csv" | head -1)
