@@ -191,6 +191,7 @@ int main(int argc, char **argv) {
     if (which < 0 || which == 3) run<3, halo_gr::EPI_F32>("c_fc dx", 8192, 768, 3072);
     if (which < 0 || which == 4) run<3, halo_gr::EPI_F32>("c_attn dx", 8192, 768, 2304);
     if (which < 0 || which == 5) run<6, halo_gr::EPI_CE>("lm_head + CE (bf16 logits)", 8192, 50304, 768);
+    if (which < 0 || which == 5) run<9, halo_gr::EPI_CE>("lm_head + CE (bf16 logits)", 8192, 50304, 768);
     if (which < 0 || which == 6) run<3, halo_gr::EPI_F32>("lm_head dx", 8192, 768, 50304);
     if (which < 0 || which == 7) {                    // ragged shapes: rows and columns that do not fill their last tile
         run<3, halo_gr::EPI_F32>("ragged 3", 1000, 200, 160);
