@@ -63,6 +63,11 @@ def parse_args():
     ap.add_argument('--dp-rehearsal', action='store_true',
                     help='N=1 only, a measurement aid: run the data-parallel code path (three graphs, RCCL all-reduces between them, '
                          'step-launch chain under the first bucket) on a one-rank RCCL group; the line says so in config.parallelism')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='N > 1, a rehearsal aid for a one-GPU box: every rank runs on cuda:0 and the process group is gloo (RCCL refuses two '
+                         'ranks on one device).  Exercises the whole N > 1 path of this file -- rendezvous, sharded step, collectives or the '
+                         'direct peer exchange over HIP IPC, max-over-ranks timing, dp_components_us -- with the ranks sharing one GPU: the '
+                         'value is NOT a scaling number and the line says so in config.parallelism')
     ap.add_argument('--math', choices=['f32', 'bf16x3', 'bf16'], default='bf16',
                     help="arithmetic of the dense products: 'bf16' rounds the operands to bf16 (one MFMA per product); 'f32' and "
                          "'bf16x3' meet the fp32 parity tolerances")
@@ -422,9 +427,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 and args.share_gpu:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('gloo')
+    elif world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=device)
     elif args.dp_rehearsal:
@@ -439,6 +447,10 @@ def main():
     from haloop_amd.train import LstmCtcTrainer
     _lib.lib()                                              # loud failure if the HIP library is absent
     _lib.set_math_mode(args.math)
+    if args.share_gpu and world > 1:
+        # two processes on one GPU: the persistent recurrences need the whole chip to themselves (their bounded waits would fail the
+        # step, loudly); the rehearsal runs the step-launch chain in front of the data-parallel tail it is about
+        _lib.set_lstm_persistent(False)
 
     enc, rec, params = build_model(device)
     dp_kw = dict(dp_algo=args.dp_algo, rehearse_dp=args.dp_rehearsal and args.dp_algo != 'allreduce', gather_dtype=args.gather_dtype)
@@ -523,7 +535,8 @@ def main():
             'config': {'workload': 'LC-2x1024: conv(80->128,k5,s4) + 2-layer LSTM H=1024 + Linear(1024->32) + CTC, '
                                    '80 frames x 80 mels, vocab 32, targets 5-10 symbols, dropout 0.2',
                        'batch_per_gpu': B_PER_GPU, 'global_batch': world * B_PER_GPU, 'frames': T, 'mels': F,
-                       'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else ''), 'hip_graph': use_graph, 'launch_mode_probe': mode_probe, 'math': args.math,
+                       'parallelism': f'dp{world}' + (' (data-parallel code path rehearsed on one rank)' if args.dp_rehearsal else '')
+                                      + (' (REHEARSAL: all ranks share ONE GPU, gloo rendezvous -- not a scaling number)' if args.share_gpu and world > 1 else ''), 'hip_graph': use_graph, 'launch_mode_probe': mode_probe, 'math': args.math,
                        'grad_allreduce_dtype': args.grad_dtype if world > 1 else None,
                        'dp_algo': trainer.dp_algo if (world > 1 or args.dp_rehearsal) else None,
                        'dp_gather_dtype': (('bf16' if getattr(trainer.sharded, 'gather_bf16', False) else 'f32') if (world > 1 or args.dp_rehearsal) else None),

@@ -384,3 +384,28 @@ def test_rccl_backend_runs_the_sharded_step(math_mode):
     assert wire[2] and wire[1][0] == plain[1][0]
     np.testing.assert_allclose(wire[1], plain[1], rtol=2e-2)
     assert not np.array_equal(wire[0], plain[0])
+
+
+def test_bench_line_of_two_ranks_sharing_the_gpu():
+    """bench.py's whole N > 1 path -- it starts its own ranks, gloo rendezvous, the direct peer exchange over HIP IPC, max-over-ranks timing,
+    dp_components_us -- rehearsed with both ranks on this one GPU (--share-gpu): the line's contract, not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-gpu', '--dp-algo', 'direct', '--steps', '4',
+                        '--warmup', '2'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 2 * d['config']['batch_per_gpu'] and d['config']['dp_algo'] == 'direct'
+    assert 'REHEARSAL' in d['config']['parallelism']
+    assert abs(d['value'] - d['config']['global_batch'] / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    comp = d['config']['dp_components_us']
+    for k in ('forward_backward', 'reduce_scatter_late', 'all_reduce_small', 'clip_and_adamw_on_owned_ranges', 'all_gather', 'step_total'):
+        assert comp[k] > 0
+    assert np.isfinite(d['final_loss'])
