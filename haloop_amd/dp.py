@@ -404,9 +404,11 @@ class DirectExchange(SpanSharded):
     the all-gather as ``SpanSharded``; the bootstrap (one exchange of 64-byte IPC handles) goes over ``group`` -- any backend.
 
     One process per GPU on a node, or several processes on ONE GPU (the tests: correctness only).  The small replicated range is
-    all-reduced as "everybody pushes to everybody, everybody sums in rank order": bit-identical on every rank."""
+    all-reduced as "everybody pushes to everybody, everybody sums in rank order" (one exchange; every rank sends the whole range to every
+    peer: the cheaper form up to three ranks) or, from four ranks on, in two exchanges -- 1/N pieces to their owners, rank-order sums, the
+    summed pieces to everybody -- which moves 2 (N-1)/N of the range per rank instead of N-1 times it.  Bit-identical on every rank either way."""
 
-    KINDS = ('early', 'late', 'small', 'norm', 'gather')
+    KINDS = ('early', 'late', 'small', 'norm', 'gather', 'small2')
 
     def __init__(self, flat_params, flat_grads, early, late, small, group=None, gather_bf16=False, norm_parts=None):
         super().__init__(flat_params, flat_grads, early, late, small, group, always=False, gather_bf16=gather_bf16)
@@ -428,7 +430,10 @@ class DirectExchange(SpanSharded):
                 self._off[name] = off
                 off += a16(w * self.spans[name][2] * 4)
         self._off['small'] = off
-        off += a16(w * max(hi_s - lo_s, 4) * 4)
+        n_small = hi_s - lo_s
+        self._small_chunk = n_small // w if (w >= 4 and n_small > 0 and n_small % (4 * w) == 0) else 0      # > 0: the two-exchange form
+        self._off['small2'] = off + a16(w * self._small_chunk * 4)       # (the summed pieces land behind the inbox, inside the same region)
+        off += a16(w * max(n_small, 4) * 4)
         self._off['norm'] = off
         off += a16(w * self._norm_parts * 4)
         self._off['gather'] = off
@@ -515,8 +520,21 @@ class DirectExchange(SpanSharded):
         if not self.active or hi <= lo:
             return
         own = self.grads[lo:hi]
-        self._exchange('small', own.data_ptr(), (hi - lo) * 4, 0, True)
-        self._reduce('small', own, 1.0 / self.world)
+        c = self._small_chunk
+        if not c:
+            self._exchange('small', own.data_ptr(), (hi - lo) * 4, 0, True)
+            self._reduce('small', own, 1.0 / self.world)
+            return
+        # piece p -> rank p, which sums the world's pieces in rank order; then every rank's summed piece -> everybody
+        mine = own[self.rank * c:(self.rank + 1) * c]
+        self._exchange('small', own.data_ptr(), c * 4, c * 4, False)
+        self._reduce('small', mine, 1.0 / self.world)
+        self._exchange('small2', mine.data_ptr(), c * 4, 0, True)
+        got = self._arena[self._off['small2']:self._off['small2'] + self.world * c * 4].view(torch.float32)
+        if self.rank > 0:
+            own[:self.rank * c].copy_(got[:self.rank * c])
+        if self.rank + 1 < self.world:
+            own[(self.rank + 1) * c:].copy_(got[(self.rank + 1) * c:])
 
     def all_reduce_sum(self, t):
         if not self.active:

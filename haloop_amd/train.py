@@ -79,11 +79,15 @@ class FlatParams:
                   sorted([(n, p) for n, p in enc_decay if is_top(n)], key=lambda t: t[0])]
         dev = next(encoder.parameters()).device
         off, bounds, self.slots = 0, [], []
-        for g in groups:
+        for gi, g in enumerate(groups):
             start = off
             for n, p in g:
                 self.slots.append((n, p, off))
                 off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            if gi == 3:
+                # the small range ends here: a multiple of 64 elements (zero padding: zero gradients, zero moments, never updated), so
+                # that up to 16 ranks can cut it into equal 16-byte-aligned pieces (dp.DirectExchange's two-exchange all-reduce)
+                off = (off + 63) // 64 * 64
             bounds.append((start, off))
         self.total = off
         self.encoder_range = (bounds[2][0], off)

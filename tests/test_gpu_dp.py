@@ -66,6 +66,8 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
             from haloop_amd import _lib
             assert isinstance(tr.sharded, dp.SpanSharded) and tr.sharded.gather_bf16 == (_lib.get_math_mode() == 'bf16')
             assert isinstance(tr.sharded, dp.DirectExchange) == (dp_algo == 'direct')
+            if dp_algo == 'direct':         # the small range's all-reduce: one exchange up to three ranks, two from four on
+                assert (tr.sharded._small_chunk > 0) == (world >= 4)
         x, il, tg, tl = cpu_ref.synthetic_batch(c['B'], c['T'], c['F_'], c['V'], c['S'], 7)
         sl = dp.shard_slice(c['B'], rank, world)
         for _ in range(2):
@@ -93,13 +95,27 @@ def _worker_body(rank, world, out, use_graph, c, grad_dtype, dp_algo):
     # HIP-IPC-mapped arena (epoch words, bounded waits); fp32 gather, and the bf16 gather of bf16 arithmetic
     (False, 'tiny', 'f32', 'direct', None), (True, 'persist', 'f32', 'direct', None), (False, 'persist', 'f32', 'direct', 'bf16')])
 def test_two_ranks_equal_single_process_on_concatenated_batch(use_graph, cfg_name, grad_dtype, dp_algo, math_mode):
+    _ranks_equal_single_process(2, use_graph, cfg_name, grad_dtype, dp_algo, math_mode)
+
+
+# four PROCESSES on one GPU: the direct exchange with three peers per rank, and the small range's all-reduce in its two-exchange form
+# (pieces to their owners, rank-order sums, summed pieces to everybody: chosen from four ranks on)
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('cfg_name,math_mode', [('tiny', None), ('persist', 'bf16')])
+def test_four_ranks_equal_single_process_with_the_direct_exchange(cfg_name, math_mode):
+    _ranks_equal_single_process(4, False, cfg_name, 'f32', 'direct', math_mode)
+
+
+def _ranks_equal_single_process(world, use_graph, cfg_name, grad_dtype, dp_algo, math_mode):
     from haloop_amd.train import LstmCtcTrainer
     from oracle import cpu_ref
     cfg = CFG if cfg_name == 'tiny' else CFG_PERSIST
+    if cfg['B'] % world:
+        cfg = dict(cfg, B=(cfg['B'] + world - 1) // world * world)        # equal shards: the mean of the ranks' means is the batch mean
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, use_graph, cfg, grad_dtype, dp_algo, math_mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, use_graph, cfg, grad_dtype, dp_algo, math_mode)) for r in range(world)]
     for p in procs:
         p.start()
     import time
