@@ -1,6 +1,6 @@
 """Randomised shape sweep of round 5's kernels behind GUARD BANDS (run once on the GPU box; not part of the test suite):
 halo_gemm_rows (fp32 / + residual / bf16 results, forced and chosen tile widths), halo_gemm_rows_ce, halo_attention_fwd_b16 /
-halo_attention_bwd_b16 on random ragged shapes, every output allocated inside a larger buffer filled with a sentinel that must survive,
+halo_attention_bwd_b16, halo_gemm_tn_bf16_group on random ragged shapes, every output allocated inside a larger buffer filled with a sentinel that must survive,
 results against fp64 references of the same bf16 operand values.
 
     python tools/fuzz_round5.py [cases] [seed]
@@ -129,6 +129,35 @@ def fuzz_attention(g, cases):
     return bad
 
 
+def fuzz_tn_group(g, cases):
+    """halo_gemm_tn_bf16_group: 1-4 products a_i [K, M_i]^T b_i [K, N_i] of one K per launch, results inside guard bands."""
+    import ctypes as C
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bad = 0
+    for c in range(cases):
+        n = int(torch.randint(1, 5, (1,), generator=g))
+        K = int(torch.randint(1, 40, (1,), generator=g)) * 32
+        Ms = [int(torch.randint(1, 60, (1,), generator=g)) * 8 for _ in range(n)]
+        Ns = [int(torch.randint(1, 60, (1,), generator=g)) * 8 for _ in range(n)]
+        As = [torch.randn(K, m, generator=g).to(DEV).bfloat16() for m in Ms]
+        Bs = [torch.randn(K, nn, generator=g).to(DEV).bfloat16() for nn in Ns]
+        Cs = [Guarded((m, nn), torch.float32) for m, nn in zip(Ms, Ns)]
+        vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        rc = L.halo_gemm_tn_bf16_group(n, vp(As), (C.c_long * n)(*Ms), vp(Bs), (C.c_long * n)(*Ns), (C.c_int * n)(*Ms), (C.c_int * n)(*Ns), K,
+                                       vp([c_.t for c_ in Cs]), (C.c_int * n)(*Ns), 0, st)
+        _lib.check(rc, 'halo_gemm_tn_bf16_group')
+        torch.cuda.synchronize()
+        for a, b, cc in zip(As, Bs, Cs):
+            want = a.double().t() @ b.double()
+            err = (cc.t.double() - want).abs().max().item()
+            tol = 2e-6 * K ** 0.5 * 16 + 1e-5
+            if err > tol or not cc.intact():
+                bad += 1
+                print(f'gemm_tn_group MISMATCH n {n} K {K} M {a.shape[1]} N {b.shape[1]}: err {err:.3e} (tol {tol:.3e}) guard {cc.intact()}', flush=True)
+    return bad
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -139,7 +168,9 @@ def main():
     print(f'gemm_rows / gemm_rows_ce: {cases} random shapes, {b1} failures', flush=True)
     b2 = fuzz_attention(g, max(cases // 2, 1))
     print(f'attention fwd / bwd from bf16 rows: {max(cases // 2, 1)} random shapes, {b2} failures', flush=True)
-    raise SystemExit(1 if b1 + b2 else 0)
+    b3 = fuzz_tn_group(g, max(cases // 2, 1))
+    print(f'grouped TN weight-gradient products: {max(cases // 2, 1)} random groups, {b3} failures', flush=True)
+    raise SystemExit(1 if b1 + b2 + b3 else 0)
 
 
 if __name__ == '__main__':
