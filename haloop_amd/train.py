@@ -631,7 +631,11 @@ class LstmCtcTrainer:
             self._sharded_tail()
             return self.loss
         self._tail_calls = getattr(self, '_tail_calls', 0) + 1
-        if self._tail_calls == 2 and self.sharded._native and os.environ.get('HALO_DP_CAPTURE', '1') != '0':
+        # (HALO_DP_CAPTURE: 1 / 0 force it; unset = capture on a one-rank group only -- the rehearsal, measured on this pool's one-GPU
+        #  boxes -- and plain eager RCCL calls between real ranks: collectives inside a captured graph have never run on more than one
+        #  rank here, and a capture that disagrees between ranks is a hang, not an exception)
+        want_capture = os.environ.get('HALO_DP_CAPTURE', '1' if self.world == 1 else '0') != '0'
+        if self._tail_calls == 2 and self.sharded._native and want_capture:
             # the first tail ran eagerly (communicator and kernels warm); record the second
             try:
                 torch.cuda.synchronize()
