@@ -467,13 +467,23 @@ class DirectExchange(SpanSharded):
             dist.barrier(group=self.group)         # every arena is mapped everywhere before the first push
 
     def close(self):
-        for p in self._opened:
+        """Unmap the peers' arenas and free this rank's (idempotent; also run when the object is collected).  Call it on every rank behind
+        the last step: a rank's last wait has seen every peer's last push into its arena, so nothing writes there any more."""
+        if getattr(self, '_base', None):
+            torch.cuda.synchronize()
+        for p in getattr(self, '_opened', []):
             self._lib.lib().halo_dx_close(p)
         self._opened = []
-        if self._base:
+        if getattr(self, '_base', None):
             self._arena = self._stage = None
             self._lib.lib().halo_dx_free(self._base)
             self._base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:              # (interpreter shutdown: the runtime may be gone already)
+            pass
 
     # ---- the three launches of a collective -----------------------------------------------------
     def _stream(self):
