@@ -13,7 +13,7 @@
 // the expansion of the gathered bf16 records).  Epochs only grow (the step count); a slot is rewritten by the next step's push only
 // after its owner has signalled a LATER collective of the step before (the all-gather closes every step), so no back-signal is needed.
 // The arena is allocated uncached (hipDeviceMallocUncached: what RCCL uses for the buffers its peers write), falling back to
-// fine-grained, then plain device memory where the runtime refuses the flag.
+// fine-grained memory where the runtime refuses the flag -- never to plain (L2-cached, non-coherent) device memory.
 #include <string.h>
 #include "halo_common.h"
 #include "halo_internal.h"
@@ -86,11 +86,13 @@ int halo_dx_alloc(size_t bytes, void **ptr, void *handle64) {
     HALO_CHECK_ARG(bytes > 0 && ptr && handle64);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the IPC handle travels as 64 bytes");
     void *p = nullptr;
+    // (never plain device memory: a peer's stores over xGMI would not be coherent with this GPU's L2 -- a single-GPU test would pass
+    //  and eight GPUs would sum stale pieces; a runtime that refuses both coherent kinds fails the construction, loudly)
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
-            if (hipMalloc(&p, bytes) != hipSuccess) return HALO_ELAUNCH;
+            return HALO_ELAUNCH;
         }
     }
     if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return HALO_ELAUNCH; }
