@@ -203,3 +203,41 @@ def test_span_sharded_update_equals_the_single_process_step(gather_bf16):
         np.testing.assert_array_equal(rounded, masters)
         assert wire['all_gather'] == 4 * (64 + 96) * world // 2
     assert wire['reduce_scatter_early'] == 4 * 96 * world // 2 and wire['reduce_scatter_late'] == 4 * 64 * world // 2
+
+
+def test_flat_params_layout_on_cpu():
+    """FlatParams: every tensor 16-byte aligned and inside exactly one AdamW range; the small (replicated) range is a prefix whose length is
+    a multiple of 64 elements (up to 16 ranks cut it into equal 16-byte-aligned pieces: dp.DirectExchange), its padding never belongs to a
+    parameter; the late / early spans are the lower layers' and the top LSTM layer's matrices; unexpected LSTM parameter names (a
+    bidirectional or projected nn.LSTM) fall into the small range instead of raising."""
+    from haloop_amd import rnn, recognizer
+    from haloop_amd.train import FlatParams
+    enc = rnn.Encoder(12, 16, 32, num_layers=3); rec = recognizer.TemporalClassifier(32, 9)
+    f = FlatParams(enc, rec, pad_to=16)
+    assert f.small_range[0] == 0 and f.small_range[1] % 64 == 0 and f.small_range[1] == f.big_late[0] and f.big_late[1] == f.big_early[0]
+    assert f.big_early[1] == f.total and f.padded % 16 == 0 and f.padded >= f.total
+    H = 32
+    assert f.big_early[1] - f.big_early[0] == 2 * 4 * H * H                       # the top layer's W_ih and W_hh
+    assert f.big_late[1] - f.big_late[0] == 4 * H * H + 2 * 4 * H * H             # layer 0's W_hh, layer 1's W_ih and W_hh
+    covered = torch.zeros(f.padded, dtype=torch.int32)
+    for name, p, off in f.slots:
+        assert off % 4 == 0
+        covered[off:off + p.numel()] += 1
+        inside = [r for r in f.ranges if r[0] <= off and off + p.numel() <= r[1]]
+        assert len(inside) == 1, name
+        big = name.startswith('encoder.lstm.weight_') and not name.endswith('ih_l0')
+        assert (off >= f.small_range[1]) == big, name
+    assert int(covered.max()) == 1
+    assert int(covered[f.small_range[1]:f.total].min()) == 1                      # no padding inside the matrix spans
+    # the parameters are views of the flat buffer
+    name, p, off = f.slots[0]
+    assert p.data_ptr() == f.params[off:].data_ptr()
+
+    class Odd(torch.nn.Module):                                                   # names the layout code must tolerate
+        def __init__(self):
+            super().__init__()
+            self.subsample = torch.nn.Conv1d(12, 16, 5)
+            self.lstm = torch.nn.LSTM(16, 32, num_layers=2, bidirectional=True, proj_size=8)
+    f2 = FlatParams(Odd(), rec, pad_to=4)
+    names = {n for n, _, off in f2.slots if off < f2.small_range[1]}
+    assert any(n.endswith('_reverse') for n in names) and any('weight_hr' in n for n in names)
