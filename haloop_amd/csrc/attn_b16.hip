@@ -8,6 +8,7 @@
 //     tile ahead, and its workgroups -- two per CU -- wait for that request on every tile: the forward spent most of its 41 us at B = 8,
 //     T = 1024 waiting, its MFMAs busy for a sixth of it).
 // Causal or full, any Tq / Tk (edge tiles clamp their rows), no key lengths, no dropout (the callers keep attn_mx.hip for those).
+#include <stdlib.h>
 #include "halo_common.h"
 #include "halo_internal.h"
 #include "attn_args.h"
@@ -40,8 +41,9 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char *img, int rowA, int rowB, 
     return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 }
 
+template <int QB>
 __global__ __launch_bounds__(256, 2) void attention_fwd_b16_kernel(const B16Args a) {
-    constexpr int QB = 2, WQ = 16 * QB, TQ = 64 * QB, KSTEPS = HD / 32;
+    constexpr int WQ = 16 * QB, TQ = 64 * QB, KSTEPS = HD / 32;
     __shared__ __attribute__((aligned(16))) char Kimg[IMG];
     __shared__ __attribute__((aligned(16))) char Vimg[IMG];
     // one query tile per workgroup, longest first when causal (as attn_mx.hip): grid (heads * N, tiles)
@@ -510,7 +512,13 @@ int halo_attention_fwd_b16(const void *q, long q_row_stride, long q_batch_stride
     a.yb = (__bf16 *)y_bf16; a.yb_rs = yb_row_stride; a.yb_bs = yb_batch_stride;
     a.lse = lse; a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.causal = causal;
     a.scale = 1.0f / sqrtf((float)head_dim);
-    hipLaunchKernelGGL(attention_fwd_b16_kernel, dim3((unsigned)(heads * N), (unsigned)((Tq + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
+    // one block of 16 queries per wave (64 per workgroup: twice the workgroups, 28.5 against 30.1 us on 8 x 1024 x 12 heads); HALO_ATTN_B16_QB=2:
+    // two blocks per wave (every K / V fragment feeds two MFMAs)
+    const char *qb_env = getenv("HALO_ATTN_B16_QB");
+    if (!qb_env || atoi(qb_env) != 2)
+        hipLaunchKernelGGL(attention_fwd_b16_kernel<1>, dim3((unsigned)(heads * N), (unsigned)((Tq + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attention_fwd_b16_kernel<2>, dim3((unsigned)(heads * N), (unsigned)((Tq + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
     return halo_launch_status();
 }
 

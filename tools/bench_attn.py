@@ -37,3 +37,15 @@ t_b = event_us(lambda: ops.attention_bwd(q, k, v, y, dy, lse, dq, dk, dv, B, H, 
 flops = 4.0 * B * H * T * T * hd / 2
 print(f'attention B={B} T={T} H={H} hd={hd} causal math={_lib.get_math_mode()}: fwd {t_f:.1f} us ({flops / t_f / 1e6:.1f} TFLOP/s)  '
       f'bwd {t_b:.1f} us ({2.5 * flops / t_b / 1e6:.1f} TFLOP/s)  checksum {y.double().sum().item():.6f} {dqkv.double().abs().sum().item():.4f}')
+
+if _lib.get_math_mode() == 'bf16':
+    # the same shape from row-major bf16 q | k | v (csrc/attn_b16.hip: what the GPT blocks run in bf16 arithmetic)
+    qkvb = qkv.bfloat16()
+    qb, kb, vb = qkvb[:, :C], qkvb[:, C:2 * C], qkvb[:, 2 * C:]
+    dyb = dy.bfloat16()
+    dqkvb = torch.empty_like(qkvb)
+    _, lse_b, yb = ops.attention_fwd_b16(qb, kb, vb, B, H, hd, T, T, causal=True, want_lse=True)
+    t_f = event_us(lambda: ops.attention_fwd_b16(qb, kb, vb, B, H, hd, T, T, causal=True, want_lse=True))
+    t_b = event_us(lambda: ops.attention_bwd_b16(qb, kb, vb, yb, dyb, lse_b, dqkvb[:, :C], dqkvb[:, C:2 * C], dqkvb[:, 2 * C:], B, H, hd, T, T, causal=True))
+    print(f'  from bf16 rows: fwd {t_f:.1f} us ({flops / t_f / 1e6:.1f} TFLOP/s)  bwd {t_b:.1f} us ({2.5 * flops / t_b / 1e6:.1f} TFLOP/s)  '
+          f'checksum {yb.double().sum().item():.4f} {dqkvb.double().abs().sum().item():.2f}')
