@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 17
+HALO_ABI_VERSION = 18
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -46,6 +46,9 @@ SIGNATURES = {
     'halo_gelu_bf16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_bf16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_gemm_tn_bf16_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    'halo_gemm_tn_rows_supported': (_i, [_i, _vp, _vp, _i]),
+    'halo_gemm_tn_rows_preferred': (_i, [_i, _vp, _vp, _i]),
+    'halo_gemm_tn_rows_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'halo_gelu_b16': (_i, [_vp, _vp, _sz, _i, _vp]),
     'halo_gelu_bwd_b16': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'halo_dx_alloc': (_i, [_sz, _vp, _vp]),

@@ -540,7 +540,7 @@ class GPT(nn.Module):
         if logits.dtype == torch.bfloat16:
             # the stored bf16 logits become d loss / d logits IN PLACE: the row-major bf16 operand of both gradient products
             dl = ops.cross_entropy_bwd_bf16_(logits, targets, row_lse, grad_per_tok, ignore_index=0)
-            dw_head = ops.gemm_tn(dl, xf)                                                    # [V, C]; the tied wte gradient lands here too
+            dw_head = ops.gemm_tn_group([(dl, xf)])[0]                                       # [V, C]; the tied wte gradient lands here too
             dxf = ops.gemm_rows(dl, img.split_t((self.lm_head.weight,)), M, C, V)
             del dl, logits
         elif use_split(M, C, V) and use_split(V, C, M):

@@ -225,8 +225,11 @@ def gemm_tn(a, b, out=None, accumulate=False):
 
 def gemm_tn_group(pairs):
     """[a_i [K, M_i]^T b_i [K, N_i] for (a_i, b_i) in pairs] -> list of fp32 [M_i, N_i], row-major bf16 operands with ONE contraction length
-    K: up to four products per launch on whole-K tiles (halo_gemm_tn_bf16_group) -- a GPT block's four weight gradients."""
+    K: up to four products per launch on whole-K tiles -- a GPT block's four weight gradients, the lm_head's.  In single-pass bf16
+    arithmetic a group of at least two rounds of 256 x 256 tiles (the lm_head) runs on halo_gemm_tn_rows_group's 256-row tiles
+    (csrc/gemm_tn_rows.hip), everything else on the 128 x 128 tiles of halo_gemm_tn_bf16_group; HALO_GEMM_TN_ROWS=1 / 0 force one."""
     import ctypes as C
+    import os
     outs = []
     for i0 in range(0, len(pairs), 4):
         grp = pairs[i0:i0 + 4]
@@ -238,6 +241,15 @@ def gemm_tn_group(pairs):
                 raise ValueError('gemm_tn_group: row-major bf16 a [K, M], b [K, N] with one K')
         cs = [torch.empty(a.shape[1], b.shape[1], device=a.device, dtype=torch.float32) for a, b in grp]
         vp = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        Ms, Ns = (C.c_int * n)(*[a.shape[1] for a, _ in grp]), (C.c_int * n)(*[b.shape[1] for _, b in grp])
+        force = os.environ.get('HALO_GEMM_TN_ROWS', '')
+        if force != '0' and (lib().halo_gemm_tn_rows_supported if force == '1' else lib().halo_gemm_tn_rows_preferred)(n, Ms, Ns, K) \
+                and all(a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 for a, b in grp):
+            check(lib().halo_gemm_tn_rows_group(n, vp([a for a, _ in grp]), (C.c_long * n)(*[a.stride(0) for a, _ in grp]),
+                                                vp([b for _, b in grp]), (C.c_long * n)(*[b.stride(0) for _, b in grp]), Ms, Ns, K,
+                                                vp(cs), (C.c_long * n)(*[c.stride(0) for c in cs]), _stream()), 'halo_gemm_tn_rows_group')
+            outs += cs
+            continue
         check(lib().halo_gemm_tn_bf16_group(n, vp([a for a, _ in grp]), (C.c_long * n)(*[a.stride(0) for a, _ in grp]),
                                             vp([b for _, b in grp]), (C.c_long * n)(*[b.stride(0) for _, b in grp]),
                                             (C.c_int * n)(*[a.shape[1] for a, _ in grp]), (C.c_int * n)(*[b.shape[1] for _, b in grp]), K,

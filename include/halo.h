@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 17
+#define HALO_ABI_VERSION 18
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -196,6 +196,18 @@ int halo_gemm_tn_bf16(const void *a, long lda, const void *b, long ldb, int M, i
  * rows and have 36 .. 144 output tiles each; together they fill the chip.  Arrays of n entries; flags: 0 or HALO_GEMM_ACCUM for all. */
 int halo_gemm_tn_bf16_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
                             float *const *C, const int *ldc, int flags, halo_stream_t stream);
+
+/* The same grouped weight-gradient products (C_i [M_i][N_i] = A_i^T B_i, A_i [K][M_i] and B_i [K][N_i] row-major bf16, fp32 results
+ * overwritten; replaces: the autograd of a GPT block's Linear layers and of the tied lm_head, ha/attention.py:117-143,228-231) on 256-row
+ * tiles of whole K -- 256 x 128 or 256 x 256, picked per group so that the tiles fill whole rounds of the CUs (csrc/gemm_tn_rows.hip:
+ * LDS-DMA of whole operand rows, transposing LDS reads into the MFMA; twice the arithmetic per operand byte of the 128 x 128 tiles).
+ * Single-pass bf16 arithmetic only (HALO_ENOTSUP otherwise); K % 32 == 0, M_i % 8 == 0, N_i % 8 == 0, lda / ldb % 8 == 0, ldc % 4 == 0,
+ * 16-byte aligned operands and results; n <= 4. */
+int halo_gemm_tn_rows_supported(int n, const int *M, const int *N, int K);
+/* 1 where these tiles measured faster than halo_gemm_tn_bf16_group's (at least two rounds of 256 x 256 tiles over the CUs: the lm_head) */
+int halo_gemm_tn_rows_preferred(int n, const int *M, const int *N, int K);
+int halo_gemm_tn_rows_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
+                            float *const *C, const long *ldc, halo_stream_t stream);
 
 /* halo_gemm_split with row-major bf16 activations on either side, so that consecutive Linears hand their activations on without an
  * operand-image pass (ha/attention.py:136-143: c_fc -> gelu -> c_proj).  A comes either from an image (a_image) or from a row-major

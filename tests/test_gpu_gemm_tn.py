@@ -123,3 +123,81 @@ def test_grouped_tn_products_equal_the_single_launches():
             torch.testing.assert_close(o, ops.gemm_tn(a, b), rtol=0, atol=2e-3)
     finally:
         _lib.set_math_mode(prev)
+
+
+# ---- the 256-row tiles (csrc/gemm_tn_rows.hip): what ops.gemm_tn_group runs in single-pass bf16 arithmetic ----
+@pytest.fixture
+def bf16_mode():
+    from haloop_amd import _lib
+    _lib.lib(); _lib.lend_scratch(256 << 20)
+    prev = _lib.get_math_mode()
+    _lib.set_math_mode('bf16')
+    yield
+    _lib.set_math_mode(prev)
+
+
+def _tn_rows_case(K, shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    pairs = [(torch.randn(K, m, generator=g).cuda().bfloat16(), torch.randn(K, n, generator=g).cuda().bfloat16()) for m, n in shapes]
+    return pairs, g
+
+
+# a GPT block's four weight gradients (216 tiles of 256 x 128), the lm_head's (256 x 256 tiles), ragged rows / columns that do not fill
+# their last tile, one k-block, 8-wide operands, both tile widths forced
+@pytest.mark.parametrize('K,shapes,tn', [(8192, [(2304, 768), (768, 768), (3072, 768), (768, 3072)], 0), (2048, [(50304, 768)], 0),
+                                         (2048, [(50304, 768)], 4), (1024, [(776, 2304), (40, 8), (264, 136)], 4),
+                                         (1024, [(776, 2304), (40, 8), (264, 136)], 8), (32, [(8, 8)], 0), (96, [(520, 264), (256, 128)], 8),
+                                         (160, [(1000, 200)], 4)])
+def test_tn_products_on_256_row_tiles(bf16_mode, monkeypatch, K, shapes, tn):
+    from haloop_amd import ops
+    if tn:
+        monkeypatch.setenv('HALO_GEMM_TN_ROWS_TN', str(tn))
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS', '1')
+    pairs, g = _tn_rows_case(K, shapes, K + len(shapes) + tn)
+    got = ops.gemm_tn_group(pairs)
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS', '0')
+    old = ops.gemm_tn_group(pairs)                                      # the 128 x 128 tiles: the same products, another summation order
+    tol = 2e-6 * K ** 0.5 * 16 + 1e-5
+    for (a, b), c, c_old in zip(pairs, got, old):
+        M = a.shape[1]
+        rows = torch.cat([torch.arange(0, min(M, 24)), torch.arange(max(0, M - 24), M), torch.randint(0, M, (48,), generator=g)]).cuda()
+        want = a.double()[:, rows].t() @ b.double()
+        assert (c[rows].double() - want).abs().max().item() <= tol
+        assert (c - c_old).abs().max().item() <= 2 * tol
+
+
+def test_tn_rows_refusals(bf16_mode):
+    import ctypes as C
+    from haloop_amd import _lib
+    L = _lib.lib()
+    one = lambda v: (C.c_int * 1)(v)
+    assert L.halo_gemm_tn_rows_supported(1, one(64), one(64), 64) == 1
+    assert L.halo_gemm_tn_rows_supported(1, one(60), one(64), 64) == 0      # M % 8
+    assert L.halo_gemm_tn_rows_supported(1, one(64), one(64), 48) == 0      # K % 32
+    assert L.halo_gemm_tn_rows_supported(5, one(64), one(64), 64) == 0      # more than four products
+    assert L.halo_gemm_tn_rows_preferred(1, one(50304), one(768), 8192) == 1 and L.halo_gemm_tn_rows_preferred(1, one(3072), one(768), 8192) == 0
+    _lib.set_math_mode('bf16x3')
+    assert L.halo_gemm_tn_rows_supported(1, one(64), one(64), 64) == 0      # single-pass bf16 arithmetic only
+
+
+def test_gpt_step_with_the_256_row_weight_gradients(bf16_mode, monkeypatch):
+    """The GPT training step's gradients with the weight gradients on the 256-row tiles against the 128 x 128 tiles (same operands, another
+    summation order): every gradient within fp32 accumulation noise."""
+    from haloop_amd import attention
+    torch.manual_seed(3)
+    cfg = attention.GPTConfig(block_size=256, vocab_size=1024, n_layer=2, n_head=4, n_embd=256)
+    model = attention.GPT(cfg).cuda().train()
+    ids = torch.randint(1, 1024, (4, 256), device='cuda')
+    tg = torch.roll(ids, -1, 1)
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        model.forward_all(ids, tg).backward()
+        return [p.grad.clone() for p in model.parameters()]
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS', '1')
+    new = grads()
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS', '0')
+    old = grads()
+    for a, b in zip(new, old):
+        assert (a - b).abs().max().item() <= 1e-5 + 1e-4 * b.abs().max().item()
