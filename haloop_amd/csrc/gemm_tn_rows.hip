@@ -41,6 +41,12 @@ struct TnrArgs {
     long lda[TNR_MAX], ldb[TNR_MAX], ldc[TNR_MAX];
     int M[TNR_MAX], N[TNR_MAX], tiles_n[TNR_MAX], first[TNR_MAX];
     int n, KT, nitems;
+    // the LAST n_split tiles of the group run as S = slices K-slices each (the tail of a launch whose tiles do not fill their last round of the
+    // CUs: 591 tiles on 256 CUs are two rounds and 79 tiles -- as 237 thirds they finish in a third of a round): workgroups [0, n_full) take
+    // whole tiles, workgroup n_full + i slice i % S of tile n_full + i / S and writes its plain sums to slab[(i / S) * S + i % S] (256 x BN
+    // floats each, in the scratch lent by halo_set_scratch); a second launch adds a tile's slabs in slice order
+    int n_full, slices, ktper;
+    float *slab;
 };
 
 template <int TN> struct Cfg {
@@ -79,13 +85,16 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int lr = lane & 31, lh = lane >> 5;
     // item -> (product, tile row, tile column): items are product-major, tile-row-major, so an XCD's contiguous run shares A panels
-    const int item = xcd_order((int)blockIdx.x, g.nitems);
+    const bool split = (int)blockIdx.x >= g.n_full;
+    const int sidx = split ? (int)blockIdx.x - g.n_full : 0;
+    const int item = split ? g.n_full + sidx / g.slices : xcd_order((int)blockIdx.x, g.n_full), kslice = split ? sidx % g.slices : 0;
+    const int kb0 = split ? kslice * g.ktper : 0;
     int q = 0;
 #pragma unroll
     for (int i = 1; i < TNR_MAX; ++i)
         if (i < g.n && item >= g.first[i]) q = i;
     const int local = item - g.first[q], tile_m = local / g.tiles_n[q], tile_n = local % g.tiles_n[q];
-    const int M = g.M[q], N = g.N[q], KT = g.KT;
+    const int M = g.M[q], N = g.N[q], KT = split ? min(g.ktper, g.KT - kb0) : g.KT;
     const long lda = g.lda[q], ldb = g.ldb[q];
 
     // ---- LDS-DMA sources.  Piece pc < 16: k-rows 2 pc, 2 pc + 1 of the A block (32 chunks of 16 B each); else piece pb = pc - 16 of the B
@@ -100,13 +109,13 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
         if (pc < 16) {
             const int r = 2 * pc + (lane >> 5), chunk = (lane & 31) ^ (4 * (r & 3));
             const int m0 = min(tile_m * 256 + 8 * chunk, M - 8);
-            src[i] = reinterpret_cast<const char *>(g.a[q] + (long)r * lda + m0);
+            src[i] = reinterpret_cast<const char *>(g.a[q] + ((long)kb0 * 32 + r) * lda + m0);
             kstride[i] = 64 * lda;                           // 32 rows x lda elements x 2 B
             dst[i] = pc * 1024;
         } else {
             const int pb = pc - 16, r = pb * (1024 / BROW) + lane / CB, chunk = (lane % CB) ^ (4 * (r & 3));
             const int n0 = min(tile_n * K::BN + 8 * chunk, N - 8);
-            src[i] = reinterpret_cast<const char *>(g.b[q] + (long)r * ldb + n0);
+            src[i] = reinterpret_cast<const char *>(g.b[q] + ((long)kb0 * 32 + r) * ldb + n0);
             kstride[i] = 64 * ldb;
             dst[i] = A_BYTES + pb * 1024;
         }
@@ -198,6 +207,15 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     wait_vm<0>();
 
     // ---- epilogue (gemm_rows.h's fp32 form): this lane's result row m; element (t, r): column 32 t + (r & 3) + 8 (r >> 2) + 4 lh of the tile
+    if (split) {                                             // the whole 256 x BN tile of plain sums (the sum launch knows the bounds)
+        float *srow = g.slab + ((long)sidx * 256 + 32 * wave + lr) * K::BN + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<f32x4v *>(srow + 32 * t + 8 * gq) = f32x4v{acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+        return;
+    }
     const int m = tile_m * 256 + 32 * wave + lr;
     if (m >= M) return;
     const int ncol0 = tile_n * K::BN;
@@ -211,14 +229,49 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
         }
 }
 
+// C tile <- the sum of its S slabs in slice order; grid (split tiles, 16 row groups of 16), a thread = 4 columns of 16 rows
 template <int TN>
-hipError_t launch(const TnrArgs &g, hipStream_t st, int slot_id) {
+__global__ __launch_bounds__(256) void tn_rows_slab_sum_kernel(const TnrArgs g) {
+    constexpr int BN = 32 * TN;
+    const int item = g.n_full + (int)blockIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < TNR_MAX; ++i)
+        if (i < g.n && item >= g.first[i]) q = i;
+    const int local = item - g.first[q], tile_m = local / g.tiles_n[q], tile_n = local % g.tiles_n[q];
+    const float *slab = g.slab + (long)blockIdx.x * g.slices * 256 * BN;
+    for (int u = threadIdx.x; u < 16 * (BN / 4); u += 256) {
+        const int r = (int)blockIdx.y * 16 + u / (BN / 4), c = (u % (BN / 4)) * 4;
+        const int m = tile_m * 256 + r, n = tile_n * BN + c;
+        if (m >= g.M[q] || n >= g.N[q]) continue;
+        f32x4v sum = *reinterpret_cast<const f32x4v *>(slab + (long)r * BN + c);
+        for (int k = 1; k < g.slices; ++k) sum += *reinterpret_cast<const f32x4v *>(slab + ((long)k * 256 + r) * BN + c);
+        *reinterpret_cast<f32x4v *>(g.c[q] + (long)m * g.ldc[q] + n) = sum;
+    }
+}
+
+template <int TN>
+hipError_t launch(TnrArgs &g, hipStream_t st, int slot_id) {
     if (!halo_func_attr_done(slot_id)) {
         const hipError_t e = hipFuncSetAttribute((const void *)gemm_tn_rows_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<TN>::LDS_BYTES);
         if (e != hipSuccess) return e;
         halo_func_attr_set(slot_id);
     }
-    hipLaunchKernelGGL((gemm_tn_rows_kernel<TN>), dim3((unsigned)g.nitems), dim3(512), Cfg<TN>::LDS_BYTES, st, g);
+    // the tail as K-slices: more than one round, a last round at most half full, slices of at least 16 k-blocks, scratch for the slabs
+    const int cus = halo_cu_count(), rem = g.nitems % cus;
+    g.n_full = g.nitems; g.slices = 1; g.ktper = g.KT; g.slab = nullptr;
+    const char *e = getenv("HALO_GEMM_TN_ROWS_TAIL");
+    if ((!e || atoi(e) != 0) && g.nitems > cus && rem > 0 && 2 * rem <= cus) {
+        const int S = min(min(4, cus / rem), g.KT / 16);
+        void *scratch; size_t bytes;
+        halo_get_scratch(&scratch, &bytes);
+        if (S >= 2 && scratch && bytes >= (size_t)rem * S * 256 * Cfg<TN>::BN * sizeof(float)) {
+            g.n_full = g.nitems - rem; g.slices = S; g.ktper = (g.KT + S - 1) / S; g.slab = (float *)scratch;
+        }
+    }
+    const int split_wgs = (g.nitems - g.n_full) * g.slices;
+    hipLaunchKernelGGL((gemm_tn_rows_kernel<TN>), dim3((unsigned)(g.n_full + split_wgs)), dim3(512), Cfg<TN>::LDS_BYTES, st, g);
+    if (split_wgs) hipLaunchKernelGGL((tn_rows_slab_sum_kernel<TN>), dim3((unsigned)(g.nitems - g.n_full), 16), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 

@@ -166,6 +166,32 @@ def test_tn_products_on_256_row_tiles(bf16_mode, monkeypatch, K, shapes, tn):
         assert (c - c_old).abs().max().item() <= 2 * tol
 
 
+def test_tn_rows_tail_as_k_slices(bf16_mode, monkeypatch):
+    """A group whose tiles do not fill their last round of the CUs (591 tiles of 256 x 256 on 256 CUs: two rounds and 79) runs the last
+    tiles as K-slices into scratch slabs + a sum launch: the same products as whole-K tiles up to the summation order; without scratch the
+    launch falls back to whole tiles."""
+    from haloop_amd import _lib, ops
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS', '1')
+    K = 2048
+    pairs, g = _tn_rows_case(K, [(50304, 768)], 77)
+    got = ops.gemm_tn_group(pairs)[0]
+    monkeypatch.setenv('HALO_GEMM_TN_ROWS_TAIL', '0')
+    whole = ops.gemm_tn_group(pairs)[0]
+    tol = 2e-6 * K ** 0.5 * 16 + 1e-5
+    assert not torch.equal(got, whole)                                  # (the tail really ran in slices: another summation order)
+    assert (got - whole).abs().max().item() <= 2 * tol
+    a, b = pairs[0]
+    rows = torch.cat([torch.arange(50304 - 300, 50304), torch.randint(0, 50304, (64,), generator=g)]).cuda()       # the tail tiles' rows
+    want = a.double()[:, rows].t() @ b.double()
+    assert (got[rows].double() - want).abs().max().item() <= tol
+    monkeypatch.delenv('HALO_GEMM_TN_ROWS_TAIL')
+    _lib.lib().halo_set_scratch(None, 0)
+    try:
+        assert torch.equal(ops.gemm_tn_group(pairs)[0], whole)         # no scratch: whole tiles
+    finally:
+        _lib.lib().halo_set_scratch(_lib._scratch.data_ptr(), _lib._scratch.numel())
+
+
 def test_tn_rows_refusals(bf16_mode):
     import ctypes as C
     from haloop_amd import _lib

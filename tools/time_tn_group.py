@@ -24,13 +24,16 @@ def t_us(fn, reps=10):
 
 for name, pairs in cases.items():
     flops = sum(2.0 * a.shape[0] * a.shape[1] * b.shape[1] for a, b in pairs)
-    out = []
-    for env, tn in (('1', ''), ('1', '4'), ('1', '8'), ('0', '')):
-        os.environ['HALO_GEMM_TN_ROWS'] = env
-        if tn:
-            os.environ['HALO_GEMM_TN_ROWS_TN'] = tn
-        else:
-            os.environ.pop('HALO_GEMM_TN_ROWS_TN', None)
-        us = t_us(lambda: ops.gemm_tn_group(pairs))
-        out.append(f"{'256-row tiles' + (' TN ' + tn if tn else '') if env == '1' else '128 x 128 tiles'}: {us:.1f} us ({flops / us / 1e6:.0f} TF)")
+    variants = (('1', ''), ('1', '4'), ('1', '8'), ('0', ''))
+    best = {v: 1e30 for v in variants}
+    for rep in range(3):                                    # interleaved, the minimum of three rounds per variant
+        for env, tn in variants:
+            os.environ['HALO_GEMM_TN_ROWS'] = env
+            if tn:
+                os.environ['HALO_GEMM_TN_ROWS_TN'] = tn
+            else:
+                os.environ.pop('HALO_GEMM_TN_ROWS_TN', None)
+            best[(env, tn)] = min(best[(env, tn)], t_us(lambda: ops.gemm_tn_group(pairs)))
+    out = [f"{'256-row tiles' + (' TN ' + tn if tn else ' (chosen width)') if env == '1' else '128 x 128 tiles'}: {us:.1f} us ({flops / us / 1e6:.0f} TF)"
+           for (env, tn), us in best.items()]
     print(name + ': ' + ' | '.join(out), flush=True)
