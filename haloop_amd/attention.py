@@ -235,6 +235,7 @@ def block_forward_train_rm(images, blk, x0, B, T, cfg, sites):
     rows = rows_ok(M, C)
     s_att, s_res, s_mlp = sites.next(), sites.next(), sites.next()
     if rows:
+        _lib.lend_scratch(128 << 20, device=x0.device)      # K-slice slabs of the lm_head's input gradient and of the weight gradients' tails
         # round 5: every activation-by-weight product on halo_gemm_rows (256-row tiles cut to whole rounds of the CUs, A staged from the
         # row-major bf16 rows the producing launch left); c_fc's result and the MLP's hidden activations stay bf16 (what the reference's
         # autocast path holds there, ha/attention_loop.py:164) -- the fp32 [M, 4C] round trip between c_fc and new_gelu is gone

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     const int lr = lane & 31, lh = lane >> 5;
     // item -> (product, tile row, tile column): items are product-major, tile-row-major, so an XCD's contiguous run shares A panels
     const bool split = (int)blockIdx.x >= g.n_full;
-    const int sidx = split ? (int)blockIdx.x - g.n_full : 0;
+    const int sidx = split ? xcd_order((int)blockIdx.x - g.n_full, (g.nitems - g.n_full) * g.slices) : 0;      // (an XCD's run: slices of neighbouring tiles)
     const int item = split ? g.n_full + sidx / g.slices : xcd_order((int)blockIdx.x, g.n_full), kslice = split ? sidx % g.slices : 0;
     const int kb0 = split ? kslice * g.ktper : 0;
     int q = 0;
@@ -250,6 +250,26 @@ __global__ __launch_bounds__(256) void tn_rows_slab_sum_kernel(const TnrArgs g) 
     }
 }
 
+void *halo_scratch_ptr() { void *p; size_t b; halo_get_scratch(&p, &b); return p; }
+
+// Which tiles of a launch of `nitems` tiles run as S K-slices (+ the sum launch): ALL of them when they fill at most half a round of the CUs
+// (a GPT block's four gradients on 256 x 256 tiles are 108), else the last round's when that is at most half full (the lm_head's 591 = two
+// rounds and 79); slices of at least 16 k-blocks, at most four, and only with scratch for the slabs (halo_set_scratch).  S = 1: none.
+void plan_slices(int nitems, int KT, int BN, int &n_full, int &S) {
+    n_full = nitems; S = 1;
+    const char *e = getenv("HALO_GEMM_TN_ROWS_TAIL");
+    if (e && atoi(e) == 0) return;
+    const int cus = halo_cu_count();
+    int n_split = 0;
+    if (2 * nitems <= cus) n_split = nitems;
+    else if (nitems > cus && nitems % cus > 0 && 2 * (nitems % cus) <= cus) n_split = nitems % cus;
+    if (!n_split) return;
+    const int s = min(min(4, cus / n_split), KT / 16);
+    void *scratch; size_t bytes;
+    halo_get_scratch(&scratch, &bytes);
+    if (s >= 2 && scratch && bytes >= (size_t)n_split * s * 256 * BN * sizeof(float)) { n_full = nitems - n_split; S = s; }
+}
+
 template <int TN>
 hipError_t launch(TnrArgs &g, hipStream_t st, int slot_id) {
     if (!halo_func_attr_done(slot_id)) {
@@ -257,35 +277,30 @@ hipError_t launch(TnrArgs &g, hipStream_t st, int slot_id) {
         if (e != hipSuccess) return e;
         halo_func_attr_set(slot_id);
     }
-    // the tail as K-slices: more than one round, a last round at most half full, slices of at least 16 k-blocks, scratch for the slabs
-    const int cus = halo_cu_count(), rem = g.nitems % cus;
     g.n_full = g.nitems; g.slices = 1; g.ktper = g.KT; g.slab = nullptr;
-    const char *e = getenv("HALO_GEMM_TN_ROWS_TAIL");
-    if ((!e || atoi(e) != 0) && g.nitems > cus && rem > 0 && 2 * rem <= cus) {
-        const int S = min(min(4, cus / rem), g.KT / 16);
-        void *scratch; size_t bytes;
-        halo_get_scratch(&scratch, &bytes);
-        if (S >= 2 && scratch && bytes >= (size_t)rem * S * 256 * Cfg<TN>::BN * sizeof(float)) {
-            g.n_full = g.nitems - rem; g.slices = S; g.ktper = (g.KT + S - 1) / S; g.slab = (float *)scratch;
-        }
-    }
+    int n_full, S;
+    plan_slices(g.nitems, g.KT, Cfg<TN>::BN, n_full, S);
+    if (S > 1) { g.n_full = n_full; g.slices = S; g.ktper = (g.KT + S - 1) / S; g.slab = (float *)halo_scratch_ptr(); }
     const int split_wgs = (g.nitems - g.n_full) * g.slices;
     hipLaunchKernelGGL((gemm_tn_rows_kernel<TN>), dim3((unsigned)(g.n_full + split_wgs)), dim3(512), Cfg<TN>::LDS_BYTES, st, g);
     if (split_wgs) hipLaunchKernelGGL((tn_rows_slab_sum_kernel<TN>), dim3((unsigned)(g.nitems - g.n_full), 16), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 
-// tile columns for a group: fewest rounds of the CUs x the time of a tile (a 256 x 256 tile streams 32 KiB per k-block, a 256 x 128 one 24)
-int pick_tn(int n, const int *M, const int *N) {
+// tile columns for a group: the rounds of the CUs its whole tiles take + the sliced tiles' share of a round (+ a tenth for the sum launch),
+// x the time of a tile (a 256 x 256 tile streams 32 KiB per k-block, a 256 x 128 one 24)
+int pick_tn(int n, const int *M, const int *N, int KT) {
     const char *e = getenv("HALO_GEMM_TN_ROWS_TN");
     if (e && (atoi(e) == 4 || atoi(e) == 8)) return atoi(e);
     const int cus = halo_cu_count();
-    long best = -1;
+    double best = -1;
     int pick = 4;
     for (int tn : {4, 8}) {
         long items = 0;
         for (int i = 0; i < n; ++i) items += (long)((M[i] + 255) / 256) * ((N[i] + 32 * tn - 1) / (32 * tn));
-        const long cost = ((items + cus - 1) / cus) * (tn == 4 ? 3 : 4);
+        int n_full, S;
+        plan_slices((int)items, KT, 32 * tn, n_full, S);
+        const double cost = (tn == 4 ? 3.0 : 4.0) * ((n_full + cus - 1) / cus + (S > 1 ? 1.0 / S + 0.1 : 0.0));
         if (best < 0 || cost < best) { best = cost; pick = tn; }
     }
     return pick;
@@ -308,7 +323,9 @@ int halo_gemm_tn_rows_preferred(int n, const int *M, const int *N, int K) {
     if (!halo_gemm_tn_rows_supported(n, M, N, K)) return 0;
     long t8 = 0;
     for (int i = 0; i < n; ++i) t8 += (long)((M[i] + 255) / 256) * ((N[i] + 255) / 256);
-    return t8 >= 2L * halo_cu_count();
+    int n_full, S;
+    plan_slices((int)t8, K / 32, 256, n_full, S);
+    return t8 >= 2L * halo_cu_count() || (n_full == 0 && S > 1 && 4 * t8 * S >= 3L * halo_cu_count());    // (sliced: at least three quarters of a round)
 }
 
 int halo_gemm_tn_rows_group(int n, const void *const *a, const long *lda, const void *const *b, const long *ldb, const int *M, const int *N, int K,
@@ -317,7 +334,7 @@ int halo_gemm_tn_rows_group(int n, const void *const *a, const long *lda, const 
     if (halo_math_mode() != HALO_MATH_BF16) return HALO_ENOTSUP;
     TnrArgs g = {};
     g.n = n; g.KT = K / 32;
-    const int tn = pick_tn(n, M, N);
+    const int tn = pick_tn(n, M, N, K / 32);
     int items = 0;
     for (int i = 0; i < n; ++i) {
         HALO_CHECK_ARG(a[i] && b[i] && C[i] && M[i] >= 8 && N[i] >= 8 && M[i] % 8 == 0 && N[i] % 8 == 0);
