@@ -128,10 +128,15 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     // block and k-block (slot base + abase / bbase[t]); the k-step and the half -- rows +16 ks, +4 h -- are the instruction's immediate offset.
     const int i16 = lane & 15, grp = (lane >> 4) & 1, rp = i16 >> 2, clow = 2 * grp + ((i16 & 3) >> 1), sub = (i16 & 1) * 8;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
-    const unsigned abase = lds_base + (8 * lh + rp) * 512 + (((wave ^ rp) & 7) << 6) + (clow << 4) + sub;      // chunk 4 (wave ^ rp) + clow
-    unsigned bbase[TN];
+    // A wave multiplies 64 result rows (two 32-row blocks) by HALF the tile's columns -- waves 0-3 the left half, 4-7 the right: 2 + TN / 2
+    // fragments per k-step for TN MFMAs (one row block x all columns would be 1 + TN: every wave re-reading every B fragment).
+    constexpr int TH = TN / 2;
+    const int wr = wave & 3, wc = wave >> 2;
+    unsigned abase[2], bbase[TH];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) bbase[t] = lds_base + (8 * lh + rp) * BROW + ((t ^ rp) << 6) + (clow << 4) + sub;   // chunk 4 (t ^ rp) + clow
+    for (int i = 0; i < 2; ++i) abase[i] = lds_base + (8 * lh + rp) * 512 + ((((2 * wr + i) ^ rp) & 7) << 6) + (clow << 4) + sub;     // chunk 4 ((2 wr + i) ^ rp) + clow
+#pragma unroll
+    for (int t = 0; t < TH; ++t) bbase[t] = lds_base + (8 * lh + rp) * BROW + (((wc * TH + t) ^ rp) << 6) + (clow << 4) + sub;         // chunk 4 ((wc TH + t) ^ rp) + clow
     // (inline assembly, not the builtin: the compiler cannot see that these reads never touch a ring slot an LDS-DMA is still filling, and
     //  puts vmcnt(0) in front of the builtin's reads -- every k-block would wait for the whole prefetch.  The reads are waited for by the
     //  explicit lgkmcnt(0) behind the phase's first barrier.)
@@ -142,11 +147,13 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
         return bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
     };
 
-    f32x16 acc[TN];
+    f32x16 acc[2][TH];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
     // ---- prologue and loop: gemm_rows.h's schedule (k-block j + D issued during k-block j; vmcnt((D - 1) P) in front of the phase's first
     // barrier retires this wave's loads up to k-block j + 1; waves 4-7 one barrier behind waves 0-3)
@@ -160,24 +167,27 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     int slot = 0, pslot = D;
     for (int j = 0; j < KT; ++j) {
         const unsigned cur = slot * SLOT;
-        const unsigned acur = abase + cur;
-        unsigned bcur[TN];
+        const unsigned acur[2] = {abase[0] + cur, abase[1] + cur};
+        unsigned bcur[TH];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) bcur[t] = bbase[t] + cur;
+        for (int t = 0; t < TH; ++t) bcur[t] = bbase[t] + cur;
         static_for<NPH>([&](auto phc) {
             constexpr int ph = decltype(phc)::value;
-            bf16x8 fa[KPH], fb[KPH][TN];
+            bf16x8 fa[KPH][2], fb[KPH][TH];
             static_for<KPH>([&](auto uc) {
                 constexpr int u = decltype(uc)::value, ks = ph * KPH + u;
                 if (!(TNR_LAB & 2) || j == 0) {
-                    fa[u] = tr8(acur, std::integral_constant<int, 16 * 512 * ks>{}, std::integral_constant<int, 16 * 512 * ks + 4 * 512>{});
 #pragma unroll
-                    for (int t = 0; t < TN; ++t)
+                    for (int i = 0; i < 2; ++i)
+                        fa[u][i] = tr8(acur[i], std::integral_constant<int, 16 * 512 * ks>{}, std::integral_constant<int, 16 * 512 * ks + 4 * 512>{});
+#pragma unroll
+                    for (int t = 0; t < TH; ++t)
                         fb[u][t] = tr8(bcur[t], std::integral_constant<int, A_BYTES + 16 * BROW * ks>{}, std::integral_constant<int, A_BYTES + 16 * BROW * ks + 4 * BROW>{});
                 } else {
-                    asm volatile("" : "=v"(fa[u]));
 #pragma unroll
-                    for (int t = 0; t < TN; ++t) asm volatile("" : "=v"(fb[u][t]));
+                    for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(fa[u][i]));
+#pragma unroll
+                    for (int t = 0; t < TH; ++t) asm volatile("" : "=v"(fb[u][t]));
                 }
             });
 #pragma unroll
@@ -192,10 +202,12 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
 #pragma unroll
             for (int u = 0; u < KPH; ++u)
 #pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    if (!(TNR_LAB & 8)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u][t], fa[u], acc[t], 0, 0, 0);
-                    else asm volatile("" : "+v"(acc[t]) : "v"(fb[u][t]), "v"(fa[u]));
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < TH; ++t) {
+                        if (!(TNR_LAB & 8)) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u][t], fa[u][i], acc[i][t], 0, 0, 0);
+                        else asm volatile("" : "+v"(acc[i][t]) : "v"(fb[u][t]), "v"(fa[u][i]));
+                    }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -207,26 +219,34 @@ __global__ __launch_bounds__(512) void gemm_tn_rows_kernel(const TnrArgs g) {
     wait_vm<0>();
 
     // ---- epilogue (gemm_rows.h's fp32 form): this lane's result row m; element (t, r): column 32 t + (r & 3) + 8 (r >> 2) + 4 lh of the tile
+    // this lane's result rows 64 wr + 32 i + lr; element (i, t, r): column 32 (wc TH + t) + (r & 3) + 8 (r >> 2) + 4 lh of the tile
+    const int colw = 32 * wc * TH + 4 * lh;
     if (split) {                                             // the whole 256 x BN tile of plain sums (the sum launch knows the bounds)
-        float *srow = g.slab + ((long)sidx * 256 + 32 * wave + lr) * K::BN + 4 * lh;
 #pragma unroll
-        for (int t = 0; t < TN; ++t)
+        for (int i = 0; i < 2; ++i) {
+            float *srow = g.slab + ((long)sidx * 256 + 64 * wr + 32 * i + lr) * K::BN + colw;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<f32x4v *>(srow + 32 * t + 8 * gq) = f32x4v{acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<f32x4v *>(srow + 32 * t + 8 * gq) = f32x4v{acc[i][t][4 * gq], acc[i][t][4 * gq + 1], acc[i][t][4 * gq + 2], acc[i][t][4 * gq + 3]};
+        }
         return;
     }
-    const int m = tile_m * 256 + 32 * wave + lr;
-    if (m >= M) return;
-    const int ncol0 = tile_n * K::BN;
-    float *crow = g.c[q] + (long)m * g.ldc[q] + ncol0 + 4 * lh;
+    const int ncol0 = tile_n * K::BN + colw;
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int i = 0; i < 2; ++i) {
+        const int m = tile_m * 256 + 64 * wr + 32 * i + lr;
+        if (m >= M) continue;
+        float *crow = g.c[q] + (long)m * g.ldc[q] + ncol0;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4v v = {acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
-            if (ncol0 + 32 * t + 8 * gq + 4 * lh < N) *reinterpret_cast<f32x4v *>(crow + 32 * t + 8 * gq) = v;
-        }
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4v v = {acc[i][t][4 * gq], acc[i][t][4 * gq + 1], acc[i][t][4 * gq + 2], acc[i][t][4 * gq + 3]};
+                if (ncol0 + 32 * t + 8 * gq < N) *reinterpret_cast<f32x4v *>(crow + 32 * t + 8 * gq) = v;
+            }
+    }
 }
 
 // C tile <- the sum of its S slabs in slice order; grid (split tiles, 16 row groups of 16), a thread = 4 columns of 16 rows
