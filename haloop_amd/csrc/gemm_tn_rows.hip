@@ -51,7 +51,7 @@ struct TnrArgs {
 
 template <int TN> struct Cfg {
     static constexpr int BN = 32 * TN;
-    static constexpr int KPH = TN >= 6 ? 1 : 2;            // 16-deep k-steps per phase
+    static constexpr int KPH = 2;                          // 16-deep k-steps per phase
     static constexpr int NPH = 2 / KPH;
     static constexpr int BROW = 64 * TN;                   // bytes of a B row in the slot
     static constexpr int BPIECES = 32 * BROW / 1024;       // 2 TN
@@ -307,7 +307,7 @@ hipError_t launch(TnrArgs &g, hipStream_t st, int slot_id) {
     return hipGetLastError();
 }
 
-// tile columns for a group: the rounds of the CUs its whole tiles take + the sliced tiles' share of a round (+ a tenth for the sum launch),
+// tile columns for a group: the rounds of the CUs its whole tiles take + the sliced tiles' share of a round (+ a quarter for the sum launch),
 // x the time of a tile (a 256 x 256 tile streams 32 KiB per k-block, a 256 x 128 one 24)
 int pick_tn(int n, const int *M, const int *N, int KT) {
     const char *e = getenv("HALO_GEMM_TN_ROWS_TN");
@@ -320,7 +320,7 @@ int pick_tn(int n, const int *M, const int *N, int KT) {
         for (int i = 0; i < n; ++i) items += (long)((M[i] + 255) / 256) * ((N[i] + 32 * tn - 1) / (32 * tn));
         int n_full, S;
         plan_slices((int)items, KT, 32 * tn, n_full, S);
-        const double cost = (tn == 4 ? 3.0 : 4.0) * ((n_full + cus - 1) / cus + (S > 1 ? 1.0 / S + 0.1 : 0.0));
+        const double cost = (tn == 4 ? 3.0 : 4.0) * ((n_full + cus - 1) / cus + (S > 1 ? 1.0 / S + 0.25 : 0.0));
         if (best < 0 || cost < best) { best = cost; pick = tn; }
     }
     return pick;
