@@ -138,7 +138,7 @@ def fuzz_tn_group(g, cases):
     for c in range(cases):
         n = int(torch.randint(1, 5, (1,), generator=g))
         K = int(torch.randint(1, 40, (1,), generator=g)) * 32
-        Ms = [int(torch.randint(1, 60, (1,), generator=g)) * 8 for _ in range(n)]
+        Ms = [int(torch.randint(1, 60 if c % 8 else 700, (1,), generator=g)) * 8 for _ in range(n)]      # (every eighth group: many tiles -> K-slices)
         Ns = [int(torch.randint(1, 60, (1,), generator=g)) * 8 for _ in range(n)]
         As = [torch.randn(K, m, generator=g).to(DEV).bfloat16() for m in Ms]
         Bs = [torch.randn(K, nn, generator=g).to(DEV).bfloat16() for nn in Ns]
@@ -147,7 +147,19 @@ def fuzz_tn_group(g, cases):
         rc = L.halo_gemm_tn_bf16_group(n, vp(As), (C.c_long * n)(*Ms), vp(Bs), (C.c_long * n)(*Ns), (C.c_int * n)(*Ms), (C.c_int * n)(*Ns), K,
                                        vp([c_.t for c_ in Cs]), (C.c_int * n)(*Ns), 0, st)
         _lib.check(rc, 'halo_gemm_tn_bf16_group')
+        # the same products on the 256-row tiles of csrc/gemm_tn_rows.hip (a random tile width; under-filled rounds as K-slices)
+        Rs = [Guarded((m, nn), torch.float32) for m, nn in zip(Ms, Ns)]
+        os.environ['HALO_GEMM_TN_ROWS_TN'] = ['4', '8'][int(torch.randint(0, 2, (1,), generator=g))]
+        rc = L.halo_gemm_tn_rows_group(n, vp(As), (C.c_long * n)(*Ms), vp(Bs), (C.c_long * n)(*Ns), (C.c_int * n)(*Ms), (C.c_int * n)(*Ns), K,
+                                       vp([c_.t for c_ in Rs]), (C.c_long * n)(*Ns), st)
+        _lib.check(rc, 'halo_gemm_tn_rows_group')
         torch.cuda.synchronize()
+        for a, b, cc in zip(As, Bs, Rs):
+            want = a.double().t() @ b.double()
+            err = (cc.t.double() - want).abs().max().item()
+            if err > 2e-6 * K ** 0.5 * 16 + 1e-5 or not cc.intact():
+                bad += 1
+                print(f'gemm_tn_rows MISMATCH n {n} K {K} M {a.shape[1]} N {b.shape[1]} tn {os.environ["HALO_GEMM_TN_ROWS_TN"]}: err {err:.3e} guard {cc.intact()}', flush=True)
         for a, b, cc in zip(As, Bs, Cs):
             want = a.double().t() @ b.double()
             err = (cc.t.double() - want).abs().max().item()
@@ -155,6 +167,7 @@ def fuzz_tn_group(g, cases):
             if err > tol or not cc.intact():
                 bad += 1
                 print(f'gemm_tn_group MISMATCH n {n} K {K} M {a.shape[1]} N {b.shape[1]}: err {err:.3e} (tol {tol:.3e}) guard {cc.intact()}', flush=True)
+    os.environ.pop('HALO_GEMM_TN_ROWS_TN', None)
     return bad
 
 
