@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libhalo.so')
 
-HALO_ABI_VERSION = 18
+HALO_ABI_VERSION = 19
 HALO_GEMM_RELU = 1
 HALO_GEMM_GELU = 2
 HALO_GEMM_ACCUM = 4
@@ -158,6 +158,7 @@ SIGNATURES = {
     'halo_decode_image': (_i, [_vp, _i, _i, _l, _vp, _vp]),
     'halo_decode_linear_supported': (_i, [_i, _i]),
     'halo_decode_linear': (_i, [_vp, _l, _i, _i, _vp, _f, _vp, _i, _vp, _l, _i, _vp]),
+    'halo_decode_linear_pair': (_i, [_vp, _vp, _l, _i, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp]),
     'halo_decode_attention_pair': (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _l, _vp]),
     'halo_decode_memory_caches': (_i, [_vp, _l, _i, _vp, _i, _i, _i, _i, _vp]),
     'halo_decode_token': (_i, [_vp, _l, _i, _i, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

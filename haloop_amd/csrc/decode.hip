@@ -58,6 +58,12 @@ struct DecLinearArgs {
     float *out;            // [rows][n_out], leading dimension ldo
     long ldo;
     int flags;             // HALO_GEMM_ACCUM: out += ...; HALO_GEMM_GELU_ERF: exact GELU
+    // The residual stream as a PAIR (main, side): x = main + side.  LN variants: x2 != NULL is the side (same strides as x), added to the rows
+    // before the statistics.  Accumulating products with side_out != NULL run as TWO K-slices (grid.z): slice 0 writes
+    // out = (out + side_in) + its half of the product, slice 1 its half alone to side_out -- twice the workgroups, each streaming half of K,
+    // every sum in a fixed order; the next launch reads out + side_out.
+    const float *x2, *side_in;
+    float *side_out;
 };
 
 // grid (feature groups of 16*NT, row groups of 16); KSW_LN > 0: F.layer_norm (no bias) of the rows first, K == 128 * KSW_LN
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const DecLinearArgs p) 
     const int row = blockIdx.y * 16 + r;
     const bool rok = row < p.rows;
     const int nt0 = blockIdx.x * NT;
-    const int KS = p.K / 32, ksw = KS / 4, ks0 = wave * ksw;
+    const int nsl = (KSW_LN == 0 && p.side_out) ? 2 : 1, kslice = nsl == 2 ? (int)blockIdx.z : 0;
+    const int KS = p.K / 32, ksw = KS / nsl / 4, ks0 = kslice * (KS / nsl) + wave * ksw;
     const float *xr = p.x + (long)(rok ? row : 0) * p.ldx + g * 8;
     f32x4 acc[NT];
 #pragma unroll
@@ -95,7 +102,12 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const DecLinearArgs p) 
         bf16x8 wh[NK][NT], wl[NK][NT];
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + (ks0 + i) * 32), b = *reinterpret_cast<const f32x4 *>(xr + (ks0 + i) * 32 + 4);
+            f32x4 a = *reinterpret_cast<const f32x4 *>(xr + (ks0 + i) * 32), b = *reinterpret_cast<const f32x4 *>(xr + (ks0 + i) * 32 + 4);
+            if (p.x2) {                                      // x = main + side (uniform branch)
+                const float *x2r = p.x2 + (xr - p.x);
+                a += *reinterpret_cast<const f32x4 *>(x2r + (ks0 + i) * 32);
+                b += *reinterpret_cast<const f32x4 *>(x2r + (ks0 + i) * 32 + 4);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { xv[i][j] = rok ? a[j] : 0.f; xv[i][4 + j] = rok ? b[j] : 0.f; }
         }
@@ -182,8 +194,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const DecLinearArgs p) 
             if (orow >= p.rows) continue;
             float v = (red[0][nt][l][e] + red[1][nt][l][e]) + (red[2][nt][l][e] + red[3][nt][l][e]);
             v = gemm_activation(v, p.flags & 8);
-            float *o = p.out + (long)orow * p.ldo + col;
-            if (p.flags & 4) v += *o;
+            const long oi = (long)orow * p.ldo + col;
+            if (kslice == 1) { p.side_out[oi] = v; continue; }         // the second half of K: alone, for the next launch to add
+            float *o = p.out + oi;
+            if (p.flags & 4) v += p.side_in ? *o + p.side_in[oi] : *o;
             *o = v;
         }
     }
@@ -505,17 +519,28 @@ int halo_decode_linear_supported(int k, int layernorm) {
 
 int halo_decode_linear(const float *x, long ldx, int rows, int k, const float *ln_weight, float eps, const void *w_image, int n_out,
                        float *out, long ldo, int flags, halo_stream_t stream) {
+    return halo_decode_linear_pair(x, nullptr, ldx, rows, k, ln_weight, eps, w_image, n_out, out, nullptr, nullptr, ldo, flags, stream);
+}
+
+int halo_decode_linear_pair(const float *x, const float *x_side, long ldx, int rows, int k, const float *ln_weight, float eps, const void *w_image,
+                            int n_out, float *out, const float *side_in, float *side_out, long ldo, int flags, halo_stream_t stream) {
     HALO_CHECK_ARG(x && w_image && out && rows > 0 && n_out > 0 && ldx >= k && ldo >= n_out);
+    // the side of the input rows: LayerNorm variants only; the K-sliced accumulate: no LayerNorm, ACCUM alone, whole k-steps per wave and slice
+    HALO_CHECK_ARG(!x_side || ln_weight);
+    HALO_CHECK_ARG(!side_out || (!ln_weight && flags == HALO_GEMM_ACCUM && k % 256 == 0 && side_out != out && side_out != side_in));
+    HALO_CHECK_ARG(!side_in || side_out);
+    HALO_CHECK_ARG(((uintptr_t)x_side) % 16 == 0);
     HALO_CHECK_ARG(halo_decode_linear_supported(k, ln_weight != nullptr));
     HALO_CHECK_ARG((flags & ~(HALO_GEMM_ACCUM | HALO_GEMM_GELU_ERF)) == 0);
     HALO_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_image | (uintptr_t)ln_weight) % 16 == 0 && ldx % 4 == 0);
     DecLinearArgs p;
     p.x = x; p.ldx = ldx; p.rows = rows; p.K = k; p.lnw = ln_weight; p.eps = eps; p.w = (const char *)w_image;
     p.n_tiles = (n_out + 15) / 16; p.n_out = n_out; p.out = out; p.ldo = ldo; p.flags = flags;
-    const int row_groups = (rows + 15) / 16;
+    p.x2 = x_side; p.side_in = side_in; p.side_out = side_out;
+    const int row_groups = (rows + 15) / 16, slices = side_out ? 2 : 1;
     // two feature tiles per workgroup while that still gives the chip a workgroup per CU, else one
-    const bool two = (long)((p.n_tiles + 1) / 2) * row_groups >= 256;
-    const dim3 grid((unsigned)(two ? (p.n_tiles + 1) / 2 : p.n_tiles), (unsigned)row_groups);
+    const bool two = (long)((p.n_tiles + 1) / 2) * row_groups * slices >= 256;
+    const dim3 grid((unsigned)(two ? (p.n_tiles + 1) / 2 : p.n_tiles), (unsigned)row_groups, (unsigned)slices);
     hipStream_t st = (hipStream_t)stream;
 #define HALO_DEC_LAUNCH(LN)                                                                     \
     do {                                                                                        \

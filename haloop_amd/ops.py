@@ -1141,12 +1141,25 @@ def decode_image(weight):
     return img
 
 
-def decode_linear(x, image, n_out, out, ln_weight=None, eps=1e-5, accumulate=False, gelu=False):
-    """out (+)= act(layer_norm?(x) W^T) with W given by its decode image; x [rows, k] and out [rows, >= n_out] fp32 (row strides kept)."""
+def decode_linear(x, image, n_out, out, ln_weight=None, eps=1e-5, accumulate=False, gelu=False, x_side=None, side_in=None, side_out=None):
+    """out (+)= act(layer_norm?(x) W^T) with W given by its decode image; x [rows, k] and out [rows, >= n_out] fp32 (row strides kept).
+    The residual stream as a pair (halo_decode_linear_pair): ``x_side`` (LayerNorm variants) is added to the input rows; ``side_out``
+    (accumulating, no LayerNorm, k % 256 == 0) runs the product as two K-slices: out = (out + side_in) + the first half, side_out = the
+    second -- the next launch reads out + side_out."""
     rows, k = x.shape
     flags = (_lib.HALO_GEMM_ACCUM if accumulate else 0) | (_lib.HALO_GEMM_GELU_ERF if gelu else 0)
-    check(lib().halo_decode_linear(ptr(x), x.stride(0), rows, k, ptr(ln_weight), eps, ptr(image), n_out, ptr(out), out.stride(0), flags,
-                                   _stream()), 'halo_decode_linear')
+    if x_side is None and side_out is None and side_in is None:
+        check(lib().halo_decode_linear(ptr(x), x.stride(0), rows, k, ptr(ln_weight), eps, ptr(image), n_out, ptr(out), out.stride(0), flags,
+                                       _stream()), 'halo_decode_linear')
+        return out
+    for t in (x_side,):
+        if t is not None and (t.shape != x.shape or t.stride(0) != x.stride(0)):
+            raise ValueError('decode_linear: x_side must have the shape and row stride of x')
+    for t in (side_in, side_out):
+        if t is not None and (t.shape != out.shape or t.stride(0) != out.stride(0)):
+            raise ValueError('decode_linear: side_in / side_out must have the shape and row stride of out')
+    check(lib().halo_decode_linear_pair(ptr(x), ptr(x_side), x.stride(0), rows, k, ptr(ln_weight), eps, ptr(image), n_out, ptr(out), ptr(side_in),
+                                        ptr(side_out), out.stride(0), flags, _stream()), 'halo_decode_linear_pair')
     return out
 
 

@@ -606,15 +606,23 @@ class Decoder(nn.Module):
         logits = torch.empty(N, V, device=dev, dtype=torch.float32)
         wte = self.wte.weight.detach()
         y = ops.embed_fwd(tokens[:, 0:1], wte, None)                         # [N, C]; later steps: written by decode_token
+        # The two accumulating products of a layer (K = 2C, 4C into C features: 128 workgroups at N = 64, each streaming its weights and
+        # its rows over the whole K) run as two K-slices on twice the workgroups: the residual stream is the pair (y, side) -- slice 0
+        # writes y = (y + side) + its half, slice 1 its half to the OTHER side buffer; the LayerNorm launches read y + side.  Every sum in
+        # a fixed order (HALO_DECODE_KSPLIT=0: one slice, the round-4 launches).
+        ksplit = os.environ.get('HALO_DECODE_KSPLIT', '1') != '0' and (2 * C) % 256 == 0
+        sa, sb = (torch.empty(N, C, device=dev, dtype=torch.float32) for _ in range(2)) if ksplit else (None, None)
         for t in range(T):
+            side = None                                                      # (y alone: the embedding of the step's token)
             for l, block in enumerate(self.h):
                 w_qkv, w_proj, w_fc, w_fc2 = layers[l]
-                ops.decode_linear(y, w_qkv, 4 * C, a, ln_weight=block.ln_time.weight)       # both attentions read ln_time(x) (:476-494)
+                ops.decode_linear(y, w_qkv, 4 * C, a, ln_weight=block.ln_time.weight, x_side=side)      # both attentions read ln_time(x) (:476-494)
                 ops.decode_attention_pair(a, mem_cache[l, 0], mem_cache[l, 1], mlen, time_cache[l, 0], time_cache[l, 1], t + 1, table, att)
-                ops.decode_linear(att, w_proj, C, y, accumulate=True)                       # x += cross proj + self proj
-                ops.decode_linear(y, w_fc, 4 * C, hid, ln_weight=block.ln_chan.weight, gelu=True)
-                ops.decode_linear(hid, w_fc2, C, y, accumulate=True)
-            ops.decode_linear(y, head_img, V, logits, ln_weight=self.ln_f.weight)
+                ops.decode_linear(att, w_proj, C, y, accumulate=True, side_in=side, side_out=sa)         # x += cross proj + self proj
+                ops.decode_linear(y, w_fc, 4 * C, hid, ln_weight=block.ln_chan.weight, gelu=True, x_side=sa)
+                ops.decode_linear(hid, w_fc2, C, y, accumulate=True, side_in=sa, side_out=sb)
+                side = sb
+            ops.decode_linear(y, head_img, V, logits, ln_weight=self.ln_f.weight, x_side=side)
             ops.decode_token(logits, tokens, t, plen, ETX, alive, out_len, log_probs, sum_entropies, wte, y if t + 1 < T else None)
         return tokens, out_len, log_probs, sum_entropies
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 18
+#define HALO_ABI_VERSION 19
 
 #define HALO_OK 0
 #define HALO_EINVAL (-22)    /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -719,6 +719,13 @@ int halo_decode_image(const float *weight, int n_out, int k, long ld, void *imag
 int halo_decode_linear_supported(int k, int layernorm);
 int halo_decode_linear(const float *x, long ldx, int rows, int k, const float *ln_weight, float eps, const void *w_image,
                        int n_out, float *out, long ldo, int flags, halo_stream_t stream);
+/* The same launch with the residual stream as a PAIR (main, side), x = main + side -- what lets the two accumulating products of a decoder
+ * layer (x += proj(...), x += mix_chan[2](...): ha/transformer.py:476-494) run as TWO K-slices on twice the workgroups with every sum in a
+ * fixed order: x_side (LayerNorm variants) is added to the input rows before the statistics; side_out != NULL (no LayerNorm, flags ==
+ * HALO_GEMM_ACCUM, k % 256 == 0): slice 0 writes out = (out + side_in) + its half of the product (side_in may be NULL), slice 1 its half
+ * alone to side_out [rows][ldo]; the next launch reads out + side_out.  side_out must differ from out and side_in. */
+int halo_decode_linear_pair(const float *x, const float *x_side, long ldx, int rows, int k, const float *ln_weight, float eps, const void *w_image,
+                            int n_out, float *out, const float *side_in, float *side_out, long ldo, int flags, halo_stream_t stream);
 int halo_decode_attention_pair(const float *a, long a_row_stride, int N, int heads, int head_dim, const void *mem_k,
                                const void *mem_v, int S, const int *memory_lengths, void *time_k, void *time_v,
                                int cache_len, int n_keys, const float *cos_table, const float *sin_table, float *y,

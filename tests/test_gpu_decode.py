@@ -54,6 +54,51 @@ def test_decode_linear(hal, rows, K, n_out, ln, accumulate, gelu):
     assert torch.equal(got[:, n_out:], out0[:, n_out:])                             # nothing written past the features
 
 
+@pytest.mark.parametrize('rows,K,n_out', [(64, 1024, 512), (64, 2048, 512), (21, 1024, 100), (128, 2048, 1024)])
+def test_decode_linear_with_the_residual_stream_as_a_pair(hal, rows, K, n_out):
+    """halo_decode_linear_pair: an accumulating product as two K-slices -- out = (out + side_in) + the first half, side_out = the second
+    half -- against the fp64 product; out + side_out is the accumulated stream; the same bits on every run; a LayerNorm launch given the
+    pair reads exactly what it reads from the summed rows."""
+    ops, lib = hal['ops'], hal['lib']
+    g = torch.Generator().manual_seed(rows + K + n_out)
+    x = torch.randn(rows, K, generator=g) * 1.5 + 0.3
+    w = torch.randn(n_out, K, generator=g) / K ** 0.5
+    main0 = torch.randn(rows, n_out + 8, generator=g)
+    side0 = torch.randn(rows, n_out + 8, generator=g)
+    img = ops.decode_image(w.to(DEV))
+    ref = x.double() @ w.double().t() + main0[:, :n_out].double() + side0[:, :n_out].double()
+    runs = []
+    for _ in range(2):
+        main, side_in, side_out = main0.to(DEV), side0.to(DEV), torch.full((rows, n_out + 8), 7.0, device=DEV)
+        ops.decode_linear(x.to(DEV), img, n_out, main, accumulate=True, side_in=side_in, side_out=side_out)
+        runs.append((main.cpu(), side_out.cpu()))
+    (main, side), (main_b, side_b) = runs
+    assert torch.equal(main, main_b) and torch.equal(side, side_b)
+    got = main[:, :n_out].double() + side[:, :n_out].double()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
+    assert torch.equal(main[:, n_out:], main0[:, n_out:]) and bool((side[:, n_out:] == 7.0).all())       # nothing written past the features
+    # without a side coming in
+    main = main0.to(DEV); side_out = torch.zeros(rows, n_out + 8, device=DEV)
+    ops.decode_linear(x.to(DEV), img, n_out, main, accumulate=True, side_out=side_out)
+    got = (main[:, :n_out].double() + side_out[:, :n_out].double()).cpu()
+    np.testing.assert_allclose(got.numpy(), (ref - side0[:, :n_out].double()).numpy(), rtol=0, atol=3e-5 * float(ref.abs().max()))
+    # a LayerNorm launch reading the pair == the same launch on the summed rows
+    if ops.decode_linear_supported(n_out, True):
+        lnw = (torch.rand(n_out, generator=g) + 0.5).to(DEV)
+        w2 = torch.randn(64, n_out, generator=g) / n_out ** 0.5
+        img2 = ops.decode_image(w2.to(DEV))
+        a = main[:, :n_out].contiguous(); b = side_out[:, :n_out].contiguous()
+        o1, o2 = torch.zeros(rows, 64, device=DEV), torch.zeros(rows, 64, device=DEV)
+        ops.decode_linear(a, img2, 64, o1, ln_weight=lnw, x_side=b)
+        ops.decode_linear(a + b, img2, 64, o2, ln_weight=lnw)
+        assert torch.equal(o1, o2)
+    # refusals: the sliced form needs ACCUM alone and distinct buffers
+    with pytest.raises(lib.HaloError):
+        ops.decode_linear(x.to(DEV), img, n_out, main, accumulate=False, side_out=side_out)
+    with pytest.raises(lib.HaloError):
+        ops.decode_linear(x.to(DEV), img, n_out, main, accumulate=True, side_in=side_out, side_out=side_out)
+
+
 def test_decode_linear_refusals(hal):
     ops, lib = hal['ops'], hal['lib']
     assert not ops.decode_linear_supported(500, False) and not ops.decode_linear_supported(640, True)
