@@ -1,6 +1,6 @@
 // Weight-gradient products C [M][N] = A^T B, A [K][M] and B [K][N] ROW-MAJOR bf16 with the contraction along the ROWS (dW = dy^T x of a
-// Linear: K = the B T token rows), on 256 x 128 or 256 x 256 tiles of whole K -- gemm_rows.h's machine (LDS-DMA ring, eight waves of 32
-// result rows x all tile columns, transposed accumulators, counted vmcnt, two wave groups one barrier apart) with k-major operands:
+// Linear: K = the B T token rows), on 256 x 128 or 256 x 256 tiles of whole K -- gemm_rows.h's machine (LDS-DMA ring, eight waves,
+// transposed accumulators, counted vmcnt, two wave groups one barrier apart) with k-major operands:
 //
 //   * why: gemm_bf16x3.hip's TN product cuts the four weight gradients of a GPT block into 432 tiles of 128 x 128 -- 1.69 per CU, 64 FLOP
 //     per operand byte, and a CU takes in ~56-60 GB/s from L2 whatever the kernel (profiles/r05_experiments.md): 151 us per layer, 33 % MFMA
@@ -12,7 +12,9 @@
 //     (16 lanes read 4 rows x 16 columns and receive them transposed), two per operand fragment.  All rows of an operand start at the same
 //     LDS bank (512 / 256-byte pitch), so the 16-byte chunks of row r sit XOR-swizzled by 4 (r & 3) (permuted on the SOURCE address of the
 //     DMA, the same permutation on the read): the 4 rows x 2 lane groups of a transposing read land on 8 distinct 32-byte bank spans.
-//   * one tile = one workgroup (no K-slices, no scratch, no reduce launch); up to four products of one K per launch; fp32 results.
+//   * a wave multiplies two 32-row blocks by half the tile's columns: 2 + TN / 2 fragments per k-step for TN MFMAs.
+//   * one tile = one workgroup; tiles that do not fill a round of the CUs run as K-slices into scratch slabs + a sum launch in slice order
+//     (plan_slices); up to four products of one K per launch; fp32 results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -30,7 +32,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 constexpr int TNR_MAX = 4;
 constexpr int A_BYTES = 16384;               // 32 k-rows x 256 columns x 2 B
@@ -51,7 +52,7 @@ struct TnrArgs {
 
 template <int TN> struct Cfg {
     static constexpr int BN = 32 * TN;
-    static constexpr int KPH = 2;                          // 16-deep k-steps per phase
+    static constexpr int KPH = 2;                          // 16-deep k-steps per phase: one phase = the whole k-block (8 or 16 MFMAs per wave)
     static constexpr int NPH = 2 / KPH;
     static constexpr int BROW = 64 * TN;                   // bytes of a B row in the slot
     static constexpr int BPIECES = 32 * BROW / 1024;       // 2 TN
